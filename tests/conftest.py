@@ -1,0 +1,24 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+sys.dont_write_bytecode = True
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "needs_reference: needs the read-only reference tree (build container only)")
+
+
+def pytest_collection_modifyitems(config, items):
+    from oracle.ref_shim import reference_available
+    if reference_available():
+        return
+    skip = pytest.mark.skip(reason="reference tree not present (GPU box)")
+    for item in items:
+        if "needs_reference" in item.keywords:
+            item.add_marker(skip)
