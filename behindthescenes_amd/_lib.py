@@ -1,0 +1,96 @@
+"""ctypes binding of libbts_render.so (the C ABI in include/bts_render.h).
+
+The library is the product: there is NO Python/torch fallback for anything it exports.  If it is missing or a call
+fails, a ``BtsNativeError`` is raised."""
+import ctypes as C
+import os
+import threading
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG, "libbts_render.so")
+ABI_VERSION = 1
+
+BTS_MAX_VIEWS = 8
+ERRORS = {-1: "BTS_E_INVALID", -2: "BTS_E_UNSUPPORTED", -3: "BTS_E_LAUNCH", -4: "BTS_E_WORKSPACE"}
+
+
+class BtsNativeError(RuntimeError):
+    pass
+
+
+class BtsFieldCfg(C.Structure):
+    _fields_ = [(k, C.c_int32) for k in ("n", "H", "W", "C", "d_hidden", "n_blocks", "nv", "num_freqs", "code_mode", "inv_z",
+                                         "learn_empty", "empty_empty")] + \
+               [("freq_factor", C.c_float), ("d_min", C.c_float), ("d_max", C.c_float)]
+
+
+class BtsFieldTensors(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("feat_nhwc", "K_enc", "w2c_enc", "imgs_nhwc4", "K_r", "w2c_r", "empty_feature",
+                                          "mlp_params")]
+
+
+class BtsRenderArgs(C.Structure):
+    _fields_ = [(k, C.c_int32) for k in ("rays_per_sample", "K", "hard_alpha_cap", "white_bkgd")] + \
+               [(k, C.c_void_p) for k in ("rays", "z_samp", "rgb", "depth", "weights", "alphas", "invalid", "rgb_samps",
+                                          "sigma_raw")]
+
+
+class BtsRenderGrads(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("g_rgb", "g_depth", "g_weights", "g_alphas", "d_feat_nhwc", "d_mlp_params",
+                                          "d_empty_feature")]
+
+
+# every symbol include/bts_render.h declares: name -> (restype, argtypes)
+_P = C.c_void_p
+_I = C.c_int32
+SYMBOLS = {
+    "bts_abi_version": (C.c_int, []),
+    "bts_last_error": (C.c_char_p, []),
+    "bts_supported": (C.c_int, [C.POINTER(BtsFieldCfg)]),
+    "bts_mlp_param_count": (C.c_int64, [C.POINTER(BtsFieldCfg)]),
+    "bts_render_fwd": (C.c_int, [C.POINTER(BtsFieldCfg), C.POINTER(BtsFieldTensors), C.POINTER(BtsRenderArgs), _P]),
+    "bts_render_bwd_workspace": (C.c_size_t, [C.POINTER(BtsFieldCfg), C.POINTER(BtsRenderArgs)]),
+    "bts_render_bwd": (C.c_int, [C.POINTER(BtsFieldCfg), C.POINTER(BtsFieldTensors), C.POINTER(BtsRenderArgs),
+                                 C.POINTER(BtsRenderGrads), _P, C.c_size_t, _P]),
+    "bts_field_query": (C.c_int, [C.POINTER(BtsFieldCfg), C.POINTER(BtsFieldTensors), _P, _I, _I, _P, _P, _P, _P]),
+    "bts_nchw_to_nhwc": (C.c_int, [_P, _P, _I, _I, _I, _I, _P]),
+    "bts_nhwc_to_nchw": (C.c_int, [_P, _P, _I, _I, _I, _I, _P]),
+    "bts_pack_rgb": (C.c_int, [_P, _P, _I, _I, _I, C.c_float, C.c_float, _P]),
+    "bts_gen_rays": (C.c_int, [_P, _P, _I, _I, _I, C.c_float, C.c_float, _I, _P, _P]),
+    "bts_sample_coarse": (C.c_int, [_P, _P, C.c_int64, _I, _I, _P, _P]),
+    "bts_distance_to_z": (C.c_int, [_P, _P, _I, _I, _I, _P, _P]),
+}
+
+_lock = threading.Lock()
+_lib = None
+
+
+def load():
+    """Loads the shared library (once).  Raises BtsNativeError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise BtsNativeError(
+                f"{LIB_PATH} not found: the HIP renderer has not been built. Run `python -m behindthescenes_amd.build` "
+                "(needs hipcc, no GPU). There is no fallback path.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            try:
+                fn = getattr(lib, name)
+            except AttributeError as e:
+                raise BtsNativeError(f"{LIB_PATH} does not export {name}; rebuild it") from e
+            fn.restype, fn.argtypes = res, args
+        if lib.bts_abi_version() != ABI_VERSION:
+            raise BtsNativeError(f"ABI mismatch: library {lib.bts_abi_version()} vs binding {ABI_VERSION}; rebuild")
+        _lib = lib
+    return _lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = load().bts_last_error().decode(errors="replace")
+        raise BtsNativeError(f"{what} failed: {ERRORS.get(rc, rc)}: {msg}")

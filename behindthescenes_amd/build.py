@@ -1,0 +1,67 @@
+"""Builds libbts_render.so (hand-written HIP for gfx950) in-tree with hipcc.  No GPU is needed to build.
+
+    python -m behindthescenes_amd.build [--force]
+
+The shared object is git-ignored but travels to the GPU box with the source snapshot.
+"""
+import hashlib
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG, "csrc")
+ROOT = os.path.dirname(PKG)
+LIB = os.path.join(PKG, "libbts_render.so")
+OBJ = os.path.join(PKG, "csrc", "_obj")
+SOURCES = ["bts_fwd.hip", "bts_bwd.hip", "bts_aux.hip", "bts_api.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-fno-gpu-rdc"]
+
+
+def _digest():
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(CSRC)) + [os.path.join("..", "..", "include", "bts_render.h")]:
+        path = os.path.join(CSRC, name)
+        if os.path.isfile(path) and name.split(".")[-1] in ("hip", "h"):
+            h.update(name.encode()), h.update(open(path, "rb").read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    return "hipcc"
+
+
+def build_library(force: bool = False, verbose: bool = False) -> str:
+    stamp = os.path.join(OBJ, "digest.txt")
+    dig = _digest()
+    if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read().strip() == dig:
+        return LIB
+    os.makedirs(OBJ, exist_ok=True)
+    cc = hipcc()
+
+    def compile_one(src):
+        obj = os.path.join(OBJ, src.replace(".hip", ".o"))
+        cmd = [cc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr[-4000:]}")
+        return obj
+
+    with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    r = subprocess.run([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stderr[-4000:]}")
+    open(stamp, "w").write(dig)
+    if verbose:
+        print(f"built {LIB}")
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_library(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,166 @@
+// extern "C" entry points of libbts_render.so (declared in include/bts_render.h): argument validation and launch
+// geometry only -- no allocation, no synchronisation, no exceptions.
+#include "bts_common.h"
+
+#include <cstdio>
+#include <cstring>
+
+namespace bts {
+struct FwdParams;
+void set_error(const char* fmt, const char* a = "", long b = 0, long c = 0, long d = 0);
+const char* last_error();
+bool shape_supported(int C, int HD, int NB);
+
+int transpose_launch(const float* src, float* dst, int N, int C, int H, int W, bool to_nhwc, hipStream_t s);
+int pack_rgb_launch(const float* src, float* dst, int N, int H, int W, float scale, float shift, hipStream_t s);
+int gen_rays_launch(const float* poses, const float* projs, int V, int H, int W, float zn, float zf, int norm_dir, float* rays,
+                    hipStream_t s);
+int sample_coarse_launch(const float* rays, const float* u, long B, int K, int lindisp, float* z, hipStream_t s);
+int distance_to_z_launch(const float* depths, const float* invK, int N, int H, int W, float* out, hipStream_t s);
+
+int render_fwd_impl(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const BtsRenderArgs* a, hipStream_t s);
+int field_query_impl(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const float* xyz, int P, int only_density, float* rgb,
+                     float* invalid, float* sigma, hipStream_t s);
+size_t render_bwd_workspace_impl(const BtsFieldCfg* cfg, const BtsRenderArgs* a);
+int render_bwd_impl(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const BtsRenderArgs* a, const BtsRenderGrads* g, void* ws,
+                    size_t ws_bytes, hipStream_t s);
+}  // namespace bts
+
+using namespace bts;
+
+static int check_cfg(const BtsFieldCfg* cfg, const BtsFieldTensors* t, bool need_imgs) {
+  if (!cfg || !t) {
+    set_error("%s: NULL cfg/tensors", "bts");
+    return BTS_E_INVALID;
+  }
+  if (cfg->n <= 0 || cfg->H <= 0 || cfg->W <= 0 || cfg->nv < 0) {
+    set_error("%s: non-positive size n=%ld H=%ld W=%ld", "bts", cfg->n, cfg->H, cfg->W);
+    return BTS_E_INVALID;
+  }
+  if (!bts_supported(cfg)) {
+    set_error("%s: configuration outside the compiled envelope (C=%ld d_hidden=%ld n_blocks=%ld; also needs num_freqs=6, nv<=8)",
+              "bts", cfg->C, cfg->d_hidden, cfg->n_blocks);
+    return BTS_E_UNSUPPORTED;
+  }
+  if (!t->feat_nhwc || !t->K_enc || !t->w2c_enc || !t->mlp_params) {
+    set_error("%s: NULL field tensor", "bts");
+    return BTS_E_INVALID;
+  }
+  if (need_imgs && cfg->nv > 0 && (!t->imgs_nhwc4 || !t->K_r || !t->w2c_r)) {
+    set_error("%s: NULL colour-view tensor with nv=%ld", "bts", cfg->nv);
+    return BTS_E_INVALID;
+  }
+  if (cfg->learn_empty && !t->empty_feature) {
+    set_error("%s: learn_empty set but empty_feature is NULL", "bts");
+    return BTS_E_INVALID;
+  }
+  if (cfg->code_mode != 0 && cfg->code_mode != 1) {
+    set_error("%s: unknown code_mode %ld", "bts", cfg->code_mode);
+    return BTS_E_INVALID;
+  }
+  return BTS_OK;
+}
+
+extern "C" {
+
+int bts_abi_version(void) { return BTS_ABI_VERSION; }
+const char* bts_last_error(void) { return last_error(); }
+
+int bts_supported(const BtsFieldCfg* cfg) {
+  if (!cfg) return 0;
+  return shape_supported(cfg->C, cfg->d_hidden, cfg->n_blocks) && cfg->num_freqs == kNumFreqs && cfg->nv <= BTS_MAX_VIEWS ? 1 : 0;
+}
+
+int64_t bts_mlp_param_count(const BtsFieldCfg* cfg) {
+  if (!cfg) return -1;
+  return MlpLayout{cfg->C + 3 + 6 * cfg->num_freqs, cfg->d_hidden, cfg->n_blocks}.total();
+}
+
+int bts_render_fwd(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const BtsRenderArgs* a, void* stream) {
+  int rc = check_cfg(cfg, t, true);
+  if (rc) return rc;
+  if (!a || !a->rays || !a->z_samp || !a->rgb || !a->depth) {
+    set_error("%s: NULL render argument", "bts_render_fwd");
+    return BTS_E_INVALID;
+  }
+  if (a->rays_per_sample <= 0 || a->K <= 0) {
+    set_error("%s: non-positive rays_per_sample=%ld K=%ld", "bts_render_fwd", a->rays_per_sample, a->K);
+    return BTS_E_INVALID;
+  }
+  return render_fwd_impl(cfg, t, a, (hipStream_t)stream);
+}
+
+size_t bts_render_bwd_workspace(const BtsFieldCfg* cfg, const BtsRenderArgs* a) {
+  if (!cfg || !a) return 0;
+  return render_bwd_workspace_impl(cfg, a);
+}
+
+int bts_render_bwd(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const BtsRenderArgs* a, const BtsRenderGrads* g,
+                   void* workspace, size_t workspace_bytes, void* stream) {
+  int rc = check_cfg(cfg, t, true);
+  if (rc) return rc;
+  if (!a || !g || !a->rays || !a->z_samp || !a->sigma_raw) {
+    set_error("%s: NULL argument (rays, z_samp and the forward's sigma_raw are required)", "bts_render_bwd");
+    return BTS_E_INVALID;
+  }
+  if (a->rays_per_sample <= 0 || a->K <= 0) {
+    set_error("%s: non-positive rays_per_sample=%ld K=%ld", "bts_render_bwd", a->rays_per_sample, a->K);
+    return BTS_E_INVALID;
+  }
+  if (workspace_bytes < render_bwd_workspace_impl(cfg, a) || (!workspace && render_bwd_workspace_impl(cfg, a) > 0)) {
+    set_error("%s: workspace too small (%ld bytes needed)", "bts_render_bwd", (long)render_bwd_workspace_impl(cfg, a));
+    return BTS_E_WORKSPACE;
+  }
+  return render_bwd_impl(cfg, t, a, g, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int bts_field_query(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const float* xyz, int32_t P, int32_t only_density,
+                    float* rgb, float* invalid, float* sigma, void* stream) {
+  int rc = check_cfg(cfg, t, !only_density);
+  if (rc) return rc;
+  if (!xyz || !sigma || P <= 0 || (!only_density && cfg->nv > 0 && !rgb)) {
+    set_error("%s: NULL/empty query argument (P=%ld)", "bts_field_query", P);
+    return BTS_E_INVALID;
+  }
+  return field_query_impl(cfg, t, xyz, P, only_density, rgb, invalid, sigma, (hipStream_t)stream);
+}
+
+#define BTS_CHECK_LAYOUT(cond, name)                      \
+  if (!(cond)) {                                          \
+    set_error("%s: NULL pointer or non-positive size", name); \
+    return BTS_E_INVALID;                                 \
+  }
+#define BTS_RET_LAUNCH(expr, name)                              \
+  {                                                             \
+    int rc_ = (expr);                                           \
+    if (rc_) set_error("%s: kernel launch failed", name);       \
+    return rc_;                                                 \
+  }
+
+int bts_nchw_to_nhwc(const float* src, float* dst, int32_t N, int32_t C, int32_t H, int32_t W, void* stream) {
+  BTS_CHECK_LAYOUT(src && dst && N > 0 && C > 0 && H > 0 && W > 0, "bts_nchw_to_nhwc");
+  BTS_RET_LAUNCH(transpose_launch(src, dst, N, C, H, W, true, (hipStream_t)stream), "bts_nchw_to_nhwc");
+}
+int bts_nhwc_to_nchw(const float* src, float* dst, int32_t N, int32_t C, int32_t H, int32_t W, void* stream) {
+  BTS_CHECK_LAYOUT(src && dst && N > 0 && C > 0 && H > 0 && W > 0, "bts_nhwc_to_nchw");
+  BTS_RET_LAUNCH(transpose_launch(src, dst, N, C, H, W, false, (hipStream_t)stream), "bts_nhwc_to_nchw");
+}
+int bts_pack_rgb(const float* src, float* dst, int32_t N, int32_t H, int32_t W, float scale, float shift, void* stream) {
+  BTS_CHECK_LAYOUT(src && dst && N > 0 && H > 0 && W > 0, "bts_pack_rgb");
+  BTS_RET_LAUNCH(pack_rgb_launch(src, dst, N, H, W, scale, shift, (hipStream_t)stream), "bts_pack_rgb");
+}
+int bts_gen_rays(const float* poses, const float* projs, int32_t V, int32_t H, int32_t W, float z_near, float z_far,
+                 int32_t norm_dir, float* rays, void* stream) {
+  BTS_CHECK_LAYOUT(poses && projs && rays && V > 0 && H > 0 && W > 0, "bts_gen_rays");
+  BTS_RET_LAUNCH(gen_rays_launch(poses, projs, V, H, W, z_near, z_far, norm_dir, rays, (hipStream_t)stream), "bts_gen_rays");
+}
+int bts_sample_coarse(const float* rays, const float* u, int64_t B, int32_t K, int32_t lindisp, float* z_samp, void* stream) {
+  BTS_CHECK_LAYOUT(rays && u && z_samp && B > 0 && K > 0, "bts_sample_coarse");
+  BTS_RET_LAUNCH(sample_coarse_launch(rays, u, (long)B, K, lindisp, z_samp, (hipStream_t)stream), "bts_sample_coarse");
+}
+int bts_distance_to_z(const float* depths, const float* inv_K, int32_t N, int32_t H, int32_t W, float* out, void* stream) {
+  BTS_CHECK_LAYOUT(depths && inv_K && out && N > 0 && H > 0 && W > 0, "bts_distance_to_z");
+  BTS_RET_LAUNCH(distance_to_z_launch(depths, inv_K, N, H, W, out, (hipStream_t)stream), "bts_distance_to_z");
+}
+
+}  // extern "C"

@@ -1,0 +1,176 @@
+// Small HBM-bound kernels at the edges of the render path: layout changes at the hand-off from the PyTorch encoder,
+// ray generation (util.py:113-149, 244-273), stratified depth sampling (nerf.py:103-123) and distance->z
+// (projection_operations.py:4-16).  All are coalesced streaming kernels; none does arithmetic worth an MFMA.
+#include "bts_common.h"
+
+namespace bts {
+
+void set_error(const char* fmt, const char* a = "", long b = 0, long c = 0, long d = 0);
+
+// ----------------------------------------------------------------------------------------------------------------
+// (N, C, HW) <-> (N, HW, C) through a 64x65 LDS tile: both the read and the write are 256-byte coalesced rows.
+// ----------------------------------------------------------------------------------------------------------------
+template <bool TO_NHWC>
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ src, float* __restrict__ dst, int C, int HW) {
+  __shared__ float tile[64][65];
+  const int n = blockIdx.z;
+  const int c0 = blockIdx.y * 64, p0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 64 x 4
+  const float* s = src + (long)n * C * HW;
+  float* d = dst + (long)n * C * HW;
+  if (TO_NHWC) {
+    // read rows = channels, cols = pixels
+    for (int i = ty; i < 64; i += 4) {
+      const int c = c0 + i, p = p0 + tx;
+      if (c < C && p < HW) tile[i][tx] = s[(long)c * HW + p];
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+      const int p = p0 + i, c = c0 + tx;
+      if (c < C && p < HW) d[(long)p * C + c] = tile[tx][i];
+    }
+  } else {
+    for (int i = ty; i < 64; i += 4) {
+      const int p = p0 + i, c = c0 + tx;
+      if (c < C && p < HW) tile[i][tx] = s[(long)p * C + c];
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+      const int c = c0 + i, p = p0 + tx;
+      if (c < C && p < HW) d[(long)c * HW + p] = tile[tx][i];
+    }
+  }
+}
+
+int transpose_launch(const float* src, float* dst, int N, int C, int H, int W, bool to_nhwc, hipStream_t s) {
+  const int HW = H * W;
+  dim3 grid((HW + 63) / 64, (C + 63) / 64, N);
+  if (to_nhwc) transpose_kernel<true><<<grid, 256, 0, s>>>(src, dst, C, HW);
+  else transpose_kernel<false><<<grid, 256, 0, s>>>(src, dst, C, HW);
+  return hipGetLastError() == hipSuccess ? BTS_OK : BTS_E_LAUNCH;
+}
+
+// (N, 3, H, W) -> (N, H, W, 4) rgb0, x*scale + shift  (encode's images * .5 + .5, models_bts.py:82)
+__global__ __launch_bounds__(256) void pack_rgb_kernel(const float* __restrict__ src, float4* __restrict__ dst, long HW, long total,
+                                                       float scale, float shift) {
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long n = i / HW, p = i - n * HW;
+    const float* s = src + n * 3 * HW + p;
+    float4 o;
+    o.x = s[0] * scale + shift;
+    o.y = s[HW] * scale + shift;
+    o.z = s[2 * HW] * scale + shift;
+    o.w = 0.0f;
+    dst[i] = o;
+  }
+}
+
+int pack_rgb_launch(const float* src, float* dst, int N, int H, int W, float scale, float shift, hipStream_t s) {
+  const long HW = (long)H * W, total = HW * N;
+  const int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+  pack_rgb_kernel<<<grid, 256, 0, s>>>(src, reinterpret_cast<float4*>(dst), HW, total, scale, shift);
+  return hipGetLastError() == hipSuccess ? BTS_OK : BTS_E_LAUNCH;
+}
+
+// torch.linspace(start, end, steps)[i] as ATen's device kernel evaluates it (symmetric about the midpoint)
+__device__ __forceinline__ float linspace_at(float start, float end, int steps, int i) {
+  const float step = (end - start) / (float)(steps - 1);
+  return i < steps / 2 ? start + step * (float)i : end - step * (float)(steps - i - 1);
+}
+
+// gen_rays: rays (V, H, W, 8) = [c2w translation, R @ unproj(pixel), near, far]
+__global__ __launch_bounds__(256) void gen_rays_kernel(const float* __restrict__ poses, const float* __restrict__ projs, int V, int H, int W,
+                                                       float z_near, float z_far, int norm_dir, float4* __restrict__ rays) {
+  const long total = (long)V * H * W;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int v = (int)(i / ((long)H * W));
+    const int rem = (int)(i - (long)v * H * W);
+    const int y = rem / W, x = rem - y * W;
+    const float* P = poses + v * 16;
+    const float* Kp = projs + v * 9;
+    const float fx = Kp[0], fy = Kp[4], cx = Kp[2], cy = Kp[5];
+    const float gx = W > 1 ? linspace_at(-1.0f, 1.0f, W, x) : -1.0f;
+    const float gy = H > 1 ? linspace_at(-1.0f, 1.0f, H, y) : -1.0f;
+    float d0 = (gx - cx) / fx, d1 = (gy - cy) / fy, d2 = 1.0f;
+    if (norm_dir) {
+      const float nrm = sqrtf(d0 * d0 + d1 * d1 + d2 * d2);
+      d0 = d0 / nrm, d1 = d1 / nrm, d2 = d2 / nrm;
+    }
+    float w[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      float a = P[4 * r + 0] * d0;
+      a = __builtin_fmaf(P[4 * r + 1], d1, a);
+      a = __builtin_fmaf(P[4 * r + 2], d2, a);
+      w[r] = a;
+    }
+    rays[2 * i] = make_float4(P[3], P[7], P[11], w[0]);
+    rays[2 * i + 1] = make_float4(w[1], w[2], z_near, z_far);
+  }
+}
+
+int gen_rays_launch(const float* poses, const float* projs, int V, int H, int W, float zn, float zf, int norm_dir, float* rays,
+                    hipStream_t s) {
+  const long total = (long)V * H * W;
+  const int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+  gen_rays_kernel<<<grid, 256, 0, s>>>(poses, projs, V, H, W, zn, zf, norm_dir, reinterpret_cast<float4*>(rays));
+  return hipGetLastError() == hipSuccess ? BTS_OK : BTS_E_LAUNCH;
+}
+
+// sample_coarse: s = linspace(0, 1-1/K, K)[k] + u/K ; z = near(1-s) + far s   or   1/((1/near)(1-s) + (1/far) s)
+__global__ __launch_bounds__(256) void sample_coarse_kernel(const float* __restrict__ rays, const float* __restrict__ u, long B, int K, int lindisp,
+                                                            float* __restrict__ z) {
+  const long total = B * K;
+  const float step = 1.0f / (float)K;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long b = i / K;
+    const int k = (int)(i - b * K);
+    const float near = rays[b * 8 + 6], far = rays[b * 8 + 7];
+    const float base = K > 1 ? linspace_at(0.0f, 1.0f - step, K, k) : 0.0f;
+    const float sv = base + u[i] * step;
+    float out;
+    if (!lindisp) out = near * (1.0f - sv) + far * sv;
+    else out = 1.0f / ((1.0f / near) * (1.0f - sv) + (1.0f / far) * sv);
+    z[i] = out;
+  }
+}
+
+int sample_coarse_launch(const float* rays, const float* u, long B, int K, int lindisp, float* z, hipStream_t s) {
+  const long total = B * K;
+  const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  sample_coarse_kernel<<<grid, 256, 0, s>>>(rays, u, B, K, lindisp, z);
+  return hipGetLastError() == hipSuccess ? BTS_OK : BTS_E_LAUNCH;
+}
+
+// distance_to_z: z = depth * cam.z / |cam|,  cam = inv_K @ [gx, gy, 1]
+__global__ __launch_bounds__(256) void distance_to_z_kernel(const float* __restrict__ depths, const float* __restrict__ invK, int N, int H, int W,
+                                                            float* __restrict__ out) {
+  const long total = (long)N * H * W;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int n = (int)(i / ((long)H * W));
+    const int rem = (int)(i - (long)n * H * W);
+    const int y = rem / W, x = rem - y * W;
+    const float* M = invK + n * 9;
+    const float gx = W > 1 ? linspace_at(-1.0f, 1.0f, W, x) : -1.0f;
+    const float gy = H > 1 ? linspace_at(-1.0f, 1.0f, H, y) : -1.0f;
+    float c[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      float a = M[3 * r + 0] * gx;
+      a = __builtin_fmaf(M[3 * r + 1], gy, a);
+      a = __builtin_fmaf(M[3 * r + 2], 1.0f, a);
+      c[r] = a;
+    }
+    const float nrm = sqrtf(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
+    out[i] = depths[i] * (c[2] / nrm);
+  }
+}
+
+int distance_to_z_launch(const float* depths, const float* invK, int N, int H, int W, float* out, hipStream_t s) {
+  const long total = (long)N * H * W;
+  const int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+  distance_to_z_kernel<<<grid, 256, 0, s>>>(depths, invK, N, H, W, out);
+  return hipGetLastError() == hipSuccess ? BTS_OK : BTS_E_LAUNCH;
+}
+
+}  // namespace bts

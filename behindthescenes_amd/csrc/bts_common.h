@@ -1,0 +1,185 @@
+// Shared device-side pieces of the gfx950 renderer: projection, bilinear taps, positional encoding, MFMA helpers.
+// Written for CDNA4 only (wave64, v_mfma_f32_32x32x2_f32, v_permlane32_swap); compiled with -ffp-contract=off so that
+// the scalar geometry follows the reference's unfused fp32 op sequence (only explicit __builtin_fmaf fuses).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/bts_render.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define BTS_EPS 1e-3f  // models_bts.py:14
+
+namespace bts {
+
+constexpr int kNumFreqs = 6;            // every shipped config (configs/*.yaml `code.num_freqs`)
+constexpr int kPeDim = 3 + 6 * kNumFreqs;  // 39
+
+// ---------------------------------------------------------------------------------------------------------------
+// wave-level helpers
+// ---------------------------------------------------------------------------------------------------------------
+// v_permlane32_swap: afterwards a = {a.lo, b.lo}, b = {a.hi, b.hi} (lo = lanes 0-31, hi = lanes 32-63).
+// With one ray per lane and (a, b) = the ray's inputs (2s, 2s+1) this yields exactly the two B operands of
+// v_mfma_f32_32x32x2_f32 for point tile 0 (rays 0-31) and point tile 1 (rays 32-63): B[k = lane>>5][j = lane&31].
+__device__ __forceinline__ void swap32(float& a, float& b) {
+  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  a = __uint_as_float(r[0]);
+  b = __uint_as_float(r[1]);
+}
+
+// row of the 32x32 MFMA C/D tile held in accumulator register r by a lane of half h (= lane >> 5)
+__device__ __forceinline__ constexpr int mfma_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+__device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// camera: rows of w2c[:3,:4] and K(3x3) kept in scalar registers (wave-uniform batch element)
+// ---------------------------------------------------------------------------------------------------------------
+struct Cam {
+  float r[12];  // w2c rows 0..2, 4 entries each
+  float k[9];
+};
+
+__device__ __forceinline__ Cam load_cam(const float* __restrict__ w2c, const float* __restrict__ K) {
+  Cam c;
+#pragma unroll
+  for (int i = 0; i < 12; ++i) c.r[i] = w2c[i];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) c.k[i] = K[i];
+  return c;
+}
+
+struct Proj {
+  float x, y;     // normalised image coordinates
+  float z;        // q.z  (depth after K)
+  float dist;     // |R p + t|   (only meaningful when requested)
+  bool invalid;
+};
+
+// models_bts.py:144-155 / 220-231.  (n,nv,3,4)@(n,1,4,P) then K@: sequential-k fused multiply-adds like a BLAS
+// micro-kernel; divide and compares unfused.
+template <bool WANT_DIST>
+__device__ __forceinline__ Proj project(const Cam& c, float px, float py, float pz) {
+  float cam[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    float a = c.r[4 * i + 0] * px;
+    a = __builtin_fmaf(c.r[4 * i + 1], py, a);
+    a = __builtin_fmaf(c.r[4 * i + 2], pz, a);
+    a = __builtin_fmaf(c.r[4 * i + 3], 1.0f, a);
+    cam[i] = a;
+  }
+  float q[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    float a = c.k[3 * i + 0] * cam[0];
+    a = __builtin_fmaf(c.k[3 * i + 1], cam[1], a);
+    a = __builtin_fmaf(c.k[3 * i + 2], cam[2], a);
+    q[i] = a;
+  }
+  Proj p;
+  p.z = q[2];
+  float zc = fmaxf(q[2], BTS_EPS);
+  p.x = q[0] / zc;
+  p.y = q[1] / zc;
+  p.invalid = (q[2] <= BTS_EPS) | (p.x < -1.0f) | (p.x > 1.0f) | (p.y < -1.0f) | (p.y > 1.0f);
+  p.dist = WANT_DIST ? sqrtf(cam[0] * cam[0] + cam[1] * cam[1] + cam[2] * cam[2]) : 0.0f;
+  return p;
+}
+
+// F.grid_sample(bilinear, border, align_corners=False) coordinates (ATen GridSampler.h:
+// unnormalize ((x+1)*size-1)/2, clip to [0,size-1], floor, 4 weights).
+struct Taps {
+  int o00, o01, o10, o11;  // texel indices (y*W + x) of nw, ne, sw, se (clamped in-bounds; OOB taps have weight 0)
+  float w00, w01, w10, w11;
+};
+
+__device__ __forceinline__ Taps make_taps(float x, float y, int H, int W) {
+  float ix = ((x + 1.0f) * (float)W - 1.0f) / 2.0f;
+  float iy = ((y + 1.0f) * (float)H - 1.0f) / 2.0f;
+  ix = fminf((float)(W - 1), fmaxf(ix, 0.0f));
+  iy = fminf((float)(H - 1), fmaxf(iy, 0.0f));
+  float fx = floorf(ix), fy = floorf(iy);
+  float ex = fx + 1.0f, ey = fy + 1.0f;  // ix_se, iy_se
+  Taps t;
+  t.w00 = (ex - ix) * (ey - iy);
+  t.w01 = (ix - fx) * (ey - iy);
+  t.w10 = (ex - ix) * (iy - fy);
+  t.w11 = (ix - fx) * (iy - fy);
+  int x0 = (int)fx, y0 = (int)fy;
+  int x1 = min(x0 + 1, W - 1), y1 = min(y0 + 1, H - 1);
+  // NaN coordinates (never produced by finite inputs) would give x0 = INT_MIN: clamp for memory safety
+  x0 = max(0, min(x0, W - 1));
+  y0 = max(0, min(y0, H - 1));
+  t.o00 = y0 * W + x0;
+  t.o01 = y0 * W + x1;
+  t.o10 = y1 * W + x0;
+  t.o11 = y1 * W + x1;
+  return t;
+}
+
+// depth code in [-1,1] (models_bts.py:157-171)
+__device__ __forceinline__ float depth_code(float v, bool inv_z, float inv_dmax, float inv_range, float d_min, float range) {
+  float r;
+  if (inv_z) {
+    r = (1.0f / fmaxf(v, BTS_EPS) - inv_dmax) / inv_range;
+  } else {
+    r = (v - d_min) / range;
+  }
+  return 2.0f * r - 1.0f;
+}
+
+// PE entry i of [x, y, zn | per octave k: sin(f_k x), sin(f_k y), sin(f_k zn), sin(f_k x + pi/2), ... ] (code.py:30-42);
+// i == kPeDim is the constant 1 that multiplies the bias row.
+template <int I>
+__device__ __forceinline__ float pe_entry(const float (&v)[3], float freq_factor) {
+  if constexpr (I < 3) {
+    return v[I];
+  } else if constexpr (I < kPeDim) {
+    constexpr int j = I - 3;
+    constexpr int oct = j / 6;
+    constexpr int within = j % 6;
+    constexpr int comp = within % 3;
+    constexpr bool is_cos = within >= 3;
+    const float f = freq_factor * (float)(1 << oct);  // exact power-of-two scaling, like freq_factor * 2.0**k in fp32
+    float arg = v[comp] * f;
+    if constexpr (is_cos) arg = arg + 1.57079637050628662109375f;  // fl32(pi/2) phase, addcmul(phase, x, f)
+    return sinf(arg);
+  } else if constexpr (I == kPeDim) {
+    return 1.0f;
+  } else {
+    return 0.0f;
+  }
+}
+
+__device__ __forceinline__ float softplus(float s) { return s > 20.0f ? s : log1pf(expf(s)); }  // F.softplus defaults
+__device__ __forceinline__ float sigmoidf(float s) { return 1.0f / (1.0f + expf(-s)); }
+
+// XCD-aware work-group remap: hardware places block b on XCD b % 8; give each XCD one contiguous range of tiles so
+// that neighbouring rays (which share texels) hit the same L2.  Bijective for any nwg.
+__device__ __forceinline__ int xcd_remap(int b, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7;
+  const int xcd = b & 7, idx = b >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+// packed MLP parameter offsets (see include/bts_render.h)
+struct MlpLayout {
+  int d_in, hd, nb;
+  __host__ __device__ int w_in() const { return 0; }
+  __host__ __device__ int b_in() const { return hd * d_in; }
+  __host__ __device__ int blk(int i) const { return hd * d_in + hd + i * (2 * hd * hd + 2 * hd); }
+  __host__ __device__ int blk_w0(int i) const { return blk(i); }
+  __host__ __device__ int blk_b0(int i) const { return blk(i) + hd * hd; }
+  __host__ __device__ int blk_w1(int i) const { return blk(i) + hd * hd + hd; }
+  __host__ __device__ int blk_b1(int i) const { return blk(i) + 2 * hd * hd + hd; }
+  __host__ __device__ int w_out() const { return blk(nb); }
+  __host__ __device__ int b_out() const { return blk(nb) + hd; }
+  __host__ __device__ int total() const { return blk(nb) + hd + 1; }
+};
+
+}  // namespace bts

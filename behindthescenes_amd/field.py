@@ -1,0 +1,144 @@
+"""``BTSNet`` -- the density field, with the reference's constructor keys, attributes, ``encode`` / ``forward`` protocol and
+state-dict layout (models/bts/model/models_bts.py:17-338), but whose per-point work (projection, bilinear feature fetch,
+positional encoding, MLP, softplus, colour fetch) is done by the fused HIP kernels in libbts_render.so.
+
+What stays PyTorch-ROCm: the CNN encoder call inside ``encode`` and the 4x4 pose inverse.  ``encode`` additionally hands
+the feature map / colour frames over to the renderer's HBM layouts (channels-last F, rgb0-packed frames) with the HIP
+layout kernels; under autograd the F hand-over is differentiable (its backward is the inverse transpose), so gradients of
+the renderer reach the CNN exactly as they do in the reference."""
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import native
+from .backbone import make_backbone
+from .code import PositionalEncoding
+from .mlp import make_mlp
+
+EPS = 1e-3
+
+
+class BTSNet(nn.Module):
+    def __init__(self, conf):
+        super().__init__()
+        self.d_min = conf.get("z_near")
+        self.d_max = conf.get("z_far")
+        self.learn_empty = conf.get("learn_empty", True)
+        self.empty_empty = conf.get("empty_empty", False)
+        self.inv_z = conf.get("inv_z", True)
+        self.color_interpolation = conf.get("color_interpolation", "bilinear")
+        self.code_mode = conf.get("code_mode", "z")
+        if self.code_mode not in ["z", "distance"]:
+            raise NotImplementedError(f"Unknown mode for positional encoding: {self.code_mode}")
+        if self.color_interpolation != "bilinear":
+            raise NotImplementedError("only bilinear colour interpolation (the default of every config) is implemented")
+
+        self.encoder = make_backbone(conf["encoder"])
+        self.code_xyz = PositionalEncoding.from_conf(conf["code"], d_in=3)
+        self.flip_augmentation = conf.get("flip_augmentation", False)
+        self.return_sample_depth = conf.get("return_sample_depth", False)
+        self.sample_color = conf.get("sample_color", True)
+        if not self.sample_color or self.return_sample_depth:
+            raise NotImplementedError("sample_color=False / return_sample_depth are not used by any shipped config")
+
+        d_in = self.encoder.latent_size + self.code_xyz.d_out
+        self._d_in, self._d_out = d_in, 1
+        self.mlp_coarse = make_mlp(conf["mlp_coarse"], d_in, d_out=1)
+        self.mlp_fine = make_mlp(conf["mlp_fine"], d_in, d_out=1, allow_empty=True)
+        if self.mlp_fine is not None:
+            raise NotImplementedError("a separate fine MLP is not used by any shipped config (mlp_fine.type: empty)")
+        if self.learn_empty:
+            self.empty_feature = nn.Parameter(torch.randn((self.encoder.latent_size,), requires_grad=True))
+        self._scale = 0
+        self._native = {}   # scale -> native.FieldTensors
+        self.spec = native.FieldSpec(C=self.encoder.latent_size, d_hidden=self.mlp_coarse.d_hidden,
+                                     n_blocks=self.mlp_coarse.n_blocks, num_freqs=self.code_xyz.num_freqs,
+                                     freq_factor=self.code_xyz.freq_factor, d_min=float(self.d_min), d_max=float(self.d_max),
+                                     inv_z=bool(self.inv_z), code_mode=self.code_mode, learn_empty=bool(self.learn_empty),
+                                     empty_empty=bool(self.empty_empty))
+        if not self.code_xyz.include_input:
+            raise NotImplementedError("include_input=False is not used by any shipped config")
+
+    # ---- reference protocol -------------------------------------------------------------------------------------
+    def set_scale(self, scale):
+        self._scale = scale
+
+    def get_scale(self):
+        return self._scale
+
+    def compute_grid_transforms(self, *args, **kwargs):
+        pass
+
+    def encode(self, images, Ks, poses_c2w, ids_encoder=None, ids_render=None, images_alt=None, combine_ids=None):
+        """images (n,v,3,H,W) in [-1,1]; Ks (n,v,3,3) normalised intrinsics; poses_c2w (n,v,4,4)  (models_bts.py:65-136)."""
+        if combine_ids is not None:
+            raise NotImplementedError("combine_ids (waymo multi-encoder-view mode) is not part of the HIP render path")
+        poses_w2c = torch.inverse(poses_c2w)
+        if ids_encoder is None:
+            ids_encoder = list(range(images.shape[1]))
+        images_encoder, Ks_encoder, poses_w2c_encoder = images[:, ids_encoder], Ks[:, ids_encoder], poses_w2c[:, ids_encoder]
+        colours = images_alt if images_alt is not None else None
+        if ids_render is None:
+            ids_render = list(range(images.shape[1]))
+        n, nv_enc, c, h, w = images_encoder.shape
+        if nv_enc != 1:
+            raise NotImplementedError("the HIP render path takes exactly one encoder view (ids_encoder=[0] in every shipped mode)")
+        c_l = self.encoder.latent_size
+
+        do_flip = bool(self.flip_augmentation and self.training and (torch.rand(1) > .5).item())
+        if do_flip:
+            images_encoder = torch.flip(images_encoder, dims=(-1,))
+        image_latents_ms = self.encoder(images_encoder.reshape(n * nv_enc, c, h, w))
+        if do_flip:
+            image_latents_ms = [torch.flip(il, dims=(-1,)) for il in image_latents_ms]
+        _, _, h_, w_ = image_latents_ms[0].shape
+        image_latents_ms = [(il if il.shape[-2:] == (h_, w_) else F.interpolate(il, (h_, w_))).view(n, nv_enc, c_l, h_, w_)
+                            for il in image_latents_ms]
+
+        self.grid_f_features = image_latents_ms
+        self.grid_f_Ks = Ks_encoder
+        self.grid_f_poses_w2c = poses_w2c_encoder
+        self.grid_f_combine = None
+        # colours: (x*.5+.5) fused into the rgb0 packing kernel unless the caller supplies processed frames
+        src = (colours if colours is not None else images)[:, ids_render]
+        self.grid_c_imgs = src if colours is not None else src * .5 + .5
+        self.grid_c_Ks = Ks[:, ids_render]
+        self.grid_c_poses_w2c = poses_w2c[:, ids_render]
+        self.grid_c_combine = None
+
+        # ---- hand-over into the renderer's HBM layouts
+        self._native = {}
+        nv = self.grid_c_imgs.shape[1]
+        native.check_supported(self.spec, nv)
+        if nv:
+            self._imgs_nhwc4 = native.pack_rgb(self.grid_c_imgs.detach().float().contiguous())
+            self._K_r = self.grid_c_Ks.detach().float().contiguous()
+            self._w2c_r = self.grid_c_poses_w2c.detach().float().contiguous()
+        else:
+            self._imgs_nhwc4 = self._K_r = self._w2c_r = None
+        self._K_enc = Ks_encoder[:, 0].detach().float().contiguous()
+        self._w2c_enc = poses_w2c_encoder[:, 0].detach().float().contiguous()
+
+    def native_field(self) -> "native.FieldTensors":
+        """Field state of the current scale in the C-ABI layouts (built lazily per scale, cached until the next encode)."""
+        s = self._scale
+        if s not in self._native:
+            f = self.grid_f_features[s][:, 0]                      # (n, C, H, W)
+            feat_nhwc = native.NhwcFunction.apply(f.float())       # differentiable layout change
+            self._native[s] = native.FieldTensors(self.spec, feat_nhwc, self._K_enc, self._w2c_enc, self._imgs_nhwc4, self._K_r,
+                                                  self._w2c_r, self.empty_feature if self.learn_empty else None)
+        return self._native[s]
+
+    def forward(self, xyz, coarse=True, viewdirs=None, far=False, only_density=False):
+        """xyz (n, P, 3) world points -> rgb (n,P,nv*3), invalid (n,P,nv) float, sigma (n,P,1)  (models_bts.py:266-338).
+        Forward-only (the reference's callers of this entry point -- occupancy profiles, LiDAR / 3D-bbox evaluators -- run it
+        under no_grad); training goes through the renderer's composite, which is differentiable."""
+        ft = self.native_field()
+        with torch.no_grad():
+            rgb, invalid, sigma = native.field_query(ft, self.mlp_coarse.packed().detach(), xyz.detach().float().contiguous(),
+                                                     only_density=only_density)
+        nv = self.grid_c_imgs.shape[1]
+        if only_density:
+            rgb = torch.zeros((xyz.shape[0], xyz.shape[1], nv * 3), device=sigma.device)
+            invalid = invalid.unsqueeze(1)   # the reference returns (n, nv_enc=1, P, 1) here (models_bts.py:337)
+        return rgb, invalid, sigma

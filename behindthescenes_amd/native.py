@@ -1,0 +1,305 @@
+"""Tensor-level access to the HIP renderer: validates torch tensors (device, dtype, contiguity, shape), hands raw
+device pointers + the current HIP stream to the C ABI (include/bts_render.h) and wraps the forward/backward pair in a
+``torch.autograd.Function``.  PyTorch is plumbing here (memory, streams, autograd bookkeeping); every computation of
+the render path happens in libbts_render.so and nothing in this module falls back to torch ops."""
+from dataclasses import dataclass
+from typing import Optional
+
+import ctypes as C
+import torch
+
+from . import _lib
+from ._lib import BtsFieldCfg, BtsFieldTensors, BtsNativeError, BtsRenderArgs, BtsRenderGrads
+
+
+@dataclass(frozen=True)
+class FieldSpec:
+    """Static shape/config of the field (mirrors BtsFieldCfg minus n/H/W/nv, which come from the tensors)."""
+    C: int
+    d_hidden: int
+    n_blocks: int
+    num_freqs: int = 6
+    freq_factor: float = 1.5
+    d_min: float = 3.0
+    d_max: float = 80.0
+    inv_z: bool = True
+    code_mode: str = "z"
+    learn_empty: bool = False
+    empty_empty: bool = False
+
+    @property
+    def d_in(self):
+        return self.C + 3 + 6 * self.num_freqs
+
+    def mlp_param_count(self):
+        hd = self.d_hidden
+        return hd * self.d_in + hd + self.n_blocks * (2 * hd * hd + 2 * hd) + hd + 1
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream(t: torch.Tensor):
+    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _req(t: torch.Tensor, name: str, shape=None):
+    if not isinstance(t, torch.Tensor):
+        raise BtsNativeError(f"{name}: expected a tensor")
+    if not t.is_cuda:
+        raise BtsNativeError(f"{name}: must live on the GPU (got {t.device}); the HIP renderer has no CPU path")
+    if t.dtype != torch.float32:
+        raise BtsNativeError(f"{name}: must be float32 (got {t.dtype})")
+    if not t.is_contiguous():
+        raise BtsNativeError(f"{name}: must be contiguous")
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise BtsNativeError(f"{name}: expected shape {tuple(shape)}, got {tuple(t.shape)}")
+    return t
+
+
+# --------------------------------------------------------------------------------------------------------------
+# layout / edge kernels
+# --------------------------------------------------------------------------------------------------------------
+def nchw_to_nhwc(x: torch.Tensor) -> torch.Tensor:
+    """(N, C, H, W) -> (N, H, W, C) copy (bts_nchw_to_nhwc)."""
+    _req(x, "x")
+    N, Cc, H, W = x.shape
+    out = torch.empty((N, H, W, Cc), device=x.device, dtype=torch.float32)
+    _lib.check(_lib.load().bts_nchw_to_nhwc(_ptr(x), _ptr(out), N, Cc, H, W, _stream(x)), "bts_nchw_to_nhwc")
+    return out
+
+
+def nhwc_to_nchw(x: torch.Tensor) -> torch.Tensor:
+    _req(x, "x")
+    N, H, W, Cc = x.shape
+    out = torch.empty((N, Cc, H, W), device=x.device, dtype=torch.float32)
+    _lib.check(_lib.load().bts_nhwc_to_nchw(_ptr(x), _ptr(out), N, Cc, H, W, _stream(x)), "bts_nhwc_to_nchw")
+    return out
+
+
+def pack_rgb(images: torch.Tensor, scale: float = 1.0, shift: float = 0.0) -> torch.Tensor:
+    """(..., 3, H, W) -> (..., H, W, 4) rgb0 with x*scale+shift (bts_pack_rgb)."""
+    _req(images, "images")
+    lead, (c, H, W) = images.shape[:-3], images.shape[-3:]
+    if c != 3:
+        raise BtsNativeError(f"images: expected 3 channels, got {c}")
+    N = 1
+    for d in lead:
+        N *= d
+    out = torch.empty(tuple(lead) + (H, W, 4), device=images.device, dtype=torch.float32)
+    _lib.check(_lib.load().bts_pack_rgb(_ptr(images), _ptr(out), N, H, W, scale, shift, _stream(images)), "bts_pack_rgb")
+    return out
+
+
+def gen_rays(poses_c2w: torch.Tensor, projs: torch.Tensor, H: int, W: int, z_near: float, z_far: float,
+             norm_dir: bool = True) -> torch.Tensor:
+    """poses (V,4,4), projs (V,3,3) -> rays (V,H,W,8) (bts_gen_rays)."""
+    V = poses_c2w.shape[0]
+    _req(poses_c2w, "poses_c2w", (V, 4, 4)), _req(projs, "projs", (V, 3, 3))
+    out = torch.empty((V, H, W, 8), device=poses_c2w.device, dtype=torch.float32)
+    _lib.check(_lib.load().bts_gen_rays(_ptr(poses_c2w), _ptr(projs), V, H, W, z_near, z_far, int(norm_dir), _ptr(out),
+                                        _stream(out)), "bts_gen_rays")
+    return out
+
+
+def sample_coarse(rays: torch.Tensor, u: torch.Tensor, lindisp: bool) -> torch.Tensor:
+    """rays (B,8), u (B,K) uniform jitter -> z_samp (B,K) (bts_sample_coarse)."""
+    B, K = u.shape
+    _req(rays, "rays", (B, 8)), _req(u, "u")
+    out = torch.empty_like(u)
+    _lib.check(_lib.load().bts_sample_coarse(_ptr(rays), _ptr(u), B, K, int(lindisp), _ptr(out), _stream(out)),
+               "bts_sample_coarse")
+    return out
+
+
+def distance_to_z(depths: torch.Tensor, projs: torch.Tensor) -> torch.Tensor:
+    """depths (n,nv,H,W), projs (n,nv,3,3) -> z (n,nv,H,W) (bts_distance_to_z).  The 3x3 inverse stays in torch."""
+    n, nv, H, W = depths.shape
+    _req(depths, "depths")
+    inv_K = torch.inverse(projs).reshape(n * nv, 3, 3).contiguous()
+    _req(inv_K, "inv_K", (n * nv, 3, 3))
+    out = torch.empty_like(depths)
+    _lib.check(_lib.load().bts_distance_to_z(_ptr(depths), _ptr(inv_K), n * nv, H, W, _ptr(out), _stream(out)),
+               "bts_distance_to_z")
+    return out
+
+
+# --------------------------------------------------------------------------------------------------------------
+# field state handed to the renderer
+# --------------------------------------------------------------------------------------------------------------
+class FieldTensors:
+    """Device tensors in the layouts of include/bts_render.h.  ``feat_nhwc`` may require grad (it is produced by
+    ``nchw_to_nhwc`` of the encoder output inside autograd, see NhwcFunction)."""
+
+    def __init__(self, spec: FieldSpec, feat_nhwc, K_enc, w2c_enc, imgs_nhwc4, K_r, w2c_r, empty_feature=None):
+        n, H, W, Cc = feat_nhwc.shape
+        if Cc != spec.C:
+            raise BtsNativeError(f"feat_nhwc has {Cc} channels, spec says {spec.C}")
+        nv = 0 if imgs_nhwc4 is None else imgs_nhwc4.shape[1]
+        _req(feat_nhwc.detach(), "feat_nhwc"), _req(K_enc, "K_enc", (n, 3, 3)), _req(w2c_enc, "w2c_enc", (n, 4, 4))
+        if nv:
+            _req(imgs_nhwc4, "imgs_nhwc4", (n, nv, H, W, 4)), _req(K_r, "K_r", (n, nv, 3, 3)), _req(w2c_r, "w2c_r", (n, nv, 4, 4))
+        if nv > _lib.BTS_MAX_VIEWS:
+            raise BtsNativeError(f"nv={nv} render views exceed BTS_MAX_VIEWS={_lib.BTS_MAX_VIEWS}")
+        if spec.learn_empty:
+            if empty_feature is None:
+                raise BtsNativeError("learn_empty needs empty_feature")
+            _req(empty_feature.detach(), "empty_feature", (spec.C,))
+        self.spec, self.n, self.H, self.W, self.nv = spec, n, H, W, nv
+        self.feat_nhwc, self.K_enc, self.w2c_enc = feat_nhwc, K_enc, w2c_enc
+        self.imgs_nhwc4, self.K_r, self.w2c_r = imgs_nhwc4, K_r, w2c_r
+        self.empty_feature = empty_feature
+
+    def cfg(self, nv=None) -> BtsFieldCfg:
+        s = self.spec
+        return BtsFieldCfg(n=self.n, H=self.H, W=self.W, C=s.C, d_hidden=s.d_hidden, n_blocks=s.n_blocks,
+                           nv=self.nv if nv is None else nv, num_freqs=s.num_freqs,
+                           code_mode={"z": 0, "distance": 1}[s.code_mode], inv_z=int(s.inv_z), learn_empty=int(s.learn_empty),
+                           empty_empty=int(s.empty_empty), freq_factor=s.freq_factor, d_min=s.d_min, d_max=s.d_max)
+
+    def tensors(self, mlp_params: torch.Tensor) -> BtsFieldTensors:
+        return BtsFieldTensors(feat_nhwc=self.feat_nhwc.data_ptr(), K_enc=self.K_enc.data_ptr(), w2c_enc=self.w2c_enc.data_ptr(),
+                               imgs_nhwc4=None if self.imgs_nhwc4 is None else self.imgs_nhwc4.data_ptr(),
+                               K_r=None if self.K_r is None else self.K_r.data_ptr(),
+                               w2c_r=None if self.w2c_r is None else self.w2c_r.data_ptr(),
+                               empty_feature=None if self.empty_feature is None else self.empty_feature.data_ptr(),
+                               mlp_params=mlp_params.data_ptr())
+
+
+def check_supported(spec: FieldSpec, nv: int = 1):
+    cfg = BtsFieldCfg(n=1, H=1, W=1, C=spec.C, d_hidden=spec.d_hidden, n_blocks=spec.n_blocks, nv=nv, num_freqs=spec.num_freqs)
+    if not _lib.load().bts_supported(C.byref(cfg)):
+        raise BtsNativeError(f"field shape outside the compiled envelope: C={spec.C} d_hidden={spec.d_hidden} "
+                             f"n_blocks={spec.n_blocks} num_freqs={spec.num_freqs} nv={nv}")
+
+
+# --------------------------------------------------------------------------------------------------------------
+# render forward / backward
+# --------------------------------------------------------------------------------------------------------------
+def _render_args(ft: FieldTensors, rays, z_samp, hard_alpha_cap, white_bkgd, outs):
+    return BtsRenderArgs(rays_per_sample=rays.shape[0] // ft.n, K=z_samp.shape[1], hard_alpha_cap=int(hard_alpha_cap),
+                         white_bkgd=int(white_bkgd), rays=rays.data_ptr(), z_samp=z_samp.data_ptr(),
+                         **{k: (None if v is None else v.data_ptr()) for k, v in outs.items()})
+
+
+def render_fwd(ft: FieldTensors, mlp_params: torch.Tensor, rays: torch.Tensor, z_samp: torch.Tensor, *, hard_alpha_cap: bool,
+               white_bkgd: bool = False, want_weights=False, want_alphas=False, want_invalid=True, want_rgb_samps=False,
+               want_sigma_raw=False):
+    """rays (n*Bp, 8), z_samp (n*Bp, K) -> dict of fresh tensors (bts_render_fwd)."""
+    B, K = z_samp.shape
+    _req(rays, "rays", (B, 8)), _req(z_samp, "z_samp"), _req(mlp_params.detach(), "mlp_params", (ft.spec.mlp_param_count(),))
+    if B % ft.n != 0:
+        raise BtsNativeError(f"{B} rays do not split evenly over n={ft.n} samples")
+    dev, nv = rays.device, ft.nv
+
+    def new(*shape):
+        return torch.empty(shape, device=dev, dtype=torch.float32)
+
+    outs = dict(rgb=new(B, nv * 3), depth=new(B), weights=new(B, K) if want_weights else None,
+                alphas=new(B, K) if want_alphas else None, invalid=new(B, K, nv) if want_invalid else None,
+                rgb_samps=new(B, K, nv * 3) if want_rgb_samps else None, sigma_raw=new(B, K) if want_sigma_raw else None)
+    cfg, tens = ft.cfg(), ft.tensors(mlp_params)
+    args = _render_args(ft, rays, z_samp, hard_alpha_cap, white_bkgd, outs)
+    _lib.check(_lib.load().bts_render_fwd(C.byref(cfg), C.byref(tens), C.byref(args), _stream(rays)), "bts_render_fwd")
+    return outs
+
+
+def render_bwd(ft: FieldTensors, mlp_params, rays, z_samp, sigma_raw, *, hard_alpha_cap, white_bkgd=False, g_rgb=None,
+               g_depth=None, g_weights=None, g_alphas=None, need_feat=True, need_mlp=True, need_empty=False):
+    """Returns (d_feat_nhwc | None, d_mlp_params | None, d_empty_feature | None) (bts_render_bwd)."""
+    B, K = z_samp.shape
+    for name, g in (("g_rgb", g_rgb), ("g_depth", g_depth), ("g_weights", g_weights), ("g_alphas", g_alphas)):
+        if g is not None:
+            _req(g, name)
+    _req(sigma_raw, "sigma_raw", (B, K))
+    dev = rays.device
+    d_feat = torch.zeros_like(ft.feat_nhwc, requires_grad=False) if need_feat else None
+    d_mlp = torch.zeros(ft.spec.mlp_param_count(), device=dev, dtype=torch.float32) if need_mlp else None
+    d_empty = torch.zeros(ft.spec.C, device=dev, dtype=torch.float32) if need_empty else None
+    cfg, tens = ft.cfg(), ft.tensors(mlp_params)
+    outs = dict(rgb=None, depth=None, weights=None, alphas=None, invalid=None, rgb_samps=None, sigma_raw=sigma_raw)
+    args = _render_args(ft, rays, z_samp, hard_alpha_cap, white_bkgd, outs)
+    grads = BtsRenderGrads(g_rgb=None if g_rgb is None else g_rgb.data_ptr(), g_depth=None if g_depth is None else g_depth.data_ptr(),
+                           g_weights=None if g_weights is None else g_weights.data_ptr(),
+                           g_alphas=None if g_alphas is None else g_alphas.data_ptr(),
+                           d_feat_nhwc=None if d_feat is None else d_feat.data_ptr(),
+                           d_mlp_params=None if d_mlp is None else d_mlp.data_ptr(),
+                           d_empty_feature=None if d_empty is None else d_empty.data_ptr())
+    lib = _lib.load()
+    ws_bytes = lib.bts_render_bwd_workspace(C.byref(cfg), C.byref(args))
+    ws = torch.empty(max(int(ws_bytes), 4) // 4 + 1, device=dev, dtype=torch.float32)
+    _lib.check(lib.bts_render_bwd(C.byref(cfg), C.byref(tens), C.byref(args), C.byref(grads), _ptr(ws), ws_bytes, _stream(rays)),
+               "bts_render_bwd")
+    return d_feat, d_mlp, d_empty
+
+
+def field_query(ft: FieldTensors, mlp_params: torch.Tensor, xyz: torch.Tensor, only_density: bool = False):
+    """xyz (n, P, 3) -> rgb (n,P,nv*3) | None, invalid (n,P,nv or 1), sigma (n,P,1)  (bts_field_query)."""
+    n, P, _ = xyz.shape
+    _req(xyz, "xyz", (ft.n, P, 3))
+    dev = xyz.device
+    nv = 0 if only_density else ft.nv
+    rgb = torch.empty((n, P, nv * 3), device=dev, dtype=torch.float32) if nv else None
+    invalid = torch.empty((n, P, max(nv, 1)), device=dev, dtype=torch.float32)
+    sigma = torch.empty((n, P, 1), device=dev, dtype=torch.float32)
+    if nv == 0 and not only_density:  # no colour views: invalid is the feature-frustum test only
+        only_density = True
+    cfg, tens = ft.cfg(), ft.tensors(mlp_params)
+    _lib.check(_lib.load().bts_field_query(C.byref(cfg), C.byref(tens), _ptr(xyz), P, int(only_density), _ptr(rgb), _ptr(invalid),
+                                           _ptr(sigma), _stream(xyz)), "bts_field_query")
+    return rgb, invalid, sigma
+
+
+# --------------------------------------------------------------------------------------------------------------
+# autograd glue
+# --------------------------------------------------------------------------------------------------------------
+class NhwcFunction(torch.autograd.Function):
+    """F (N,C,H,W) -> (N,H,W,C) with the inverse transpose as backward, both through the HIP layout kernels."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return nchw_to_nhwc(x.contiguous())
+
+    @staticmethod
+    def backward(ctx, g):
+        return nhwc_to_nchw(g.contiguous())
+
+
+class RenderFunction(torch.autograd.Function):
+    """composite() as one differentiable op.  Differentiable inputs: feat_nhwc, mlp_params, empty_feature.
+    Differentiable outputs: rgb, depth, weights, alphas (invalid / rgb_samps carry no gradient, as in the reference where
+    they only depend on poses and colours)."""
+
+    @staticmethod
+    def forward(ctx, feat_nhwc, mlp_params, empty_feature, ft: FieldTensors, rays, z_samp, hard_alpha_cap, white_bkgd,
+                want_weights, want_alphas, want_rgb_samps):
+        needs_grad = any(ctx.needs_input_grad[:3])
+        out = render_fwd(ft, mlp_params, rays, z_samp, hard_alpha_cap=hard_alpha_cap, white_bkgd=white_bkgd,
+                         want_weights=want_weights, want_alphas=want_alphas, want_invalid=True, want_rgb_samps=want_rgb_samps,
+                         want_sigma_raw=needs_grad)
+        ctx.ft, ctx.hard_alpha_cap, ctx.white_bkgd = ft, hard_alpha_cap, white_bkgd
+        if needs_grad:
+            ctx.save_for_backward(mlp_params, rays, z_samp, out["sigma_raw"])
+        empty = rays.new_empty(0)
+        res = (out["rgb"], out["depth"], out["weights"] if want_weights else empty, out["alphas"] if want_alphas else empty,
+               out["invalid"], out["rgb_samps"] if want_rgb_samps else empty)
+        ctx.mark_non_differentiable(res[4], res[5])
+        ctx.has = (want_weights, want_alphas)
+        return res
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_depth, g_weights, g_alphas, _g_inv, _g_rs):
+        mlp_params, rays, z_samp, sigma_raw = ctx.saved_tensors
+        if ctx.white_bkgd:
+            raise BtsNativeError("backward with white_bkgd is not supported (no shipped config trains with it)")
+
+        def prep(g, present=True):
+            return g.contiguous() if (g is not None and present and g.numel() > 0) else None
+
+        need_feat, need_mlp, need_empty = ctx.needs_input_grad[:3]
+        d_feat, d_mlp, d_empty = render_bwd(ctx.ft, mlp_params, rays, z_samp, sigma_raw, hard_alpha_cap=ctx.hard_alpha_cap,
+                                            g_rgb=prep(g_rgb), g_depth=prep(g_depth), g_weights=prep(g_weights, ctx.has[0]),
+                                            g_alphas=prep(g_alphas, ctx.has[1]), need_feat=need_feat, need_mlp=need_mlp,
+                                            need_empty=need_empty)
+        return (d_feat, d_mlp, d_empty) + (None,) * 8

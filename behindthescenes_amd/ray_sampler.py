@@ -1,0 +1,140 @@
+"""Ray samplers with the reference's constructors and ``sample`` / ``reconstruct`` contracts
+(models/bts/model/ray_sampler.py:7-321).  Ray generation (gen_rays + unproj_map, models/common/util/util.py:113-149,
+244-273) runs in the HIP kernel ``bts_gen_rays`` -- one launch for all n*v frames instead of a Python loop over n; the
+random patch / pixel choice keeps torch's CPU generator semantics of the reference (``torch.randint`` on the CPU)."""
+import torch
+
+from . import native
+
+
+def gen_rays(poses, width, height, z_near, z_far, focal=None, c=None, norm_dir=True, projs=None):
+    """(V, H, W, 8) rays for poses (V,4,4); intrinsics either as ``projs`` (V,3,3) or focal (V,2) + c (V,2)."""
+    V = poses.shape[0]
+    if projs is None:
+        projs = torch.zeros((V, 3, 3), device=poses.device, dtype=torch.float32)
+        projs[:, 0, 0], projs[:, 1, 1] = focal[:, 0], focal[:, 1]
+        projs[:, 0, 2], projs[:, 1, 2] = c[:, 0], c[:, 1]
+        projs[:, 2, 2] = 1.0
+    return native.gen_rays(poses.float().contiguous(), projs.float().contiguous(), height, width, float(z_near), float(z_far),
+                           norm_dir)
+
+
+def _all_rays(poses, projs, h, w, z_near, z_far, norm_dir=True):
+    n, v = poses.shape[:2]
+    rays = native.gen_rays(poses.reshape(n * v, 4, 4).float().contiguous(), projs.reshape(n * v, 3, 3).float().contiguous(),
+                           h, w, float(z_near), float(z_far), norm_dir)
+    return rays.view(n, v, h, w, 8)
+
+
+class RaySampler:
+    def sample(self, images, poses, projs):
+        raise NotImplementedError
+
+    def reconstruct(self, render_dict):
+        raise NotImplementedError
+
+    @staticmethod
+    def _reshape_all(render_dict, lead, channels, rgb_gt_shape=None):
+        """Shared body of the three reconstruct() variants: view every per-ray tensor as lead + (...)."""
+        for key in ("coarse", "fine"):
+            part = render_dict[key]
+            n = part["rgb"].shape[0]
+            v = part["rgb"].shape[-1] // channels
+            K = part["weights"].shape[-1]
+            part["rgb"] = part["rgb"].view(n, *lead, v, channels)
+            part["weights"] = part["weights"].view(n, *lead, K)
+            part["depth"] = part["depth"].view(n, *lead)
+            part["invalid"] = part["invalid"].view(n, *lead, K, v)
+            if "alphas" in part:
+                part["alphas"] = part["alphas"].view(n, *lead, K)
+            if "z_samps" in part:
+                part["z_samps"] = part["z_samps"].view(n, *lead, K)
+            if "rgb_samps" in part:
+                part["rgb_samps"] = part["rgb_samps"].view(n, *lead, K, v, channels)
+            render_dict[key] = part
+        if "rgb_gt" in render_dict and render_dict["rgb_gt"] is not None:
+            g = render_dict["rgb_gt"]
+            render_dict["rgb_gt"] = g.view(g.shape[0], *lead, channels)
+        return render_dict
+
+
+class RandomRaySampler(RaySampler):
+    def __init__(self, ray_batch_size, z_near, z_far, channels=3):
+        self.ray_batch_size, self.z_near, self.z_far, self.channels = ray_batch_size, z_near, z_far, channels
+
+    def sample(self, images, poses, projs):
+        n, v, c, h, w = images.shape
+        rays = _all_rays(poses, projs, h, w, self.z_near, self.z_far).view(n, -1, 8)
+        gt = images.permute(0, 1, 3, 4, 2).reshape(n, -1, self.channels)
+        idx = torch.stack([torch.randint(0, v * h * w, (self.ray_batch_size,)) for _ in range(n)]).to(rays.device)
+        return (torch.gather(rays, 1, idx.unsqueeze(-1).expand(-1, -1, 8)),
+                torch.gather(gt, 1, idx.unsqueeze(-1).expand(-1, -1, self.channels)))
+
+    def reconstruct(self, render_dict, channels=None):
+        channels = self.channels if channels is None else channels
+        return self._reshape_all(render_dict, (render_dict["coarse"]["rgb"].shape[1],), channels)
+
+
+class PatchRaySampler(RaySampler):
+    def __init__(self, ray_batch_size, z_near, z_far, patch_size, channels=3):
+        self.ray_batch_size, self.z_near, self.z_far = ray_batch_size, z_near, z_far
+        if isinstance(patch_size, int):
+            self.patch_size_x, self.patch_size_y = patch_size, patch_size
+        elif hasattr(patch_size, "__len__") and len(patch_size) == 2:
+            self.patch_size_y, self.patch_size_x = patch_size[0], patch_size[1]
+        else:
+            raise ValueError("Invalid format for patch size")
+        self.channels = channels
+        assert (ray_batch_size % (self.patch_size_x * self.patch_size_y)) == 0
+        self._patch_count = self.ray_batch_size // (self.patch_size_x * self.patch_size_y)
+
+    def draw_patches(self, n, v, h, w):
+        """The reference's CPU RNG draws, in its order (ray_sampler.py:141-143): per sample v, y, x vectors."""
+        pv, py, px = [], [], []
+        for _ in range(n):
+            pv.append(torch.randint(0, v, (self._patch_count,)))
+            py.append(torch.randint(0, h - self.patch_size_y, (self._patch_count,)))
+            px.append(torch.randint(0, w - self.patch_size_x, (self._patch_count,)))
+        return torch.stack(pv), torch.stack(py), torch.stack(px)
+
+    def sample(self, images, poses, projs, patches=None):
+        n, v, c, h, w = images.shape
+        dev = images.device
+        rays = _all_rays(poses, projs, h, w, self.z_near, self.z_far)               # (n, v, h, w, 8)
+        pv, py, px = self.draw_patches(n, v, h, w) if patches is None else patches
+        pv, py, px = pv.to(dev), py.to(dev), px.to(dev)
+        oy = torch.arange(self.patch_size_y, device=dev).view(1, 1, -1, 1)
+        ox = torch.arange(self.patch_size_x, device=dev).view(1, 1, 1, -1)
+        yy = (py.view(n, -1, 1, 1) + oy).expand(-1, -1, -1, self.patch_size_x)     # (n, pc, ph, pw)
+        xx = (px.view(n, -1, 1, 1) + ox).expand(-1, -1, self.patch_size_y, -1)
+        flat = ((pv.view(n, -1, 1, 1) * h + yy) * w + xx).reshape(n, -1)           # index into (v*h*w)
+        all_rays = torch.gather(rays.view(n, -1, 8), 1, flat.unsqueeze(-1).expand(-1, -1, 8))
+        gt = images.permute(0, 1, 3, 4, 2).reshape(n, -1, c)
+        all_rgb_gt = torch.gather(gt, 1, flat.unsqueeze(-1).expand(-1, -1, c))
+        return all_rays, all_rgb_gt
+
+    def reconstruct(self, render_dict, channels=None):
+        channels = self.channels if channels is None else channels
+        return self._reshape_all(render_dict, (self._patch_count, self.patch_size_y, self.patch_size_x), channels)
+
+
+class ImageRaySampler(RaySampler):
+    def __init__(self, z_near, z_far, height=None, width=None, channels=3, norm_dir=True):
+        self.z_near, self.z_far, self.height, self.width = z_near, z_far, height, width
+        self.channels, self.norm_dir = channels, norm_dir
+
+    def sample(self, images, poses, projs):
+        n, v = poses.shape[:2]
+        if self.height is None:
+            self.height, self.width = images.shape[-2:]
+        all_rays = _all_rays(poses, projs, self.height, self.width, self.z_near, self.z_far, self.norm_dir).view(n, -1, 8)
+        all_rgb_gt = None
+        if images is not None:
+            all_rgb_gt = images.reshape(n, -1, self.channels, self.height, self.width).permute(0, 1, 3, 4, 2).reshape(n, -1, self.channels)
+        return all_rays, all_rgb_gt
+
+    def reconstruct(self, render_dict, channels=None):
+        channels = self.channels if channels is None else channels
+        n_pts = render_dict["coarse"]["rgb"].shape[1]
+        v_in = n_pts // (self.height * self.width)
+        return self._reshape_all(render_dict, (v_in, self.height, self.width), channels)

@@ -1,0 +1,197 @@
+"""``NeRFRenderer`` / ``_RenderWrapper`` with the reference's constructor, buffers, call signature and output dict
+(models/common/render/nerf.py:12-457).  ``composite`` -- the hot loop of the reference (chunked field queries + ~80 small
+kernels per chunk) -- is ONE fused HIP kernel here (plus its backward); there is no chunking and no torch fallback: a model
+that is not a ``behindthescenes_amd.BTSNet`` is rejected."""
+import torch
+
+from . import native
+from .field import BTSNet
+
+
+class _RenderWrapper(torch.nn.Module):
+    def __init__(self, net, renderer, simple_output):
+        super().__init__()
+        self.net = net
+        self.renderer = renderer
+        self.simple_output = simple_output
+
+    def forward(self, rays, want_weights=False, want_alphas=False, want_z_samps=False, want_rgb_samps=False,
+                sample_from_dist=None):
+        if rays.shape[0] == 0:
+            return torch.zeros(0, 3, device=rays.device), torch.zeros(0, device=rays.device)
+        outputs = self.renderer(self.net, rays, want_weights=want_weights and not self.simple_output,
+                                want_alphas=want_alphas and not self.simple_output,
+                                want_z_samps=want_z_samps and not self.simple_output,
+                                want_rgb_samps=want_rgb_samps and not self.simple_output, sample_from_dist=sample_from_dist)
+        if self.simple_output:
+            part = outputs["fine"] if self.renderer.using_fine else outputs["coarse"]
+            return part["rgb"], part["depth"]
+        return outputs
+
+
+class NeRFRenderer(torch.nn.Module):
+    def __init__(self, n_coarse=128, n_fine=0, n_fine_depth=0, noise_std=0.0, depth_std=0.01, eval_batch_size=100000,
+                 white_bkgd=False, lindisp=False, sched=None, hard_alpha_cap=False):
+        super().__init__()
+        self.n_coarse, self.n_fine, self.n_fine_depth = n_coarse, n_fine, n_fine_depth
+        self.noise_std, self.depth_std = noise_std, depth_std
+        self.eval_batch_size = eval_batch_size      # kept for config compatibility; the fused kernel never chunks
+        self.white_bkgd, self.lindisp = white_bkgd, lindisp
+        self.using_fine = n_fine > 0
+        self.sched = sched if sched is not None and len(sched) > 0 else None
+        self.register_buffer("iter_idx", torch.tensor(0, dtype=torch.long), persistent=True)
+        self.register_buffer("last_sched", torch.tensor(0, dtype=torch.long), persistent=True)
+        self.hard_alpha_cap = hard_alpha_cap
+        if noise_std > 0.0:
+            raise NotImplementedError("sigma noise (noise_std > 0) is disabled in every shipped config and is not implemented")
+
+    # ---- sampling (nerf.py:103-208) ---------------------------------------------------------------------------------
+    def sample_coarse(self, rays, u=None):
+        """rays (B, 8) -> z (B, Kc).  The jitter ``u`` ~ U[0,1) (B, Kc) is drawn with torch's generator on the rays' device
+        when not given (the reference jitters even in eval, nerf.py:116)."""
+        B = rays.shape[0]
+        if u is None:
+            u = torch.rand((B, self.n_coarse), device=rays.device, dtype=torch.float32)
+        return native.sample_coarse(rays.float().contiguous(), u.contiguous(), self.lindisp)
+
+    def sample_coarse_from_dist(self, rays, weights, z_samp):
+        B = rays.shape[0]
+        num_samples = self.n_coarse
+        weights = weights.detach() + 1e-5
+        pdf = weights / torch.sum(weights, -1, keepdim=True)
+        cdf = torch.cat([torch.zeros_like(pdf[:, :1]), torch.cumsum(pdf, -1)], -1)
+        u = torch.rand(B, num_samples, dtype=torch.float32, device=rays.device)
+        ids = torch.clamp(torch.searchsorted(cdf, u, right=True) - 1, 0, num_samples - 1)
+        interp = torch.rand_like(ids, dtype=torch.float32)
+        if self.lindisp:
+            z_samp = 1 / z_samp
+        centers = .5 * (z_samp[:, 1:] + z_samp[:, :-1])
+        borders = torch.cat((z_samp[:, :1], centers, z_samp[:, -1:]), dim=-1)
+        left, right = torch.gather(borders, -1, ids), torch.gather(borders, -1, ids + 1)
+        z_new = left * (1 - interp) + right * interp
+        if self.lindisp:
+            z_new = 1 / z_new
+        assert not torch.any(torch.isnan(z_new))
+        return z_new
+
+    def sample_fine(self, rays, weights):
+        B = rays.shape[0]
+        weights = weights.detach() + 1e-5
+        pdf = weights / torch.sum(weights, -1, keepdim=True)
+        cdf = torch.cat([torch.zeros_like(pdf[:, :1]), torch.cumsum(pdf, -1)], -1)
+        u = torch.rand(B, self.n_fine - self.n_fine_depth, dtype=torch.float32, device=rays.device)
+        inds = torch.clamp_min(torch.searchsorted(cdf, u, right=True).float() - 1.0, 0.0)
+        z_steps = (inds + torch.rand_like(inds)) / self.n_coarse
+        near, far = rays[:, -2:-1], rays[:, -1:]
+        if not self.lindisp:
+            z = near * (1 - z_steps) + far * z_steps
+        else:
+            z = 1 / (1 / near * (1 - z_steps) + 1 / far * z_steps)
+        assert not torch.any(torch.isnan(z))
+        return z
+
+    def sample_fine_depth(self, rays, depth):
+        z = depth.unsqueeze(1).repeat((1, self.n_fine_depth))
+        z = z + torch.randn_like(z) * self.depth_std
+        z = torch.max(torch.min(z, rays[:, -1:]), rays[:, -2:-1])
+        assert not torch.any(torch.isnan(z))
+        return z
+
+    # ---- the hot path (nerf.py:210-313) -------------------------------------------------------------------------------
+    def composite(self, model, rays, z_samp, coarse=True, sb=0, want_weights=True, want_alphas=True, want_rgb_samps=True):
+        """rays (B, 8), z_samp (B, K) -> (weights, rgb, depth, alphas, invalid, z_samp, rgb_samps) like the reference.
+        Entries that were not requested come back as ``None`` (the reference always materialises all of them)."""
+        if not isinstance(model, BTSNet):
+            raise native.BtsNativeError("composite() needs a behindthescenes_amd.BTSNet (the fused HIP kernel IS the field query)")
+        if not coarse and model.mlp_fine is not None:
+            raise NotImplementedError("separate fine MLP")
+        ft = model.native_field()
+        n = ft.n
+        if sb > 0 and sb != n:
+            raise native.BtsNativeError(f"super-batch {sb} does not match the encoded batch {n}")
+        if sb <= 0 and n != 1:
+            raise native.BtsNativeError("sb=0 (no super-batch) is only meaningful for an encoded batch of 1")
+        rays = rays.float().contiguous()
+        z_samp = z_samp.float().contiguous()
+        mlp_params = model.mlp_coarse.packed()
+        empty = model.empty_feature if model.learn_empty else None
+        rgb, depth, weights, alphas, invalid, rgb_samps = native.RenderFunction.apply(
+            ft.feat_nhwc, mlp_params, empty, ft, rays, z_samp, bool(self.hard_alpha_cap), bool(self.white_bkgd),
+            bool(want_weights), bool(want_alphas), bool(want_rgb_samps))
+        return (weights if want_weights else None, rgb, depth, alphas if want_alphas else None, invalid, z_samp,
+                rgb_samps if want_rgb_samps else None)
+
+    def forward(self, model, rays, want_weights=False, want_alphas=False, want_z_samps=False, want_rgb_samps=False,
+                sample_from_dist=None):
+        """rays (SB, B', 8) -> {"coarse": {...}[, "fine": {...}]} (nerf.py:315-401)."""
+        if self.sched is not None and self.last_sched.item() > 0:
+            self.n_coarse = self.sched[1][self.last_sched.item() - 1]
+            self.n_fine = self.sched[2][self.last_sched.item() - 1]
+        assert len(rays.shape) == 3
+        sb = rays.shape[0]
+        rays = rays.reshape(-1, 8)
+        if sample_from_dist is None:
+            z_coarse = self.sample_coarse(rays)
+        else:
+            prop_weights, prop_z = sample_from_dist
+            ns = prop_weights.shape[-1]
+            z_coarse = self.sample_coarse_from_dist(rays, prop_weights.reshape(-1, ns), prop_z.reshape(-1, ns))
+            z_coarse, _ = torch.sort(z_coarse, dim=-1)
+        need_w = want_weights or self.using_fine
+        comp = self.composite(model, rays, z_coarse, coarse=True, sb=sb, want_weights=need_w, want_alphas=want_alphas,
+                              want_rgb_samps=want_rgb_samps)
+        outputs = dict(coarse=self._format_outputs(comp, sb, want_weights, want_alphas, want_z_samps, want_rgb_samps))
+        if self.using_fine:
+            all_samps = [z_coarse]
+            if self.n_fine - self.n_fine_depth > 0:
+                all_samps.append(self.sample_fine(rays, comp[0].detach()))
+            if self.n_fine_depth > 0:
+                all_samps.append(self.sample_fine_depth(rays, comp[2]))
+            z_comb, _ = torch.sort(torch.cat(all_samps, dim=-1), dim=-1)
+            fine = self.composite(model, rays, z_comb, coarse=False, sb=sb, want_weights=want_weights, want_alphas=want_alphas,
+                                  want_rgb_samps=want_rgb_samps)
+            outputs["fine"] = self._format_outputs(fine, sb, want_weights, want_alphas, want_z_samps, want_rgb_samps)
+        return outputs
+
+    def _format_outputs(self, rendered, sb, want_weights=False, want_alphas=False, want_z_samps=False, want_rgb_samps=False):
+        weights, rgb, depth, alphas, invalid, z_samps, rgb_samps = rendered
+        K = z_samps.shape[-1]
+        if sb > 0:
+            rgb = rgb.reshape(sb, -1, rgb.shape[-1])
+            depth = depth.reshape(sb, -1)
+            invalid = invalid.reshape(sb, -1, K, invalid.shape[-1])
+        ret = dict(rgb=rgb, depth=depth, invalid=invalid)
+        if want_weights:
+            ret["weights"] = weights.reshape(sb, -1, K) if sb > 0 else weights
+        if want_alphas:
+            ret["alphas"] = alphas.reshape(sb, -1, K) if sb > 0 else alphas
+        if want_z_samps:
+            ret["z_samps"] = z_samps.reshape(sb, -1, K) if sb > 0 else z_samps
+        if want_rgb_samps:
+            ret["rgb_samps"] = rgb_samps.reshape(sb, -1, K, rgb_samps.shape[-1]) if sb > 0 else rgb_samps
+        return ret
+
+    def sched_step(self, steps=1):
+        if self.sched is None:
+            return
+        self.iter_idx += steps
+        while self.last_sched.item() < len(self.sched[0]) and self.iter_idx.item() >= self.sched[0][self.last_sched.item()]:
+            self.n_coarse = self.sched[1][self.last_sched.item()]
+            self.n_fine = self.sched[2][self.last_sched.item()]
+            self.using_fine = self.n_fine > 0
+            self.last_sched += 1
+
+    @classmethod
+    def from_conf(cls, conf, white_bkgd=False, eval_batch_size=100000):
+        return cls(conf.get("n_coarse", 128), conf.get("n_fine", 0), n_fine_depth=conf.get("n_fine_depth", 0),
+                   noise_std=conf.get("noise_std", 0.0), depth_std=conf.get("depth_std", 0.01),
+                   white_bkgd=conf.get("white_bkgd", white_bkgd), lindisp=conf.get("lindisp", True),
+                   eval_batch_size=conf.get("eval_batch_size", eval_batch_size), sched=conf.get("sched", None),
+                   hard_alpha_cap=conf.get("hard_alpha_cap", False))
+
+    def bind_parallel(self, net, gpus=None, simple_output=False):
+        """Same contract as nerf.py:440-457.  Multi-GPU is one process per GPU (DDP over RCCL); the reference's dead
+        ``torch.nn.DataParallel`` hook is deliberately not reproduced."""
+        if gpus is not None and len(gpus) > 1:
+            raise NotImplementedError("use one process per GPU (torch.distributed / DDP over RCCL) instead of DataParallel")
+        return _RenderWrapper(net, self, simple_output=simple_output)

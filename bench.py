@@ -1,0 +1,175 @@
+"""bench.py -- rendered rays/sec of the fused HIP renderer on BASELINE.json's configs[1]:
+KITTI eval_depth forward pass, bs=1, 192x640 frames, 64 samples/ray, both stereo views' rays rendered from the single
+encoder view (245 760 rays, 15.7 M field queries per step), fp32.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One step = what the reference's evaluator does per frame after the CNN (models/bts/evaluator.py:60-79): hand the feature
+map / frames over to the renderer (`encode` without a CNN: layout kernels only), draw the stratified jitter, render all
+rays (`renderer(all_rays, want_weights=True, want_alphas=True)`), `reconstruct`, `distance_to_z`.  Inputs are synthetic and
+resident in HBM before the timed region.  N > 1: every rank renders its own frame (frames are independent -> weak scaling,
+no collective on the data path); value = total rays of all ranks / max-over-ranks time.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (field_kernel = bts_render_fwd), timed live with HIP
+events on the launch stream; `cpu_baseline` times the CPU oracle port on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOP_PER_POINT = 2 * (103 * 64 + 64)          # 13 312 FLOP per field query (KITTI MLP)
+PEAK_FP32_MATRIX_TFLOPS = 157.3               # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / fp32 vector peak
+H, W, K, C, HD, V = 192, 640, 64, 64, 64, 2
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-rows", type=int, default=24, help="image rows of view 0 rendered by the CPU oracle sample")
+    return ap.parse_args()
+
+
+def cpu_baseline(scene, mlp, cfg, rows):
+    """The oracle ("port" of the reference algorithm, same torch CPU ops) on a bounded sample: `rows` full image rows of
+    both views (rows*640*2 rays, K=64), best of 2 after one warm-up."""
+    from oracle import bts_oracle as O
+    rays = O.image_rays(scene["poses"], scene["projs"], H, W, cfg.d_min, cfg.d_max).view(1, V, H, W, 8)
+    r0 = (H - rows) // 2
+    rays = rays[:, :, r0:r0 + rows].reshape(1, -1, 8).contiguous()
+    g = torch.Generator().manual_seed(1)
+    u = torch.rand(rays.shape[1], K, generator=g)
+    st = O.make_state(scene, [0], cfg)
+    best = float("inf")
+    with torch.no_grad():
+        for i in range(3):
+            t0 = time.perf_counter()
+            z = O.sample_coarse(rays.reshape(-1, 8), K, True, u)
+            O.composite(rays.reshape(-1, 8), z, 1, st, mlp, cfg, hard_alpha_cap=True)
+            dt = time.perf_counter() - t0
+            if i > 0:
+                best = min(best, dt)
+    n_rays = rays.shape[1]
+    return dict(value=n_rays / best, unit="rays/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"{rows} rows x {W} px x {V} views = {n_rays} rays x {K} samples, renderer only, best of 2")
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+
+    import behindthescenes_amd as bts
+    from behindthescenes_amd import _lib
+    from oracle import bts_oracle as O          # synthetic input generator + cpu_baseline leg only
+    from tests._hip_helpers import make_conf, load_mlp
+
+    _lib.load()
+    cfg = O.FieldConfig()                       # z in [3, 80], inv_z, code_mode z (eval_depth.yaml)
+    scene = O.synthetic_scene(1, V, H, W, C, seed=1000 + rank, intrinsics=O.K_KITTIRAW)
+    g = torch.Generator().manual_seed(7)
+    mlp = O.init_mlp(C + 39, HD, 0, gen=g)
+    net = bts.BTSNet(make_conf(cfg, C, HD, 0, H, W))
+    load_mlp(net, mlp)
+    with torch.no_grad():
+        net.encoder.feats[0].data = scene["feat"].clone()
+    net = net.to(dev).eval()
+    wrapped = bts.NeRFRenderer.from_conf(dict(n_coarse=K, lindisp=True, hard_alpha_cap=True)).bind_parallel(net).eval().to(dev)
+    sampler = bts.ImageRaySampler(cfg.d_min, cfg.d_max)
+    images, projs, poses = scene["images"].to(dev), scene["projs"].to(dev), scene["poses"].to(dev)
+    n_rays = V * H * W
+
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    kernel_events = []
+
+    # time the dominant kernel alone: wrap the C-ABI forward launch with events on the launch stream
+    from behindthescenes_amd import native
+    orig_render_fwd = native.render_fwd
+
+    def timed_render_fwd(*a, **kw):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = orig_render_fwd(*a, **kw)
+        e1.record()
+        kernel_events.append((e0, e1))
+        return out
+
+    def step():
+        with torch.no_grad():
+            net.encode(images, projs, poses, ids_encoder=[0], ids_render=[0])
+            all_rays, all_rgb_gt = sampler.sample(images * .5 + .5, poses, projs)
+            rd = wrapped(all_rays, want_weights=True, want_alphas=True)
+            rd["fine"] = dict(rd["coarse"])
+            rd["rgb_gt"] = all_rgb_gt
+            rd = sampler.reconstruct(rd)
+            depth_z = bts.distance_to_z(rd["coarse"]["depth"], projs)
+        return depth_z
+
+    for _ in range(args.warmup):
+        step()
+    native.render_fwd = timed_render_fwd
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+        torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ev[i][0].record()
+        step()
+        ev[i][1].record()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+        torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    native.render_fwd = orig_render_fwd
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = t.item()
+
+    kernel_ms = sum(a.elapsed_time(b) for a, b in kernel_events) / max(len(kernel_events), 1)
+    step_ms = elapsed * 1e3 / args.steps
+    value = world * n_rays * args.steps / elapsed
+    if rank == 0:
+        flop_per_launch = n_rays * K * FLOP_PER_POINT
+        achieved = flop_per_launch / (kernel_ms * 1e-3) / 1e12
+        out = {
+            "metric": "rendered rays/sec (192x640x64 samples)", "value": value, "unit": "rays/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": step_ms, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "KITTI eval_depth.yaml forward, bs=1/GPU, 192x640, 2 views x 122880 rays, 64 samples/ray, "
+                                   "nv=1, want_weights+alphas, renderer only (feature-map encoder stand-in)",
+                       "rays_per_step_per_gpu": n_rays, "samples_per_ray": K, "parallelism": f"frames x{world}"},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_FP32_MATRIX_TFLOPS, "traffic": None, "kernel": "bts::field_kernel<64,64,0,1>",
+                         "kernel_ms": kernel_ms, "algorithmic_flop_per_launch": flop_per_launch},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(scene, mlp, cfg, args.cpu_rows)
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

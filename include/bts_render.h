@@ -1,0 +1,149 @@
+/*
+ * bts_render.h -- C ABI of the MI355X-native BehindTheScenes density-field renderer (libbts_render.so).
+ *
+ * The reference (Brummi/BehindTheScenes @ 2024_10_08) is pure Python/PyTorch and has no FFI of its own; its seam for
+ * this path is a Python object protocol.  The entry points below are what a binding for that seam
+ * needs and nothing more; each one names the reference function(s) it replaces.  Plain pointers and sizes only: no torch
+ * types, no allocation inside, no exceptions -- every function returns 0 on success or a negative BTS_E_* code and
+ * leaves a message retrievable with bts_last_error().  All pointers are DEVICE pointers to fp32 data unless noted; all
+ * work is enqueued on the caller's HIP stream (`stream` is a hipStream_t passed as void*; NULL = default stream) and the
+ * functions are re-entrant (autograd may call the backward from another thread).
+ *
+ * Data layout in HBM:
+ *   feat_nhwc   (n, H, W, C)        channels-last copy of the encoder's feature map F  -> one 4*C-byte row per texel
+ *   imgs_nhwc4  (n, nv, H, W, 4)    rgb0-packed colour frames in [0,1]                 -> one 16-byte load per tap
+ *   rays        (n*Bp, 8)           [origin(3), direction(3), near, far]   (reference layout, util.py:270-273)
+ *   z_samp      (n*Bp, K)           sample depths per ray                  (reference layout, nerf.py:210-218)
+ *   mlp_params  packed fp32: w_in (Hd x d_in, row-major = nn.Linear.weight), b_in (Hd),
+ *               n_blocks x [fc_0.weight (Hd x Hd), fc_0.bias (Hd), fc_1.weight (Hd x Hd), fc_1.bias (Hd)],
+ *               w_out (Hd), b_out (1);  d_in = C + 3 + 6*num_freqs.
+ */
+#ifndef BTS_RENDER_H
+#define BTS_RENDER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BTS_ABI_VERSION 1
+
+enum {
+  BTS_OK = 0,
+  BTS_E_INVALID = -1,     /* NULL pointer / non-positive size / inconsistent arguments */
+  BTS_E_UNSUPPORTED = -2, /* configuration outside the compiled envelope (see bts_supported) */
+  BTS_E_LAUNCH = -3,      /* HIP runtime reported an error at launch */
+  BTS_E_WORKSPACE = -4    /* workspace too small (see bts_render_bwd_workspace) */
+};
+
+/* Scalar configuration of the field: BTSNet.__init__ (models/bts/model/models_bts.py:18-54),
+ * PositionalEncoding (models/common/model/code.py:11-28), ResnetFC shape (models/common/model/resnetfc.py:65-130). */
+typedef struct BtsFieldCfg {
+  int32_t n;           /* batch ("super-batch") size */
+  int32_t H, W;        /* feature-map and colour-frame size */
+  int32_t C;           /* feature channels (encoder.latent_size) */
+  int32_t d_hidden;    /* MLP hidden width */
+  int32_t n_blocks;    /* number of ResnetBlockFC */
+  int32_t nv;          /* number of render (colour) views, 0..BTS_MAX_VIEWS */
+  int32_t num_freqs;   /* PE octaves (6 in every shipped config) */
+  int32_t code_mode;   /* 0 = "z", 1 = "distance"  (models_bts.py:157-171) */
+  int32_t inv_z;       /* 1 = inverse-depth normalisation */
+  int32_t learn_empty; /* 1 = replace features of out-of-frustum points by empty_feature (models_bts.py:176-182) */
+  int32_t empty_empty; /* 1 = sigma := 0 for out-of-frustum points (models_bts.py:323-324) */
+  float freq_factor;   /* PE base frequency (1.5) */
+  float d_min, d_max;  /* z_near, z_far of the field */
+} BtsFieldCfg;
+
+#define BTS_MAX_VIEWS 8
+
+/* State left behind by BTSNet.encode (models_bts.py:128-136), in the layouts above. */
+typedef struct BtsFieldTensors {
+  const float* feat_nhwc;     /* (n, H, W, C) */
+  const float* K_enc;         /* (n, 3, 3)   normalised intrinsics of the encoder view */
+  const float* w2c_enc;       /* (n, 4, 4)   world -> encoder camera */
+  const float* imgs_nhwc4;    /* (n, nv, H, W, 4), may be NULL iff nv == 0 */
+  const float* K_r;           /* (n, nv, 3, 3) */
+  const float* w2c_r;         /* (n, nv, 4, 4) */
+  const float* empty_feature; /* (C) or NULL */
+  const float* mlp_params;    /* packed, see above */
+} BtsFieldTensors;
+
+/* One call of NeRFRenderer.composite (models/common/render/nerf.py:210-313) on n*Bp rays. */
+typedef struct BtsRenderArgs {
+  int32_t rays_per_sample; /* Bp */
+  int32_t K;               /* samples per ray */
+  int32_t hard_alpha_cap;  /* nerf.py:285-286 */
+  int32_t white_bkgd;      /* nerf.py:301-304 */
+  const float* rays;       /* (n*Bp, 8) */
+  const float* z_samp;     /* (n*Bp, K) */
+  /* outputs; the per-sample ones may be NULL when not wanted */
+  float* rgb;              /* (n*Bp, nv*3) */
+  float* depth;            /* (n*Bp) */
+  float* weights;          /* (n*Bp, K)        or NULL */
+  float* alphas;           /* (n*Bp, K)        or NULL */
+  float* invalid;          /* (n*Bp, K, nv)    or NULL   1.0 = sample outside a frustum */
+  float* rgb_samps;        /* (n*Bp, K, nv*3)  or NULL */
+  float* sigma_raw;        /* (n*Bp, K)        or NULL   pre-softplus MLP output, the only activation the backward keeps */
+} BtsRenderArgs;
+
+/* Gradients flowing into / out of the renderer (what torch.autograd would compute through nerf.py:283-299,
+ * models_bts.py:266-338 and resnetfc.py:132-184).  No gradient is produced for rays, z_samp, poses or colours. */
+typedef struct BtsRenderGrads {
+  const float* g_rgb;      /* (n*Bp, nv*3) or NULL */
+  const float* g_depth;    /* (n*Bp)       or NULL */
+  const float* g_weights;  /* (n*Bp, K)    or NULL */
+  const float* g_alphas;   /* (n*Bp, K)    or NULL */
+  float* d_feat_nhwc;      /* (n, H, W, C)  ACCUMULATED into (caller zero-fills), or NULL to skip */
+  float* d_mlp_params;     /* packed like mlp_params, ACCUMULATED into (caller zero-fills), or NULL to skip */
+  float* d_empty_feature;  /* (C) accumulated, or NULL */
+} BtsRenderGrads;
+
+int bts_abi_version(void);
+const char* bts_last_error(void);
+
+/* 1 if (C, d_hidden, n_blocks, nv, num_freqs) is inside the compiled envelope, else 0. */
+int bts_supported(const BtsFieldCfg* cfg);
+/* number of floats in mlp_params for cfg */
+int64_t bts_mlp_param_count(const BtsFieldCfg* cfg);
+
+/* Fused sample -> project -> bilinear(F) -> PE -> MLP -> softplus -> colour taps -> alpha-composite.
+ * Replaces NeRFRenderer.composite + BTSNet.forward + sample_features + sample_colors + ResnetFC.forward +
+ * PositionalEncoding.forward (nerf.py:210-313, models_bts.py:138-338, resnetfc.py:132-184, code.py:30-42). */
+int bts_render_fwd(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const BtsRenderArgs* a, void* stream);
+
+/* Backward of bts_render_fwd.  `a` must carry sigma_raw written by the forward (weights/alphas are not needed).
+ * workspace: bts_render_bwd_workspace(cfg, a) bytes of device scratch. */
+size_t bts_render_bwd_workspace(const BtsFieldCfg* cfg, const BtsRenderArgs* a);
+int bts_render_bwd(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const BtsRenderArgs* a, const BtsRenderGrads* g,
+                   void* workspace, size_t workspace_bytes, void* stream);
+
+/* BTSNet.forward on raw points (models_bts.py:266-338): xyz (n, P, 3) -> rgb (n, P, nv*3), invalid (n, P, max(nv,1)),
+ * sigma (n, P).  only_density != 0 skips the colour taps: rgb may be NULL and invalid is (n, P, 1). */
+int bts_field_query(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const float* xyz, int32_t P, int32_t only_density,
+                    float* rgb, float* invalid, float* sigma, void* stream);
+
+/* Layout changes at the hand-off from the (PyTorch) encoder: F (N, C, H, W) <-> (N, H, W, C); frames (N, 3, H, W) ->
+ * (N, H, W, 4) with `scale`*x + `shift` applied (encode's x*0.5+0.5, models_bts.py:82). */
+int bts_nchw_to_nhwc(const float* src, float* dst, int32_t N, int32_t C, int32_t H, int32_t W, void* stream);
+int bts_nhwc_to_nchw(const float* src, float* dst, int32_t N, int32_t C, int32_t H, int32_t W, void* stream);
+int bts_pack_rgb(const float* src_nchw, float* dst_nhwc4, int32_t N, int32_t H, int32_t W, float scale, float shift,
+                 void* stream);
+
+/* gen_rays (models/common/util/util.py:244-273 + unproj_map :113-149) for full images:
+ * poses_c2w (V, 4, 4), projs (V, 3, 3) -> rays (V, H, W, 8). */
+int bts_gen_rays(const float* poses_c2w, const float* projs, int32_t V, int32_t H, int32_t W, float z_near, float z_far,
+                 int32_t norm_dir, float* rays, void* stream);
+
+/* NeRFRenderer.sample_coarse (nerf.py:103-123) with the uniform jitter u (B, K) in [0,1) supplied by the caller. */
+int bts_sample_coarse(const float* rays, const float* u, int64_t B, int32_t K, int32_t lindisp, float* z_samp,
+                      void* stream);
+
+/* distance_to_z (utils/projection_operations.py:4-16): depths (N, H, W), inv_K (N, 3, 3) = inverse(projs) -> z (N, H, W) */
+int bts_distance_to_z(const float* depths, const float* inv_K, int32_t N, int32_t H, int32_t W, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BTS_RENDER_H */
