@@ -25,19 +25,19 @@ class BtsFieldCfg(C.Structure):
 
 
 class BtsFieldTensors(C.Structure):
-    _fields_ = [(k, C.c_void_p) for k in ("feat_nhwc", "K_enc", "w2c_enc", "imgs_nhwc4", "K_r", "w2c_r", "empty_feature",
-                                          "mlp_params")]
+    _fields_ = [(k, C.c_void_p) for k in ("feat_nhwc", "proj_nhwc", "K_enc", "w2c_enc", "imgs_nhwc4", "K_r", "w2c_r",
+                                          "empty_feature", "mlp_params")]
 
 
 class BtsRenderArgs(C.Structure):
     _fields_ = [(k, C.c_int32) for k in ("rays_per_sample", "K", "hard_alpha_cap", "white_bkgd")] + \
                [(k, C.c_void_p) for k in ("rays", "z_samp", "rgb", "depth", "weights", "alphas", "invalid", "rgb_samps",
-                                          "sigma_raw")]
+                                          "sigma_raw", "trans")]
 
 
 class BtsRenderGrads(C.Structure):
-    _fields_ = [(k, C.c_void_p) for k in ("g_rgb", "g_depth", "g_weights", "g_alphas", "d_feat_nhwc", "d_mlp_params",
-                                          "d_empty_feature")]
+    _fields_ = [(k, C.c_void_p) for k in ("g_rgb", "g_depth", "g_weights", "g_alphas", "d_proj_nhwc", "d_mlp_params",
+                                          "d_empty_proj")]
 
 
 # every symbol include/bts_render.h declares: name -> (restype, argtypes)
@@ -52,6 +52,8 @@ SYMBOLS = {
     "bts_render_bwd_workspace": (C.c_size_t, [C.POINTER(BtsFieldCfg), C.POINTER(BtsRenderArgs)]),
     "bts_render_bwd": (C.c_int, [C.POINTER(BtsFieldCfg), C.POINTER(BtsFieldTensors), C.POINTER(BtsRenderArgs),
                                  C.POINTER(BtsRenderGrads), _P, C.c_size_t, _P]),
+    "bts_project_features": (C.c_int, [C.POINTER(BtsFieldCfg), _P, _P, _I, _P, _P]),
+    "bts_project_features_bwd": (C.c_int, [C.POINTER(BtsFieldCfg), _P, _P, _P, _I, _P, _P, _P]),
     "bts_field_query": (C.c_int, [C.POINTER(BtsFieldCfg), C.POINTER(BtsFieldTensors), _P, _I, _I, _P, _P, _P, _P]),
     "bts_nchw_to_nhwc": (C.c_int, [_P, _P, _I, _I, _I, _I, _P]),
     "bts_nhwc_to_nchw": (C.c_int, [_P, _P, _I, _I, _I, _I, _P]),

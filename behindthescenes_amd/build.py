@@ -15,8 +15,8 @@ CSRC = os.path.join(PKG, "csrc")
 ROOT = os.path.dirname(PKG)
 LIB = os.path.join(PKG, "libbts_render.so")
 OBJ = os.path.join(PKG, "csrc", "_obj")
-SOURCES = ["bts_fwd.hip", "bts_bwd.hip", "bts_aux.hip", "bts_api.hip"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-fno-gpu-rdc"]
+SOURCES = ["bts_fwd.hip", "bts_fwd_proj.hip", "bts_bwd.hip", "bts_prep.hip", "bts_aux.hip", "bts_api.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-fno-gpu-rdc", "-munsafe-fp-atomics"]
 
 
 def _digest():

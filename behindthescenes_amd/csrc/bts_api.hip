@@ -18,6 +18,9 @@ int gen_rays_launch(const float* poses, const float* projs, int V, int H, int W,
 int sample_coarse_launch(const float* rays, const float* u, long B, int K, int lindisp, float* z, hipStream_t s);
 int distance_to_z_launch(const float* depths, const float* invK, int N, int H, int W, float* out, hipStream_t s);
 
+int project_features_impl(int C, int HD, const float* feat, const float* mlp, int N, int HW, float* proj, hipStream_t s);
+int project_features_bwd_impl(int C, int HD, const float* feat, const float* dproj, const float* mlp, int N, int HW, float* dfeat,
+                              float* d_mlp, hipStream_t s);
 int render_fwd_impl(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const BtsRenderArgs* a, hipStream_t s);
 int field_query_impl(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const float* xyz, int P, int only_density, float* rgb,
                      float* invalid, float* sigma, hipStream_t s);
@@ -42,7 +45,7 @@ static int check_cfg(const BtsFieldCfg* cfg, const BtsFieldTensors* t, bool need
               "bts", cfg->C, cfg->d_hidden, cfg->n_blocks);
     return BTS_E_UNSUPPORTED;
   }
-  if (!t->feat_nhwc || !t->K_enc || !t->w2c_enc || !t->mlp_params) {
+  if ((!t->feat_nhwc && !t->proj_nhwc) || !t->K_enc || !t->w2c_enc || !t->mlp_params) {
     set_error("%s: NULL field tensor", "bts");
     return BTS_E_INVALID;
   }
@@ -99,8 +102,8 @@ int bts_render_bwd(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const BtsRe
                    void* workspace, size_t workspace_bytes, void* stream) {
   int rc = check_cfg(cfg, t, true);
   if (rc) return rc;
-  if (!a || !g || !a->rays || !a->z_samp || !a->sigma_raw) {
-    set_error("%s: NULL argument (rays, z_samp and the forward's sigma_raw are required)", "bts_render_bwd");
+  if (!a || !g || !a->rays || !a->z_samp || !a->sigma_raw || !a->trans || !t->proj_nhwc) {
+    set_error("%s: NULL argument (rays, z_samp, the forward's sigma_raw + trans and proj_nhwc are required)", "bts_render_bwd");
     return BTS_E_INVALID;
   }
   if (a->rays_per_sample <= 0 || a->K <= 0) {
@@ -112,6 +115,39 @@ int bts_render_bwd(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const BtsRe
     return BTS_E_WORKSPACE;
   }
   return render_bwd_impl(cfg, t, a, g, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int bts_project_features(const BtsFieldCfg* cfg, const float* feat_nchw, const float* mlp_params, int32_t N, float* proj_nhwc,
+                         void* stream) {
+  if (!cfg || !feat_nchw || !mlp_params || !proj_nhwc || N <= 0 || cfg->H <= 0 || cfg->W <= 0) {
+    set_error("%s: NULL pointer or non-positive size", "bts_project_features");
+    return BTS_E_INVALID;
+  }
+  if (!bts_supported(cfg)) {
+    set_error("%s: configuration outside the compiled envelope (C=%ld d_hidden=%ld n_blocks=%ld)", "bts_project_features", cfg->C,
+              cfg->d_hidden, cfg->n_blocks);
+    return BTS_E_UNSUPPORTED;
+  }
+  int rc = project_features_impl(cfg->C, cfg->d_hidden, feat_nchw, mlp_params, N, cfg->H * cfg->W, proj_nhwc, (hipStream_t)stream);
+  if (rc) set_error("%s: kernel launch failed", "bts_project_features");
+  return rc;
+}
+
+int bts_project_features_bwd(const BtsFieldCfg* cfg, const float* feat_nchw, const float* d_proj_nhwc, const float* mlp_params,
+                             int32_t N, float* d_feat_nchw, float* d_mlp_params, void* stream) {
+  if (!cfg || !d_proj_nhwc || !mlp_params || N <= 0 || cfg->H <= 0 || cfg->W <= 0 || (d_mlp_params && !feat_nchw)) {
+    set_error("%s: NULL pointer or non-positive size", "bts_project_features_bwd");
+    return BTS_E_INVALID;
+  }
+  if (!bts_supported(cfg)) {
+    set_error("%s: configuration outside the compiled envelope (C=%ld d_hidden=%ld n_blocks=%ld)", "bts_project_features_bwd", cfg->C,
+              cfg->d_hidden, cfg->n_blocks);
+    return BTS_E_UNSUPPORTED;
+  }
+  int rc = project_features_bwd_impl(cfg->C, cfg->d_hidden, feat_nchw, d_proj_nhwc, mlp_params, N, cfg->H * cfg->W, d_feat_nchw,
+                                     d_mlp_params, (hipStream_t)stream);
+  if (rc) set_error("%s: kernel launch failed", "bts_project_features_bwd");
+  return rc;
 }
 
 int bts_field_query(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const float* xyz, int32_t P, int32_t only_density,

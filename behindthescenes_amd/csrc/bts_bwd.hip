@@ -1,10 +1,384 @@
-// Backward of the fused renderer (placeholder until the kernels land).
-#include "bts_common.h"
+// Backward of the fused renderer (projected-feature path) for gfx950.
+//
+// One lane = one ray, walked BACK TO FRONT so that the suffix sum the compositing gradient needs
+//     g_alpha_k = g_w_k * T_k - (sum_{m>k} g_w_m w_m) / (1 - alpha_k + 1e-10)
+// is a running register.  The forward saved two floats per sample (pre-softplus s_k and the transmittance T_k); everything else
+// is recomputed: projection, taps, PE, h = bilinear(G) + W_pe . pe (+ blocks) on MFMA exactly as in the forward.  Then per sample
+//     g_s   = g_alpha * |delta| * exp(-|delta| sigma) * sigmoid(s)
+//     g_h   = relu'(h) * w_out * g_s                                   (kept in the MFMA C layout: rows hidden, columns points)
+//     dG   += bilinear-weights * g_h     -> float atomics on the 4 taps (skipped for inactive hidden units)
+//     dW_pe+= g_h . pe^T                 -> MFMA with the contraction over the wave's 64 points; both operands are transposed
+//                                           through per-wave LDS tiles ([point][hidden], [point][pe input]); 4 persistent
+//                                           32x32 accumulator tiles per wave, flushed once per work-group
+//     dw_out += relu(h) g_s, db_out += g_s  -> per-lane partial sums, reduced across lanes once at the end.
+// The feature-map / w_in[:, :C] gradients follow from dG in bts_prep.hip (per-pixel GEMMs).
+//
+// What torch.autograd would do for nerf.py:283-299 + models_bts.py:266-338 + resnetfc.py:132-184 of the reference.
+#include "bts_field_kernel.h"
+
 namespace bts {
-void set_error(const char* fmt, const char* a = "", long b = 0, long c = 0, long d = 0);
+
+struct BwdParams {
+  FwdParams f;            // field + rays (+ sigma_raw, trans as inputs)
+  const float* g_rgb;     // (B, nv*3)
+  const float* g_depth;   // (B)
+  const float* g_weights; // (B, K)
+  const float* g_alphas;  // (B, K)
+  float* d_proj;          // (n,H,W,HD)
+  float* d_mlp;           // packed
+  float* d_empty_proj;    // (HD)
+};
+
+template <int HD, int NB>
+struct BwdLds {
+  static constexpr int PE_ROWS = kPeDim + 1;            // 40
+  static constexpr int LDG = HD + 1;                    // g_h tile leading dim  [64 points][HD] (+1: conflict-free column access)
+  static constexpr int LDX = PE_ROWS + 1;               // pe tile leading dim   [64 points][40]
+  static constexpr int W_PE = 0;                        // [40][HD] k-major (forward A operand)
+  static constexpr int W_OUT = W_PE + PE_ROWS * HD;     // [HD]
+  static constexpr int EMPTY = W_OUT + HD;              // [HD] projected empty feature
+  static constexpr int D_EMPTY = EMPTY + HD;            // [HD] gradient accumulator for it
+  static constexpr int D_WPE = D_EMPTY + HD;            // [40][HD] work-group accumulator for dW_pe (k-major like W_PE)
+  static constexpr int D_WOUT = D_WPE + PE_ROWS * HD;   // [HD] + 1 (db_out)
+  static constexpr int TILES = D_WOUT + HD + 1;         // per wave: g_h tile then pe tile
+  static constexpr int TILE_STRIDE = 64 * LDG + 64 * LDX;
+  static constexpr int TOTAL = TILES + 4 * TILE_STRIDE;
+};
+
+__device__ __forceinline__ void atomic_add_f32(float* p, float v) {
+  __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <int C, int HD, int NVMAX>
+__global__ __launch_bounds__(256, 1) void render_bwd_kernel(const BwdParams bp) {
+  constexpr int NB = 0;
+  constexpr int HT = HD / 32;
+  using L = BwdLds<HD, NB>;
+  constexpr int D_IN = C + kPeDim;
+  const FwdParams& p = bp.f;
+  extern __shared__ float lds[];
+  const MlpLayout ml{D_IN, HD, NB};
+
+  // ---- stage: PE rows of w_in (k-major), w_out, projected empty feature; zero the work-group gradient accumulators
+  for (int i = threadIdx.x; i < L::PE_ROWS * HD; i += blockDim.x) {
+    const int k = i / HD, hid = i % HD;
+    const int src = kernel_to_ref_input<C>(k + C);
+    lds[L::W_PE + i] = src >= 0 ? p.mlp[ml.w_in() + hid * D_IN + src] : p.mlp[ml.b_in() + hid];
+    lds[L::D_WPE + i] = 0.0f;
+  }
+  for (int hid = threadIdx.x; hid < HD; hid += blockDim.x) {
+    lds[L::W_OUT + hid] = p.mlp[ml.w_out() + hid];
+    float a = 0.0f;
+    if (p.empty_feature)
+      for (int c = 0; c < C; ++c) a = __builtin_fmaf(p.mlp[ml.w_in() + hid * D_IN + c], p.empty_feature[c], a);
+    lds[L::EMPTY + hid] = a;
+    lds[L::D_EMPTY + hid] = 0.0f;
+    lds[L::D_WOUT + hid] = 0.0f;
+  }
+  if (threadIdx.x == 0) lds[L::D_WOUT + HD] = 0.0f;
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int h = lane >> 5, col = lane & 31;
+  const int wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int sample = wg / p.tiles_per_sample;
+  const int tile = wg - sample * p.tiles_per_sample;
+  const int Bp = p.Bp, K = p.K;
+  const int r_raw = tile * 256 + wave * 64 + lane;
+  const bool active = r_raw < Bp;
+  const int r = active ? r_raw : Bp - 1;
+  const long ray = (long)sample * Bp + r;
+  const int lane_off = h * HD + col;
+  const int H = p.H, W = p.W, nv = p.nv;
+  float* gh_tile = lds + L::TILES + wave * L::TILE_STRIDE;  // [64][LDG]
+  float* pe_tile = gh_tile + 64 * L::LDG;                   // [64][LDX]
+
+  const Cam enc = load_cam(p.w2c_enc + sample * 16, p.K_enc + sample * 9);
+  const float4* __restrict__ G = reinterpret_cast<const float4*>(p.proj) + (long)sample * H * W * (HD / 4);
+  float* __restrict__ dG = bp.d_proj ? bp.d_proj + (long)sample * H * W * HD : nullptr;
+
+  const float4 r0 = reinterpret_cast<const float4*>(p.rays)[ray * 2];
+  const float4 r1 = reinterpret_cast<const float4*>(p.rays)[ray * 2 + 1];
+  const float ox = r0.x, oy = r0.y, oz = r0.z, dx = r0.w, dy = r1.x, dz = r1.y;
+  const float* zrow = p.z_samp + ray * K;
+  const float* srow = p.sigma_raw + ray * K;
+  const float* trow = p.trans + ray * K;
+
+  float g_rgb[NVMAX * 3];
+#pragma unroll
+  for (int i = 0; i < NVMAX * 3; ++i) g_rgb[i] = (bp.g_rgb && active && i < nv * 3) ? bp.g_rgb[ray * nv * 3 + i] : 0.0f;
+  const float g_depth = (bp.g_depth && active) ? bp.g_depth[ray] : 0.0f;
+
+  // persistent per-wave gradient state
+  f32x16 dwpe[HT][2];  // dW_pe^T tiles: rows hidden (ht), columns pe input (2 tiles of 32, 40 used)
+  float dw2[HT][16];   // per-lane partial of dw_out for the accumulator rows this lane holds
+#pragma unroll
+  for (int ht = 0; ht < HT; ++ht) {
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) dwpe[ht][kt][q] = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) dw2[ht][q] = 0.0f;
+  }
+  float db2 = 0.0f;
+  float S = 0.0f;  // sum_{m>k} g_w_m w_m
+  float z_after = 0.0f;
+
+  for (int k = K - 1; k >= 0; --k) {
+    const float z = zrow[k];
+    const float s_raw = srow[k];
+    const float T = trow[k];
+    const float px = ox + z * dx, py = oy + z * dy, pz = oz + z * dz;
+
+    // ---------------- colours of this sample -> g_w = sum_j g_rgb_j . c_kj + g_depth z_k (+ g_weights_k)
+    float g_w = g_depth * z;
+    if (bp.g_weights && active) g_w += bp.g_weights[ray * K + k];
+#pragma unroll
+    for (int j = 0; j < NVMAX; ++j) {
+      if (j < nv) {
+        const Cam cj = load_cam(p.w2c_r + ((long)sample * nv + j) * 16, p.K_r + ((long)sample * nv + j) * 9);
+        const Proj pc = project<false>(cj, px, py, pz);
+        const Taps tc = make_taps(pc.x, pc.y, H, W);
+        const float4* img = reinterpret_cast<const float4*>(p.imgs) + ((long)sample * nv + j) * H * W;
+        const float4 a = img[tc.o00], b = img[tc.o01], cc = img[tc.o10], d = img[tc.o11];
+        const float c0 = ((a.x * tc.w00 + b.x * tc.w01) + cc.x * tc.w10) + d.x * tc.w11;
+        const float c1 = ((a.y * tc.w00 + b.y * tc.w01) + cc.y * tc.w10) + d.y * tc.w11;
+        const float c2 = ((a.z * tc.w00 + b.z * tc.w01) + cc.z * tc.w10) + d.z * tc.w11;
+        g_w += g_rgb[3 * j] * c0 + g_rgb[3 * j + 1] * c1 + g_rgb[3 * j + 2] * c2;
+      }
+    }
+
+    // ---------------- encoder view
+    const Proj pe = p.code_mode == 1 ? project<true>(enc, px, py, pz) : project<false>(enc, px, py, pz);
+    const Taps tp = make_taps(pe.x, pe.y, H, W);
+    float v3[3];
+    v3[0] = pe.x, v3[1] = pe.y;
+    v3[2] = depth_code(p.code_mode == 1 ? pe.dist : pe.z, p.inv_z != 0, p.inv_dmax, p.inv_range, p.d_min, p.range);
+    const bool use_empty = (p.learn_empty != 0) & pe.invalid;
+
+    // ---------------- compositing gradient (nerf.py:283-299)
+    float sigma = softplus(s_raw);
+    const bool dead = (p.empty_empty != 0) & pe.invalid;  // sigma forced to 0: no gradient
+    if (dead) sigma = 0.0f;
+    const bool last = (k == K - 1);
+    const float delta = last ? 1e10f : (z_after - z);
+    const float ex = expf(-fabsf(delta) * fmaxf(sigma, 0.0f));
+    const bool capped = (p.hard_cap != 0) & last;
+    const float alpha = capped ? 1.0f : 1.0f - ex;
+    const float wgt = alpha * T;
+    float g_alpha = g_w * T - S / ((1.0f - alpha) + 1e-10f);
+    if (bp.g_alphas && active) g_alpha += bp.g_alphas[ray * K + k];
+    S = S + g_w * wgt;
+    z_after = z;
+    float g_s = 0.0f;
+    if (!capped && !dead && active) g_s = g_alpha * fabsf(delta) * ex * (s_raw > 20.0f ? 1.0f : sigmoidf(s_raw));
+
+    // ---------------- recompute h (forward, PROJ path)
+    f32x16 acc[HT][2];
+    int o[2][4];
+    float wq[2][4];
+    bool emp[2];
+    {
+      unsigned t0, t1;
+      bcast_tiles((unsigned)tp.o00, t0, t1), o[0][0] = (int)t0, o[1][0] = (int)t1;
+      bcast_tiles((unsigned)tp.o01, t0, t1), o[0][1] = (int)t0, o[1][1] = (int)t1;
+      bcast_tiles((unsigned)tp.o10, t0, t1), o[0][2] = (int)t0, o[1][2] = (int)t1;
+      bcast_tiles((unsigned)tp.o11, t0, t1), o[0][3] = (int)t0, o[1][3] = (int)t1;
+      bcast_tiles(__float_as_uint(tp.w00), t0, t1), wq[0][0] = __uint_as_float(t0), wq[1][0] = __uint_as_float(t1);
+      bcast_tiles(__float_as_uint(tp.w01), t0, t1), wq[0][1] = __uint_as_float(t0), wq[1][1] = __uint_as_float(t1);
+      bcast_tiles(__float_as_uint(tp.w10), t0, t1), wq[0][2] = __uint_as_float(t0), wq[1][2] = __uint_as_float(t1);
+      bcast_tiles(__float_as_uint(tp.w11), t0, t1), wq[0][3] = __uint_as_float(t0), wq[1][3] = __uint_as_float(t1);
+      bcast_tiles(use_empty ? 1u : 0u, t0, t1), emp[0] = t0 != 0, emp[1] = t1 != 0;
+      GBuf ga, gb;
+      gload<HD>(ga, G, o[0], h);
+      gather_seq<HD, 0>(acc, ga, gb, G, o, wq, emp, lds + L::EMPTY, h);
+    }
+    // PE inputs of this lane's point -> LDS tile row (for the dW_pe contraction) and through the MFMAs
+    float* my_pe = pe_tile + lane * L::LDX;
+    const float* wl = lds + L::W_PE + lane_off;
+    my_pe[0] = v3[0], my_pe[1] = v3[1], my_pe[2] = v3[2], my_pe[3] = 1.0f;
+    kstep<HD>(acc, wl, 0, v3[0], v3[1]);
+    kstep<HD>(acc, wl + 2 * HD, 0, v3[2], 1.0f);
+    wl += 4 * HD;
+    {
+      float sc[6], sn[6];
+      pe_octave(sc, v3, p.freq_factor);
+      float ff = p.freq_factor;
+#pragma unroll 1
+      for (int oct = 0; oct < kNumFreqs; ++oct) {
+        ff = ff * 2.0f;
+        if (oct + 1 < kNumFreqs) pe_octave(sn, v3, ff);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) my_pe[4 + 6 * oct + i] = sc[i];
+        kstep<HD>(acc, wl, 0, sc[0], sc[1]);
+        kstep<HD>(acc, wl + 2 * HD, 0, sc[2], sc[3]);
+        kstep<HD>(acc, wl + 4 * HD, 0, sc[4], sc[5]);
+        wl += 6 * HD;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) sc[i] = sn[i];
+      }
+    }
+
+    // ---------------- g_h in the C layout; dw_out / db_out partials; transposed copy for the dW_pe MFMA
+    float gs_t[2];
+    {
+      unsigned t0, t1;
+      bcast_tiles(__float_as_uint(g_s), t0, t1);
+      gs_t[0] = __uint_as_float(t0), gs_t[1] = __uint_as_float(t1);
+    }
+    db2 += g_s;
+#pragma unroll
+    for (int ht = 0; ht < HT; ++ht)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int hid = ht * 32 + mfma_row(q, 0) + 4 * h;
+        const float w2 = lds[L::W_OUT + hid];
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt) {
+          const float hv = acc[ht][pt][q];
+          dw2[ht][q] = __builtin_fmaf(fmaxf(hv, 0.0f), gs_t[pt], dw2[ht][q]);
+          const float gh = hv > 0.0f ? w2 * gs_t[pt] : 0.0f;
+          acc[ht][pt][q] = gh;                                  // acc now holds g_h
+          gh_tile[(pt * 32 + col) * L::LDG + hid] = gh;
+        }
+      }
+
+    // ---------------- dG += w_tap * g_h on the four taps (float atomics; inactive hidden units are skipped)
+    if (dG) {
+#pragma unroll
+      for (int pt = 0; pt < 2; ++pt) {
+#pragma unroll
+        for (int ht = 0; ht < HT; ++ht)
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            const float gh = acc[ht][pt][q];
+            const int hid = ht * 32 + mfma_row(q, 0) + 4 * h;
+            if (gh != 0.0f) {
+              if (emp[pt]) {
+                atomicAdd(&lds[L::D_EMPTY + hid], gh);
+              } else {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) atomic_add_f32(dG + (long)o[pt][t] * HD + hid, wq[pt][t] * gh);
+              }
+            }
+          }
+      }
+    }
+
+    // ---------------- dW_pe^T[hid][kin] += sum_points g_h[hid][p] * pe[p][kin]   (k-step s pairs points s and s + 32)
+    if (bp.d_mlp) {
+#pragma unroll 4
+      for (int s = 0; s < 32; ++s) {
+        const int pnt = s + 32 * h;
+        float a[HT], b[2];
+#pragma unroll
+        for (int ht = 0; ht < HT; ++ht) a[ht] = gh_tile[pnt * L::LDG + ht * 32 + col];
+        b[0] = pe_tile[pnt * L::LDX + col];
+        b[1] = col < L::PE_ROWS - 32 ? pe_tile[pnt * L::LDX + 32 + col] : 0.0f;
+#pragma unroll
+        for (int ht = 0; ht < HT; ++ht) {
+          dwpe[ht][0] = mfma(a[ht], b[0], dwpe[ht][0]);
+          dwpe[ht][1] = mfma(a[ht], b[1], dwpe[ht][1]);
+        }
+      }
+    }
+  }
+
+  // ---------------- flush: per-wave registers -> work-group LDS accumulators -> one global atomic per parameter
+  if (bp.d_mlp) {
+#pragma unroll
+    for (int ht = 0; ht < HT; ++ht) {
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int hid = ht * 32 + mfma_row(q, h), kin = kt * 32 + col;
+          if (kin < L::PE_ROWS) atomicAdd(&lds[L::D_WPE + kin * HD + hid], dwpe[ht][kt][q]);
+        }
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        // reduce the 32 point-columns of each lane half, then one LDS atomic per hidden unit
+        float v = dw2[ht][q];
+#pragma unroll
+        for (int off = 16; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+        if (col == 0) atomicAdd(&lds[L::D_WOUT + ht * 32 + mfma_row(q, h)], v);
+      }
+    }
+    float v = db2;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    if (lane == 0) atomicAdd(&lds[L::D_WOUT + HD], v);
+  }
+  __syncthreads();
+  if (bp.d_mlp) {
+    for (int i = threadIdx.x; i < L::PE_ROWS * HD; i += blockDim.x) {
+      const int k = i / HD, hid = i % HD;
+      const int src = kernel_to_ref_input<C>(k + C);
+      const float v = lds[L::D_WPE + i];
+      if (v != 0.0f) atomic_add_f32(bp.d_mlp + (src >= 0 ? ml.w_in() + hid * D_IN + src : ml.b_in() + hid), v);
+    }
+    for (int i = threadIdx.x; i <= HD; i += blockDim.x) {
+      const float v = lds[L::D_WOUT + i];
+      if (v != 0.0f) atomic_add_f32(bp.d_mlp + (i < HD ? ml.w_out() + i : ml.b_out()), v);
+    }
+  }
+  if (bp.d_empty_proj) {
+    for (int i = threadIdx.x; i < HD; i += blockDim.x) {
+      const float v = lds[L::D_EMPTY + i];
+      if (v != 0.0f) atomic_add_f32(bp.d_empty_proj + i, v);
+    }
+  }
+}
+
+template <int C, int HD>
+static int launch_bwd(const BwdParams& bp, int grid, hipStream_t s) {
+  using L = BwdLds<HD, 0>;
+  const size_t shmem = L::TOTAL * sizeof(float);
+  auto go = [&](auto kern) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    kern<<<grid, 256, shmem, s>>>(bp);
+  };
+  if (bp.f.nv <= 1) go(render_bwd_kernel<C, HD, 1>);
+  else if (bp.f.nv <= 2) go(render_bwd_kernel<C, HD, 2>);
+  else if (bp.f.nv <= 4) go(render_bwd_kernel<C, HD, 4>);
+  else go(render_bwd_kernel<C, HD, 8>);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: backward kernel launch failed (%ld)", hipGetErrorString(e), (long)e);
+    return BTS_E_LAUNCH;
+  }
+  return BTS_OK;
+}
+
+FwdParams make_params(const BtsFieldCfg* cfg, const BtsFieldTensors* t);
+
 size_t render_bwd_workspace_impl(const BtsFieldCfg*, const BtsRenderArgs*) { return 0; }
-int render_bwd_impl(const BtsFieldCfg*, const BtsFieldTensors*, const BtsRenderArgs*, const BtsRenderGrads*, void*, size_t, hipStream_t) {
-  set_error("%s: backward not built", "bts_render_bwd");
+
+int render_bwd_impl(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const BtsRenderArgs* a, const BtsRenderGrads* g, void*, size_t,
+                    hipStream_t s) {
+  if (a->white_bkgd) {
+    set_error("%s: white_bkgd has no backward (no shipped config trains with it)", "bts_render_bwd");
+    return BTS_E_UNSUPPORTED;
+  }
+  if (cfg->n_blocks != 0) {
+    set_error("%s: backward for n_blocks=%ld is not built yet", "bts_render_bwd", cfg->n_blocks);
+    return BTS_E_UNSUPPORTED;
+  }
+  BwdParams bp;
+  bp.f = make_params(cfg, t);
+  bp.f.rays = a->rays, bp.f.z_samp = a->z_samp;
+  bp.f.Bp = a->rays_per_sample, bp.f.K = a->K, bp.f.hard_cap = a->hard_alpha_cap, bp.f.white_bkgd = 0;
+  bp.f.sigma_raw = a->sigma_raw, bp.f.trans = a->trans;
+  bp.f.tiles_per_sample = (a->rays_per_sample + 255) / 256;
+  bp.g_rgb = g->g_rgb, bp.g_depth = g->g_depth, bp.g_weights = g->g_weights, bp.g_alphas = g->g_alphas;
+  bp.d_proj = g->d_proj_nhwc, bp.d_mlp = g->d_mlp_params, bp.d_empty_proj = g->d_empty_proj;
+  const int grid = bp.f.tiles_per_sample * cfg->n;
+  if (cfg->C == 64 && cfg->d_hidden == 64) return launch_bwd<64, 64>(bp, grid, s);
+  if (cfg->C == 32 && cfg->d_hidden == 32) return launch_bwd<32, 32>(bp, grid, s);
+  set_error("%s: unsupported MLP shape C=%ld d_hidden=%ld", "bts_render_bwd", cfg->C, cfg->d_hidden);
   return BTS_E_UNSUPPORTED;
 }
+
 }  // namespace bts

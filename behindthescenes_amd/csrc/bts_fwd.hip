@@ -1,461 +1,30 @@
-// Fused forward of the BehindTheScenes density-field renderer for gfx950 (MI355X).
-//
-// One lane = one ray (or one query point).  A wave walks its 64 rays front-to-back, one sample per iteration:
-//   project into the encoder view -> 4 bilinear taps of the channels-last feature map (float4 loads, 8 channels per
-//   chunk, software-prefetched one chunk ahead) -> positional encoding -> lin_in as  H^T[Hd x 64 pts] = W^T . X^T  on
-//   v_mfma_f32_32x32x2_f32 (weights = A operand from LDS, the lane's own inputs = B operand after one v_permlane32_swap
-//   per k-pair) -> optional ResnetBlockFC layers (C-layout -> B-layout is free through a k permutation) -> lin_out as
-//   an in-lane dot product over the accumulator registers -> softplus -> colour taps of the nv render views ->
-//   alpha compositing in registers.  sigma / alpha / T never leave the chip.
-//
-// Replaces: nerf.py:210-313 (composite), models_bts.py:138-338 (sample_features / sample_colors / forward),
-//           resnetfc.py:132-184, code.py:30-42 of the reference.
-#include "bts_common.h"
-
-#include <cstdio>
-#include <cstring>
+// Host side of the fused forward + the PROJ = false instantiations (raw channels-last features).
+#include "bts_field_kernel.h"
 
 namespace bts {
-
-struct FwdParams {
-  // field
-  const float* feat;   // (n,H,W,C)
-  const float* K_enc;  // (n,3,3)
-  const float* w2c_enc;
-  const float* imgs;   // (n,nv,H,W,4)
-  const float* K_r;
-  const float* w2c_r;
-  const float* empty_feature;
-  const float* mlp;
-  int n, H, W, nv;
-  int code_mode, inv_z, learn_empty, empty_empty;
-  float freq_factor, d_min, d_max;
-  float inv_dmax, inv_range, range;
-  // render
-  const float* rays;
-  const float* z_samp;
-  int Bp, K, hard_cap, white_bkgd;
-  float* rgb;
-  float* depth;
-  float* weights;
-  float* alphas;
-  float* invalid;
-  float* rgb_samps;
-  float* sigma_raw;
-  // query
-  const float* xyz;
-  float* q_sigma;
-  int only_density;
-  int tiles_per_sample;
-};
-
-template <int C, int HD, int NB>
-struct Lds {
-  static constexpr int KIN = C + kPeDim + 1;         // features + PE + bias row (even)
-  static constexpr int W_IN = 0;                     // [KIN][HD]  k-major: Wl[k*HD + hid] = w_in[hid][k]
-  static constexpr int BLK = W_IN + KIN * HD;        // per block: w0 [HD in][HD out], b0 [HD], w1 [HD][HD], b1 [HD]
-  static constexpr int BLK_STRIDE = 2 * HD * HD + 2 * HD;
-  static constexpr int W_OUT = BLK + NB * BLK_STRIDE;  // [HD]
-  static constexpr int EMPTY = W_OUT + HD;             // [C]
-  static constexpr int TOTAL = EMPTY + C;
-};
-
-// Kernel-side order of the lin_in inputs (any permutation of k is free as long as A and B agree):
-//   [0, C) features | C: x, C+1: y | C+2: depth code, C+3: constant 1 (bias row) | C+4+6*oct+{0,1,2}: sin(f x,y,z),
-//   +{3,4,5}: sin(f . + pi/2).   Reference order (code.py:37-42): [features, x, y, z, oct0: sin(3) cos(3), oct1 ...].
-template <int C>
-__host__ __device__ constexpr int kernel_to_ref_input(int k) {
-  if (k < C + 2) return k;
-  if (k == C + 2) return C + 2;
-  if (k == C + 3) return -1;
-  return k - 1;
-}
-
-// stage the MLP into LDS in the k-major layouts the MFMA A operand wants
-template <int C, int HD, int NB>
-__device__ __forceinline__ void stage_weights(float* lds, const float* __restrict__ mlp, const float* __restrict__ empty) {
-  using L = Lds<C, HD, NB>;
-  constexpr int D_IN = C + kPeDim;
-  const MlpLayout ml{D_IN, HD, NB};
-  for (int i = threadIdx.x; i < L::KIN * HD; i += blockDim.x) {
-    const int k = i / HD, hid = i % HD;
-    const int src = kernel_to_ref_input<C>(k);  // -1: bias row
-    lds[L::W_IN + i] = src >= 0 ? mlp[ml.w_in() + hid * D_IN + src] : mlp[ml.b_in() + hid];
-  }
-#pragma unroll
-  for (int b = 0; b < NB; ++b) {
-    float* base = lds + L::BLK + b * L::BLK_STRIDE;
-    for (int i = threadIdx.x; i < HD * HD; i += blockDim.x) {
-      const int k = i / HD, out = i % HD;
-      base[i] = mlp[ml.blk_w0(b) + out * HD + k];
-      base[HD * HD + HD + i] = mlp[ml.blk_w1(b) + out * HD + k];
-    }
-    for (int i = threadIdx.x; i < HD; i += blockDim.x) {
-      base[HD * HD + i] = mlp[ml.blk_b0(b) + i];
-      base[2 * HD * HD + HD + i] = mlp[ml.blk_b1(b) + i];
-    }
-  }
-  for (int i = threadIdx.x; i < HD; i += blockDim.x) lds[L::W_OUT + i] = mlp[ml.w_out() + i];
-  for (int i = threadIdx.x; i < C; i += blockDim.x) lds[L::EMPTY + i] = empty ? empty[i] : 0.0f;
-}
-
-// one k-pair of lin_in: inputs (a, b) = the lane's x[2s], x[2s+1]
-template <int HD>
-__device__ __forceinline__ void kstep(f32x16 (&acc)[HD / 32][2], const float* wl, int lane_off, float a, float b) {
-  swap32(a, b);
-#pragma unroll
-  for (int ht = 0; ht < HD / 32; ++ht) {
-    const float w = wl[lane_off + ht * 32];
-    acc[ht][0] = mfma(w, a, acc[ht][0]);
-    acc[ht][1] = mfma(w, b, acc[ht][1]);
-  }
-}
-
-// out[ot][pt] += W^T(k-major, [HD in][HD out]) . relu(in)   (one ResnetBlockFC linear; C-layout of `in` feeds B directly)
-template <int HD>
-__device__ __forceinline__ void hidden_layer(f32x16 (&out)[HD / 32][2], const f32x16 (&in)[HD / 32][2], const float* w, int lane) {
-  const int h = lane >> 5, col = lane & 31;
-#pragma unroll
-  for (int it = 0; it < HD / 32; ++it) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int kin = it * 32 + mfma_row(r, 0) + 4 * h;
-      const float b0 = fmaxf(in[it][0][r], 0.0f);
-      const float b1 = fmaxf(in[it][1][r], 0.0f);
-#pragma unroll
-      for (int ot = 0; ot < HD / 32; ++ot) {
-        const float a = w[kin * HD + ot * 32 + col];
-        out[ot][0] = mfma(a, b0, out[ot][0]);
-        out[ot][1] = mfma(a, b1, out[ot][1]);
-      }
-    }
-  }
-}
-
-__device__ __forceinline__ void load_chunk(float4 (&buf)[4][2], const float4* t00, const float4* t01, const float4* t10,
-                                           const float4* t11, int c) {
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    buf[0][j] = t00[2 * c + j], buf[1][j] = t01[2 * c + j];
-    buf[2][j] = t10[2 * c + j], buf[3][j] = t11[2 * c + j];
-  }
-}
-
-// bilinear blend of one 8-channel chunk (ATen accumulates nw, ne, sw, se in this order) and its 4 k-pairs of lin_in
-template <int HD>
-__device__ __forceinline__ void feature_chunk(f32x16 (&acc)[HD / 32][2], const float4 (&buf)[4][2], const Taps& tp, bool learn_empty,
-                                              bool use_empty, const float* empty, const float* wl) {
-  float f[8];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const float* a = reinterpret_cast<const float*>(&buf[0][j]);
-    const float* b = reinterpret_cast<const float*>(&buf[1][j]);
-    const float* c = reinterpret_cast<const float*>(&buf[2][j]);
-    const float* d = reinterpret_cast<const float*>(&buf[3][j]);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      float s = a[e] * tp.w00;
-      s = s + b[e] * tp.w01;
-      s = s + c[e] * tp.w10;
-      s = s + d[e] * tp.w11;
-      f[4 * j + e] = s;
-    }
-  }
-  if (learn_empty) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) f[e] = use_empty ? empty[e] : f[e];
-  }
-#pragma unroll
-  for (int s = 0; s < 4; ++s) kstep<HD>(acc, wl + 2 * s * HD, 0, f[2 * s], f[2 * s + 1]);
-}
-
-// one PE octave: sin(f x), sin(f y), sin(f code), then the same with the fl32(pi/2) phase (code.py:25-28, 38)
-__device__ __forceinline__ void pe_octave(float (&o)[6], const float (&v)[3], float f) {
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    const float arg = v[i] * f;
-    o[i] = sinf(arg);
-    o[3 + i] = sinf(arg + 1.57079637050628662109375f);
-  }
-}
-
-template <int C, int HD, int NB, int NVMAX, bool QUERY>
-__global__ __launch_bounds__(256, 2) void field_kernel(const FwdParams p) {
-  using L = Lds<C, HD, NB>;
-  constexpr int HT = HD / 32;
-  __shared__ float lds[L::TOTAL];
-  stage_weights<C, HD, NB>(lds, p.mlp, p.empty_feature);
-  __syncthreads();
-
-  const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
-  const int wg = xcd_remap(blockIdx.x, gridDim.x);
-  const int sample = wg / p.tiles_per_sample;  // wave-uniform batch element
-  const int tile = wg - sample * p.tiles_per_sample;
-  const int Bp = p.Bp;
-  const int r_raw = tile * 256 + wave * 64 + lane;
-  const bool active = r_raw < Bp;
-  const int r = active ? r_raw : Bp - 1;
-  const long ray = (long)sample * Bp + r;
-  const int lane_off = (lane >> 5) * HD + (lane & 31);
-  const int H = p.H, W = p.W, nv = p.nv;
-
-  // wave-uniform cameras -> scalar registers
-  const Cam enc = load_cam(p.w2c_enc + sample * 16, p.K_enc + sample * 9);
-  const float4* __restrict__ featp = reinterpret_cast<const float4*>(p.feat) + (long)sample * H * W * (C / 4);
-
-  const float b_out = p.mlp[MlpLayout{C + kPeDim, HD, NB}.b_out()];
-
-  float ox, oy, oz, dx, dy, dz;
-  const float* zrow = nullptr;
-  int K = 1;
-  if constexpr (QUERY) {
-    ox = p.xyz[ray * 3 + 0], oy = p.xyz[ray * 3 + 1], oz = p.xyz[ray * 3 + 2];
-    dx = dy = dz = 0.0f;
-  } else {
-    const float4 r0 = reinterpret_cast<const float4*>(p.rays)[ray * 2];
-    const float4 r1 = reinterpret_cast<const float4*>(p.rays)[ray * 2 + 1];
-    ox = r0.x, oy = r0.y, oz = r0.z, dx = r0.w, dy = r1.x, dz = r1.y;
-    K = p.K;
-    zrow = p.z_samp + ray * K;
-  }
-
-  float T = 1.0f, depth = 0.0f, wsum = 0.0f;
-  float rgb_acc[NVMAX * 3];
-#pragma unroll
-  for (int i = 0; i < NVMAX * 3; ++i) rgb_acc[i] = 0.0f;
-  float z_next = QUERY ? 0.0f : zrow[0];
-
-  for (int k = 0; k < K; ++k) {
-    const float z = z_next;
-    if constexpr (!QUERY) z_next = (k + 1 < K) ? zrow[k + 1] : 0.0f;
-    // nerf.py:231  points = o + z * d   (mul, then add)
-    const float px = QUERY ? ox : ox + z * dx;
-    const float py = QUERY ? oy : oy + z * dy;
-    const float pz = QUERY ? oz : oz + z * dz;
-
-    // ---------------- encoder view: projection, taps, depth code
-    const Proj pe = p.code_mode == 1 ? project<true>(enc, px, py, pz) : project<false>(enc, px, py, pz);
-    const Taps tp = make_taps(pe.x, pe.y, H, W);
-    float v3[3];
-    v3[0] = pe.x, v3[1] = pe.y;
-    v3[2] = depth_code(p.code_mode == 1 ? pe.dist : pe.z, p.inv_z != 0, p.inv_dmax, p.inv_range, p.d_min, p.range);
-    const bool use_empty = (p.learn_empty != 0) & pe.invalid;
-
-    f32x16 acc[HT][2];
-#pragma unroll
-    for (int ht = 0; ht < HT; ++ht)
-#pragma unroll
-      for (int pt = 0; pt < 2; ++pt)
-#pragma unroll
-        for (int q = 0; q < 16; ++q) acc[ht][pt][q] = 0.0f;
-
-    // ---------------- features: 8 channels per chunk; rolled ping-pong loop, the next chunk's 8 float4 loads are in
-    // flight while this chunk's 16 MFMAs run (a fully unrolled loop lets the scheduler hoist all 64 loads and spill)
-    const float4* t00 = featp + (long)tp.o00 * (C / 4);
-    const float4* t01 = featp + (long)tp.o01 * (C / 4);
-    const float4* t10 = featp + (long)tp.o10 * (C / 4);
-    const float4* t11 = featp + (long)tp.o11 * (C / 4);
-    float4 bufA[4][2], bufB[4][2];
-    load_chunk(bufA, t00, t01, t10, t11, 0);
-    const float* wl = lds + L::W_IN + lane_off;
-    const float* empty = lds + L::EMPTY;
-#pragma unroll 1
-    for (int c = 0; c < C / 8; c += 2) {
-      load_chunk(bufB, t00, t01, t10, t11, c + 1);
-      feature_chunk<HD>(acc, bufA, tp, p.learn_empty != 0, use_empty, empty + c * 8, wl + c * 8 * HD);
-      if (c + 2 < C / 8) load_chunk(bufA, t00, t01, t10, t11, c + 2);
-      feature_chunk<HD>(acc, bufB, tp, p.learn_empty != 0, use_empty, empty + (c + 1) * 8, wl + (c + 1) * 8 * HD);
-    }
-    // ---------------- positional encoding (+ bias row): [x, y] [code, 1] then 3 k-pairs per octave, sines of the next
-    // octave computed while the current octave's MFMAs run
-    wl += C * HD;
-    kstep<HD>(acc, wl, 0, v3[0], v3[1]);
-    kstep<HD>(acc, wl + 2 * HD, 0, v3[2], 1.0f);
-    wl += 4 * HD;
-    float sc[6], sn[6];
-    pe_octave(sc, v3, p.freq_factor);
-    float ff = p.freq_factor;
-#pragma unroll 1
-    for (int oct = 0; oct < kNumFreqs; ++oct) {
-      ff = ff * 2.0f;
-      if (oct + 1 < kNumFreqs) pe_octave(sn, v3, ff);
-      kstep<HD>(acc, wl, 0, sc[0], sc[1]);
-      kstep<HD>(acc, wl + 2 * HD, 0, sc[2], sc[3]);
-      kstep<HD>(acc, wl + 4 * HD, 0, sc[4], sc[5]);
-      wl += 6 * HD;
-#pragma unroll
-      for (int i = 0; i < 6; ++i) sc[i] = sn[i];
-    }
-
-    // ---------------- ResnetBlockFC layers: h = h + fc_1(relu(fc_0(relu(h))))   (resnetfc.py:53-62)
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-      const float* base = lds + L::BLK + b * L::BLK_STRIDE;
-      f32x16 net[HT][2];
-#pragma unroll
-      for (int ot = 0; ot < HT; ++ot)
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          const float bias = base[HD * HD + ot * 32 + mfma_row(q, 0) + 4 * (lane >> 5)];
-          net[ot][0][q] = bias, net[ot][1][q] = bias;
-        }
-      hidden_layer<HD>(net, acc, base, lane);
-#pragma unroll
-      for (int ot = 0; ot < HT; ++ot)
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          const float bias = base[2 * HD * HD + HD + ot * 32 + mfma_row(q, 0) + 4 * (lane >> 5)];
-          acc[ot][0][q] += bias, acc[ot][1][q] += bias;
-        }
-      hidden_layer<HD>(acc, net, base + HD * HD + HD, lane);
-    }
-
-    // ---------------- lin_out: in-lane dot over the hidden rows this lane holds, then fold the two lane halves
-    float p0 = 0.0f, p1 = 0.0f;
-#pragma unroll
-    for (int ht = 0; ht < HT; ++ht)
-#pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const float w2 = lds[L::W_OUT + ht * 32 + mfma_row(q, 0) + 4 * (lane >> 5)];
-        p0 = __builtin_fmaf(fmaxf(acc[ht][0][q], 0.0f), w2, p0);
-        p1 = __builtin_fmaf(fmaxf(acc[ht][1][q], 0.0f), w2, p1);
-      }
-    swap32(p0, p1);  // p0 = {tile0.lo, tile1.lo}, p1 = {tile0.hi, tile1.hi}: lane l now holds both halves of ITS ray
-    const float s_raw = (p0 + p1) + b_out;
-    float sigma = softplus(s_raw);
-    if (p.empty_empty) sigma = pe.invalid ? 0.0f : sigma;
-
-    // ---------------- colour taps (models_bts.py:218-264)
-    float col[NVMAX * 3];
-    bool inv[NVMAX];
-#pragma unroll
-    for (int j = 0; j < NVMAX; ++j) {
-      col[3 * j] = col[3 * j + 1] = col[3 * j + 2] = 0.0f;
-      inv[j] = pe.invalid;
-      if (j < nv) {
-        const Cam cj = load_cam(p.w2c_r + ((long)sample * nv + j) * 16, p.K_r + ((long)sample * nv + j) * 9);
-        const Proj pc = project<false>(cj, px, py, pz);
-        const Taps tc = make_taps(pc.x, pc.y, H, W);
-        const float4* img = reinterpret_cast<const float4*>(p.imgs) + ((long)sample * nv + j) * H * W;
-        const float4 a = img[tc.o00], b = img[tc.o01], cc = img[tc.o10], d = img[tc.o11];
-        col[3 * j + 0] = ((a.x * tc.w00 + b.x * tc.w01) + cc.x * tc.w10) + d.x * tc.w11;
-        col[3 * j + 1] = ((a.y * tc.w00 + b.y * tc.w01) + cc.y * tc.w10) + d.y * tc.w11;
-        col[3 * j + 2] = ((a.z * tc.w00 + b.z * tc.w01) + cc.z * tc.w10) + d.z * tc.w11;
-        inv[j] = pc.invalid | pe.invalid;
-      }
-    }
-
-    if constexpr (QUERY) {
-      if (active) {
-        p.q_sigma[ray] = sigma;
-        if (p.only_density) {
-          if (p.invalid) p.invalid[ray] = pe.invalid ? 1.0f : 0.0f;
-        } else {
-#pragma unroll
-          for (int j = 0; j < NVMAX; ++j)
-            if (j < nv) {
-              if (p.invalid) p.invalid[ray * nv + j] = inv[j] ? 1.0f : 0.0f;
-              p.rgb[(ray * nv + j) * 3 + 0] = col[3 * j + 0];
-              p.rgb[(ray * nv + j) * 3 + 1] = col[3 * j + 1];
-              p.rgb[(ray * nv + j) * 3 + 2] = col[3 * j + 2];
-            }
-        }
-      }
-    } else {
-      // ---------------- alpha compositing (nerf.py:225-299)
-      const float delta = (k + 1 < K) ? (z_next - z) : 1e10f;
-      float alpha = 1.0f - expf(-fabsf(delta) * fmaxf(sigma, 0.0f));
-      if (p.hard_cap && k == K - 1) alpha = 1.0f;
-      const float wgt = alpha * T;
-      T = T * ((1.0f - alpha) + 1e-10f);
-      depth = depth + wgt * z;
-      wsum = wsum + wgt;
-#pragma unroll
-      for (int i = 0; i < NVMAX * 3; ++i) rgb_acc[i] = rgb_acc[i] + wgt * col[i];
-      if (active) {
-        const long pk = ray * K + k;
-        if (p.weights) p.weights[pk] = wgt;
-        if (p.alphas) p.alphas[pk] = alpha;
-        if (p.sigma_raw) p.sigma_raw[pk] = s_raw;
-        if (p.invalid) {
-#pragma unroll
-          for (int j = 0; j < NVMAX; ++j)
-            if (j < nv) p.invalid[pk * nv + j] = inv[j] ? 1.0f : 0.0f;
-        }
-        if (p.rgb_samps) {
-#pragma unroll
-          for (int j = 0; j < NVMAX; ++j)
-            if (j < nv) {
-              p.rgb_samps[(pk * nv + j) * 3 + 0] = col[3 * j + 0];
-              p.rgb_samps[(pk * nv + j) * 3 + 1] = col[3 * j + 1];
-              p.rgb_samps[(pk * nv + j) * 3 + 2] = col[3 * j + 2];
-            }
-        }
-      }
-    }
-  }
-
-  if constexpr (!QUERY) {
-    if (active) {
-      p.depth[ray] = depth;
-#pragma unroll
-      for (int j = 0; j < NVMAX; ++j)
-        if (j < nv) {
-#pragma unroll
-          for (int c = 0; c < 3; ++c) {
-            float v = rgb_acc[3 * j + c];
-            if (p.white_bkgd) v = (v + 1.0f) - wsum;  // nerf.py:301-304
-            p.rgb[(ray * nv + j) * 3 + c] = v;
-          }
-        }
-    }
-  }
-}
 
 // ---------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
-void set_error(const char* fmt, const char* a = "", long b = 0, long c = 0, long d = 0) {
+void set_error(const char* fmt, const char* a, long b, long c, long d) {
   snprintf(g_err, sizeof(g_err), fmt, a, b, c, d);
 }
 const char* last_error() { return g_err; }
-
-template <int C, int HD, int NB, bool QUERY>
-static int launch_nv(const FwdParams& p, int grid, hipStream_t s) {
-  if (p.nv <= 1) field_kernel<C, HD, NB, 1, QUERY><<<grid, 256, 0, s>>>(p);
-  else if (p.nv <= 2) field_kernel<C, HD, NB, 2, QUERY><<<grid, 256, 0, s>>>(p);
-  else if (p.nv <= 4) field_kernel<C, HD, NB, 4, QUERY><<<grid, 256, 0, s>>>(p);
-  else field_kernel<C, HD, NB, 8, QUERY><<<grid, 256, 0, s>>>(p);
-  const hipError_t e = hipGetLastError();
-  if (e != hipSuccess) {
-    set_error("%s: kernel launch failed (%ld)", hipGetErrorString(e), (long)e);
-    return BTS_E_LAUNCH;
-  }
-  return BTS_OK;
-}
 
 bool shape_supported(int C, int HD, int NB) {
   return (C == 64 && HD == 64 && NB == 0) || (C == 32 && HD == 32 && NB == 1) || (C == 32 && HD == 32 && NB == 0);
 }
 
-template <bool QUERY>
-int launch_field(const FwdParams& p, int C, int HD, int NB, int grid, hipStream_t s) {
-  if (C == 64 && HD == 64 && NB == 0) return launch_nv<64, 64, 0, QUERY>(p, grid, s);
-  if (C == 32 && HD == 32 && NB == 1) return launch_nv<32, 32, 1, QUERY>(p, grid, s);
-  if (C == 32 && HD == 32 && NB == 0) return launch_nv<32, 32, 0, QUERY>(p, grid, s);
-  set_error("%s: unsupported MLP shape C=%ld d_hidden=%ld n_blocks=%ld", "bts", C, HD, NB);
-  return BTS_E_UNSUPPORTED;
-}
+template int launch_field<false, false>(const FwdParams&, int, int, int, int, hipStream_t);
+template int launch_field<true, false>(const FwdParams&, int, int, int, int, hipStream_t);
+extern template int launch_field<false, true>(const FwdParams&, int, int, int, int, hipStream_t);
+extern template int launch_field<true, true>(const FwdParams&, int, int, int, int, hipStream_t);
 
-template int launch_field<false>(const FwdParams&, int, int, int, int, hipStream_t);
-template int launch_field<true>(const FwdParams&, int, int, int, int, hipStream_t);
-
-static FwdParams make_params(const BtsFieldCfg* cfg, const BtsFieldTensors* t) {
+FwdParams make_params(const BtsFieldCfg* cfg, const BtsFieldTensors* t) {
   FwdParams p;
   memset(&p, 0, sizeof(p));
-  p.feat = t->feat_nhwc, p.K_enc = t->K_enc, p.w2c_enc = t->w2c_enc;
+  p.feat = t->feat_nhwc, p.proj = t->proj_nhwc, p.K_enc = t->K_enc, p.w2c_enc = t->w2c_enc;
   p.imgs = t->imgs_nhwc4, p.K_r = t->K_r, p.w2c_r = t->w2c_r;
   p.empty_feature = t->empty_feature, p.mlp = t->mlp_params;
   p.n = cfg->n, p.H = cfg->H, p.W = cfg->W, p.nv = cfg->nv;
@@ -473,9 +42,10 @@ int render_fwd_impl(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const BtsR
   p.rays = a->rays, p.z_samp = a->z_samp;
   p.Bp = a->rays_per_sample, p.K = a->K, p.hard_cap = a->hard_alpha_cap, p.white_bkgd = a->white_bkgd;
   p.rgb = a->rgb, p.depth = a->depth, p.weights = a->weights, p.alphas = a->alphas, p.invalid = a->invalid;
-  p.rgb_samps = a->rgb_samps, p.sigma_raw = a->sigma_raw;
+  p.rgb_samps = a->rgb_samps, p.sigma_raw = a->sigma_raw, p.trans = a->trans;
   p.tiles_per_sample = (a->rays_per_sample + 255) / 256;
-  return launch_field<false>(p, cfg->C, cfg->d_hidden, cfg->n_blocks, p.tiles_per_sample * cfg->n, s);
+  if (p.proj) return launch_field<false, true>(p, cfg->C, cfg->d_hidden, cfg->n_blocks, p.tiles_per_sample * cfg->n, s);
+  return launch_field<false, false>(p, cfg->C, cfg->d_hidden, cfg->n_blocks, p.tiles_per_sample * cfg->n, s);
 }
 
 int field_query_impl(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const float* xyz, int P, int only_density, float* rgb,
@@ -485,7 +55,8 @@ int field_query_impl(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const flo
   if (only_density) p.nv = 0;
   p.rgb = rgb, p.invalid = invalid, p.q_sigma = sigma;
   p.tiles_per_sample = (P + 255) / 256;
-  return launch_field<true>(p, cfg->C, cfg->d_hidden, cfg->n_blocks, p.tiles_per_sample * cfg->n, s);
+  if (p.proj) return launch_field<true, true>(p, cfg->C, cfg->d_hidden, cfg->n_blocks, p.tiles_per_sample * cfg->n, s);
+  return launch_field<true, false>(p, cfg->C, cfg->d_hidden, cfg->n_blocks, p.tiles_per_sample * cfg->n, s);
 }
 
 }  // namespace bts

@@ -3,9 +3,9 @@ state-dict layout (models/bts/model/models_bts.py:17-338), but whose per-point w
 positional encoding, MLP, softplus, colour fetch) is done by the fused HIP kernels in libbts_render.so.
 
 What stays PyTorch-ROCm: the CNN encoder call inside ``encode`` and the 4x4 pose inverse.  ``encode`` additionally hands
-the feature map / colour frames over to the renderer's HBM layouts (channels-last F, rgb0-packed frames) with the HIP
-layout kernels; under autograd the F hand-over is differentiable (its backward is the inverse transpose), so gradients of
-the renderer reach the CNN exactly as they do in the reference."""
+the feature map / colour frames over to the renderer's HBM layouts (projected channels-last G = F . w_in[:, :C]^T, rgb0-packed
+frames) with HIP kernels; under autograd the hand-over is differentiable (per-pixel GEMMs), so gradients of the renderer reach
+the CNN and lin_in exactly as they do in the reference."""
 import torch
 import torch.nn.functional as F
 from torch import nn
@@ -120,14 +120,19 @@ class BTSNet(nn.Module):
         self._w2c_enc = poses_w2c_encoder[:, 0].detach().float().contiguous()
 
     def native_field(self) -> "native.FieldTensors":
-        """Field state of the current scale in the C-ABI layouts (built lazily per scale, cached until the next encode)."""
+        """Field state of the current scale in the C-ABI layouts.  The projected feature map G = F . w_in[:, :C]^T is built lazily
+        per scale (one HIP pass that also does the NCHW -> channels-last hand-over) and cached until the next ``encode`` or until
+        lin_in.weight changes.  Under autograd the projection is differentiable w.r.t. F and the MLP parameters."""
         s = self._scale
-        if s not in self._native:
-            f = self.grid_f_features[s][:, 0]                      # (n, C, H, W)
-            feat_nhwc = native.NhwcFunction.apply(f.float())       # differentiable layout change
-            self._native[s] = native.FieldTensors(self.spec, feat_nhwc, self._K_enc, self._w2c_enc, self._imgs_nhwc4, self._K_r,
-                                                  self._w2c_r, self.empty_feature if self.learn_empty else None)
-        return self._native[s]
+        version = (self.mlp_coarse.lin_in.weight._version, torch.is_grad_enabled())
+        hit = self._native.get(s)
+        if hit is None or hit[1] != version:
+            f = self.grid_f_features[s][:, 0].float()              # (n, C, H, W)
+            proj = native.ProjectFunction.apply(f, self.mlp_coarse.packed(), self.spec)
+            ft = native.FieldTensors(self.spec, proj, self._K_enc, self._w2c_enc, self._imgs_nhwc4, self._K_r, self._w2c_r,
+                                     self.empty_feature if self.learn_empty else None)
+            self._native[s] = (ft, version)
+        return self._native[s][0]
 
     def forward(self, xyz, coarse=True, viewdirs=None, far=False, only_density=False):
         """xyz (n, P, 3) world points -> rgb (n,P,nv*3), invalid (n,P,nv) float, sigma (n,P,1)  (models_bts.py:266-338).

@@ -128,16 +128,48 @@ def distance_to_z(depths: torch.Tensor, projs: torch.Tensor) -> torch.Tensor:
 # --------------------------------------------------------------------------------------------------------------
 # field state handed to the renderer
 # --------------------------------------------------------------------------------------------------------------
-class FieldTensors:
-    """Device tensors in the layouts of include/bts_render.h.  ``feat_nhwc`` may require grad (it is produced by
-    ``nchw_to_nhwc`` of the encoder output inside autograd, see NhwcFunction)."""
+def _spec_cfg(spec: FieldSpec, n=1, H=1, W=1, nv=0) -> BtsFieldCfg:
+    return BtsFieldCfg(n=n, H=H, W=W, C=spec.C, d_hidden=spec.d_hidden, n_blocks=spec.n_blocks, nv=nv, num_freqs=spec.num_freqs,
+                       code_mode={"z": 0, "distance": 1}[spec.code_mode], inv_z=int(spec.inv_z), learn_empty=int(spec.learn_empty),
+                       empty_empty=int(spec.empty_empty), freq_factor=spec.freq_factor, d_min=spec.d_min, d_max=spec.d_max)
 
-    def __init__(self, spec: FieldSpec, feat_nhwc, K_enc, w2c_enc, imgs_nhwc4, K_r, w2c_r, empty_feature=None):
-        n, H, W, Cc = feat_nhwc.shape
-        if Cc != spec.C:
-            raise BtsNativeError(f"feat_nhwc has {Cc} channels, spec says {spec.C}")
+
+def project_features(spec: FieldSpec, feat_nchw: torch.Tensor, mlp_params: torch.Tensor) -> torch.Tensor:
+    """F (N,C,H,W) -> G (N,H,W,Hd) = F . w_in[:, :C]^T  (bts_project_features)."""
+    N, Cc, H, W = feat_nchw.shape
+    _req(feat_nchw, "feat_nchw", (N, spec.C, H, W)), _req(mlp_params, "mlp_params", (spec.mlp_param_count(),))
+    out = torch.empty((N, H, W, spec.d_hidden), device=feat_nchw.device, dtype=torch.float32)
+    cfg = _spec_cfg(spec, N, H, W)
+    _lib.check(_lib.load().bts_project_features(C.byref(cfg), _ptr(feat_nchw), _ptr(mlp_params), N, _ptr(out), _stream(out)),
+               "bts_project_features")
+    return out
+
+
+def project_features_bwd(spec: FieldSpec, feat_nchw, d_proj, mlp_params, need_feat=True, need_mlp=True):
+    """-> (d_feat_nchw | None, d_mlp_params | None) (bts_project_features_bwd)."""
+    N, Cc, H, W = feat_nchw.shape
+    _req(feat_nchw, "feat_nchw"), _req(d_proj, "d_proj", (N, H, W, spec.d_hidden)), _req(mlp_params, "mlp_params")
+    d_feat = torch.empty_like(feat_nchw) if need_feat else None
+    d_mlp = torch.zeros_like(mlp_params) if need_mlp else None
+    cfg = _spec_cfg(spec, N, H, W)
+    _lib.check(_lib.load().bts_project_features_bwd(C.byref(cfg), _ptr(feat_nchw), _ptr(d_proj), _ptr(mlp_params), N, _ptr(d_feat),
+                                                    _ptr(d_mlp), _stream(d_proj)), "bts_project_features_bwd")
+    return d_feat, d_mlp
+
+
+class FieldTensors:
+    """Device tensors in the layouts of include/bts_render.h.  ``proj_nhwc`` (G) may require grad: it is produced by
+    ``ProjectFunction`` from the encoder output and the MLP parameters inside autograd."""
+
+    def __init__(self, spec: FieldSpec, proj_nhwc, K_enc, w2c_enc, imgs_nhwc4, K_r, w2c_r, empty_feature=None, feat_nhwc=None):
+        ref = proj_nhwc if proj_nhwc is not None else feat_nhwc
+        n, H, W, ch = ref.shape
+        if proj_nhwc is not None and ch != spec.d_hidden:
+            raise BtsNativeError(f"proj_nhwc has {ch} channels, spec says d_hidden={spec.d_hidden}")
+        if proj_nhwc is None and ch != spec.C:
+            raise BtsNativeError(f"feat_nhwc has {ch} channels, spec says C={spec.C}")
         nv = 0 if imgs_nhwc4 is None else imgs_nhwc4.shape[1]
-        _req(feat_nhwc.detach(), "feat_nhwc"), _req(K_enc, "K_enc", (n, 3, 3)), _req(w2c_enc, "w2c_enc", (n, 4, 4))
+        _req(ref.detach(), "proj_nhwc/feat_nhwc"), _req(K_enc, "K_enc", (n, 3, 3)), _req(w2c_enc, "w2c_enc", (n, 4, 4))
         if nv:
             _req(imgs_nhwc4, "imgs_nhwc4", (n, nv, H, W, 4)), _req(K_r, "K_r", (n, nv, 3, 3)), _req(w2c_r, "w2c_r", (n, nv, 4, 4))
         if nv > _lib.BTS_MAX_VIEWS:
@@ -147,28 +179,23 @@ class FieldTensors:
                 raise BtsNativeError("learn_empty needs empty_feature")
             _req(empty_feature.detach(), "empty_feature", (spec.C,))
         self.spec, self.n, self.H, self.W, self.nv = spec, n, H, W, nv
-        self.feat_nhwc, self.K_enc, self.w2c_enc = feat_nhwc, K_enc, w2c_enc
+        self.proj_nhwc, self.feat_nhwc, self.K_enc, self.w2c_enc = proj_nhwc, feat_nhwc, K_enc, w2c_enc
         self.imgs_nhwc4, self.K_r, self.w2c_r = imgs_nhwc4, K_r, w2c_r
         self.empty_feature = empty_feature
 
     def cfg(self, nv=None) -> BtsFieldCfg:
-        s = self.spec
-        return BtsFieldCfg(n=self.n, H=self.H, W=self.W, C=s.C, d_hidden=s.d_hidden, n_blocks=s.n_blocks,
-                           nv=self.nv if nv is None else nv, num_freqs=s.num_freqs,
-                           code_mode={"z": 0, "distance": 1}[s.code_mode], inv_z=int(s.inv_z), learn_empty=int(s.learn_empty),
-                           empty_empty=int(s.empty_empty), freq_factor=s.freq_factor, d_min=s.d_min, d_max=s.d_max)
+        return _spec_cfg(self.spec, self.n, self.H, self.W, self.nv if nv is None else nv)
 
     def tensors(self, mlp_params: torch.Tensor) -> BtsFieldTensors:
-        return BtsFieldTensors(feat_nhwc=self.feat_nhwc.data_ptr(), K_enc=self.K_enc.data_ptr(), w2c_enc=self.w2c_enc.data_ptr(),
-                               imgs_nhwc4=None if self.imgs_nhwc4 is None else self.imgs_nhwc4.data_ptr(),
-                               K_r=None if self.K_r is None else self.K_r.data_ptr(),
-                               w2c_r=None if self.w2c_r is None else self.w2c_r.data_ptr(),
-                               empty_feature=None if self.empty_feature is None else self.empty_feature.data_ptr(),
-                               mlp_params=mlp_params.data_ptr())
+        def dp(t):
+            return None if t is None else t.data_ptr()
+        return BtsFieldTensors(feat_nhwc=dp(self.feat_nhwc), proj_nhwc=dp(self.proj_nhwc), K_enc=dp(self.K_enc), w2c_enc=dp(self.w2c_enc),
+                               imgs_nhwc4=dp(self.imgs_nhwc4), K_r=dp(self.K_r), w2c_r=dp(self.w2c_r),
+                               empty_feature=dp(self.empty_feature), mlp_params=mlp_params.data_ptr())
 
 
 def check_supported(spec: FieldSpec, nv: int = 1):
-    cfg = BtsFieldCfg(n=1, H=1, W=1, C=spec.C, d_hidden=spec.d_hidden, n_blocks=spec.n_blocks, nv=nv, num_freqs=spec.num_freqs)
+    cfg = _spec_cfg(spec, nv=nv)
     if not _lib.load().bts_supported(C.byref(cfg)):
         raise BtsNativeError(f"field shape outside the compiled envelope: C={spec.C} d_hidden={spec.d_hidden} "
                              f"n_blocks={spec.n_blocks} num_freqs={spec.num_freqs} nv={nv}")
@@ -177,16 +204,20 @@ def check_supported(spec: FieldSpec, nv: int = 1):
 # --------------------------------------------------------------------------------------------------------------
 # render forward / backward
 # --------------------------------------------------------------------------------------------------------------
+_OUT_KEYS = ("rgb", "depth", "weights", "alphas", "invalid", "rgb_samps", "sigma_raw", "trans")
+
+
 def _render_args(ft: FieldTensors, rays, z_samp, hard_alpha_cap, white_bkgd, outs):
     return BtsRenderArgs(rays_per_sample=rays.shape[0] // ft.n, K=z_samp.shape[1], hard_alpha_cap=int(hard_alpha_cap),
                          white_bkgd=int(white_bkgd), rays=rays.data_ptr(), z_samp=z_samp.data_ptr(),
-                         **{k: (None if v is None else v.data_ptr()) for k, v in outs.items()})
+                         **{k: (None if outs.get(k) is None else outs[k].data_ptr()) for k in _OUT_KEYS})
 
 
 def render_fwd(ft: FieldTensors, mlp_params: torch.Tensor, rays: torch.Tensor, z_samp: torch.Tensor, *, hard_alpha_cap: bool,
                white_bkgd: bool = False, want_weights=False, want_alphas=False, want_invalid=True, want_rgb_samps=False,
-               want_sigma_raw=False):
-    """rays (n*Bp, 8), z_samp (n*Bp, K) -> dict of fresh tensors (bts_render_fwd)."""
+               want_saved=False):
+    """rays (n*Bp, 8), z_samp (n*Bp, K) -> dict of fresh tensors (bts_render_fwd).  want_saved adds the two per-sample
+    activations the backward needs (sigma_raw, trans)."""
     B, K = z_samp.shape
     _req(rays, "rays", (B, 8)), _req(z_samp, "z_samp"), _req(mlp_params.detach(), "mlp_params", (ft.spec.mlp_param_count(),))
     if B % ft.n != 0:
@@ -198,40 +229,39 @@ def render_fwd(ft: FieldTensors, mlp_params: torch.Tensor, rays: torch.Tensor, z
 
     outs = dict(rgb=new(B, nv * 3), depth=new(B), weights=new(B, K) if want_weights else None,
                 alphas=new(B, K) if want_alphas else None, invalid=new(B, K, nv) if want_invalid else None,
-                rgb_samps=new(B, K, nv * 3) if want_rgb_samps else None, sigma_raw=new(B, K) if want_sigma_raw else None)
+                rgb_samps=new(B, K, nv * 3) if want_rgb_samps else None, sigma_raw=new(B, K) if want_saved else None,
+                trans=new(B, K) if want_saved else None)
     cfg, tens = ft.cfg(), ft.tensors(mlp_params)
     args = _render_args(ft, rays, z_samp, hard_alpha_cap, white_bkgd, outs)
     _lib.check(_lib.load().bts_render_fwd(C.byref(cfg), C.byref(tens), C.byref(args), _stream(rays)), "bts_render_fwd")
     return outs
 
 
-def render_bwd(ft: FieldTensors, mlp_params, rays, z_samp, sigma_raw, *, hard_alpha_cap, white_bkgd=False, g_rgb=None,
-               g_depth=None, g_weights=None, g_alphas=None, need_feat=True, need_mlp=True, need_empty=False):
-    """Returns (d_feat_nhwc | None, d_mlp_params | None, d_empty_feature | None) (bts_render_bwd)."""
+def render_bwd(ft: FieldTensors, mlp_params, rays, z_samp, sigma_raw, trans, *, hard_alpha_cap, g_rgb=None, g_depth=None,
+               g_weights=None, g_alphas=None, need_proj=True, need_mlp=True, need_empty=False):
+    """Returns (d_proj_nhwc | None, d_mlp_params | None, d_empty_proj | None) (bts_render_bwd)."""
     B, K = z_samp.shape
     for name, g in (("g_rgb", g_rgb), ("g_depth", g_depth), ("g_weights", g_weights), ("g_alphas", g_alphas)):
         if g is not None:
             _req(g, name)
-    _req(sigma_raw, "sigma_raw", (B, K))
+    _req(sigma_raw, "sigma_raw", (B, K)), _req(trans, "trans", (B, K))
     dev = rays.device
-    d_feat = torch.zeros_like(ft.feat_nhwc, requires_grad=False) if need_feat else None
+    d_proj = torch.zeros(ft.proj_nhwc.shape, device=dev, dtype=torch.float32) if need_proj else None
     d_mlp = torch.zeros(ft.spec.mlp_param_count(), device=dev, dtype=torch.float32) if need_mlp else None
-    d_empty = torch.zeros(ft.spec.C, device=dev, dtype=torch.float32) if need_empty else None
+    d_empty = torch.zeros(ft.spec.d_hidden, device=dev, dtype=torch.float32) if need_empty else None
     cfg, tens = ft.cfg(), ft.tensors(mlp_params)
-    outs = dict(rgb=None, depth=None, weights=None, alphas=None, invalid=None, rgb_samps=None, sigma_raw=sigma_raw)
-    args = _render_args(ft, rays, z_samp, hard_alpha_cap, white_bkgd, outs)
-    grads = BtsRenderGrads(g_rgb=None if g_rgb is None else g_rgb.data_ptr(), g_depth=None if g_depth is None else g_depth.data_ptr(),
-                           g_weights=None if g_weights is None else g_weights.data_ptr(),
-                           g_alphas=None if g_alphas is None else g_alphas.data_ptr(),
-                           d_feat_nhwc=None if d_feat is None else d_feat.data_ptr(),
-                           d_mlp_params=None if d_mlp is None else d_mlp.data_ptr(),
-                           d_empty_feature=None if d_empty is None else d_empty.data_ptr())
+    args = _render_args(ft, rays, z_samp, hard_alpha_cap, False, dict(sigma_raw=sigma_raw, trans=trans))
+
+    def dp(t):
+        return None if t is None else t.data_ptr()
+    grads = BtsRenderGrads(g_rgb=dp(g_rgb), g_depth=dp(g_depth), g_weights=dp(g_weights), g_alphas=dp(g_alphas),
+                           d_proj_nhwc=dp(d_proj), d_mlp_params=dp(d_mlp), d_empty_proj=dp(d_empty))
     lib = _lib.load()
     ws_bytes = lib.bts_render_bwd_workspace(C.byref(cfg), C.byref(args))
-    ws = torch.empty(max(int(ws_bytes), 4) // 4 + 1, device=dev, dtype=torch.float32)
+    ws = torch.empty(int(ws_bytes) // 4 + 1, device=dev, dtype=torch.float32)
     _lib.check(lib.bts_render_bwd(C.byref(cfg), C.byref(tens), C.byref(args), C.byref(grads), _ptr(ws), ws_bytes, _stream(rays)),
                "bts_render_bwd")
-    return d_feat, d_mlp, d_empty
+    return d_proj, d_mlp, d_empty
 
 
 def field_query(ft: FieldTensors, mlp_params: torch.Tensor, xyz: torch.Tensor, only_density: bool = False):
@@ -254,33 +284,39 @@ def field_query(ft: FieldTensors, mlp_params: torch.Tensor, xyz: torch.Tensor, o
 # --------------------------------------------------------------------------------------------------------------
 # autograd glue
 # --------------------------------------------------------------------------------------------------------------
-class NhwcFunction(torch.autograd.Function):
-    """F (N,C,H,W) -> (N,H,W,C) with the inverse transpose as backward, both through the HIP layout kernels."""
+class ProjectFunction(torch.autograd.Function):
+    """(F nchw, packed mlp params) -> G nhwc.  Backward: per-pixel GEMMs in bts_project_features_bwd."""
 
     @staticmethod
-    def forward(ctx, x):
-        return nchw_to_nhwc(x.contiguous())
+    def forward(ctx, feat_nchw, mlp_params, spec):
+        feat_nchw = feat_nchw.contiguous()
+        ctx.spec = spec
+        ctx.save_for_backward(feat_nchw, mlp_params)
+        return project_features(spec, feat_nchw, mlp_params.contiguous())
 
     @staticmethod
     def backward(ctx, g):
-        return nhwc_to_nchw(g.contiguous())
+        feat_nchw, mlp_params = ctx.saved_tensors
+        d_feat, d_mlp = project_features_bwd(ctx.spec, feat_nchw, g.contiguous(), mlp_params, ctx.needs_input_grad[0],
+                                             ctx.needs_input_grad[1])
+        return d_feat, d_mlp, None
 
 
 class RenderFunction(torch.autograd.Function):
-    """composite() as one differentiable op.  Differentiable inputs: feat_nhwc, mlp_params, empty_feature.
+    """composite() as one differentiable op.  Differentiable inputs: proj_nhwc (G), mlp_params, empty_feature.
     Differentiable outputs: rgb, depth, weights, alphas (invalid / rgb_samps carry no gradient, as in the reference where
     they only depend on poses and colours)."""
 
     @staticmethod
-    def forward(ctx, feat_nhwc, mlp_params, empty_feature, ft: FieldTensors, rays, z_samp, hard_alpha_cap, white_bkgd,
+    def forward(ctx, proj_nhwc, mlp_params, empty_feature, ft: FieldTensors, rays, z_samp, hard_alpha_cap, white_bkgd,
                 want_weights, want_alphas, want_rgb_samps):
         needs_grad = any(ctx.needs_input_grad[:3])
         out = render_fwd(ft, mlp_params, rays, z_samp, hard_alpha_cap=hard_alpha_cap, white_bkgd=white_bkgd,
                          want_weights=want_weights, want_alphas=want_alphas, want_invalid=True, want_rgb_samps=want_rgb_samps,
-                         want_sigma_raw=needs_grad)
+                         want_saved=needs_grad)
         ctx.ft, ctx.hard_alpha_cap, ctx.white_bkgd = ft, hard_alpha_cap, white_bkgd
         if needs_grad:
-            ctx.save_for_backward(mlp_params, rays, z_samp, out["sigma_raw"])
+            ctx.save_for_backward(mlp_params, rays, z_samp, out["sigma_raw"], out["trans"])
         empty = rays.new_empty(0)
         res = (out["rgb"], out["depth"], out["weights"] if want_weights else empty, out["alphas"] if want_alphas else empty,
                out["invalid"], out["rgb_samps"] if want_rgb_samps else empty)
@@ -290,16 +326,26 @@ class RenderFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_rgb, g_depth, g_weights, g_alphas, _g_inv, _g_rs):
-        mlp_params, rays, z_samp, sigma_raw = ctx.saved_tensors
+        mlp_params, rays, z_samp, sigma_raw, trans = ctx.saved_tensors
         if ctx.white_bkgd:
             raise BtsNativeError("backward with white_bkgd is not supported (no shipped config trains with it)")
 
         def prep(g, present=True):
             return g.contiguous() if (g is not None and present and g.numel() > 0) else None
 
-        need_feat, need_mlp, need_empty = ctx.needs_input_grad[:3]
-        d_feat, d_mlp, d_empty = render_bwd(ctx.ft, mlp_params, rays, z_samp, sigma_raw, hard_alpha_cap=ctx.hard_alpha_cap,
+        ft = ctx.ft
+        need_proj, need_mlp, need_empty = ctx.needs_input_grad[:3]
+        d_proj, d_mlp, d_eproj = render_bwd(ft, mlp_params, rays, z_samp, sigma_raw, trans, hard_alpha_cap=ctx.hard_alpha_cap,
                                             g_rgb=prep(g_rgb), g_depth=prep(g_depth), g_weights=prep(g_weights, ctx.has[0]),
-                                            g_alphas=prep(g_alphas, ctx.has[1]), need_feat=need_feat, need_mlp=need_mlp,
-                                            need_empty=need_empty)
-        return (d_feat, d_mlp, d_empty) + (None,) * 8
+                                            g_alphas=prep(g_alphas, ctx.has[1]), need_proj=need_proj, need_mlp=need_mlp,
+                                            need_empty=need_empty or (need_mlp and ft.spec.learn_empty))
+        d_empty = None
+        if d_eproj is not None:
+            # the projected empty feature is w_in[:, :C] @ empty_feature (a 64x64 GEMV): chain rule on parameter-sized tensors
+            spec = ft.spec
+            w_f = mlp_params[:spec.d_hidden * spec.d_in].view(spec.d_hidden, spec.d_in)[:, :spec.C]
+            if need_empty:
+                d_empty = w_f.t() @ d_eproj
+            if need_mlp:
+                d_mlp[:spec.d_hidden * spec.d_in].view(spec.d_hidden, spec.d_in)[:, :spec.C] += torch.outer(d_eproj, ft.empty_feature.detach())
+        return (d_proj, d_mlp, d_empty) + (None,) * 8

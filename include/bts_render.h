@@ -10,7 +10,11 @@
  * functions are re-entrant (autograd may call the backward from another thread).
  *
  * Data layout in HBM:
- *   feat_nhwc   (n, H, W, C)        channels-last copy of the encoder's feature map F  -> one 4*C-byte row per texel
+ *   proj_nhwc   (n, H, W, Hd)       "projected" feature map G = F . w_in[:, :C]^T, channels-last: bilinear interpolation and
+ *                                   lin_in are both linear, so lin_in(bilinear(F)) == bilinear(G) + w_in[:, C:] . PE + b_in;
+ *                                   bts_project_features builds G from the encoder's NCHW output in one pass (it replaces the
+ *                                   NCHW->NHWC hand-over), the render kernels gather G straight into the MFMA accumulators.
+ *   feat_nhwc   (n, H, W, C)        alternative: raw channels-last F, lin_in evaluated per point (forward / query only)
  *   imgs_nhwc4  (n, nv, H, W, 4)    rgb0-packed colour frames in [0,1]                 -> one 16-byte load per tap
  *   rays        (n*Bp, 8)           [origin(3), direction(3), near, far]   (reference layout, util.py:270-273)
  *   z_samp      (n*Bp, K)           sample depths per ray                  (reference layout, nerf.py:210-218)
@@ -60,7 +64,8 @@ typedef struct BtsFieldCfg {
 
 /* State left behind by BTSNet.encode (models_bts.py:128-136), in the layouts above. */
 typedef struct BtsFieldTensors {
-  const float* feat_nhwc;     /* (n, H, W, C) */
+  const float* feat_nhwc;     /* (n, H, W, C)   raw features; may be NULL when proj_nhwc is given */
+  const float* proj_nhwc;     /* (n, H, W, Hd)  projected features (preferred; required by the backward) or NULL */
   const float* K_enc;         /* (n, 3, 3)   normalised intrinsics of the encoder view */
   const float* w2c_enc;       /* (n, 4, 4)   world -> encoder camera */
   const float* imgs_nhwc4;    /* (n, nv, H, W, 4), may be NULL iff nv == 0 */
@@ -85,7 +90,8 @@ typedef struct BtsRenderArgs {
   float* alphas;           /* (n*Bp, K)        or NULL */
   float* invalid;          /* (n*Bp, K, nv)    or NULL   1.0 = sample outside a frustum */
   float* rgb_samps;        /* (n*Bp, K, nv*3)  or NULL */
-  float* sigma_raw;        /* (n*Bp, K)        or NULL   pre-softplus MLP output, the only activation the backward keeps */
+  float* sigma_raw;        /* (n*Bp, K)        or NULL   pre-softplus MLP output  } the two per-sample activations the  */
+  float* trans;            /* (n*Bp, K)        or NULL   transmittance before sample } backward needs (8 B per sample)     */
 } BtsRenderArgs;
 
 /* Gradients flowing into / out of the renderer (what torch.autograd would compute through nerf.py:283-299,
@@ -95,9 +101,9 @@ typedef struct BtsRenderGrads {
   const float* g_depth;    /* (n*Bp)       or NULL */
   const float* g_weights;  /* (n*Bp, K)    or NULL */
   const float* g_alphas;   /* (n*Bp, K)    or NULL */
-  float* d_feat_nhwc;      /* (n, H, W, C)  ACCUMULATED into (caller zero-fills), or NULL to skip */
+  float* d_proj_nhwc;      /* (n, H, W, Hd) gradient w.r.t. proj_nhwc, ACCUMULATED into (caller zero-fills), or NULL to skip */
   float* d_mlp_params;     /* packed like mlp_params, ACCUMULATED into (caller zero-fills), or NULL to skip */
-  float* d_empty_feature;  /* (C) accumulated, or NULL */
+  float* d_empty_proj;     /* (Hd) gradient w.r.t. the PROJECTED empty feature (w_in[:, :C] . empty_feature), accumulated, or NULL */
 } BtsRenderGrads;
 
 int bts_abi_version(void);
@@ -118,6 +124,16 @@ int bts_render_fwd(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const BtsRe
 size_t bts_render_bwd_workspace(const BtsFieldCfg* cfg, const BtsRenderArgs* a);
 int bts_render_bwd(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const BtsRenderArgs* a, const BtsRenderGrads* g,
                    void* workspace, size_t workspace_bytes, void* stream);
+
+/* Hand-over from the (PyTorch) encoder, fused with the feature part of lin_in (resnetfc.py:147 restricted to the first C
+ * inputs): feat_nchw (N, C, H, W) -> proj_nhwc (N, H, W, Hd) = F . w_in[:, :C]^T.  Uses cfg->C, d_hidden, n_blocks, num_freqs. */
+int bts_project_features(const BtsFieldCfg* cfg, const float* feat_nchw, const float* mlp_params, int32_t N, float* proj_nhwc,
+                         void* stream);
+/* Its backward: d_feat_nchw (N, C, H, W) = d_proj . w_in[:, :C] (written, not accumulated; may be NULL) and
+ * d_mlp_params[w_in[:, :C]] += d_proj^T . F (accumulated; may be NULL).  empty_feature handling: d_empty_proj (Hd) is the
+ * gradient the render backward accumulated for the projected empty feature; d_empty_feature (C) += w_in[:, :C]^T d_empty_proj. */
+int bts_project_features_bwd(const BtsFieldCfg* cfg, const float* feat_nchw, const float* d_proj_nhwc, const float* mlp_params,
+                             int32_t N, float* d_feat_nchw, float* d_mlp_params, void* stream);
 
 /* BTSNet.forward on raw points (models_bts.py:266-338): xyz (n, P, 3) -> rgb (n, P, nv*3), invalid (n, P, max(nv,1)),
  * sigma (n, P).  only_density != 0 skips the colour taps: rgb may be NULL and invalid is (n, P, 1). */
