@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256, 1) void render_bwd_kernel(const BwdParams bp) 
     const bool capped = (p.hard_cap != 0) & last;
     const float alpha = capped ? 1.0f : 1.0f - ex;
     const float wgt = alpha * T;
-    float g_alpha = g_w * T - S / ((1.0f - alpha) + 1e-10f);
+    float g_alpha = g_w * T - S / (capped ? 1e-10f : ex + 1e-10f);  // 1 - alpha + 1e-10 with 1 - alpha = exp(-|delta| sigma) un-rounded
     if (bp.g_alphas && active) g_alpha += bp.g_alphas[ray * K + k];
     S = S + g_w * wgt;
     z_after = z;
@@ -192,8 +192,9 @@ __global__ __launch_bounds__(256, 1) void render_bwd_kernel(const BwdParams bp) 
       bcast_tiles(__float_as_uint(tp.w11), t0, t1), wq[0][3] = __uint_as_float(t0), wq[1][3] = __uint_as_float(t1);
       bcast_tiles(use_empty ? 1u : 0u, t0, t1), emp[0] = t0 != 0, emp[1] = t1 != 0;
       GBuf ga, gb;
-      gload<HD>(ga, G, o[0], h);
-      gather_seq<HD, 0>(acc, ga, gb, G, o, wq, emp, lds + L::EMPTY, h);
+      gload<HD>(ga, G, o[0], 0, 4 * h);
+      gather_seq<HD, 0>(acc, ga, gb, G, o, wq, h);
+      if (p.learn_empty && __any(use_empty)) apply_empty<HD>(acc, emp, lds + L::EMPTY, h);
     }
     // PE inputs of this lane's point -> LDS tile row (for the dW_pe contraction) and through the MFMAs
     float* my_pe = pe_tile + lane * L::LDX;
@@ -260,7 +261,8 @@ __global__ __launch_bounds__(256, 1) void render_bwd_kernel(const BwdParams bp) 
                 atomicAdd(&lds[L::D_EMPTY + hid], gh);
               } else {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) atomic_add_f32(dG + (long)o[pt][t] * HD + hid, wq[pt][t] * gh);
+                for (int t = 0; t < 4; ++t)
+                  atomic_add_f32(dG + (long)o[pt][t] * HD + ht * 32 + 16 * h + q, wq[pt][t] * gh);  // proj_storage_index(hid)
               }
             }
           }

@@ -167,6 +167,20 @@ __device__ __forceinline__ int xcd_remap(int b, int nwg) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
+// Channel order of the projected feature map G in HBM.  A lane of half h holds accumulator rows ht*32 + 8q + 4h + e (q, e = 0..3)
+// of a 32x32 MFMA tile; G stores those 16 values contiguously -- storage index ht*32 + 16h + 4q + e -- so that one lane reads ONE
+// 64-byte piece per tap and hidden tile, and the two lane halves together consume exactly one 128-byte line.
+__host__ __device__ constexpr int proj_storage_index(int hid) {
+  const int ht = hid >> 5, r = hid & 31;
+  const int q = r >> 3, h = (r >> 2) & 1, e = r & 3;
+  return ht * 32 + h * 16 + q * 4 + e;
+}
+__host__ __device__ constexpr int proj_hidden_of_storage(int s) {
+  const int ht = s >> 5, r = s & 31;
+  const int h = r >> 4, q = (r >> 2) & 3, e = r & 3;
+  return ht * 32 + 8 * q + 4 * h + e;
+}
+
 // packed MLP parameter offsets (see include/bts_render.h)
 struct MlpLayout {
   int d_in, hd, nb;

@@ -56,6 +56,9 @@ struct FwdParams {
   float* q_sigma;
   int only_density;
   int tiles_per_sample;
+  // lane = sample render kernel
+  int lpr;       // lanes per ray: 8, 16, 32 or 64 (>= min(K, 64)); 64 / lpr rays share one wave iteration
+  long groups;   // number of ray groups (= n * Bp * lpr / 64)
 };
 
 template <int C, int HD, int NB, bool PROJ>
@@ -119,58 +122,76 @@ __device__ __forceinline__ void stage_weights(float* lds, const float* __restric
 }
 
 // ---- projected features: gather G straight into the accumulator (C/D) layout --------------------------------------
-// Lane l holds rows ht*32 + 8q + 4(l>>5) + e (q = 0..3, e = 0..3) of the 32x32 tile for point (l & 31) of point tile pt:
-// four consecutive hidden units per q -> one float4 of the channels-last row of G.  A half-stage = (ht, q-pair) of one
-// point tile = 4 taps x 2 float4; the next half-stage's loads are issued before the current one is blended.
+// Lane l (half h = l >> 5) holds rows ht*32 + 8q + 4h + e (q, e = 0..3) of the 32x32 tile for point (l & 31) of point tile pt.
+// G is stored with those 16 values contiguous (proj_storage_index), so per (pt, ht, tap) a lane reads ONE 64-byte piece = 4 float4,
+// and lanes l / l+32 together consume one whole 128-byte line in the same instructions (no L1 re-fetch).  A stage = (pt, ht, tap
+// pair) = 8 float4; the next stage's loads are issued before the current one is blended (ATen's nw, ne, sw, se order is kept).
 struct GBuf {
-  float4 v[4][2];
+  float4 v[2][4];  // [tap in pair][q]
 };
 
 template <int HD>
-__device__ __forceinline__ void gload(GBuf& b, const float4* __restrict__ G, const int (&o)[4], int idx4) {
+__device__ __forceinline__ void gload(GBuf& b, const float4* __restrict__ G, const int (&o)[4], int tp2, int idx4) {
 #pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const float4* row = G + (long)o[t] * (HD / 4) + idx4;
-    b.v[t][0] = row[0];
-    b.v[t][1] = row[2];
+  for (int t = 0; t < 2; ++t) {
+    const float4* row = G + (long)o[2 * tp2 + t] * (HD / 4) + idx4;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) b.v[t][q] = row[q];
   }
 }
 
-__device__ __forceinline__ void gblend(f32x16& acc, int qp, const GBuf& b, const float (&w)[4], bool use_empty, const float* e8) {
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// blend two taps into 16 accumulator rows with packed FMAs (v_pk_fma_f32); tap order nw, ne | sw, se as in ATen
+template <bool FIRST>
+__device__ __forceinline__ void gblend(f32x16& acc, const GBuf& b, float w0, float w1) {
+  const f32x2 w0v = {w0, w0}, w1v = {w1, w1};
 #pragma unroll
-  for (int qq = 0; qq < 2; ++qq) {
-    const float* a = reinterpret_cast<const float*>(&b.v[0][qq]);
-    const float* bb = reinterpret_cast<const float*>(&b.v[1][qq]);
-    const float* c = reinterpret_cast<const float*>(&b.v[2][qq]);
-    const float* d = reinterpret_cast<const float*>(&b.v[3][qq]);
+  for (int q = 0; q < 4; ++q) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      float s = a[e] * w[0];
-      s = s + bb[e] * w[1];
-      s = s + c[e] * w[2];
-      s = s + d[e] * w[3];
-      if (use_empty) s = e8[8 * qq + e];
-      acc[4 * (2 * qp + qq) + e] = s;
+    for (int e = 0; e < 4; e += 2) {
+      const float* a = reinterpret_cast<const float*>(&b.v[0][q]) + e;
+      const float* c = reinterpret_cast<const float*>(&b.v[1][q]) + e;
+      const f32x2 av = {a[0], a[1]}, cv = {c[0], c[1]};
+      f32x2 s;
+      if constexpr (FIRST) s = av * w0v;
+      else s = __builtin_elementwise_fma(av, w0v, (f32x2){acc[4 * q + e], acc[4 * q + e + 1]});
+      s = __builtin_elementwise_fma(cv, w1v, s);
+      acc[4 * q + e] = s[0];
+      acc[4 * q + e + 1] = s[1];
     }
   }
 }
 
-// S-th half-stage of the gather sequence over (pt, ht, qp); buffers alternate
+// S-th stage of the gather sequence over (pt, ht, tap pair); buffers alternate
 template <int HD, int S>
 __device__ __forceinline__ void gather_seq(f32x16 (&acc)[HD / 32][2], GBuf& cur, GBuf& nxt, const float4* __restrict__ G,
-                                           const int (&o)[2][4], const float (&w)[2][4], const bool (&emp)[2], const float* lds_empty,
-                                           int h) {
+                                           const int (&o)[2][4], const float (&w)[2][4], int h) {
   constexpr int HT = HD / 32;
   constexpr int NS = 2 * HT * 2;
   if constexpr (S < NS) {
-    constexpr int pt = S / (2 * HT), ht = (S / 2) % HT, qp = S % 2;
+    constexpr int pt = S / (2 * HT), ht = (S / 2) % HT, tp2 = S % 2;
     if constexpr (S + 1 < NS) {
-      constexpr int pt1 = (S + 1) / (2 * HT), ht1 = ((S + 1) / 2) % HT, qp1 = (S + 1) % 2;
-      gload<HD>(nxt, G, o[pt1], ht1 * 8 + 4 * qp1 + h);
+      constexpr int pt1 = (S + 1) / (2 * HT), ht1 = ((S + 1) / 2) % HT, tp1 = (S + 1) % 2;
+      gload<HD>(nxt, G, o[pt1], tp1, ht1 * 8 + 4 * h);
     }
-    gblend(acc[ht][pt], qp, cur, w[pt], emp[pt], lds_empty + ht * 32 + 16 * qp + 4 * h);
-    gather_seq<HD, S + 1>(acc, nxt, cur, G, o, w, emp, lds_empty, h);
+    if constexpr (tp2 == 0) gblend<true>(acc[ht][pt], cur, w[pt][0], w[pt][1]);
+    else gblend<false>(acc[ht][pt], cur, w[pt][2], w[pt][3]);
+    gather_seq<HD, S + 1>(acc, nxt, cur, G, o, w, h);
   }
+}
+
+// learn_empty (models_bts.py:181-182): points outside the encoder frustum take the (projected) empty feature instead
+template <int HD>
+__device__ __forceinline__ void apply_empty(f32x16 (&acc)[HD / 32][2], const bool (&emp)[2], const float* lds_empty, int h) {
+#pragma unroll
+  for (int ht = 0; ht < HD / 32; ++ht)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const float ev = lds_empty[ht * 32 + mfma_row(q, 0) + 4 * h];
+#pragma unroll
+      for (int pt = 0; pt < 2; ++pt) acc[ht][pt][q] = emp[pt] ? ev : acc[ht][pt][q];
+    }
 }
 
 // value of this lane's ray (v) -> {value of ray (l & 31), value of ray 32 + (l & 31)} on every lane
@@ -250,14 +271,181 @@ __device__ __forceinline__ void feature_chunk(f32x16 (&acc)[HD / 32][2], const f
   for (int s = 0; s < 4; ++s) kstep<HD>(acc, wl + 2 * s * HD, 0, f[2 * s], f[2 * s + 1]);
 }
 
-// one PE octave: sin(f x), sin(f y), sin(f code), then the same with the fl32(pi/2) phase (code.py:25-28, 38)
+// sin and cos of one argument: 3-term FMA Cody-Waite reduction by pi/2 + minimax polynomials on [-pi/4, pi/4].
+// Max abs error 9.5e-8 for |arg| <= 1e5 (validated against fp64 on 4e7 PE arguments; libm sinf: 3.3e-8) at ~1/3 of ocml's
+// instruction count.  Larger arguments (points within 1e-3 of the encoder's camera plane) take the ocml path.
+__device__ __forceinline__ void sincos_small(float arg, float& s, float& c) {
+  const float j = rintf(arg * 0.63661977236758134308f);
+  float r = __builtin_fmaf(-j, 1.57079625129699707031f, arg);
+  r = __builtin_fmaf(-j, 7.54978941586159635335e-8f, r);
+  r = __builtin_fmaf(-j, 5.39030285815811e-15f, r);
+  const float r2 = r * r;
+  const float sp = __builtin_fmaf(r2, __builtin_fmaf(r2, __builtin_fmaf(r2, 2.6083159809786593541503e-06f, -1.981069071916863322258e-04f),
+                                                     8.333307858556509017944e-03f), -1.666666597127914428711e-01f);
+  const float sn = __builtin_fmaf(r * r2, sp, r);
+  const float cp = __builtin_fmaf(r2, __builtin_fmaf(r2, __builtin_fmaf(r2, 2.443315711809948e-5f, -1.388731625493765e-3f),
+                                                     4.166664568298827e-2f), -0.5f);
+  const float cs = __builtin_fmaf(r2, cp, 1.0f);
+  const int q = (int)j;
+  const float ss = (q & 1) ? cs : sn;
+  const float cc = (q & 1) ? sn : cs;
+  s = (q & 2) ? -ss : ss;
+  c = ((q + 1) & 2) ? -cc : cc;
+}
+
+// one PE octave: sin(f x), sin(f y), sin(f code), then the same with the fl32(pi/2) phase (code.py:25-28, 38).
+// The reference's "cos" entry is sin(fl(arg + P)), P = fl32(pi/2): with the exact rounding error e of that addition (TwoSum),
+// fl(arg + P) = arg + pi/2 + d, d = (P - pi/2) - e, so the entry equals cos(arg + d) = cos(arg) - d sin(arg) + O(d^2), |d| < 4e-6:
+// one sincos gives both entries with the reference's argument rounding reproduced (max deviation from it 1.2e-7).
 __device__ __forceinline__ void pe_octave(float (&o)[6], const float (&v)[3], float f) {
+  constexpr float P = 1.57079637050628662109375f;
+  float arg[3];
+  bool big = false;
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
-    const float arg = v[i] * f;
-    o[i] = sinf(arg);
-    o[3 + i] = sinf(arg + 1.57079637050628662109375f);
+    arg[i] = v[i] * f;
+    big |= !(fabsf(arg[i]) <= 1.0e5f);
   }
+  if (__builtin_expect(__any(big), 0)) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      o[i] = sinf(arg[i]);
+      o[3 + i] = sinf(arg[i] + P);
+    }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    float sn, cs;
+    sincos_small(arg[i], sn, cs);
+    const float sm = arg[i] + P;
+    const float bb = sm - arg[i];
+    const float err = (arg[i] - (sm - bb)) + (P - bb);   // arg + P = sm + err exactly
+    const float d = 4.371139000186241e-08f - err;        // (P - pi/2) - err
+    o[i] = sn;
+    o[3 + i] = __builtin_fmaf(-d, sn, cs);
+  }
+}
+
+// Everything between a world point and its pre-softplus density: projection into the encoder view, bilinear feature fetch,
+// positional encoding, lin_in (+ blocks) on MFMA, lin_out.  One lane = one point; all 64 lanes must be active (MFMA).
+template <int C, int HD, int NB, bool PROJ>
+__device__ __forceinline__ float eval_point(const FwdParams& p, const float* lds, const Cam& enc, const float4* __restrict__ featp,
+                                            int lane, float b_out, float px, float py, float pz, Proj& pe) {
+  using L = Lds<C, HD, NB, PROJ>;
+  constexpr int HT = HD / 32;
+  const int H = p.H, W = p.W;
+  const int lane_off = (lane >> 5) * HD + (lane & 31);
+  // ---------------- encoder view: projection, taps, depth code
+  pe = p.code_mode == 1 ? project<true>(enc, px, py, pz) : project<false>(enc, px, py, pz);
+  const Taps tp = make_taps(pe.x, pe.y, H, W);
+  float v3[3];
+  v3[0] = pe.x, v3[1] = pe.y;
+  v3[2] = depth_code(p.code_mode == 1 ? pe.dist : pe.z, p.inv_z != 0, p.inv_dmax, p.inv_range, p.d_min, p.range);
+  const bool use_empty = (p.learn_empty != 0) & pe.invalid;
+
+  f32x16 acc[HT][2];
+#pragma unroll
+  for (int ht = 0; ht < HT; ++ht)
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[ht][pt][q] = 0.0f;
+
+  const float* wl = lds + L::W_IN + lane_off;
+  if constexpr (PROJ) {
+    // ---------------- projected features: bilinear blend of G rows directly into the accumulators
+    int o[2][4];
+    float wq[2][4];
+    bool emp[2];
+    unsigned t0, t1;
+    bcast_tiles((unsigned)tp.o00, t0, t1), o[0][0] = (int)t0, o[1][0] = (int)t1;
+    bcast_tiles((unsigned)tp.o01, t0, t1), o[0][1] = (int)t0, o[1][1] = (int)t1;
+    bcast_tiles((unsigned)tp.o10, t0, t1), o[0][2] = (int)t0, o[1][2] = (int)t1;
+    bcast_tiles((unsigned)tp.o11, t0, t1), o[0][3] = (int)t0, o[1][3] = (int)t1;
+    bcast_tiles(__float_as_uint(tp.w00), t0, t1), wq[0][0] = __uint_as_float(t0), wq[1][0] = __uint_as_float(t1);
+    bcast_tiles(__float_as_uint(tp.w01), t0, t1), wq[0][1] = __uint_as_float(t0), wq[1][1] = __uint_as_float(t1);
+    bcast_tiles(__float_as_uint(tp.w10), t0, t1), wq[0][2] = __uint_as_float(t0), wq[1][2] = __uint_as_float(t1);
+    bcast_tiles(__float_as_uint(tp.w11), t0, t1), wq[0][3] = __uint_as_float(t0), wq[1][3] = __uint_as_float(t1);
+    bcast_tiles(use_empty ? 1u : 0u, t0, t1), emp[0] = t0 != 0, emp[1] = t1 != 0;
+    GBuf ga, gb;
+    gload<HD>(ga, featp, o[0], 0, 4 * (lane >> 5));
+    gather_seq<HD, 0>(acc, ga, gb, featp, o, wq, lane >> 5);
+    if (p.learn_empty && __any(use_empty)) apply_empty<HD>(acc, emp, lds + L::EMPTY, lane >> 5);
+  } else {
+  // ---------------- features: 8 channels per chunk; rolled ping-pong loop, the next chunk's 8 float4 loads are in
+  // flight while this chunk's 16 MFMAs run (a fully unrolled loop lets the scheduler hoist all 64 loads and spill)
+  const float4* t00 = featp + (long)tp.o00 * (C / 4);
+  const float4* t01 = featp + (long)tp.o01 * (C / 4);
+  const float4* t10 = featp + (long)tp.o10 * (C / 4);
+  const float4* t11 = featp + (long)tp.o11 * (C / 4);
+  float4 bufA[4][2], bufB[4][2];
+  load_chunk(bufA, t00, t01, t10, t11, 0);
+  const float* empty = lds + L::EMPTY;
+#pragma unroll 1
+  for (int c = 0; c < C / 8; c += 2) {
+    load_chunk(bufB, t00, t01, t10, t11, c + 1);
+    feature_chunk<HD>(acc, bufA, tp, p.learn_empty != 0, use_empty, empty + c * 8, wl + c * 8 * HD);
+    if (c + 2 < C / 8) load_chunk(bufA, t00, t01, t10, t11, c + 2);
+    feature_chunk<HD>(acc, bufB, tp, p.learn_empty != 0, use_empty, empty + (c + 1) * 8, wl + (c + 1) * 8 * HD);
+  }
+    wl += C * HD;
+  }
+  // ---------------- positional encoding (+ bias row): [x, y] [code, 1] then 3 k-pairs per octave, sines of the next
+  // octave computed while the current octave's MFMAs run
+  kstep<HD>(acc, wl, 0, v3[0], v3[1]);
+  kstep<HD>(acc, wl + 2 * HD, 0, v3[2], 1.0f);
+  wl += 4 * HD;
+  float sc[6], sn[6];
+  pe_octave(sc, v3, p.freq_factor);
+  float ff = p.freq_factor;
+#pragma unroll 1
+  for (int oct = 0; oct < kNumFreqs; ++oct) {
+    ff = ff * 2.0f;
+    if (oct + 1 < kNumFreqs) pe_octave(sn, v3, ff);
+    kstep<HD>(acc, wl, 0, sc[0], sc[1]);
+    kstep<HD>(acc, wl + 2 * HD, 0, sc[2], sc[3]);
+    kstep<HD>(acc, wl + 4 * HD, 0, sc[4], sc[5]);
+    wl += 6 * HD;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) sc[i] = sn[i];
+  }
+
+  // ---------------- ResnetBlockFC layers: h = h + fc_1(relu(fc_0(relu(h))))   (resnetfc.py:53-62)
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const float* base = lds + L::BLK + b * L::BLK_STRIDE;
+    f32x16 net[HT][2];
+#pragma unroll
+    for (int ot = 0; ot < HT; ++ot)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const float bias = base[HD * HD + ot * 32 + mfma_row(q, 0) + 4 * (lane >> 5)];
+        net[ot][0][q] = bias, net[ot][1][q] = bias;
+      }
+    hidden_layer<HD>(net, acc, base, lane);
+#pragma unroll
+    for (int ot = 0; ot < HT; ++ot)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const float bias = base[2 * HD * HD + HD + ot * 32 + mfma_row(q, 0) + 4 * (lane >> 5)];
+        acc[ot][0][q] += bias, acc[ot][1][q] += bias;
+      }
+    hidden_layer<HD>(acc, net, base + HD * HD + HD, lane);
+  }
+
+  // ---------------- lin_out: in-lane dot over the hidden rows this lane holds, then fold the two lane halves
+  float p0 = 0.0f, p1 = 0.0f;
+#pragma unroll
+  for (int ht = 0; ht < HT; ++ht)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const float w2 = lds[L::W_OUT + ht * 32 + mfma_row(q, 0) + 4 * (lane >> 5)];
+      p0 = __builtin_fmaf(fmaxf(acc[ht][0][q], 0.0f), w2, p0);
+      p1 = __builtin_fmaf(fmaxf(acc[ht][1][q], 0.0f), w2, p1);
+    }
+  swap32(p0, p1);  // p0 = {tile0.lo, tile1.lo}, p1 = {tile0.hi, tile1.hi}: lane l now holds both halves of ITS ray
+  return (p0 + p1) + b_out;
 }
 
 template <int C, int HD, int NB, int NVMAX, bool QUERY, bool PROJ>
@@ -317,115 +505,8 @@ __global__ __launch_bounds__(256, 2) void field_kernel(const FwdParams p) {
     const float py = QUERY ? oy : oy + z * dy;
     const float pz = QUERY ? oz : oz + z * dz;
 
-    // ---------------- encoder view: projection, taps, depth code
-    const Proj pe = p.code_mode == 1 ? project<true>(enc, px, py, pz) : project<false>(enc, px, py, pz);
-    const Taps tp = make_taps(pe.x, pe.y, H, W);
-    float v3[3];
-    v3[0] = pe.x, v3[1] = pe.y;
-    v3[2] = depth_code(p.code_mode == 1 ? pe.dist : pe.z, p.inv_z != 0, p.inv_dmax, p.inv_range, p.d_min, p.range);
-    const bool use_empty = (p.learn_empty != 0) & pe.invalid;
-
-    f32x16 acc[HT][2];
-#pragma unroll
-    for (int ht = 0; ht < HT; ++ht)
-#pragma unroll
-      for (int pt = 0; pt < 2; ++pt)
-#pragma unroll
-        for (int q = 0; q < 16; ++q) acc[ht][pt][q] = 0.0f;
-
-    const float* wl = lds + L::W_IN + lane_off;
-    if constexpr (PROJ) {
-      // ---------------- projected features: bilinear blend of G rows directly into the accumulators
-      int o[2][4];
-      float wq[2][4];
-      bool emp[2];
-      unsigned t0, t1;
-      bcast_tiles((unsigned)tp.o00, t0, t1), o[0][0] = (int)t0, o[1][0] = (int)t1;
-      bcast_tiles((unsigned)tp.o01, t0, t1), o[0][1] = (int)t0, o[1][1] = (int)t1;
-      bcast_tiles((unsigned)tp.o10, t0, t1), o[0][2] = (int)t0, o[1][2] = (int)t1;
-      bcast_tiles((unsigned)tp.o11, t0, t1), o[0][3] = (int)t0, o[1][3] = (int)t1;
-      bcast_tiles(__float_as_uint(tp.w00), t0, t1), wq[0][0] = __uint_as_float(t0), wq[1][0] = __uint_as_float(t1);
-      bcast_tiles(__float_as_uint(tp.w01), t0, t1), wq[0][1] = __uint_as_float(t0), wq[1][1] = __uint_as_float(t1);
-      bcast_tiles(__float_as_uint(tp.w10), t0, t1), wq[0][2] = __uint_as_float(t0), wq[1][2] = __uint_as_float(t1);
-      bcast_tiles(__float_as_uint(tp.w11), t0, t1), wq[0][3] = __uint_as_float(t0), wq[1][3] = __uint_as_float(t1);
-      bcast_tiles(use_empty ? 1u : 0u, t0, t1), emp[0] = t0 != 0, emp[1] = t1 != 0;
-      GBuf ga, gb;
-      gload<HD>(ga, featp, o[0], lane >> 5);
-      gather_seq<HD, 0>(acc, ga, gb, featp, o, wq, emp, lds + L::EMPTY, lane >> 5);
-    } else {
-    // ---------------- features: 8 channels per chunk; rolled ping-pong loop, the next chunk's 8 float4 loads are in
-    // flight while this chunk's 16 MFMAs run (a fully unrolled loop lets the scheduler hoist all 64 loads and spill)
-    const float4* t00 = featp + (long)tp.o00 * (C / 4);
-    const float4* t01 = featp + (long)tp.o01 * (C / 4);
-    const float4* t10 = featp + (long)tp.o10 * (C / 4);
-    const float4* t11 = featp + (long)tp.o11 * (C / 4);
-    float4 bufA[4][2], bufB[4][2];
-    load_chunk(bufA, t00, t01, t10, t11, 0);
-    const float* empty = lds + L::EMPTY;
-#pragma unroll 1
-    for (int c = 0; c < C / 8; c += 2) {
-      load_chunk(bufB, t00, t01, t10, t11, c + 1);
-      feature_chunk<HD>(acc, bufA, tp, p.learn_empty != 0, use_empty, empty + c * 8, wl + c * 8 * HD);
-      if (c + 2 < C / 8) load_chunk(bufA, t00, t01, t10, t11, c + 2);
-      feature_chunk<HD>(acc, bufB, tp, p.learn_empty != 0, use_empty, empty + (c + 1) * 8, wl + (c + 1) * 8 * HD);
-    }
-      wl += C * HD;
-    }
-    // ---------------- positional encoding (+ bias row): [x, y] [code, 1] then 3 k-pairs per octave, sines of the next
-    // octave computed while the current octave's MFMAs run
-    kstep<HD>(acc, wl, 0, v3[0], v3[1]);
-    kstep<HD>(acc, wl + 2 * HD, 0, v3[2], 1.0f);
-    wl += 4 * HD;
-    float sc[6], sn[6];
-    pe_octave(sc, v3, p.freq_factor);
-    float ff = p.freq_factor;
-#pragma unroll 1
-    for (int oct = 0; oct < kNumFreqs; ++oct) {
-      ff = ff * 2.0f;
-      if (oct + 1 < kNumFreqs) pe_octave(sn, v3, ff);
-      kstep<HD>(acc, wl, 0, sc[0], sc[1]);
-      kstep<HD>(acc, wl + 2 * HD, 0, sc[2], sc[3]);
-      kstep<HD>(acc, wl + 4 * HD, 0, sc[4], sc[5]);
-      wl += 6 * HD;
-#pragma unroll
-      for (int i = 0; i < 6; ++i) sc[i] = sn[i];
-    }
-
-    // ---------------- ResnetBlockFC layers: h = h + fc_1(relu(fc_0(relu(h))))   (resnetfc.py:53-62)
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-      const float* base = lds + L::BLK + b * L::BLK_STRIDE;
-      f32x16 net[HT][2];
-#pragma unroll
-      for (int ot = 0; ot < HT; ++ot)
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          const float bias = base[HD * HD + ot * 32 + mfma_row(q, 0) + 4 * (lane >> 5)];
-          net[ot][0][q] = bias, net[ot][1][q] = bias;
-        }
-      hidden_layer<HD>(net, acc, base, lane);
-#pragma unroll
-      for (int ot = 0; ot < HT; ++ot)
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          const float bias = base[2 * HD * HD + HD + ot * 32 + mfma_row(q, 0) + 4 * (lane >> 5)];
-          acc[ot][0][q] += bias, acc[ot][1][q] += bias;
-        }
-      hidden_layer<HD>(acc, net, base + HD * HD + HD, lane);
-    }
-
-    // ---------------- lin_out: in-lane dot over the hidden rows this lane holds, then fold the two lane halves
-    float p0 = 0.0f, p1 = 0.0f;
-#pragma unroll
-    for (int ht = 0; ht < HT; ++ht)
-#pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const float w2 = lds[L::W_OUT + ht * 32 + mfma_row(q, 0) + 4 * (lane >> 5)];
-        p0 = __builtin_fmaf(fmaxf(acc[ht][0][q], 0.0f), w2, p0);
-        p1 = __builtin_fmaf(fmaxf(acc[ht][1][q], 0.0f), w2, p1);
-      }
-    swap32(p0, p1);  // p0 = {tile0.lo, tile1.lo}, p1 = {tile0.hi, tile1.hi}: lane l now holds both halves of ITS ray
-    const float s_raw = (p0 + p1) + b_out;
+    Proj pe;
+    const float s_raw = eval_point<C, HD, NB, PROJ>(p, lds, enc, featp, lane, b_out, px, py, pz, pe);
     float sigma = softplus(s_raw);
     if (p.empty_empty) sigma = pe.invalid ? 0.0f : sigma;
 
@@ -519,6 +600,144 @@ __global__ __launch_bounds__(256, 2) void field_kernel(const FwdParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// The render kernel: lane = SAMPLE.  A wave takes one ray (or 64/lpr short rays) per iteration and evaluates its K samples at
+// once: z / weights / alphas / invalid rows are read and written as contiguous rows, all samples of a ray that originates at the
+// encoder camera hit the SAME four texels (one broadcast load instead of 64 gathers), and the waves resident at any moment work
+// on consecutive rays, so their texel footprints overlap in L1/L2 instead of evicting each other (with lane = ray every sample
+// step of every resident wave re-touched ~1 KB per ray: 19 % L2 hit rate, >100x the compulsory HBM/MALL traffic).
+// Alpha compositing is a segmented prefix product / sum over the lanes of a ray.
+// ---------------------------------------------------------------------------------------------------------------
+template <int C, int HD, int NB, int NVMAX, bool PROJ>
+__global__ __launch_bounds__(256, 2) void render_kernel(const FwdParams p) {
+  using L = Lds<C, HD, NB, PROJ>;
+  __shared__ float lds[L::TOTAL];
+  stage_weights<C, HD, NB, PROJ>(lds, p.mlp, p.empty_feature);
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int nwg = gridDim.x;  // multiple of 8
+  const int wg = xcd_remap(blockIdx.x, nwg);
+  const int wg_per_xcd = nwg >> 3;
+  const int xcd = wg / wg_per_xcd;
+  const int lw = (wg - xcd * wg_per_xcd) * 4 + wave;  // wave index inside its XCD
+  const int waves_per_xcd = wg_per_xcd * 4;
+  const int lpr = p.lpr, R = 64 / lpr;
+  const int kl = lane & (lpr - 1);
+  const long gx = (p.groups + 7) >> 3;
+  const long g_end = min(p.groups, (xcd + 1) * gx);
+  const int Bp = p.Bp, K = p.K, H = p.H, W = p.W, nv = p.nv;
+  const float b_out = p.mlp[MlpLayout{C + kPeDim, HD, NB}.b_out()];
+
+  for (long g = xcd * gx + lw; g < g_end; g += waves_per_xcd) {
+    const long ray = g * R + lane / lpr;
+    const int sample = __builtin_amdgcn_readfirstlane((int)((g * R) / Bp));  // all rays of a group belong to one batch element
+    const Cam enc = load_cam(p.w2c_enc + sample * 16, p.K_enc + sample * 9);
+    const float4* __restrict__ featp =
+        PROJ ? reinterpret_cast<const float4*>(p.proj) + (long)sample * H * W * (HD / 4)
+             : reinterpret_cast<const float4*>(p.feat) + (long)sample * H * W * (C / 4);
+    const float4 r0 = reinterpret_cast<const float4*>(p.rays)[ray * 2];
+    const float4 r1 = reinterpret_cast<const float4*>(p.rays)[ray * 2 + 1];
+    const float ox = r0.x, oy = r0.y, oz = r0.z, dx = r0.w, dy = r1.x, dz = r1.y;
+    const float* zrow = p.z_samp + ray * K;
+
+    float T_carry = 1.0f, depth_part = 0.0f, w_part = 0.0f;
+    float rgb_part[NVMAX * 3];
+#pragma unroll
+    for (int i = 0; i < NVMAX * 3; ++i) rgb_part[i] = 0.0f;
+
+    for (int kc = 0; kc < K; kc += 64) {
+      const int k = kc + kl;
+      const bool valid = k < K;
+      const int kk = valid ? k : K - 1;
+      const float z = zrow[kk];
+      const float z_nx = zrow[min(kk + 1, K - 1)];
+      // nerf.py:231  points = o + z * d   (mul, then add)
+      const float px = ox + z * dx, py = oy + z * dy, pz = oz + z * dz;
+      Proj pe;
+      const float s_raw = eval_point<C, HD, NB, PROJ>(p, lds, enc, featp, lane, b_out, px, py, pz, pe);
+      float sigma = softplus(s_raw);
+      if (p.empty_empty) sigma = pe.invalid ? 0.0f : sigma;
+
+      // ---------------- colour taps (models_bts.py:218-264)
+      float col[NVMAX * 3];
+      bool inv[NVMAX];
+#pragma unroll
+      for (int j = 0; j < NVMAX; ++j) {
+        col[3 * j] = col[3 * j + 1] = col[3 * j + 2] = 0.0f;
+        inv[j] = pe.invalid;
+        if (j < nv) {
+          const Cam cj = load_cam(p.w2c_r + ((long)sample * nv + j) * 16, p.K_r + ((long)sample * nv + j) * 9);
+          const Proj pc = project<false>(cj, px, py, pz);
+          const Taps tc = make_taps(pc.x, pc.y, H, W);
+          const float4* img = reinterpret_cast<const float4*>(p.imgs) + ((long)sample * nv + j) * H * W;
+          const float4 a = img[tc.o00], b = img[tc.o01], cc = img[tc.o10], d = img[tc.o11];
+          col[3 * j + 0] = ((a.x * tc.w00 + b.x * tc.w01) + cc.x * tc.w10) + d.x * tc.w11;
+          col[3 * j + 1] = ((a.y * tc.w00 + b.y * tc.w01) + cc.y * tc.w10) + d.y * tc.w11;
+          col[3 * j + 2] = ((a.z * tc.w00 + b.z * tc.w01) + cc.z * tc.w10) + d.z * tc.w11;
+          inv[j] = pc.invalid | pe.invalid;
+        }
+      }
+
+      // ---------------- alpha compositing (nerf.py:225-299) as a segmented scan over the lanes of each ray
+      const float delta = (k + 1 < K) ? (z_nx - z) : 1e10f;
+      float alpha = 1.0f - expf(-fabsf(delta) * fmaxf(sigma, 0.0f));
+      if (p.hard_cap && k == K - 1) alpha = 1.0f;
+      const float t = valid ? (1.0f - alpha) + 1e-10f : 1.0f;
+      float incl = t;  // inclusive prefix product of t over the ray's lanes
+      for (int d = 1; d < lpr; d <<= 1) {
+        const float y = __shfl_up(incl, d, lpr);
+        if (kl >= d) incl *= y;
+      }
+      float excl = __shfl_up(incl, 1, lpr);
+      if (kl == 0) excl = 1.0f;
+      const float T = T_carry * excl;
+      T_carry = T_carry * __shfl(incl, lpr - 1, lpr);
+      const float wgt = valid ? alpha * T : 0.0f;
+      depth_part = depth_part + wgt * z;
+      w_part = w_part + wgt;
+#pragma unroll
+      for (int i = 0; i < NVMAX * 3; ++i) rgb_part[i] = rgb_part[i] + wgt * col[i];
+      if (valid) {
+        const long pk = ray * K + k;
+        if (p.weights) p.weights[pk] = wgt;
+        if (p.alphas) p.alphas[pk] = alpha;
+        if (p.sigma_raw) p.sigma_raw[pk] = s_raw;
+        if (p.trans) p.trans[pk] = T;
+        if (p.invalid) {
+#pragma unroll
+          for (int j = 0; j < NVMAX; ++j)
+            if (j < nv) p.invalid[pk * nv + j] = inv[j] ? 1.0f : 0.0f;
+        }
+        if (p.rgb_samps) {
+#pragma unroll
+          for (int j = 0; j < NVMAX; ++j)
+            if (j < nv) {
+              p.rgb_samps[(pk * nv + j) * 3 + 0] = col[3 * j + 0];
+              p.rgb_samps[(pk * nv + j) * 3 + 1] = col[3 * j + 1];
+              p.rgb_samps[(pk * nv + j) * 3 + 2] = col[3 * j + 2];
+            }
+        }
+      }
+    }
+    // ---------------- per-ray sums over the lanes of the ray
+    for (int d = lpr >> 1; d >= 1; d >>= 1) {
+      depth_part += __shfl_xor(depth_part, d, lpr);
+      w_part += __shfl_xor(w_part, d, lpr);
+#pragma unroll
+      for (int i = 0; i < NVMAX * 3; ++i)
+        if (i < nv * 3) rgb_part[i] += __shfl_xor(rgb_part[i], d, lpr);
+    }
+    if (kl == 0) {
+      p.depth[ray] = depth_part;
+#pragma unroll
+      for (int i = 0; i < NVMAX * 3; ++i)
+        if (i < nv * 3) p.rgb[ray * nv * 3 + i] = p.white_bkgd ? (rgb_part[i] + 1.0f) - w_part : rgb_part[i];  // nerf.py:301-304
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // launch dispatch (instantiated per translation unit for one value of PROJ)
 // ---------------------------------------------------------------------------------------------------------------
 void set_error(const char* fmt, const char* a = "", long b = 0, long c = 0, long d = 0);
@@ -535,6 +754,29 @@ static int launch_nv(const FwdParams& p, int grid, hipStream_t s) {
     return BTS_E_LAUNCH;
   }
   return BTS_OK;
+}
+
+template <int C, int HD, int NB, bool PROJ>
+static int launch_render_nv(const FwdParams& p, int grid, hipStream_t s) {
+  if (p.nv <= 1) render_kernel<C, HD, NB, 1, PROJ><<<grid, 256, 0, s>>>(p);
+  else if (p.nv <= 2) render_kernel<C, HD, NB, 2, PROJ><<<grid, 256, 0, s>>>(p);
+  else if (p.nv <= 4) render_kernel<C, HD, NB, 4, PROJ><<<grid, 256, 0, s>>>(p);
+  else render_kernel<C, HD, NB, 8, PROJ><<<grid, 256, 0, s>>>(p);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: kernel launch failed (%ld)", hipGetErrorString(e), (long)e);
+    return BTS_E_LAUNCH;
+  }
+  return BTS_OK;
+}
+
+template <bool PROJ>
+int launch_render(const FwdParams& p, int C, int HD, int NB, int grid, hipStream_t s) {
+  if (C == 64 && HD == 64 && NB == 0) return launch_render_nv<64, 64, 0, PROJ>(p, grid, s);
+  if (C == 32 && HD == 32 && NB == 1) return launch_render_nv<32, 32, 1, PROJ>(p, grid, s);
+  if (C == 32 && HD == 32 && NB == 0) return launch_render_nv<32, 32, 0, PROJ>(p, grid, s);
+  set_error("%s: unsupported MLP shape C=%ld d_hidden=%ld n_blocks=%ld", "bts", C, HD, NB);
+  return BTS_E_UNSUPPORTED;
 }
 
 template <bool QUERY, bool PROJ>

@@ -1,6 +1,8 @@
 // Host side of the fused forward + the PROJ = false instantiations (raw channels-last features).
 #include "bts_field_kernel.h"
 
+#include <cstdlib>
+
 namespace bts {
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -20,6 +22,8 @@ template int launch_field<false, false>(const FwdParams&, int, int, int, int, hi
 template int launch_field<true, false>(const FwdParams&, int, int, int, int, hipStream_t);
 extern template int launch_field<false, true>(const FwdParams&, int, int, int, int, hipStream_t);
 extern template int launch_field<true, true>(const FwdParams&, int, int, int, int, hipStream_t);
+template int launch_render<false>(const FwdParams&, int, int, int, int, hipStream_t);
+extern template int launch_render<true>(const FwdParams&, int, int, int, int, hipStream_t);
 
 FwdParams make_params(const BtsFieldCfg* cfg, const BtsFieldTensors* t) {
   FwdParams p;
@@ -37,6 +41,26 @@ FwdParams make_params(const BtsFieldCfg* cfg, const BtsFieldTensors* t) {
   return p;
 }
 
+// lanes per ray / ray groups of the lane = sample kernels: short rays (K <= 32) share a wave iteration when the per-sample ray
+// count allows whole groups
+void render_geometry(FwdParams& p, int n) {
+  int lpr = 64;
+  if (p.K <= 32) {
+    lpr = p.K <= 8 ? 8 : (p.K <= 16 ? 16 : 32);
+    if (p.Bp % (64 / lpr) != 0) lpr = 64;
+  }
+  p.lpr = lpr;
+  p.groups = (long)n * p.Bp / (64 / lpr);
+}
+
+// persistent grid: 2 work-groups (8 waves) per CU, multiple of 8 so that every XCD owns an equal contiguous share of the rays
+int render_grid(const FwdParams& p) {
+  const long want = (p.groups + 3) / 4;
+  long g = want < 512 ? want : 512;
+  g = (g + 7) / 8 * 8;
+  return (int)g;
+}
+
 int render_fwd_impl(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const BtsRenderArgs* a, hipStream_t s) {
   FwdParams p = make_params(cfg, t);
   p.rays = a->rays, p.z_samp = a->z_samp;
@@ -44,8 +68,14 @@ int render_fwd_impl(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const BtsR
   p.rgb = a->rgb, p.depth = a->depth, p.weights = a->weights, p.alphas = a->alphas, p.invalid = a->invalid;
   p.rgb_samps = a->rgb_samps, p.sigma_raw = a->sigma_raw, p.trans = a->trans;
   p.tiles_per_sample = (a->rays_per_sample + 255) / 256;
-  if (p.proj) return launch_field<false, true>(p, cfg->C, cfg->d_hidden, cfg->n_blocks, p.tiles_per_sample * cfg->n, s);
-  return launch_field<false, false>(p, cfg->C, cfg->d_hidden, cfg->n_blocks, p.tiles_per_sample * cfg->n, s);
+  if (getenv("BTS_LANE_IS_RAY")) {  // previous mapping (one lane = one ray), kept for A/B measurements
+    if (p.proj) return launch_field<false, true>(p, cfg->C, cfg->d_hidden, cfg->n_blocks, p.tiles_per_sample * cfg->n, s);
+    return launch_field<false, false>(p, cfg->C, cfg->d_hidden, cfg->n_blocks, p.tiles_per_sample * cfg->n, s);
+  }
+  render_geometry(p, cfg->n);
+  const int grid = render_grid(p);
+  if (p.proj) return launch_render<true>(p, cfg->C, cfg->d_hidden, cfg->n_blocks, grid, s);
+  return launch_render<false>(p, cfg->C, cfg->d_hidden, cfg->n_blocks, grid, s);
 }
 
 int field_query_impl(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const float* xyz, int P, int only_density, float* rgb,

@@ -4,4 +4,5 @@
 namespace bts {
 template int launch_field<false, true>(const FwdParams&, int, int, int, int, hipStream_t);
 template int launch_field<true, true>(const FwdParams&, int, int, int, int, hipStream_t);
+template int launch_render<true>(const FwdParams&, int, int, int, int, hipStream_t);
 }  // namespace bts

@@ -21,10 +21,10 @@ __global__ __launch_bounds__(256) void project_kernel(const float* __restrict__ 
                                                       int HW, int tiles_per_img) {
   constexpr int HT = HD / 32;
   constexpr int D_IN = C + kPeDim;
-  __shared__ float wl[C * HD];  // wl[c*HD + hid] = w_in[hid][c]
+  __shared__ float wl[C * HD];  // wl[c*HD + s] = w_in[hidden_of_storage(s)][c]: G comes out in its storage channel order
   for (int i = threadIdx.x; i < C * HD; i += blockDim.x) {
-    const int c = i / HD, hid = i % HD;
-    wl[i] = mlp[hid * D_IN + c];
+    const int c = i / HD, st = i % HD;
+    wl[i] = mlp[proj_hidden_of_storage(st) * D_IN + c];
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -100,14 +100,16 @@ __global__ __launch_bounds__(256) void project_bwd_feat_kernel(const float* __re
       for (int q = 0; q < 16; ++q) acc[ct][pt][q] = 0.0f;
   const int px0 = min(p0 + col, HW - 1), px1 = min(p0 + 32 + col, HW - 1);
 #pragma unroll 2
-  for (int q = 0; q < HD / 8; ++q) {
-    const float4 v0 = dG[(long)px0 * (HD / 4) + 2 * q + h];
-    const float4 v1 = dG[(long)px1 * (HD / 4) + 2 * q + h];
+  for (int qq = 0; qq < HD / 8; ++qq) {
+    // storage float4 (ht*8 + 4h + q) holds hidden ht*32 + 8q + 4h + e, e = 0..3  (proj_storage_index)
+    const int ht = qq >> 2, q = qq & 3;
+    const float4 v0 = dG[(long)px0 * (HD / 4) + ht * 8 + 4 * h + q];
+    const float4 v1 = dG[(long)px1 * (HD / 4) + ht * 8 + 4 * h + q];
     const float* b0 = reinterpret_cast<const float*>(&v0);
     const float* b1 = reinterpret_cast<const float*>(&v1);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const int hid = 8 * q + 4 * h + e;
+      const int hid = ht * 32 + 8 * q + 4 * h + e;
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct) {
         const float a = wl[hid * C + ct * 32 + col];
@@ -162,7 +164,7 @@ __global__ __launch_bounds__(256) void project_bwd_weight_kernel(const float* __
       const int pc = ok ? pix : HW - 1;
       float a[HT], b[CT];
 #pragma unroll
-      for (int ht = 0; ht < HT; ++ht) a[ht] = ok ? dG[(long)pc * HD + ht * 32 + col] : 0.0f;
+      for (int ht = 0; ht < HT; ++ht) a[ht] = ok ? dG[(long)pc * HD + proj_storage_index(ht * 32 + col)] : 0.0f;
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct) b[ct] = F[(long)(ct * 32 + col) * HW + pc];
 #pragma unroll

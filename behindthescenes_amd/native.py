@@ -134,8 +134,18 @@ def _spec_cfg(spec: FieldSpec, n=1, H=1, W=1, nv=0) -> BtsFieldCfg:
                        empty_empty=int(spec.empty_empty), freq_factor=spec.freq_factor, d_min=spec.d_min, d_max=spec.d_max)
 
 
+def proj_storage_order(d_hidden: int) -> torch.Tensor:
+    """order[s] = hidden unit stored at channel s of proj_nhwc (bts_common.h: proj_hidden_of_storage): within each group of 32
+    hidden units the renderer keeps the 16 accumulator rows of one lane half contiguous."""
+    s = torch.arange(d_hidden)
+    ht, r = s // 32, s % 32
+    h, q, e = r // 16, (r // 4) % 4, r % 4
+    return ht * 32 + 8 * q + 4 * h + e
+
+
 def project_features(spec: FieldSpec, feat_nchw: torch.Tensor, mlp_params: torch.Tensor) -> torch.Tensor:
-    """F (N,C,H,W) -> G (N,H,W,Hd) = F . w_in[:, :C]^T  (bts_project_features)."""
+    """F (N,C,H,W) -> G (N,H,W,Hd) = F . w_in[:, :C]^T with the channels in storage order (proj_storage_order)
+    (bts_project_features)."""
     N, Cc, H, W = feat_nchw.shape
     _req(feat_nchw, "feat_nchw", (N, spec.C, H, W)), _req(mlp_params, "mlp_params", (spec.mlp_param_count(),))
     out = torch.empty((N, H, W, spec.d_hidden), device=feat_nchw.device, dtype=torch.float32)

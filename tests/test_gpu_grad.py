@@ -55,7 +55,17 @@ def test_gradients_vs_reference_golden(hip):
         assert _rel_to_max(g, c.t[nme].view_as(g.cpu())) <= GRAD_RTOL, (nme, _rel_to_max(g, c.t[nme].view_as(g.cpu())))
 
 
-def _oracle_grads(scene, mlp, cfg, ids_render, rays, z, n, hard_cap, loss_fn, empty=None):
+def _oracle_grads(scene, mlp, cfg, ids_render, rays, z, n, hard_cap, loss_fn, empty=None, dtype=torch.float32):
+    if dtype == torch.float64:   # fp64 evaluation of the same formulas: the arbiter
+        torch.set_default_dtype(torch.float64)
+        try:
+            scene64 = {k: v.double() for k, v in scene.items()}
+            mlp64 = O.MlpParams(mlp.w_in.double(), mlp.b_in.double(), [tuple(t.double() for t in b) for b in mlp.blocks],
+                                mlp.w_out.double(), mlp.b_out.double())
+            return _oracle_grads(scene64, mlp64, cfg, ids_render, rays.double(), z.double(), n, hard_cap, loss_fn,
+                                 None if empty is None else empty.double(), dtype=None)
+        finally:
+            torch.set_default_dtype(torch.float32)
     params = [t.clone().requires_grad_(True) for t in mlp.tensors()]
     feat = scene["feat"].clone().requires_grad_(True)
     nb = len(mlp.blocks)
@@ -96,17 +106,28 @@ def test_gradients_vs_oracle_autograd(hip, learn_empty):
     c_w = torch.randn(n * 700, K, generator=g) * 0.1
 
     def loss_fn(w, rgb, depth, a):
-        dev = rgb.device
-        return (rgb * c_rgb.to(dev)).sum() + 0.05 * depth.sum() + (w * c_w.to(dev)).sum() + 0.01 * (a ** 2).sum()
+        dev, dt = rgb.device, rgb.dtype
+        return (rgb * c_rgb.to(dev, dt)).sum() + 0.05 * depth.sum() + (w * c_w.to(dev, dt)).sum() + 0.01 * (a ** 2).sum()
 
     ref = _oracle_grads(scene, mlp, cfg, [1, 2, 3, 4], rays, z, n, True, loss_fn, empty)
+    truth = _oracle_grads(scene, mlp, cfg, [1, 2, 3, 4], rays, z, n, True, loss_fn, empty, dtype=torch.float64)
     net = build_net(cfg, mlp, scene, [1, 2, 3, 4], empty_feature=empty, train=True)
     renderer = hip.NeRFRenderer(n_coarse=K, lindisp=True, hard_alpha_cap=True).cuda()
     ours = _hip_grads(hip, net, renderer, rays.reshape(-1, 8).cuda(), z.cuda(), n, loss_fn)
     names = ["w_in", "b_in", "w_out", "b_out", "feat"] + (["empty_feature"] if learn_empty else [])
-    for a, b, nme in zip(ours, ref, names):
+    # Weight gradients are sums over ~10^5 samples x 64 hidden units of terms gated by relu'(h): where |h| is within rounding of 0
+    # two fp32 evaluations gate differently, and one flipped term moves one gradient entry by ~1e-4 of the largest entry (measured:
+    # the fp32 oracle itself is 6e-5 .. 2e-4 away from an fp64 evaluation in the max norm).  So: max-norm within 1e-3 of the fp32
+    # oracle, and in the L2 norm -- which single flips barely move -- as close to the fp64 evaluation as the fp32 oracle is.
+    for a, b, t, nme in zip(ours, ref, truth, names):
         assert a is not None, nme
-        assert _rel_to_max(a, b.view_as(a.cpu())) <= GRAD_RTOL, (nme, _rel_to_max(a, b.view_as(a.cpu())))
+        t = t.view_as(a.cpu())
+        l2_hip = ((a.cpu().double() - t).norm() / t.norm()).item()
+        l2_ref = ((b.view_as(a.cpu()).double() - t).norm() / t.norm()).item()
+        assert l2_hip <= max(3.0 * l2_ref, 3 * GRAD_RTOL), (nme, l2_hip, l2_ref)
+        mx_hip = (a.cpu().double() - t).abs().max().item() / t.abs().max().item()
+        mx_ref = (b.view_as(a.cpu()).double() - t).abs().max().item() / t.abs().max().item()
+        assert mx_hip <= max(3.0 * mx_ref, 10 * GRAD_RTOL), (nme, mx_hip, mx_ref)
 
 
 def test_projection_kernels_vs_torch(hip):
@@ -118,13 +139,16 @@ def test_projection_kernels_vs_torch(hip):
         F_ = torch.randn(N, C, H, W, generator=g).cuda()
         mlp = torch.randn(spec.mlp_param_count(), generator=g).cuda() * 0.2
         w = mlp[:Hd * spec.d_in].view(Hd, spec.d_in)[:, :C]
+        order = native.proj_storage_order(Hd).cuda()      # channel s of the stored map holds hidden unit order[s]
         G = native.project_features(spec, F_, mlp)
-        G_ref = torch.einsum("nchw,jc->nhwj", F_.double(), w.double())
+        G_ref = torch.einsum("nchw,jc->nhwj", F_.double(), w.double())[..., order]
         assert (G.double() - G_ref).abs().max().item() <= 2e-5 * G_ref.abs().max().item()
-        dG = torch.randn(N, H, W, Hd, generator=g).cuda()
+        dG = torch.randn(N, H, W, Hd, generator=g).cuda()   # gradient w.r.t. the stored map
         dF, dM = native.project_features_bwd(spec, F_, dG, mlp)
-        dF_ref = torch.einsum("nhwj,jc->nchw", dG.double(), w.double())
-        dW_ref = torch.einsum("nhwj,nchw->jc", dG.double(), F_.double())
+        dG_nat = torch.empty_like(dG)
+        dG_nat[..., order] = dG
+        dF_ref = torch.einsum("nhwj,jc->nchw", dG_nat.double(), w.double())
+        dW_ref = torch.einsum("nhwj,nchw->jc", dG_nat.double(), F_.double())
         assert (dF.double() - dF_ref).abs().max().item() <= 2e-5 * dF_ref.abs().max().item()
         dW = dM[:Hd * spec.d_in].view(Hd, spec.d_in)
         assert (dW[:, :C].double() - dW_ref).abs().max().item() <= 1e-4 * dW_ref.abs().max().item()

@@ -9,6 +9,7 @@ from oracle import bts_oracle as O
 from tests._hip_helpers import build_net
 
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+only = sys.argv[2] if len(sys.argv) > 2 else None
 H, W, K, V = 192, 640, 64, 2
 cfg = O.FieldConfig()
 scene = O.synthetic_scene(1, V, H, W, 64, seed=1, intrinsics=O.K_KITTIRAW)
@@ -18,15 +19,17 @@ ft = net.native_field()
 feat_nhwc = native.nchw_to_nhwc(net.grid_f_features[0][:, 0].detach().contiguous())
 ft_direct = native.FieldTensors(net.spec, None, ft.K_enc, ft.w2c_enc, ft.imgs_nhwc4, ft.K_r, ft.w2c_r, None, feat_nhwc=feat_nhwc)
 params = net.mlp_coarse.packed().detach()
-rays = bts.ImageRaySampler(3.0, 80.0).sample(None, scene["poses"].cuda(), scene["projs"].cuda())[0].reshape(-1, 8).contiguous()
+rays = bts.ImageRaySampler(3.0, 80.0, H, W).sample(None, scene["poses"].cuda(), scene["projs"].cuda())[0].reshape(-1, 8).contiguous()
 z = native.sample_coarse(rays, torch.rand(rays.shape[0], K, device="cuda"), True)
 variants = {
-    "proj  all-out": (ft, dict(want_weights=True, want_alphas=True, want_invalid=True)),
-    "proj  no w/a ": (ft, dict(want_invalid=True)),
-    "proj  no out ": (ft, dict(want_invalid=False)),
+    "proj__all-out": (ft, dict(want_weights=True, want_alphas=True, want_invalid=True)),
+    "proj__no-wa  ": (ft, dict(want_invalid=True)),
+    "proj__no-out ": (ft, dict(want_invalid=False)),
     "direct all   ": (ft_direct, dict(want_weights=True, want_alphas=True, want_invalid=True)),
     "direct no out": (ft_direct, dict(want_invalid=False)),
 }
+if only:
+    variants = {k: v for k, v in variants.items() if k.startswith(only)}
 res = {k: [] for k in variants}
 for r in range(rounds + 1):
     for name, (f, kw) in variants.items():
