@@ -161,7 +161,7 @@ def main():
                                    "nv=1, want_weights+alphas, renderer only (feature-map encoder stand-in)",
                        "rays_per_step_per_gpu": n_rays, "samples_per_ray": K, "parallelism": f"frames x{world}"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_MATRIX_TFLOPS, "traffic": None, "kernel": "bts::field_kernel<64,64,0,1>",
+                         "frac": achieved / PEAK_FP32_MATRIX_TFLOPS, "traffic": None, "kernel": "bts::render_kernel<64,64,0,1,true>",
                          "kernel_ms": kernel_ms, "algorithmic_flop_per_launch": flop_per_launch},
         }
         if world == 1 and not args.no_cpu_baseline:
