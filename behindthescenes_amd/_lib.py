@@ -7,7 +7,8 @@ import os
 import threading
 
 PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG, "libbts_render.so")
+# BTS_RENDER_LIB lets the profiling tools load the instrumented probe build (libbts_probe.so); the product always loads libbts_render.so
+LIB_PATH = os.environ.get("BTS_RENDER_LIB") or os.path.join(PKG, "libbts_render.so")
 ABI_VERSION = 1
 
 BTS_MAX_VIEWS = 8

@@ -36,17 +36,22 @@ def hipcc():
     return "hipcc"
 
 
-def build_library(force: bool = False, verbose: bool = False) -> str:
-    stamp = os.path.join(OBJ, "digest.txt")
+def build_library(force: bool = False, verbose: bool = False, probe: bool = False) -> str:
+    """probe=True builds libbts_probe.so: the same sources with -DBTS_PROBE (section-ablation hooks for tools/ablate_probe.py;
+    never loaded by the product path)."""
+    lib = LIB.replace("libbts_render", "libbts_probe") if probe else LIB
+    obj_dir = OBJ + ("_probe" if probe else "")
+    flags = FLAGS + (["-DBTS_PROBE"] if probe else [])
+    stamp = os.path.join(obj_dir, "digest.txt")
     dig = _digest()
-    if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read().strip() == dig:
-        return LIB
-    os.makedirs(OBJ, exist_ok=True)
+    if not force and os.path.exists(lib) and os.path.exists(stamp) and open(stamp).read().strip() == dig:
+        return lib
+    os.makedirs(obj_dir, exist_ok=True)
     cc = hipcc()
 
     def compile_one(src):
-        obj = os.path.join(OBJ, src.replace(".hip", ".o"))
-        cmd = [cc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        obj = os.path.join(obj_dir, src.replace(".hip", ".o"))
+        cmd = [cc] + flags + ["-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr[-4000:]}")
@@ -54,14 +59,14 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
 
     with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
         objs = list(ex.map(compile_one, SOURCES))
-    r = subprocess.run([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs, capture_output=True, text=True)
+    r = subprocess.run([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stderr[-4000:]}")
     open(stamp, "w").write(dig)
     if verbose:
-        print(f"built {LIB}")
-    return LIB
+        print(f"built {lib}")
+    return lib
 
 
 if __name__ == "__main__":
-    print(build_library(force="--force" in sys.argv, verbose=True))
+    print(build_library(force="--force" in sys.argv, verbose=True, probe="--probe" in sys.argv))

@@ -44,7 +44,14 @@ struct Cam {
   float k[9];
 };
 
-__device__ __forceinline__ Cam load_cam(const float* __restrict__ w2c, const float* __restrict__ K) {
+// Read-only kernel inputs addressed wave-uniformly (cameras, a wave's ray, scalars of the MLP) are read through the constant
+// address space: the compiler then emits s_load into SGPRs instead of vector loads that pin ~50 VGPRs per wave.  Only valid for
+// buffers the kernel never writes.
+typedef const float __attribute__((address_space(4)))* cfp;
+__device__ __forceinline__ cfp as_const(const float* p) { return (cfp)(unsigned long)p; }
+
+__device__ __forceinline__ Cam load_cam(const float* w2c_, const float* K_) {
+  const cfp w2c = as_const(w2c_), K = as_const(K_);
   Cam c;
 #pragma unroll
   for (int i = 0; i < 12; ++i) c.r[i] = w2c[i];

@@ -57,9 +57,16 @@ struct FwdParams {
   int only_density;
   int tiles_per_sample;
   // lane = sample render kernel
+  int ablate;    // probe builds only (-DBTS_PROBE): bit mask of kernel sections to skip (tools/ablate_probe.py)
   int lpr;       // lanes per ray: 8, 16, 32 or 64 (>= min(K, 64)); 64 / lpr rays share one wave iteration
   long groups;   // number of ray groups (= n * Bp * lpr / 64)
 };
+
+#ifdef BTS_PROBE
+#define BTS_ABL(bit) ((p.ablate & (bit)) != 0)
+#else
+#define BTS_ABL(bit) false
+#endif
 
 template <int C, int HD, int NB, bool PROJ>
 struct Lds {
@@ -203,11 +210,15 @@ __device__ __forceinline__ void bcast_tiles(unsigned v, unsigned& t0, unsigned& 
 
 // one k-pair of lin_in: inputs (a, b) = the lane's x[2s], x[2s+1]
 template <int HD>
-__device__ __forceinline__ void kstep(f32x16 (&acc)[HD / 32][2], const float* wl, int lane_off, float a, float b) {
+__device__ __forceinline__ void kstep(f32x16 (&acc)[HD / 32][2], const float* wl, int lane_off, float a, float b, bool nomfma = false) {
   swap32(a, b);
 #pragma unroll
   for (int ht = 0; ht < HD / 32; ++ht) {
     const float w = wl[lane_off + ht * 32];
+    if (nomfma) {  // probe builds only
+      acc[ht][0][0] += w * a, acc[ht][1][0] += w * b;
+      continue;
+    }
     acc[ht][0] = mfma(w, a, acc[ht][0]);
     acc[ht][1] = mfma(w, b, acc[ht][1]);
   }
@@ -297,34 +308,42 @@ __device__ __forceinline__ void sincos_small(float arg, float& s, float& c) {
 // The reference's "cos" entry is sin(fl(arg + P)), P = fl32(pi/2): with the exact rounding error e of that addition (TwoSum),
 // fl(arg + P) = arg + pi/2 + d, d = (P - pi/2) - e, so the entry equals cos(arg + d) = cos(arg) - d sin(arg) + O(d^2), |d| < 4e-6:
 // one sincos gives both entries with the reference's argument rounding reproduced (max deviation from it 1.2e-7).
-__device__ __forceinline__ void pe_octave(float (&o)[6], const float (&v)[3], float f) {
+// pe_octave_fast: branch-free (valid while every |argument| <= 1e5); pe_octave_exact: libm range reduction for any argument.
+__device__ __forceinline__ void pe_octave_fast(float (&o)[6], const float (&v)[3], float f) {
   constexpr float P = 1.57079637050628662109375f;
-  float arg[3];
-  bool big = false;
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
-    arg[i] = v[i] * f;
-    big |= !(fabsf(arg[i]) <= 1.0e5f);
-  }
-  if (__builtin_expect(__any(big), 0)) {
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      o[i] = sinf(arg[i]);
-      o[3 + i] = sinf(arg[i] + P);
-    }
-    return;
-  }
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
+    const float arg = v[i] * f;
     float sn, cs;
-    sincos_small(arg[i], sn, cs);
-    const float sm = arg[i] + P;
-    const float bb = sm - arg[i];
-    const float err = (arg[i] - (sm - bb)) + (P - bb);   // arg + P = sm + err exactly
-    const float d = 4.371139000186241e-08f - err;        // (P - pi/2) - err
+    sincos_small(arg, sn, cs);
+    const float sm = arg + P;
+    const float bb = sm - arg;
+    const float err = (arg - (sm - bb)) + (P - bb);   // arg + P = sm + err exactly
+    const float d = 4.371139000186241e-08f - err;     // (P - pi/2) - err
     o[i] = sn;
     o[3 + i] = __builtin_fmaf(-d, sn, cs);
   }
+}
+__device__ __forceinline__ void pe_octave_exact(float (&o)[6], const float (&v)[3], float f) {
+  constexpr float P = 1.57079637050628662109375f;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const float arg = v[i] * f;
+    o[i] = sinf(arg);
+    o[3 + i] = sinf(arg + P);
+  }
+}
+// true when some octave argument of this point leaves the fast path's range (points within ~1e-3 of the encoder's camera plane)
+__device__ __forceinline__ bool pe_needs_exact(const float (&v)[3], float freq_factor) {
+  const float fmax_ = freq_factor * (float)(1 << (kNumFreqs - 1));
+  return !(fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fabsf(v[2])) * fmax_ <= 1.0e5f);
+}
+__device__ __forceinline__ void pe_octave(float (&o)[6], const float (&v)[3], float f) {
+  bool big = false;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) big |= !(fabsf(v[i] * f) <= 1.0e5f);
+  if (__builtin_expect(__any(big), 0)) pe_octave_exact(o, v, f);
+  else pe_octave_fast(o, v, f);
 }
 
 // Everything between a world point and its pre-softplus density: projection into the encoder view, bilinear feature fetch,
@@ -368,9 +387,14 @@ __device__ __forceinline__ float eval_point(const FwdParams& p, const float* lds
     bcast_tiles(__float_as_uint(tp.w10), t0, t1), wq[0][2] = __uint_as_float(t0), wq[1][2] = __uint_as_float(t1);
     bcast_tiles(__float_as_uint(tp.w11), t0, t1), wq[0][3] = __uint_as_float(t0), wq[1][3] = __uint_as_float(t1);
     bcast_tiles(use_empty ? 1u : 0u, t0, t1), emp[0] = t0 != 0, emp[1] = t1 != 0;
+    if (!BTS_ABL(1)) {
     GBuf ga, gb;
     gload<HD>(ga, featp, o[0], 0, 4 * (lane >> 5));
     gather_seq<HD, 0>(acc, ga, gb, featp, o, wq, lane >> 5);
+    } else {
+      acc[0][0][0] = wq[0][0] + wq[0][1] + wq[0][2] + wq[0][3] + (float)(o[0][0] + o[0][1] + o[0][2] + o[0][3]);
+      acc[0][1][0] = wq[1][0] + wq[1][1] + wq[1][2] + wq[1][3] + (float)(o[1][0] + o[1][1] + o[1][2] + o[1][3]);
+    }
     if (p.learn_empty && __any(use_empty)) apply_empty<HD>(acc, emp, lds + L::EMPTY, lane >> 5);
   } else {
   // ---------------- features: 8 channels per chunk; rolled ping-pong loop, the next chunk's 8 float4 loads are in
@@ -393,19 +417,32 @@ __device__ __forceinline__ float eval_point(const FwdParams& p, const float* lds
   }
   // ---------------- positional encoding (+ bias row): [x, y] [code, 1] then 3 k-pairs per octave, sines of the next
   // octave computed while the current octave's MFMAs run
-  kstep<HD>(acc, wl, 0, v3[0], v3[1]);
-  kstep<HD>(acc, wl + 2 * HD, 0, v3[2], 1.0f);
+  const bool nomfma = BTS_ABL(4);
+  kstep<HD>(acc, wl, 0, v3[0], v3[1], nomfma);
+  kstep<HD>(acc, wl + 2 * HD, 0, v3[2], 1.0f, nomfma);
   wl += 4 * HD;
   float sc[6], sn[6];
-  pe_octave(sc, v3, p.freq_factor);
+  if (BTS_ABL(2)) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) sc[i] = v3[i % 3] * p.freq_factor;
+  } else {
+    pe_octave(sc, v3, p.freq_factor);
+  }
   float ff = p.freq_factor;
 #pragma unroll 1
   for (int oct = 0; oct < kNumFreqs; ++oct) {
     ff = ff * 2.0f;
-    if (oct + 1 < kNumFreqs) pe_octave(sn, v3, ff);
-    kstep<HD>(acc, wl, 0, sc[0], sc[1]);
-    kstep<HD>(acc, wl + 2 * HD, 0, sc[2], sc[3]);
-    kstep<HD>(acc, wl + 4 * HD, 0, sc[4], sc[5]);
+    if (oct + 1 < kNumFreqs) {
+      if (BTS_ABL(2)) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) sn[i] = v3[i % 3] * ff;
+      } else {
+        pe_octave(sn, v3, ff);
+      }
+    }
+    kstep<HD>(acc, wl, 0, sc[0], sc[1], nomfma);
+    kstep<HD>(acc, wl + 2 * HD, 0, sc[2], sc[3], nomfma);
+    kstep<HD>(acc, wl + 4 * HD, 0, sc[4], sc[5], nomfma);
     wl += 6 * HD;
 #pragma unroll
     for (int i = 0; i < 6; ++i) sc[i] = sn[i];
@@ -436,6 +473,13 @@ __device__ __forceinline__ float eval_point(const FwdParams& p, const float* lds
 
   // ---------------- lin_out: in-lane dot over the hidden rows this lane holds, then fold the two lane halves
   float p0 = 0.0f, p1 = 0.0f;
+  if (BTS_ABL(32)) {
+    float s0 = 0.0f, s1 = 0.0f;
+#pragma unroll
+    for (int ht = 0; ht < HT; ++ht) s0 += acc[ht][0][0] + acc[ht][0][5] + acc[ht][0][15], s1 += acc[ht][1][0] + acc[ht][1][5] + acc[ht][1][15];
+    swap32(s0, s1);
+    return (s0 + s1) + b_out;
+  }
 #pragma unroll
   for (int ht = 0; ht < HT; ++ht)
 #pragma unroll
@@ -666,7 +710,7 @@ __global__ __launch_bounds__(256, 2) void render_kernel(const FwdParams p) {
       for (int j = 0; j < NVMAX; ++j) {
         col[3 * j] = col[3 * j + 1] = col[3 * j + 2] = 0.0f;
         inv[j] = pe.invalid;
-        if (j < nv) {
+        if (j < nv && !BTS_ABL(8)) {
           const Cam cj = load_cam(p.w2c_r + ((long)sample * nv + j) * 16, p.K_r + ((long)sample * nv + j) * 9);
           const Proj pc = project<false>(cj, px, py, pz);
           const Taps tc = make_taps(pc.x, pc.y, H, W);
@@ -698,7 +742,7 @@ __global__ __launch_bounds__(256, 2) void render_kernel(const FwdParams p) {
       w_part = w_part + wgt;
 #pragma unroll
       for (int i = 0; i < NVMAX * 3; ++i) rgb_part[i] = rgb_part[i] + wgt * col[i];
-      if (valid) {
+      if (valid && !BTS_ABL(16)) {
         const long pk = ray * K + k;
         if (p.weights) p.weights[pk] = wgt;
         if (p.alphas) p.alphas[pk] = alpha;

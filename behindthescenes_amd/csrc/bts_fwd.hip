@@ -24,6 +24,7 @@ extern template int launch_field<false, true>(const FwdParams&, int, int, int, i
 extern template int launch_field<true, true>(const FwdParams&, int, int, int, int, hipStream_t);
 template int launch_render<false>(const FwdParams&, int, int, int, int, hipStream_t);
 extern template int launch_render<true>(const FwdParams&, int, int, int, int, hipStream_t);
+int launch_render_pipelined(const FwdParams& p, int C, int HD, int NB, int grid, hipStream_t s);
 
 FwdParams make_params(const BtsFieldCfg* cfg, const BtsFieldTensors* t) {
   FwdParams p;
@@ -72,9 +73,13 @@ int render_fwd_impl(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const BtsR
     if (p.proj) return launch_field<false, true>(p, cfg->C, cfg->d_hidden, cfg->n_blocks, p.tiles_per_sample * cfg->n, s);
     return launch_field<false, false>(p, cfg->C, cfg->d_hidden, cfg->n_blocks, p.tiles_per_sample * cfg->n, s);
   }
+#ifdef BTS_PROBE
+  if (const char* e = getenv("BTS_ABLATE")) p.ablate = atoi(e);
+#endif
   render_geometry(p, cfg->n);
   const int grid = render_grid(p);
-  if (p.proj) return launch_render<true>(p, cfg->C, cfg->d_hidden, cfg->n_blocks, grid, s);
+  if (p.proj && getenv("BTS_RENDER_V1")) return launch_render<true>(p, cfg->C, cfg->d_hidden, cfg->n_blocks, grid, s);  // A/B only
+  if (p.proj) return launch_render_pipelined(p, cfg->C, cfg->d_hidden, cfg->n_blocks, grid, s);
   return launch_render<false>(p, cfg->C, cfg->d_hidden, cfg->n_blocks, grid, s);
 }
 

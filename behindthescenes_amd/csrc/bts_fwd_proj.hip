@@ -1,8 +1,10 @@
-// PROJ = true instantiations of the fused forward kernel (projected feature map G; the default render path).
-#include "bts_field_kernel.h"
+// PROJ = true instantiations of the fused forward (projected feature map G; the default render path): the software-pipelined
+// render kernel (bts_render_kernel.h), the lane = point field query, and -- for A/B measurements -- the previous render kernels.
+#include "bts_render_kernel.h"
 
 namespace bts {
 template int launch_field<false, true>(const FwdParams&, int, int, int, int, hipStream_t);
 template int launch_field<true, true>(const FwdParams&, int, int, int, int, hipStream_t);
 template int launch_render<true>(const FwdParams&, int, int, int, int, hipStream_t);
+int launch_render_pipelined(const FwdParams& p, int C, int HD, int NB, int grid, hipStream_t s) { return launch_render_p(p, C, HD, NB, grid, s); }
 }  // namespace bts

@@ -23,6 +23,7 @@ rays = bts.ImageRaySampler(3.0, 80.0, H, W).sample(None, scene["poses"].cuda(), 
 z = native.sample_coarse(rays, torch.rand(rays.shape[0], K, device="cuda"), True)
 variants = {
     "proj__all-out": (ft, dict(want_weights=True, want_alphas=True, want_invalid=True)),
+    "v1____all-out": (ft, dict(want_weights=True, want_alphas=True, want_invalid=True)),
     "proj__no-wa  ": (ft, dict(want_invalid=True)),
     "proj__no-out ": (ft, dict(want_invalid=False)),
     "direct all   ": (ft_direct, dict(want_weights=True, want_alphas=True, want_invalid=True)),
@@ -34,6 +35,10 @@ res = {k: [] for k in variants}
 for r in range(rounds + 1):
     for name, (f, kw) in variants.items():
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        if name.startswith("v1"):
+            os.environ["BTS_RENDER_V1"] = "1"
+        else:
+            os.environ.pop("BTS_RENDER_V1", None)
         e0.record()
         native.render_fwd(f, params, rays, z, hard_alpha_cap=True, **kw)
         e1.record()
