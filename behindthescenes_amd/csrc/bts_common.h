@@ -60,6 +60,16 @@ __device__ __forceinline__ Cam load_cam(const float* w2c_, const float* K_) {
   return c;
 }
 
+// same through ordinary (vector) loads: the values land in VGPRs
+__device__ __forceinline__ Cam load_cam_v(const float* __restrict__ w2c, const float* __restrict__ K) {
+  Cam c;
+#pragma unroll
+  for (int i = 0; i < 12; ++i) c.r[i] = w2c[i];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) c.k[i] = K[i];
+  return c;
+}
+
 struct Proj {
   float x, y;     // normalised image coordinates
   float z;        // q.z  (depth after K)
@@ -164,6 +174,12 @@ __device__ __forceinline__ float pe_entry(const float (&v)[3], float freq_factor
 }
 
 __device__ __forceinline__ float softplus(float s) { return s > 20.0f ? s : log1pf(expf(s)); }  // F.softplus defaults
+// max(x, 0) as ONE instruction: the compiler puts a canonicalising v_max(x, x) in front of fmaxf on MFMA results
+__device__ __forceinline__ float relu1(float x) {
+  float r;
+  asm("v_max_f32_e32 %0, 0, %1" : "=v"(r) : "v"(x));
+  return r;
+}
 __device__ __forceinline__ float sigmoidf(float s) { return 1.0f / (1.0f + expf(-s)); }
 
 // XCD-aware work-group remap: hardware places block b on XCD b % 8; give each XCD one contiguous range of tiles so

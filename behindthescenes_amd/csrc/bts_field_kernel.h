@@ -57,6 +57,7 @@ struct FwdParams {
   int only_density;
   int tiles_per_sample;
   // lane = sample render kernel
+  unsigned long long* dbg;  // probe builds only: per-wave section cycle counters (bit 128 of ablate)
   int ablate;    // probe builds only (-DBTS_PROBE): bit mask of kernel sections to skip (tools/ablate_probe.py)
   int lpr;       // lanes per ray: 8, 16, 32 or 64 (>= min(K, 64)); 64 / lpr rays share one wave iteration
   long groups;   // number of ray groups (= n * Bp * lpr / 64)
@@ -288,8 +289,7 @@ __device__ __forceinline__ void feature_chunk(f32x16 (&acc)[HD / 32][2], const f
 __device__ __forceinline__ void sincos_small(float arg, float& s, float& c) {
   const float j = rintf(arg * 0.63661977236758134308f);
   float r = __builtin_fmaf(-j, 1.57079625129699707031f, arg);
-  r = __builtin_fmaf(-j, 7.54978941586159635335e-8f, r);
-  r = __builtin_fmaf(-j, 5.39030285815811e-15f, r);
+  r = __builtin_fmaf(-j, 7.54978941586159635335e-8f, r);  // third term (5.4e-15 j <= 3.5e-10 for |arg| <= 1e5) dropped
   const float r2 = r * r;
   const float sp = __builtin_fmaf(r2, __builtin_fmaf(r2, __builtin_fmaf(r2, 2.6083159809786593541503e-06f, -1.981069071916863322258e-04f),
                                                      8.333307858556509017944e-03f), -1.666666597127914428711e-01f);
@@ -308,21 +308,44 @@ __device__ __forceinline__ void sincos_small(float arg, float& s, float& c) {
 // The reference's "cos" entry is sin(fl(arg + P)), P = fl32(pi/2): with the exact rounding error e of that addition (TwoSum),
 // fl(arg + P) = arg + pi/2 + d, d = (P - pi/2) - e, so the entry equals cos(arg + d) = cos(arg) - d sin(arg) + O(d^2), |d| < 4e-6:
 // one sincos gives both entries with the reference's argument rounding reproduced (max deviation from it 1.2e-7).
-// pe_octave_fast: branch-free (valid while every |argument| <= 1e5); pe_octave_exact: libm range reduction for any argument.
-__device__ __forceinline__ void pe_octave_fast(float (&o)[6], const float (&v)[3], float f) {
+// raw sine / cosine of the three encoding arguments of one octave
+struct SinCos3 {
+  float s[3], c[3];
+};
+__device__ __forceinline__ void pe_direct(SinCos3& r, const float (&v)[3], float f) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i) sincos_small(v[i] * f, r.s[i], r.c[i]);
+}
+// next octave by angle doubling: fl(v * 2f) = 2 fl(v * f) exactly, so sin / cos of the doubled ARGUMENT are 2sc and 1 - 2s^2 of the
+// previous octave's; one doubling costs ~1e-7 extra absolute error (max 2.7e-7 vs 1.2e-7 direct, rms 4e-8 vs 2e-8 on PE
+// arguments), which is why only every other octave is derived this way.
+__device__ __forceinline__ void pe_double(SinCos3& r, const SinCos3& q) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const float t = q.s[i] + q.s[i];
+    r.s[i] = t * q.c[i];
+    r.c[i] = __builtin_fmaf(-t, q.s[i], 1.0f);
+  }
+}
+// the six encoding entries of an octave from its raw sines / cosines: sin(arg), then the reference's "cos" = sin(fl(arg + P))
+__device__ __forceinline__ void pe_entries(float (&o)[6], const SinCos3& r, const float (&v)[3], float f) {
   constexpr float P = 1.57079637050628662109375f;
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     const float arg = v[i] * f;
-    float sn, cs;
-    sincos_small(arg, sn, cs);
     const float sm = arg + P;
     const float bb = sm - arg;
     const float err = (arg - (sm - bb)) + (P - bb);   // arg + P = sm + err exactly
     const float d = 4.371139000186241e-08f - err;     // (P - pi/2) - err
-    o[i] = sn;
-    o[3 + i] = __builtin_fmaf(-d, sn, cs);
+    o[i] = r.s[i];
+    o[3 + i] = __builtin_fmaf(-d, r.s[i], r.c[i]);
   }
+}
+// pe_octave_fast: branch-free (valid while every |argument| <= 1e5); pe_octave_exact: libm range reduction for any argument.
+__device__ __forceinline__ void pe_octave_fast(float (&o)[6], const float (&v)[3], float f) {
+  SinCos3 r;
+  pe_direct(r, v, f);
+  pe_entries(o, r, v, f);
 }
 __device__ __forceinline__ void pe_octave_exact(float (&o)[6], const float (&v)[3], float f) {
   constexpr float P = 1.57079637050628662109375f;

@@ -75,6 +75,7 @@ int render_fwd_impl(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const BtsR
   }
 #ifdef BTS_PROBE
   if (const char* e = getenv("BTS_ABLATE")) p.ablate = atoi(e);
+  if (const char* e = getenv("BTS_DBG_PTR")) p.dbg = (unsigned long long*)strtoull(e, nullptr, 0);
 #endif
   render_geometry(p, cfg->n);
   const int grid = render_grid(p);

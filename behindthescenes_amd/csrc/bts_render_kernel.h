@@ -16,6 +16,17 @@
 
 namespace bts {
 
+#ifdef BTS_PROBE
+#define BTS_TICK(i)                                                  \
+  if (p.ablate & 128) {                                              \
+    const unsigned long long t_now = __builtin_readcyclecounter();   \
+    t_acc[i] += t_now - t_last;                                      \
+    t_last = t_now;                                                  \
+  }
+#else
+#define BTS_TICK(i)
+#endif
+
 // ---- DPP (data-parallel primitives) helpers: lanes whose source is outside its row / whose row is masked keep `old` ----------
 template <int CTRL, int ROW_MASK = 0xF>
 __device__ __forceinline__ float dpp_f(float old, float src) {
@@ -57,10 +68,19 @@ struct GStage {
   static constexpr int pt = S / (2 * HT), ht = (S / 2) % HT, tp2 = S % 2;
 };
 
+// 8 float4 of stage S: wave-uniform base (SGPR pair) + 32-bit per-lane byte offset (one sample's G is far below 4 GB), so that the
+// address is one v_lshl_add per row instead of 64-bit arithmetic
 template <int HD, int S>
 __device__ __forceinline__ void stage_load(GBuf& b, const float4* __restrict__ G, const int (&o)[2][4], int h) {
   using St = GStage<HD, S>;
-  gload<HD>(b, G, o[St::pt], St::tp2, St::ht * 8 + 4 * h);
+  const char* base = reinterpret_cast<const char*>(G);
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const unsigned off = (unsigned)o[St::pt][2 * St::tp2 + t] * (unsigned)(HD * 4) + (unsigned)(St::ht * 128) + (unsigned)h * 64u;
+    const float4* row = reinterpret_cast<const float4*>(base + off);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) b.v[t][q] = row[q];
+  }
 }
 template <int HD, int S>
 __device__ __forceinline__ void stage_blend(f32x16 (&acc)[HD / 32][2], const GBuf& b, const float (&w)[2][4]) {
@@ -71,28 +91,33 @@ __device__ __forceinline__ void stage_blend(f32x16 (&acc)[HD / 32][2], const GBu
 // octave OCT of the positional encoding with gather stage OCT blended behind its MFMAs (buffers alternate by parity).
 // EXACT selects libm sines (wave-level slow path for arguments beyond the fast range); the fast variant is branch-free so that the
 // whole gather + encoding + MFMA phase is ONE basic block the scheduler can interleave.
-template <bool EXACT>
-__device__ __forceinline__ void pe_octave_sel(float (&sc)[6], const float (&v3)[3], float ff, bool nosin) {
-  if (nosin) {
-#pragma unroll
-    for (int i = 0; i < 6; ++i) sc[i] = v3[i % 3] * ff;
-  } else if constexpr (EXACT) {
-    pe_octave_exact(sc, v3, ff);
-  } else {
-    pe_octave_fast(sc, v3, ff);
-  }
-}
-
-template <int HD, int OCT, bool EXACT>
+// Octave OCT of the positional encoding with gather stage OCT blended behind its MFMAs (buffers alternate by parity).
+// One scheduling region per octave: the sines of octave OCT+1 (direct for even octaves, by angle doubling for odd ones), the 12 MFMAs
+// of octave OCT, the blend of gather stage OCT and the loads of stage OCT+2 may interleave freely; nothing moves across the
+// region boundary (that bounds the live ranges: an unconstrained schedule of this block spills > 200 VGPRs).
+template <int HD, int OCT>
 __device__ __forceinline__ void octave_seq(f32x16 (&acc)[HD / 32][2], GBuf& ba, GBuf& bb, const float4* __restrict__ G,
-                                           const int (&o)[2][4], const float (&wq)[2][4], int h, const float* wl, float (&sc)[6],
+                                           const int (&o)[2][4], const float (&wq)[2][4], int h, const float* wl, SinCos3& raw,
                                            const float (&v3)[3], float ff, bool nomfma, bool nosin, bool nogather) {
   constexpr int NS = 4 * (HD / 32);
   if constexpr (OCT < kNumFreqs) {
-    // one scheduling region per octave: the sines of octave OCT+1, the 12 MFMAs of octave OCT, the blend of gather stage OCT and
-    // the loads of stage OCT+2 may interleave freely; nothing moves across the region boundary (bounds the live ranges)
-    float sn[6];
-    if constexpr (OCT + 1 < kNumFreqs) pe_octave_sel<EXACT>(sn, v3, ff * 2.0f, nosin);
+    float sc[6];
+    if (nosin) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) sc[i] = v3[i % 3] * ff;
+    } else {
+      pe_entries(sc, raw, v3, ff);
+    }
+    if constexpr (OCT + 1 < kNumFreqs) {
+      if (!nosin) {
+        if constexpr ((OCT + 1) % 2 == 0) {
+          pe_direct(raw, v3, ff * 2.0f);
+        } else {
+          const SinCos3 prev = raw;
+          pe_double(raw, prev);
+        }
+      }
+    }
     kstep<HD>(acc, wl, 0, sc[0], sc[1], nomfma);
     kstep<HD>(acc, wl + 2 * HD, 0, sc[2], sc[3], nomfma);
     kstep<HD>(acc, wl + 4 * HD, 0, sc[4], sc[5], nomfma);
@@ -102,12 +127,166 @@ __device__ __forceinline__ void octave_seq(f32x16 (&acc)[HD / 32][2], GBuf& ba, 
         if constexpr (OCT + 2 < NS) stage_load<HD, OCT + 2>(ba, G, o, h);
       }
     }
-    if constexpr (OCT + 1 < kNumFreqs) {
+    __builtin_amdgcn_sched_barrier(0);
+    octave_seq<HD, OCT + 1>(acc, bb, ba, G, o, wq, h, wl + 6 * HD, raw, v3, ff * 2.0f, nomfma, nosin, nogather);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Split-precision lin_in on the f16 matrix pipe.
+// Measured on gfx950 (tools/ubench/mfma_valu_overlap*.hip): v_mfma_f32_32x32x2_f32 occupies the SIMD for its full 64 cycles -- no
+// VALU instruction of the same or of another wave issues underneath it (fp32 "MFMA" runs at, and instead of, the vector FMA rate) --
+// whereas v_mfma_f32_32x32x16_f16 costs ~5 cycles when 8+ VALU instructions sit between two of them.  So the 36 sin/cos inputs of
+// lin_in (values in [-1, 1]) go through the f16 pipe as  W.X = Wh.Xh + Wl.Xh + Wh.Xl  with  x = xh + xl, xh = f16_rne(x),
+// xl = f16_rne(x - xh)  (two round-to-nearest halves carry 12 + 12 significand bits; the dropped Wl.Xl term is 2^-24 relative; fp32
+// accumulation in the MFMA).  tools/ubench/f16split_gemm.hip: max error 3.8e-7 / rms 8e-8 against fp64 at K = 48, |D| ~ 2 -- slightly
+// better than the fp32-input MFMA (6.1e-7 / 9.3e-8).  Weights are pre-split once per work-group and scaled by 2^S (S chosen from
+// max |w| so that the low halves stay normal f16 numbers); everything else that enters the accumulators carries the same 2^S
+// (exact), removed again after lin_out.  The raw inputs x, y, code and the bias row stay on the fp32 path (x, y are unbounded).
+// ---------------------------------------------------------------------------------------------------------------
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+template <int C, int HD, int NB>
+struct LdsH {  // in floats, placed behind Lds<C, HD, NB, true>
+  static constexpr int HT = HD / 32;
+  static constexpr int W_RAW = 0;                              // [4][HD] k-major rows x, y, code, bias -- times 2^S
+  static constexpr int W_F16 = W_RAW + 4 * HD;                 // [term hi/lo][region 3][HT][64 lanes][8 halves = 4 dwords]
+  static constexpr int TERM_STRIDE = 3 * HT * 64 * 4;
+  static constexpr int BIAS = W_F16 + 2 * TERM_STRIDE;         // per block: b0 [HD], b1 [HD] -- times 2^S
+  static constexpr int EMPTY = BIAS + NB * 2 * HD;             // projected empty feature -- times 2^S
+  static constexpr int SCALE = EMPTY + HD;                     // [0] 2^S, [1] 2^-S, [2] max |w| (as int bits)
+  static constexpr int TOTAL = SCALE + 4;
+};
+
+template <int C, int HD, int NB>
+__device__ __forceinline__ void stage_weights_h(float* lh, const float* lds_old, const float* __restrict__ mlp) {
+  using LH = LdsH<C, HD, NB>;
+  using L = Lds<C, HD, NB, true>;
+  constexpr int HT = HD / 32;
+  constexpr int D_IN = C + kPeDim;
+  const MlpLayout ml{D_IN, HD, NB};
+  int* mx = reinterpret_cast<int*>(lh + LH::SCALE + 2);
+  if (threadIdx.x == 0) *mx = 0;
+  __syncthreads();
+  float m = 0.0f;
+  for (int i = threadIdx.x; i < 36 * HD; i += blockDim.x) m = fmaxf(m, fabsf(mlp[ml.w_in() + (i % HD) * D_IN + C + 3 + i / HD]));
+  atomicMax(mx, __float_as_int(m));  // non-negative floats order like their bit patterns
+  __syncthreads();
+  const float wmax = __int_as_float(*mx);
+  int ex = 0;
+  if (wmax > 0.0f && wmax < 3.0e38f) frexpf(wmax, &ex);
+  const int S = max(-40, min(40, 14 - ex));  // max |w| 2^S in [2^13, 2^14): far below the f16 limit, low halves normal down to |w| ~ 2^-13 max
+  const float scale = ldexpf(1.0f, S);
+  if (threadIdx.x == 0) lh[LH::SCALE] = scale, lh[LH::SCALE + 1] = ldexpf(1.0f, -S);
+  for (int i = threadIdx.x; i < 4 * HD; i += blockDim.x) {
+    const int k = i / HD, hid = i % HD;
+    lh[LH::W_RAW + i] = (k < 3 ? mlp[ml.w_in() + hid * D_IN + C + k] : mlp[ml.b_in() + hid]) * scale;
+  }
+  _Float16* wf = reinterpret_cast<_Float16*>(lh + LH::W_F16);
+  for (int i = threadIdx.x; i < 3 * HT * 64 * 8; i += blockDim.x) {
+    const int e = i & 7, lane = (i >> 3) & 63, ht = (i >> 9) % HT, r = i / (HT * 512);
+    const int slot = 8 * (lane >> 5) + e, hid = ht * 32 + (lane & 31);
+    float w = 0.0f;
+    if (slot < 12) w = mlp[ml.w_in() + hid * D_IN + C + 3 + 6 * (2 * r + slot / 6) + slot % 6] * scale;
+    const _Float16 hi = (_Float16)w;
+    wf[i] = hi;
+    wf[i + LH::TERM_STRIDE * 2] = (_Float16)(w - (float)hi);  // TERM_STRIDE floats = 2 x halves
+  }
+  for (int i = threadIdx.x; i < NB * 2 * HD; i += blockDim.x) {
+    const int b = i / (2 * HD), j = i % (2 * HD);
+    lh[LH::BIAS + i] = (j < HD ? mlp[ml.blk_b0(b) + j] : mlp[ml.blk_b1(b) + j - HD]) * scale;
+  }
+  for (int i = threadIdx.x; i < HD; i += blockDim.x) lh[LH::EMPTY + i] = lds_old[L::EMPTY + i] * scale;
+}
+
+__device__ __forceinline__ void swap32u(unsigned& a, unsigned& b) {
+  auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+  a = r[0], b = r[1];
+}
+__device__ __forceinline__ unsigned pack_h2(_Float16 a, _Float16 b) {
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(unsigned, (h2){a, b});
+}
+
+// 12 encoding entries (two octaves) of this lane's sample -> both point tiles' B operands (high and low halves) -> 12 f16 MFMAs
+template <int HD>
+__device__ __forceinline__ void f16_region(f32x16 (&acc)[HD / 32][2], const float* wf /* lane-resolved, this region */, int term_stride,
+                                           const float (&e)[12]) {
+  constexpr int HT = HD / 32;
+  _Float16 hi[12], lo[12];
 #pragma unroll
-      for (int i = 0; i < 6; ++i) sc[i] = sn[i];
+  for (int i = 0; i < 12; ++i) {
+    hi[i] = (_Float16)e[i];
+    lo[i] = (_Float16)(e[i] - (float)hi[i]);
+  }
+  unsigned ph[4], qh[4], pl[4], ql[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    ph[j] = pack_h2(hi[2 * j], hi[2 * j + 1]), pl[j] = pack_h2(lo[2 * j], lo[2 * j + 1]);
+    qh[j] = j < 2 ? pack_h2(hi[8 + 2 * j], hi[9 + 2 * j]) : 0u;
+    ql[j] = j < 2 ? pack_h2(lo[8 + 2 * j], lo[9 + 2 * j]) : 0u;
+    swap32u(ph[j], qh[j]);  // p*: point tile 0 (k 0-7 from its own lanes, k 8-15 from the partner half), q*: point tile 1
+    swap32u(pl[j], ql[j]);
+  }
+  const h8 b0h = __builtin_bit_cast(h8, (u32x4){ph[0], ph[1], ph[2], ph[3]});
+  const h8 b1h = __builtin_bit_cast(h8, (u32x4){qh[0], qh[1], qh[2], qh[3]});
+  const h8 b0l = __builtin_bit_cast(h8, (u32x4){pl[0], pl[1], pl[2], pl[3]});
+  const h8 b1l = __builtin_bit_cast(h8, (u32x4){ql[0], ql[1], ql[2], ql[3]});
+  h8 ah[HT], al[HT];
+#pragma unroll
+  for (int ht = 0; ht < HT; ++ht) {
+    ah[ht] = *reinterpret_cast<const h8*>(wf + ht * 256);
+    al[ht] = *reinterpret_cast<const h8*>(wf + term_stride + ht * 256);
+  }
+#pragma unroll
+  for (int ht = 0; ht < HT; ++ht) {
+    acc[ht][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ht], b0h, acc[ht][0], 0, 0, 0);
+    acc[ht][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ht], b1h, acc[ht][1], 0, 0, 0);
+  }
+#pragma unroll
+  for (int ht = 0; ht < HT; ++ht) {
+    acc[ht][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ht], b0h, acc[ht][0], 0, 0, 0);
+    acc[ht][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ht], b1h, acc[ht][1], 0, 0, 0);
+  }
+#pragma unroll
+  for (int ht = 0; ht < HT; ++ht) {
+    acc[ht][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ht], b0l, acc[ht][0], 0, 0, 0);
+    acc[ht][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ht], b1l, acc[ht][1], 0, 0, 0);
+  }
+}
+
+// Region R = octaves 2R (sines computed directly, one region ahead) and 2R+1 (by angle doubling), with gather stages 2R and 2R+1
+// blended behind the region's MFMAs and stages 2R+2, 2R+3 issued.  One scheduling region each (see octave_seq).
+template <int HD, int R>
+__device__ __forceinline__ void region_seq(f32x16 (&acc)[HD / 32][2], GBuf& ba, GBuf& bb, const float4* __restrict__ G,
+                                           const int (&o)[2][4], const float (&wq)[2][4], int h, const float* wf, int term_stride,
+                                           SinCos3& raw, const float (&v3)[3], float ff) {
+  constexpr int HT = HD / 32;
+  constexpr int NS = 4 * HT;
+  if constexpr (R < 3) {
+    float e[12];
+    {
+      float t[6];
+      pe_entries(t, raw, v3, ff);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) e[i] = t[i];
+      SinCos3 r1;
+      pe_double(r1, raw);
+      pe_entries(t, r1, v3, ff * 2.0f);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) e[6 + i] = t[i];
+    }
+    if constexpr (R + 1 < 3) pe_direct(raw, v3, ff * 4.0f);
+    f16_region<HD>(acc, wf + R * HT * 256, term_stride, e);
+    if constexpr (2 * R < NS) {
+      stage_blend<HD, 2 * R>(acc, ba, wq);
+      if constexpr (2 * R + 2 < NS) stage_load<HD, 2 * R + 2>(ba, G, o, h);
+      stage_blend<HD, 2 * R + 1>(acc, bb, wq);
+      if constexpr (2 * R + 3 < NS) stage_load<HD, 2 * R + 3>(bb, G, o, h);
     }
     __builtin_amdgcn_sched_barrier(0);
-    octave_seq<HD, OCT + 1, EXACT>(acc, bb, ba, G, o, wq, h, wl + 6 * HD, sc, v3, ff * 2.0f, nomfma, nosin, nogather);
+    region_seq<HD, R + 1>(acc, ba, bb, G, o, wq, h, wf, term_stride, raw, v3, ff * 4.0f);
   }
 }
 
@@ -126,15 +305,24 @@ __device__ __attribute__((noinline)) float eval_point_exact(const float* lds, co
   return eval_point<C, HD, NB, true>(q, lds, enc, G, (int)(threadIdx.x & 63), b_out, px, py, pz, pe);
 }
 
-template <int C, int HD, int NB, int NVMAX, bool ONE_RAY>
+template <int C, int HD, int NB, int NVMAX, bool ONE_RAY, bool F16>
 __global__ __launch_bounds__(256, 2) void render_kernel_p(const FwdParams p) {
   using L = Lds<C, HD, NB, true>;
+  using LH = LdsH<C, HD, NB>;
   constexpr int HT = HD / 32;
   constexpr int NS = 4 * HT;
   constexpr bool EARLY_COL = NVMAX <= 2;  // colour taps issued before the MFMA phase (16 VGPRs per view)
-  __shared__ float lds[L::TOTAL];
+  __shared__ __attribute__((aligned(16))) float lds[L::TOTAL + (F16 ? LH::TOTAL + 4 : 0)];
+  float* const lh = lds + ((L::TOTAL + 3) & ~3);  // 16-byte aligned: the f16 A operands are read as ds_read_b128
   stage_weights<C, HD, NB, true>(lds, p.mlp, p.empty_feature);
   __syncthreads();
+  if constexpr (F16) {
+    stage_weights_h<C, HD, NB>(lh, lds, p.mlp);
+    __syncthreads();
+  }
+  // 2^S carried by the accumulators of the f16 path (1 on the fp32 path)
+  const float scale = F16 ? __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, lh[LH::SCALE]))) : 1.0f;
+  const float inv_scale = F16 ? __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, lh[LH::SCALE + 1]))) : 1.0f;
 
   const int lane = threadIdx.x & 63;
   const int h0 = lane >> 5;
@@ -154,6 +342,11 @@ __global__ __launch_bounds__(256, 2) void render_kernel_p(const FwdParams p) {
   const int lane_off0 = h0 * HD + (lane & 31);
   const bool nomfma = BTS_ABL(4), nosin = BTS_ABL(2);
 
+#ifdef BTS_PROBE
+  unsigned long long t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long t_last = __builtin_readcyclecounter();
+  const unsigned long long t_begin = t_last;
+#endif
   long g = xcd * gx + lw;
   // z of the first ray group
   float z_pre = 0.0f, zn_pre = 0.0f;
@@ -216,6 +409,7 @@ __global__ __launch_bounds__(256, 2) void render_kernel_p(const FwdParams p) {
       v3[2] = depth_code(p.code_mode == 1 ? pe.dist : pe.z, p.inv_z != 0, p.inv_dmax, p.inv_range, p.d_min, p.range);
       const bool use_empty = (p.learn_empty != 0) & pe.invalid;
       if (use_empty) tp.w00 = tp.w01 = tp.w10 = tp.w11 = 0.0f;  // the empty feature is added after the blend
+      if constexpr (F16) tp.w00 *= scale, tp.w01 *= scale, tp.w10 *= scale, tp.w11 *= scale;  // exact: power of two
 
       // ---------------- colour views: projection + taps; loads issued now for <= 2 views (models_bts.py:218-264)
       float col[NVMAX * 3];
@@ -229,7 +423,8 @@ __global__ __launch_bounds__(256, 2) void render_kernel_p(const FwdParams p) {
 #pragma unroll
           for (int t = 0; t < 4; ++t) ct[j][t] = make_float4(0.0f, 0.0f, 0.0f, 0.0f), cw[j][t] = 0.0f;
           if (j < nv && !BTS_ABL(8)) {
-            const Cam cj = load_cam(p.w2c_r + ((long)sample * nv + j) * 16, p.K_r + ((long)sample * nv + j) * 9);
+            // vector loads on purpose: VGPRs are plentiful in this phase (no accumulators yet), SGPRs are not
+            const Cam cj = load_cam_v(p.w2c_r + ((long)sample * nv + j) * 16, p.K_r + ((long)sample * nv + j) * 9);
             const Proj pc = project<false>(cj, px, py, pz);
             const Taps tc = make_taps(pc.x, pc.y, H, W);
             const float4* img = reinterpret_cast<const float4*>(p.imgs) + ((long)sample * nv + j) * H * W;
@@ -262,6 +457,7 @@ __global__ __launch_bounds__(256, 2) void render_kernel_p(const FwdParams p) {
         s_raw = eval_point_exact<C, HD, NB>(lds, G, p.w2c_enc + sample * 16, p.K_enc + sample * 9, H, W, p.code_mode, p.inv_z, p.inv_dmax,
                                             p.inv_range, p.d_min, p.range, p.freq_factor, p.learn_empty, b_out, px, py, pz);
       } else {
+      BTS_TICK(0)
       // ---------------- h = bilinear(G) + W_pe . PE + b: gather two stages ahead, blend between the octaves
       f32x16 acc[HT][2];
 #pragma unroll
@@ -276,14 +472,26 @@ __global__ __launch_bounds__(256, 2) void render_kernel_p(const FwdParams p) {
         stage_load<HD, 0>(ba, G, o, h);
         stage_load<HD, 1>(bb, G, o, h);
       }
-      const float* wl = lds + L::W_IN + lane_off;
-      kstep<HD>(acc, wl, 0, v3[0], v3[1], nomfma);
-      kstep<HD>(acc, wl + 2 * HD, 0, v3[2], 1.0f, nomfma);
-      float sc[6];
-      __builtin_amdgcn_sched_barrier(0);
-      pe_octave_sel<false>(sc, v3, p.freq_factor, nosin);
-      __builtin_amdgcn_sched_barrier(0);
-      octave_seq<HD, 0, false>(acc, ba, bb, G, o, wq, h, wl + 4 * HD, sc, v3, p.freq_factor, nomfma, nosin, nogather);
+      if constexpr (F16) {
+        const float* wl = lh + LH::W_RAW + lane_off;
+        kstep<HD>(acc, wl, 0, v3[0], v3[1]);
+        kstep<HD>(acc, wl + 2 * HD, 0, v3[2], 1.0f);
+        SinCos3 raw;
+        pe_direct(raw, v3, p.freq_factor);
+        __builtin_amdgcn_sched_barrier(0);
+        int lane4 = lane * 4;
+        asm volatile("" : "+v"(lane4));  // keep the A-operand reads inside the loop (see lane_off above)
+        region_seq<HD, 0>(acc, ba, bb, G, o, wq, h, lh + LH::W_F16 + lane4, LH::TERM_STRIDE, raw, v3, p.freq_factor);
+      } else {
+        const float* wl = lds + L::W_IN + lane_off;
+        kstep<HD>(acc, wl, 0, v3[0], v3[1], nomfma);
+        kstep<HD>(acc, wl + 2 * HD, 0, v3[2], 1.0f, nomfma);
+        SinCos3 raw;
+        __builtin_amdgcn_sched_barrier(0);
+        pe_direct(raw, v3, p.freq_factor);
+        __builtin_amdgcn_sched_barrier(0);
+        octave_seq<HD, 0>(acc, ba, bb, G, o, wq, h, wl + 4 * HD, raw, v3, p.freq_factor, nomfma, nosin, nogather);
+      }
       if constexpr (NS > kNumFreqs) {  // HD = 64: stages 6 and 7 are still in the buffers
         if (!nogather) {
           stage_blend<HD, 6>(acc, ba, wq);
@@ -295,7 +503,7 @@ __global__ __launch_bounds__(256, 2) void render_kernel_p(const FwdParams p) {
         for (int ht = 0; ht < HT; ++ht)
 #pragma unroll
           for (int q = 0; q < 16; ++q) {
-            const float ev = lds[L::EMPTY + ht * 32 + mfma_row(q, 0) + 4 * h];
+            const float ev = F16 ? lh[LH::EMPTY + ht * 32 + mfma_row(q, 0) + 4 * h] : lds[L::EMPTY + ht * 32 + mfma_row(q, 0) + 4 * h];
 #pragma unroll
             for (int pt = 0; pt < 2; ++pt) acc[ht][pt][q] += emp[pt] ? ev : 0.0f;
           }
@@ -310,7 +518,8 @@ __global__ __launch_bounds__(256, 2) void render_kernel_p(const FwdParams p) {
         for (int ot = 0; ot < HT; ++ot)
 #pragma unroll
           for (int q = 0; q < 16; ++q) {
-            const float bias = base[HD * HD + ot * 32 + mfma_row(q, 0) + 4 * h];
+            const int row = ot * 32 + mfma_row(q, 0) + 4 * h;
+            const float bias = F16 ? lh[LH::BIAS + b * 2 * HD + row] : base[HD * HD + row];
             net[ot][0][q] = bias, net[ot][1][q] = bias;
           }
         hidden_layer<HD>(net, acc, base, lane);
@@ -318,12 +527,14 @@ __global__ __launch_bounds__(256, 2) void render_kernel_p(const FwdParams p) {
         for (int ot = 0; ot < HT; ++ot)
 #pragma unroll
           for (int q = 0; q < 16; ++q) {
-            const float bias = base[2 * HD * HD + HD + ot * 32 + mfma_row(q, 0) + 4 * h];
+            const int row = ot * 32 + mfma_row(q, 0) + 4 * h;
+            const float bias = F16 ? lh[LH::BIAS + b * 2 * HD + HD + row] : base[2 * HD * HD + HD + row];
             acc[ot][0][q] += bias, acc[ot][1][q] += bias;
           }
         hidden_layer<HD>(acc, net, base + HD * HD + HD, lane);
       }
 
+      BTS_TICK(1)
       // ---------------- lin_out: in-lane dot over the hidden rows this lane holds, then fold the two lane halves
       float p0 = 0.0f, p1 = 0.0f;
       if (BTS_ABL(32)) {
@@ -335,15 +546,16 @@ __global__ __launch_bounds__(256, 2) void render_kernel_p(const FwdParams p) {
 #pragma unroll
           for (int q = 0; q < 16; ++q) {
             const float w2 = lds[L::W_OUT + ht * 32 + mfma_row(q, 0) + 4 * h];
-            p0 = __builtin_fmaf(fmaxf(acc[ht][0][q], 0.0f), w2, p0);
-            p1 = __builtin_fmaf(fmaxf(acc[ht][1][q], 0.0f), w2, p1);
+            p0 = __builtin_fmaf(relu1(acc[ht][0][q]), w2, p0);
+            p1 = __builtin_fmaf(relu1(acc[ht][1][q]), w2, p1);
           }
       }
       swap32(p0, p1);  // p0 = {tile0.lo, tile1.lo}, p1 = {tile0.hi, tile1.hi}: lane l now holds both halves of ITS sample
-      s_raw = (p0 + p1) + b_out;
+      s_raw = F16 ? __builtin_fmaf(p0 + p1, inv_scale, b_out) : (p0 + p1) + b_out;
       }
       float sigma = softplus(s_raw);
       if (p.empty_empty) sigma = pe.invalid ? 0.0f : sigma;
+      BTS_TICK(2)
 
       // ---------------- colours
       if constexpr (EARLY_COL) {
@@ -383,6 +595,7 @@ __global__ __launch_bounds__(256, 2) void render_kernel_p(const FwdParams p) {
       const float T = T_carry * excl;
       if (ONE_RAY && K > 64) T_carry = T_carry * __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, incl), 63));
       const float wgt = valid ? alpha * T : 0.0f;
+      BTS_TICK(3)
       depth_part = depth_part + wgt * z;
       w_part = w_part + wgt;
 #pragma unroll
@@ -409,6 +622,7 @@ __global__ __launch_bounds__(256, 2) void render_kernel_p(const FwdParams p) {
         }
       }
     }
+    BTS_TICK(4)
     // ---------------- per-ray sums: the last lane of each ray ends up with the totals
     depth_part = seg_scan_add(depth_part, lpr, kl);
     w_part = seg_scan_add(w_part, lpr, kl);
@@ -421,14 +635,23 @@ __global__ __launch_bounds__(256, 2) void render_kernel_p(const FwdParams p) {
       for (int i = 0; i < NVMAX * 3; ++i)
         if (i < nv * 3) p.rgb[ray * nv * 3 + i] = p.white_bkgd ? (rgb_part[i] + 1.0f) - w_part : rgb_part[i];  // nerf.py:301-304
     }
+    BTS_TICK(5)
   }
+#ifdef BTS_PROBE
+  if ((p.ablate & 128) && p.dbg && lane == 0) {
+    unsigned long long* d = p.dbg + ((long)blockIdx.x * 4 + wave) * 8;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) d[i] = t_acc[i];
+    d[6] = __builtin_readcyclecounter() - t_begin;
+  }
+#endif
 }
 
 #ifndef BTS_NO_LAUNCH_GLUE
 template <int C, int HD, int NB, int NVMAX>
 static int launch_render_p_one(const FwdParams& p, int grid, hipStream_t s) {
-  if (p.lpr == 64) render_kernel_p<C, HD, NB, NVMAX, true><<<grid, 256, 0, s>>>(p);
-  else render_kernel_p<C, HD, NB, NVMAX, false><<<grid, 256, 0, s>>>(p);
+  if (p.lpr == 64) render_kernel_p<C, HD, NB, NVMAX, true, true><<<grid, 256, 0, s>>>(p);
+  else render_kernel_p<C, HD, NB, NVMAX, false, true><<<grid, 256, 0, s>>>(p);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     set_error("%s: kernel launch failed (%ld)", hipGetErrorString(e), (long)e);
@@ -445,7 +668,14 @@ static int launch_render_p_nv(const FwdParams& p, int grid, hipStream_t s) {
   return launch_render_p_one<C, HD, NB, 8>(p, grid, s);
 }
 
+// A/B only (BTS_RENDER_F32MFMA=1): the same pipeline with lin_in on the fp32-input MFMA, benchmark shape only
+inline int launch_render_p_f32mfma(const FwdParams& p, int grid, hipStream_t s) {
+  render_kernel_p<64, 64, 0, 1, true, false><<<grid, 256, 0, s>>>(p);
+  return hipGetLastError() == hipSuccess ? BTS_OK : BTS_E_LAUNCH;
+}
+
 inline int launch_render_p(const FwdParams& p, int C, int HD, int NB, int grid, hipStream_t s) {
+  if (C == 64 && HD == 64 && NB == 0 && p.nv <= 1 && p.lpr == 64 && getenv("BTS_RENDER_F32MFMA")) return launch_render_p_f32mfma(p, grid, s);
   if (C == 64 && HD == 64 && NB == 0) return launch_render_p_nv<64, 64, 0>(p, grid, s);
   if (C == 32 && HD == 32 && NB == 1) return launch_render_p_nv<32, 32, 1>(p, grid, s);
   if (C == 32 && HD == 32 && NB == 0) return launch_render_p_nv<32, 32, 0>(p, grid, s);

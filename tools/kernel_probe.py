@@ -24,6 +24,7 @@ z = native.sample_coarse(rays, torch.rand(rays.shape[0], K, device="cuda"), True
 variants = {
     "proj__all-out": (ft, dict(want_weights=True, want_alphas=True, want_invalid=True)),
     "v1____all-out": (ft, dict(want_weights=True, want_alphas=True, want_invalid=True)),
+    "f32mfma_all  ": (ft, dict(want_weights=True, want_alphas=True, want_invalid=True)),
     "proj__no-wa  ": (ft, dict(want_invalid=True)),
     "proj__no-out ": (ft, dict(want_invalid=False)),
     "direct all   ": (ft_direct, dict(want_weights=True, want_alphas=True, want_invalid=True)),
@@ -35,10 +36,11 @@ res = {k: [] for k in variants}
 for r in range(rounds + 1):
     for name, (f, kw) in variants.items():
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        if name.startswith("v1"):
-            os.environ["BTS_RENDER_V1"] = "1"
-        else:
-            os.environ.pop("BTS_RENDER_V1", None)
+        for key, pref in (("BTS_RENDER_V1", "v1"), ("BTS_RENDER_F32MFMA", "f32mfma")):
+            if name.startswith(pref):
+                os.environ[key] = "1"
+            else:
+                os.environ.pop(key, None)
         e0.record()
         native.render_fwd(f, params, rays, z, hard_alpha_cap=True, **kw)
         e1.record()
