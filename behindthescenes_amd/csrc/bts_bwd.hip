@@ -116,9 +116,7 @@ __global__ __launch_bounds__(256, 1) void render_bwd_kernel(const BwdParams bp) 
 #pragma unroll
   for (int ht = 0; ht < HT; ++ht) {
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-      for (int q = 0; q < 16; ++q) dwpe[ht][kt][q] = 0.0f;
+    for (int kt = 0; kt < 2; ++kt) dwpe[ht][kt] = zero_acc();
 #pragma unroll
     for (int q = 0; q < 16; ++q) dw2[ht][q] = 0.0f;
   }

@@ -36,6 +36,19 @@ __device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
+// A zero accumulator the compiler cannot fold into the MFMA's inline-constant srcC.  With srcC = 0 the destination tuple is a fresh
+// value and hipcc (ROCm 7.2) may allocate it ON TOP of the instruction's own A / B source registers (seen: v_mfma_f32_32x32x2_f32
+// v[34:49], v35, v36, 0); MI355X then produces wrong values in the last-written lanes, timing-dependently (run-to-run differences in
+// lanes 48-63).  Starting from a register-resident zero makes the first MFMA the tied form (dst = srcC), whose sources are live
+// next to the accumulator and cannot overlap it.  tools/check_mfma_overlap.py scans the assembly for the pattern.
+__device__ __forceinline__ f32x16 zero_acc() {
+  f32x16 z;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) z[q] = 0.0f;
+  asm volatile("" : "+v"(z));
+  return z;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // camera: rows of w2c[:3,:4] and K(3x3) kept in scalar registers (wave-uniform batch element)
 // ---------------------------------------------------------------------------------------------------------------
@@ -174,12 +187,10 @@ __device__ __forceinline__ float pe_entry(const float (&v)[3], float freq_factor
 }
 
 __device__ __forceinline__ float softplus(float s) { return s > 20.0f ? s : log1pf(expf(s)); }  // F.softplus defaults
-// max(x, 0) as ONE instruction: the compiler puts a canonicalising v_max(x, x) in front of fmaxf on MFMA results
-__device__ __forceinline__ float relu1(float x) {
-  float r;
-  asm("v_max_f32_e32 %0, 0, %1" : "=v"(r) : "v"(x));
-  return r;
-}
+// max(x, 0) as ONE instruction, v_med3_f32(x, 0, FLT_MAX) (= x clamped to [0, FLT_MAX]; hidden activations never reach 3.4e38).
+// fmaxf on an MFMA result costs two: hipcc puts a canonicalising v_max(x, x) in front.  Not inline asm either: hipcc does not insert
+// the MFMA-result -> VALU-read wait states around an asm statement.
+__device__ __forceinline__ float relu1(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, 3.4028234663852886e38f); }
 __device__ __forceinline__ float sigmoidf(float s) { return 1.0f / (1.0f + expf(-s)); }
 
 // XCD-aware work-group remap: hardware places block b on XCD b % 8; give each XCD one contiguous range of tiles so

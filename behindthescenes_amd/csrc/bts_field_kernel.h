@@ -225,6 +225,28 @@ __device__ __forceinline__ void kstep(f32x16 (&acc)[HD / 32][2], const float* wl
   }
 }
 
+// First k-pair of a FRESH accumulator set: acc = W . x (srcC = inline 0, saves zero-filling 64 registers per sample).  With srcC = 0 the
+// destination is a new value and hipcc may allocate it on top of the instruction's own A / B registers, which MI355X does not
+// tolerate (see zero_acc in bts_common.h): the sources are therefore kept alive past the last MFMA of the step.
+template <int HD>
+__device__ __forceinline__ void kstep_first(f32x16 (&acc)[HD / 32][2], const float* wl, int lane_off, float a, float b) {
+  swap32(a, b);
+  float w[HD / 32];
+  f32x16 zero;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) zero[q] = 0.0f;
+#pragma unroll
+  for (int ht = 0; ht < HD / 32; ++ht) {
+    w[ht] = wl[lane_off + ht * 32];
+    acc[ht][0] = mfma(w[ht], a, zero);
+    acc[ht][1] = mfma(w[ht], b, zero);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  if constexpr (HD == 64) asm volatile("" ::"v"(w[0]), "v"(w[HD / 32 - 1]), "v"(a), "v"(b));
+  else asm volatile("" ::"v"(w[0]), "v"(a), "v"(b));
+  __builtin_amdgcn_sched_barrier(0);
+}
+
 // out[ot][pt] += W^T(k-major, [HD in][HD out]) . relu(in)   (one ResnetBlockFC linear; C-layout of `in` feeds B directly)
 template <int HD>
 __device__ __forceinline__ void hidden_layer(f32x16 (&out)[HD / 32][2], const f32x16 (&in)[HD / 32][2], const float* w, int lane) {
@@ -390,9 +412,7 @@ __device__ __forceinline__ float eval_point(const FwdParams& p, const float* lds
 #pragma unroll
   for (int ht = 0; ht < HT; ++ht)
 #pragma unroll
-    for (int pt = 0; pt < 2; ++pt)
-#pragma unroll
-      for (int q = 0; q < 16; ++q) acc[ht][pt][q] = 0.0f;
+    for (int pt = 0; pt < 2; ++pt) acc[ht][pt] = zero_acc();
 
   const float* wl = lds + L::W_IN + lane_off;
   if constexpr (PROJ) {
@@ -674,29 +694,14 @@ __global__ __launch_bounds__(256, 2) void field_kernel(const FwdParams p) {
 // step of every resident wave re-touched ~1 KB per ray: 19 % L2 hit rate, >100x the compulsory HBM/MALL traffic).
 // Alpha compositing is a segmented prefix product / sum over the lanes of a ray.
 // ---------------------------------------------------------------------------------------------------------------
+// One ray group (lpr lanes per ray, all chunks of K) rendered front to back -- the body of render_kernel, also used (out of line) by
+// the pipelined kernel to re-render the rare rays whose encoding needs libm range reduction (eval_point handles that internally).
 template <int C, int HD, int NB, int NVMAX, bool PROJ>
-__global__ __launch_bounds__(256, 2) void render_kernel(const FwdParams p) {
-  using L = Lds<C, HD, NB, PROJ>;
-  __shared__ float lds[L::TOTAL];
-  stage_weights<C, HD, NB, PROJ>(lds, p.mlp, p.empty_feature);
-  __syncthreads();
-
-  const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
-  const int nwg = gridDim.x;  // multiple of 8
-  const int wg = xcd_remap(blockIdx.x, nwg);
-  const int wg_per_xcd = nwg >> 3;
-  const int xcd = wg / wg_per_xcd;
-  const int lw = (wg - xcd * wg_per_xcd) * 4 + wave;  // wave index inside its XCD
-  const int waves_per_xcd = wg_per_xcd * 4;
+__device__ __forceinline__ void render_group(const FwdParams& p, const float* lds, long g, int lane, float b_out) {
   const int lpr = p.lpr, R = 64 / lpr;
   const int kl = lane & (lpr - 1);
-  const long gx = (p.groups + 7) >> 3;
-  const long g_end = min(p.groups, (xcd + 1) * gx);
   const int Bp = p.Bp, K = p.K, H = p.H, W = p.W, nv = p.nv;
-  const float b_out = p.mlp[MlpLayout{C + kPeDim, HD, NB}.b_out()];
-
-  for (long g = xcd * gx + lw; g < g_end; g += waves_per_xcd) {
+  {
     const long ray = g * R + lane / lpr;
     const int sample = __builtin_amdgcn_readfirstlane((int)((g * R) / Bp));  // all rays of a group belong to one batch element
     const Cam enc = load_cam(p.w2c_enc + sample * 16, p.K_enc + sample * 9);
@@ -802,6 +807,27 @@ __global__ __launch_bounds__(256, 2) void render_kernel(const FwdParams p) {
         if (i < nv * 3) p.rgb[ray * nv * 3 + i] = p.white_bkgd ? (rgb_part[i] + 1.0f) - w_part : rgb_part[i];  // nerf.py:301-304
     }
   }
+}
+
+template <int C, int HD, int NB, int NVMAX, bool PROJ>
+__global__ __launch_bounds__(256, 2) void render_kernel(const FwdParams p) {
+  using L = Lds<C, HD, NB, PROJ>;
+  __shared__ float lds[L::TOTAL];
+  stage_weights<C, HD, NB, PROJ>(lds, p.mlp, p.empty_feature);
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int nwg = gridDim.x;  // multiple of 8
+  const int wg = xcd_remap(blockIdx.x, nwg);
+  const int wg_per_xcd = nwg >> 3;
+  const int xcd = wg / wg_per_xcd;
+  const int lw = (wg - xcd * wg_per_xcd) * 4 + wave;  // wave index inside its XCD
+  const int waves_per_xcd = wg_per_xcd * 4;
+  const long gx = (p.groups + 7) >> 3;
+  const long g_end = min(p.groups, (xcd + 1) * gx);
+  const float b_out = p.mlp[MlpLayout{C + kPeDim, HD, NB}.b_out()];
+  for (long g = xcd * gx + lw; g < g_end; g += waves_per_xcd) render_group<C, HD, NB, NVMAX, PROJ>(p, lds, g, lane, b_out);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -40,9 +40,7 @@ __global__ __launch_bounds__(256) void project_kernel(const float* __restrict__ 
 #pragma unroll
   for (int pt = 0; pt < 2; ++pt)
 #pragma unroll
-    for (int ht = 0; ht < HT; ++ht)
-#pragma unroll
-      for (int q = 0; q < 16; ++q) acc[pt][ht][q] = 0.0f;
+    for (int ht = 0; ht < HT; ++ht) acc[pt][ht] = zero_acc();
   const int px0 = min(p0 + col, HW - 1), px1 = min(p0 + 32 + col, HW - 1);
 #pragma unroll 4
   for (int s = 0; s < C / 2; ++s) {
@@ -95,9 +93,7 @@ __global__ __launch_bounds__(256) void project_bwd_feat_kernel(const float* __re
 #pragma unroll
   for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-    for (int pt = 0; pt < 2; ++pt)
-#pragma unroll
-      for (int q = 0; q < 16; ++q) acc[ct][pt][q] = 0.0f;
+    for (int pt = 0; pt < 2; ++pt) acc[ct][pt] = zero_acc();
   const int px0 = min(p0 + col, HW - 1), px1 = min(p0 + 32 + col, HW - 1);
 #pragma unroll 2
   for (int qq = 0; qq < HD / 8; ++qq) {
@@ -152,9 +148,7 @@ __global__ __launch_bounds__(256) void project_bwd_weight_kernel(const float* __
 #pragma unroll
   for (int ht = 0; ht < HT; ++ht)
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-      for (int q = 0; q < 16; ++q) acc[ht][ct][q] = 0.0f;
+    for (int ct = 0; ct < CT; ++ct) acc[ht][ct] = zero_acc();
   for (int t = wave; t < tiles_per_slab; t += 4) {
     const int p0 = (slab * tiles_per_slab + t) * 64;
     if (p0 >= HW) break;

@@ -460,12 +460,6 @@ __global__ __launch_bounds__(256, 2) void render_kernel_p(const FwdParams p) {
       BTS_TICK(0)
       // ---------------- h = bilinear(G) + W_pe . PE + b: gather two stages ahead, blend between the octaves
       f32x16 acc[HT][2];
-#pragma unroll
-      for (int ht = 0; ht < HT; ++ht)
-#pragma unroll
-        for (int pt = 0; pt < 2; ++pt)
-#pragma unroll
-          for (int q = 0; q < 16; ++q) acc[ht][pt][q] = 0.0f;
       GBuf ba, bb;
       const bool nogather = BTS_ABL(1);
       if (!nogather) {
@@ -474,7 +468,7 @@ __global__ __launch_bounds__(256, 2) void render_kernel_p(const FwdParams p) {
       }
       if constexpr (F16) {
         const float* wl = lh + LH::W_RAW + lane_off;
-        kstep<HD>(acc, wl, 0, v3[0], v3[1]);
+        kstep_first<HD>(acc, wl, 0, v3[0], v3[1]);
         kstep<HD>(acc, wl + 2 * HD, 0, v3[2], 1.0f);
         SinCos3 raw;
         pe_direct(raw, v3, p.freq_factor);
@@ -484,7 +478,7 @@ __global__ __launch_bounds__(256, 2) void render_kernel_p(const FwdParams p) {
         region_seq<HD, 0>(acc, ba, bb, G, o, wq, h, lh + LH::W_F16 + lane4, LH::TERM_STRIDE, raw, v3, p.freq_factor);
       } else {
         const float* wl = lds + L::W_IN + lane_off;
-        kstep<HD>(acc, wl, 0, v3[0], v3[1], nomfma);
+        kstep_first<HD>(acc, wl, 0, v3[0], v3[1]);
         kstep<HD>(acc, wl + 2 * HD, 0, v3[2], 1.0f, nomfma);
         SinCos3 raw;
         __builtin_amdgcn_sched_barrier(0);
