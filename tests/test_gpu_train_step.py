@@ -1,0 +1,57 @@
+"""GPU: one training-step data flow after the CNN through the drop-in modules (BTSNet.encode -> NeRFRenderer.composite on the
+reference's seeded patch rays -> _format_outputs -> PatchRaySampler.reconstruct -> photometric loss -> backward), against the
+loss value and gradients the REAL reference produced for the same inputs (tests/golden/train_step.npz).
+Tolerances (north_star): loss within 1e-5 absolute; gradients within 1e-4 of the largest entry."""
+import ast
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import bts_loss as OL
+from oracle import bts_oracle as O
+from tests._cases import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+def test_train_step_loss_and_gradients_vs_reference_golden():
+    import behindthescenes_amd as bts
+    from behindthescenes_amd import _lib
+    from tests._hip_helpers import load_mlp, make_conf
+    _lib.load()
+    z = np.load(f"{GOLDEN}/train_step.npz")
+    meta = ast.literal_eval(str(z["meta"]))
+    t = {k: torch.from_numpy(z[k]) for k in z.files if k != "meta"}
+    n, pc, ps, K, H, W = meta["n"], meta["patches"], meta["patch"], meta["K"], meta["H"], meta["W"]
+    cfg = O.FieldConfig(d_min=meta["d_min"], d_max=meta["d_max"])
+    net = bts.BTSNet(make_conf(cfg, meta["C"], meta["Hd"], 0, H, W))
+    load_mlp(net, O.MlpParams(t["w_in"], t["b_in"], [], t["w_out"], t["b_out"]))
+    with torch.no_grad():
+        net.encoder.feats[0].data = t["feat"].clone()
+    net = net.cuda().train()
+    images = t["images"].cuda()
+    net.encode(images, t["projs"].cuda(), t["poses"].cuda(), ids_encoder=[0], ids_render=meta["ids_render"], images_alt=images * .5 + .5)
+    renderer = bts.NeRFRenderer(n_coarse=K, lindisp=True, hard_alpha_cap=True).cuda().train()
+    sampler = bts.PatchRaySampler(ray_batch_size=pc * ps * ps, z_near=cfg.d_min, z_far=cfg.d_max, patch_size=ps)
+    rays = t["rays"].cuda()
+    comp = renderer.composite(net, rays.reshape(-1, 8), t["z_samp"].cuda(), coarse=True, sb=n)
+    out = renderer._format_outputs(comp, n, want_weights=True, want_alphas=True, want_z_samps=False, want_rgb_samps=True)
+    rd = dict(coarse=out, rgb_gt=t["rgb_gt"].cuda())
+    rd["fine"] = dict(rd["coarse"])
+    rd = sampler.reconstruct(rd)
+    c = rd["coarse"]
+    # the renderer's outputs in the layout the loss consumes
+    assert c["rgb"].shape == t["out_rgb"].shape and c["invalid"].shape == t["out_invalid"].shape
+    torch.testing.assert_close(c["depth"].detach().cpu(), t["out_depth"], rtol=1e-4, atol=0)
+    torch.testing.assert_close(c["rgb"].detach().cpu(), t["out_rgb"], rtol=0, atol=1e-5)
+    loss, parts = OL.reconstruction_loss(c, rd["rgb_gt"])
+    assert abs(loss.item() - t["loss"].item()) <= 1e-5, (loss.item(), t["loss"].item())
+    assert abs(parts["loss_invalid_ratio"].item() - t["loss_invalid_ratio"].item()) <= 1e-6
+    loss.backward()
+    got = dict(g_w_in=net.mlp_coarse.lin_in.weight.grad, g_b_in=net.mlp_coarse.lin_in.bias.grad,
+               g_w_out=net.mlp_coarse.lin_out.weight.grad, g_b_out=net.mlp_coarse.lin_out.bias.grad, g_feat=net.encoder.feats[0].grad)
+    for k, g in got.items():
+        ref = t[k].view_as(g.cpu())
+        err = (g.cpu() - ref).abs().max().item() / (ref.abs().max().item() + 1e-20)
+        assert err <= 1e-4, (k, err)

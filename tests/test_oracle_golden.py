@@ -103,3 +103,48 @@ def test_oracle_against_live_reference_fullres_slice():
     torch.testing.assert_close(our[2], ref_out[2], rtol=2e-6, atol=0)
     torch.testing.assert_close(our[1], ref_out[1], rtol=0, atol=2e-6)
     assert torch.equal(our[4], ref_out[4])
+
+
+def _train_step_case():
+    import ast
+    z = np.load(f"{GOLDEN}/train_step.npz")
+    meta = ast.literal_eval(str(z["meta"]))
+    t = {k: torch.from_numpy(z[k]) for k in z.files if k != "meta"}
+    return meta, t
+
+
+def test_loss_matches_reference_golden():
+    """oracle/bts_loss.py on the render dict the reference's own ReconstructionLoss consumed -> the reference's loss value"""
+    from oracle import bts_loss as OL
+    meta, t = _train_step_case()
+    coarse = dict(rgb=t["out_rgb"], depth=t["out_depth"], weights=t["out_weights"], alphas=t["out_alphas"], invalid=t["out_invalid"])
+    n, pc, ps = meta["n"], meta["patches"], meta["patch"]
+    loss, parts = OL.reconstruction_loss(coarse, t["rgb_gt"].view(n, pc, ps, ps, 3))
+    assert abs(loss.item() - t["loss"].item()) <= 1e-6
+    assert abs(parts["loss_eas"].item() - t["loss_eas"].item()) <= 1e-6
+    assert abs(parts["loss_rgb_coarse"].item() - t["loss_rgb_coarse"].item()) <= 1e-6
+    assert abs(parts["loss_invalid_ratio"].item() - t["loss_invalid_ratio"].item()) <= 1e-7
+
+
+def test_train_step_oracle_end_to_end_golden():
+    """oracle renderer + oracle loss + autograd == the reference's training-step loss and gradients"""
+    from oracle import bts_loss as OL
+    meta, t = _train_step_case()
+    n, pc, ps, K = meta["n"], meta["patches"], meta["patch"], meta["K"]
+    cfg = O.FieldConfig(d_min=meta["d_min"], d_max=meta["d_max"])
+    params = [t[k].clone().requires_grad_(True) for k in ("w_in", "b_in", "w_out", "b_out")]
+    feat = t["feat"].clone().requires_grad_(True)
+    mlp = O.MlpParams(params[0], params[1], [], params[2], params[3])
+    scene = dict(images=t["images"], feat=feat, projs=t["projs"], poses=t["poses"])
+    st = O.make_state(scene, meta["ids_render"], cfg)
+    st = O.FieldState(feat, st.K_enc, st.w2c_enc, st.imgs, st.K_r, st.w2c_r)
+    w, rgb, depth, a, inv, _, _ = O.composite(t["rays"].reshape(-1, 8), t["z_samp"], n, st, mlp, cfg, hard_alpha_cap=True)
+    nv = len(meta["ids_render"])
+    coarse = dict(rgb=rgb.view(n, pc, ps, ps, nv, 3), depth=depth.view(n, pc, ps, ps), weights=w.view(n, pc, ps, ps, K),
+                  alphas=a.view(n, pc, ps, ps, K), invalid=inv.view(n, pc, ps, ps, K, nv))
+    loss, _ = OL.reconstruction_loss(coarse, t["rgb_gt"].view(n, pc, ps, ps, 3))
+    assert abs(loss.item() - t["loss"].item()) <= 1e-6
+    grads = torch.autograd.grad(loss, params + [feat])
+    for g, nme in zip(grads, ("g_w_in", "g_b_in", "g_w_out", "g_b_out", "g_feat")):
+        ref = t[nme]
+        assert (g - ref).abs().max().item() <= 2e-5 * (ref.abs().max().item() + 1e-12), nme
