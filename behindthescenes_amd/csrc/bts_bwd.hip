@@ -40,8 +40,16 @@ struct BwdLds {
   static constexpr int D_EMPTY = EMPTY + HD;            // [HD] gradient accumulator for it
   static constexpr int D_WPE = D_EMPTY + HD;            // [40][HD] work-group accumulator for dW_pe (k-major like W_PE)
   static constexpr int D_WOUT = D_WPE + PE_ROWS * HD;   // [HD] + 1 (db_out)
-  static constexpr int TILES = D_WOUT + HD + 1;         // per wave: g_h tile then pe tile
-  static constexpr int TILE_STRIDE = 64 * LDG + 64 * LDX;
+  // ResnetBlockFC layers (RE10K): per block the forward operands (k-major: w0t [in][out], b0, w1t, b1 -- the layout hidden_layer
+  // expects), the row-major weights for the backward products (w0 [out][in], w1) and the work-group gradient accumulators
+  static constexpr int BLK_F = D_WOUT + HD + 1;
+  static constexpr int BLK_F_STRIDE = 2 * HD * HD + 2 * HD;
+  static constexpr int BLK_R = BLK_F + NB * BLK_F_STRIDE;          // per block: w0 [out][in], w1 [out][in]
+  static constexpr int BLK_R_STRIDE = 2 * HD * HD;
+  static constexpr int D_BLK = BLK_R + NB * BLK_R_STRIDE;          // per block: dw0 [out][in], db0 [HD], dw1 [out][in], db1 [HD]
+  static constexpr int D_BLK_STRIDE = 2 * HD * HD + 2 * HD;
+  static constexpr int TILES = D_BLK + NB * D_BLK_STRIDE;          // per wave: g tile, pe tile (, activation tile when NB > 0)
+  static constexpr int TILE_STRIDE = 64 * LDG + 64 * LDX + (NB > 0 ? 64 * LDG : 0);
   static constexpr int TOTAL = TILES + 4 * TILE_STRIDE;
 };
 
@@ -49,9 +57,20 @@ __device__ __forceinline__ void atomic_add_f32(float* p, float v) {
   __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-template <int C, int HD, int NVMAX>
+// dW[i][j] += sum over the wave's 64 points of A[p][i] * B[p][j], both operands staged as [point][channel] LDS tiles (k-step s pairs
+// points s and s + 32); i, j < 32: one 32x32 accumulator tile
+__device__ __forceinline__ void point_contraction(f32x16& dw, const float* a_tile, int lda, const float* b_tile, int ldb, int lane) {
+  const int h = lane >> 5, col = lane & 31;
+#pragma unroll 4
+  for (int s = 0; s < 32; ++s) {
+    const int pnt = s + 32 * h;
+    dw = mfma(a_tile[pnt * lda + col], b_tile[pnt * ldb + col], dw);
+  }
+}
+
+template <int C, int HD, int NB, int NVMAX>
 __global__ __launch_bounds__(256, 1) void render_bwd_kernel(const BwdParams bp) {
-  constexpr int NB = 0;
+  static_assert(NB == 0 || HD == 32, "ResnetBlockFC backward is built for d_hidden = 32 (RE10K config)");
   constexpr int HT = HD / 32;
   using L = BwdLds<HD, NB>;
   constexpr int D_IN = C + kPeDim;
@@ -76,6 +95,24 @@ __global__ __launch_bounds__(256, 1) void render_bwd_kernel(const BwdParams bp) 
     lds[L::D_WOUT + hid] = 0.0f;
   }
   if (threadIdx.x == 0) lds[L::D_WOUT + HD] = 0.0f;
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    float* f = lds + L::BLK_F + b * L::BLK_F_STRIDE;
+    float* r = lds + L::BLK_R + b * L::BLK_R_STRIDE;
+    float* d = lds + L::D_BLK + b * L::D_BLK_STRIDE;
+    for (int i = threadIdx.x; i < HD * HD; i += blockDim.x) {
+      const int k = i / HD, o = i % HD;
+      f[i] = p.mlp[ml.blk_w0(b) + o * HD + k];                      // k-major (transposed) for the forward recompute
+      f[HD * HD + HD + i] = p.mlp[ml.blk_w1(b) + o * HD + k];
+      r[i] = p.mlp[ml.blk_w0(b) + i];                               // row-major [out][in] for W^T . g
+      r[HD * HD + i] = p.mlp[ml.blk_w1(b) + i];
+    }
+    for (int i = threadIdx.x; i < HD; i += blockDim.x) {
+      f[HD * HD + i] = p.mlp[ml.blk_b0(b) + i];
+      f[2 * HD * HD + HD + i] = p.mlp[ml.blk_b1(b) + i];
+    }
+    for (int i = threadIdx.x; i < L::D_BLK_STRIDE; i += blockDim.x) d[i] = 0.0f;
+  }
   __syncthreads();
 
   const int lane = threadIdx.x & 63;
@@ -93,6 +130,7 @@ __global__ __launch_bounds__(256, 1) void render_bwd_kernel(const BwdParams bp) 
   const int H = p.H, W = p.W, nv = p.nv;
   float* gh_tile = lds + L::TILES + wave * L::TILE_STRIDE;  // [64][LDG]
   float* pe_tile = gh_tile + 64 * L::LDG;                   // [64][LDX]
+  float* act_tile = pe_tile + 64 * L::LDX;                  // [64][LDG]  (NB > 0 only)
 
   const Cam enc = load_cam(p.w2c_enc + sample * 16, p.K_enc + sample * 9);
   const float4* __restrict__ G = reinterpret_cast<const float4*>(p.proj) + (long)sample * H * W * (HD / 4);
@@ -120,6 +158,17 @@ __global__ __launch_bounds__(256, 1) void render_bwd_kernel(const BwdParams bp) 
 #pragma unroll
     for (int q = 0; q < 16; ++q) dw2[ht][q] = 0.0f;
   }
+  // ResnetBlockFC gradients (HD = 32): one 32x32 tile per weight matrix, per-lane bias partials like dw2
+  f32x16 dwb[NB > 0 ? NB : 1][2];
+  float dbb[NB > 0 ? NB : 1][2][16];
+#pragma unroll
+  for (int b = 0; b < (NB > 0 ? NB : 1); ++b)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      dwb[b][j] = zero_acc();
+#pragma unroll
+      for (int q = 0; q < 16; ++q) dbb[b][j][q] = 0.0f;
+    }
   float db2 = 0.0f;
   float S = 0.0f;  // sum_{m>k} g_w_m w_m
   float z_after = 0.0f;
@@ -220,7 +269,34 @@ __global__ __launch_bounds__(256, 1) void render_bwd_kernel(const BwdParams bp) 
       }
     }
 
-    // ---------------- g_h in the C layout; dw_out / db_out partials; transposed copy for the dW_pe MFMA
+    // ---------------- ResnetBlockFC layers, forward recompute: keep every block's input h and its inner activation net
+    f32x16 h_in[NB > 0 ? NB : 1][HT][2], net_a[NB > 0 ? NB : 1][HT][2];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const float* base = lds + L::BLK_F + b * L::BLK_F_STRIDE;
+#pragma unroll
+      for (int ot = 0; ot < HT; ++ot)
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt) h_in[b][ot][pt] = acc[ot][pt];
+#pragma unroll
+      for (int ot = 0; ot < HT; ++ot)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const float bias = base[HD * HD + ot * 32 + mfma_row(q, 0) + 4 * h];
+          net_a[b][ot][0][q] = bias, net_a[b][ot][1][q] = bias;
+        }
+      hidden_layer<HD>(net_a[b], acc, base, lane);
+#pragma unroll
+      for (int ot = 0; ot < HT; ++ot)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const float bias = base[2 * HD * HD + HD + ot * 32 + mfma_row(q, 0) + 4 * h];
+          acc[ot][0][q] += bias, acc[ot][1][q] += bias;
+        }
+      hidden_layer<HD>(acc, net_a[b], base + HD * HD + HD, lane);
+    }
+
+    // ---------------- g_h (of the LAST layer's output) in the C layout; dw_out / db_out partials
     float gs_t[2];
     {
       unsigned t0, t1;
@@ -238,10 +314,65 @@ __global__ __launch_bounds__(256, 1) void render_bwd_kernel(const BwdParams bp) 
         for (int pt = 0; pt < 2; ++pt) {
           const float hv = acc[ht][pt][q];
           dw2[ht][q] = __builtin_fmaf(fmaxf(hv, 0.0f), gs_t[pt], dw2[ht][q]);
-          const float gh = hv > 0.0f ? w2 * gs_t[pt] : 0.0f;
-          acc[ht][pt][q] = gh;                                  // acc now holds g_h
-          gh_tile[(pt * 32 + col) * L::LDG + hid] = gh;
+          acc[ht][pt][q] = hv > 0.0f ? w2 * gs_t[pt] : 0.0f;   // acc now holds g_h
         }
+      }
+
+    // ---------------- back through the blocks (resnetfc.py:53-62): h' = h + fc_1(relu(fc_0(relu(h))))
+    //   g_dx = g_h';  dW1 += g_dx (x) relu(net);  g_net = relu'(net) . (W1^T g_dx);  dW0 += g_net (x) relu(h);  g_h = g_h' + relu'(h) . (W0^T g_net)
+#pragma unroll
+    for (int b = NB - 1; b >= 0; --b) {
+      const float* rw = lds + L::BLK_R + b * L::BLK_R_STRIDE;
+      if (bp.d_mlp) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+#pragma unroll
+          for (int pt = 0; pt < 2; ++pt) {
+            const int hid = mfma_row(q, 0) + 4 * h;
+            gh_tile[(pt * 32 + col) * L::LDG + hid] = acc[0][pt][q];
+            act_tile[(pt * 32 + col) * L::LDG + hid] = fmaxf(net_a[b][0][pt][q], 0.0f);
+            dbb[b][1][q] += acc[0][pt][q];
+          }
+        point_contraction(dwb[b][1], gh_tile, L::LDG, act_tile, L::LDG, lane);   // dW1[out][in]
+      }
+      f32x16 g_net[HT][2];
+#pragma unroll
+      for (int pt = 0; pt < 2; ++pt) g_net[0][pt] = zero_acc();
+      hidden_layer<HD, false>(g_net, acc, rw + HD * HD, lane);                   // W1^T . g_dx
+#pragma unroll
+      for (int q = 0; q < 16; ++q)
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt) g_net[0][pt][q] = net_a[b][0][pt][q] > 0.0f ? g_net[0][pt][q] : 0.0f;
+      if (bp.d_mlp) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+#pragma unroll
+          for (int pt = 0; pt < 2; ++pt) {
+            const int hid = mfma_row(q, 0) + 4 * h;
+            gh_tile[(pt * 32 + col) * L::LDG + hid] = g_net[0][pt][q];
+            act_tile[(pt * 32 + col) * L::LDG + hid] = fmaxf(h_in[b][0][pt][q], 0.0f);
+            dbb[b][0][q] += g_net[0][pt][q];
+          }
+        point_contraction(dwb[b][0], gh_tile, L::LDG, act_tile, L::LDG, lane);   // dW0[out][in]
+      }
+      f32x16 g_rh[HT][2];
+#pragma unroll
+      for (int pt = 0; pt < 2; ++pt) g_rh[0][pt] = zero_acc();
+      hidden_layer<HD, false>(g_rh, g_net, rw, lane);                            // W0^T . g_net
+#pragma unroll
+      for (int q = 0; q < 16; ++q)
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt) acc[0][pt][q] += h_in[b][0][pt][q] > 0.0f ? g_rh[0][pt][q] : 0.0f;
+    }
+
+    // ---------------- transposed copy of g_h (of lin_in's output) for the dW_pe MFMA
+#pragma unroll
+    for (int ht = 0; ht < HT; ++ht)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int hid = ht * 32 + mfma_row(q, 0) + 4 * h;
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt) gh_tile[(pt * 32 + col) * L::LDG + hid] = acc[ht][pt][q];
       }
 
     // ---------------- dG += w_tap * g_h on the four taps (float atomics; inactive hidden units are skipped)
@@ -310,6 +441,22 @@ __global__ __launch_bounds__(256, 1) void render_bwd_kernel(const BwdParams bp) 
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
     if (lane == 0) atomicAdd(&lds[L::D_WOUT + HD], v);
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      float* d = lds + L::D_BLK + b * L::D_BLK_STRIDE;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        float* dw = d + j * (HD * HD + HD);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          atomicAdd(&dw[mfma_row(q, h) * HD + col], dwb[b][j][q]);   // D[i = out][j = in]
+          float bv = dbb[b][j][q];
+#pragma unroll
+          for (int off = 16; off >= 1; off >>= 1) bv += __shfl_xor(bv, off, 64);
+          if (col == 0) atomicAdd(&dw[HD * HD + mfma_row(q, h)], bv);
+        }
+      }
+    }
   }
   __syncthreads();
   if (bp.d_mlp) {
@@ -323,6 +470,14 @@ __global__ __launch_bounds__(256, 1) void render_bwd_kernel(const BwdParams bp) 
       const float v = lds[L::D_WOUT + i];
       if (v != 0.0f) atomic_add_f32(bp.d_mlp + (i < HD ? ml.w_out() + i : ml.b_out()), v);
     }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const float* d = lds + L::D_BLK + b * L::D_BLK_STRIDE;
+      for (int i = threadIdx.x; i < L::D_BLK_STRIDE; i += blockDim.x) {
+        const float v = d[i];
+        if (v != 0.0f) atomic_add_f32(bp.d_mlp + ml.blk(b) + i, v);   // packed order: w0, b0, w1, b1 = the LDS order
+      }
+    }
   }
   if (bp.d_empty_proj) {
     for (int i = threadIdx.x; i < HD; i += blockDim.x) {
@@ -332,18 +487,18 @@ __global__ __launch_bounds__(256, 1) void render_bwd_kernel(const BwdParams bp) 
   }
 }
 
-template <int C, int HD>
+template <int C, int HD, int NB>
 static int launch_bwd(const BwdParams& bp, int grid, hipStream_t s) {
-  using L = BwdLds<HD, 0>;
+  using L = BwdLds<HD, NB>;
   const size_t shmem = L::TOTAL * sizeof(float);
   auto go = [&](auto kern) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     kern<<<grid, 256, shmem, s>>>(bp);
   };
-  if (bp.f.nv <= 1) go(render_bwd_kernel<C, HD, 1>);
-  else if (bp.f.nv <= 2) go(render_bwd_kernel<C, HD, 2>);
-  else if (bp.f.nv <= 4) go(render_bwd_kernel<C, HD, 4>);
-  else go(render_bwd_kernel<C, HD, 8>);
+  if (bp.f.nv <= 1) go(render_bwd_kernel<C, HD, NB, 1>);
+  else if (bp.f.nv <= 2) go(render_bwd_kernel<C, HD, NB, 2>);
+  else if (bp.f.nv <= 4) go(render_bwd_kernel<C, HD, NB, 4>);
+  else go(render_bwd_kernel<C, HD, NB, 8>);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     set_error("%s: backward kernel launch failed (%ld)", hipGetErrorString(e), (long)e);
@@ -362,10 +517,6 @@ int render_bwd_impl(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const BtsR
     set_error("%s: white_bkgd has no backward (no shipped config trains with it)", "bts_render_bwd");
     return BTS_E_UNSUPPORTED;
   }
-  if (cfg->n_blocks != 0) {
-    set_error("%s: backward for n_blocks=%ld is not built yet", "bts_render_bwd", cfg->n_blocks);
-    return BTS_E_UNSUPPORTED;
-  }
   BwdParams bp;
   bp.f = make_params(cfg, t);
   bp.f.rays = a->rays, bp.f.z_samp = a->z_samp;
@@ -375,9 +526,10 @@ int render_bwd_impl(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const BtsR
   bp.g_rgb = g->g_rgb, bp.g_depth = g->g_depth, bp.g_weights = g->g_weights, bp.g_alphas = g->g_alphas;
   bp.d_proj = g->d_proj_nhwc, bp.d_mlp = g->d_mlp_params, bp.d_empty_proj = g->d_empty_proj;
   const int grid = bp.f.tiles_per_sample * cfg->n;
-  if (cfg->C == 64 && cfg->d_hidden == 64) return launch_bwd<64, 64>(bp, grid, s);
-  if (cfg->C == 32 && cfg->d_hidden == 32) return launch_bwd<32, 32>(bp, grid, s);
-  set_error("%s: unsupported MLP shape C=%ld d_hidden=%ld", "bts_render_bwd", cfg->C, cfg->d_hidden);
+  if (cfg->C == 64 && cfg->d_hidden == 64 && cfg->n_blocks == 0) return launch_bwd<64, 64, 0>(bp, grid, s);
+  if (cfg->C == 32 && cfg->d_hidden == 32 && cfg->n_blocks == 0) return launch_bwd<32, 32, 0>(bp, grid, s);
+  if (cfg->C == 32 && cfg->d_hidden == 32 && cfg->n_blocks == 1) return launch_bwd<32, 32, 1>(bp, grid, s);
+  set_error("%s: unsupported MLP shape C=%ld d_hidden=%ld n_blocks=%ld", "bts_render_bwd", cfg->C, cfg->d_hidden, cfg->n_blocks);
   return BTS_E_UNSUPPORTED;
 }
 

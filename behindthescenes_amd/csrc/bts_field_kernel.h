@@ -247,8 +247,9 @@ __device__ __forceinline__ void kstep_first(f32x16 (&acc)[HD / 32][2], const flo
   __builtin_amdgcn_sched_barrier(0);
 }
 
-// out[ot][pt] += W^T(k-major, [HD in][HD out]) . relu(in)   (one ResnetBlockFC linear; C-layout of `in` feeds B directly)
-template <int HD>
+// out[ot][pt] += W^T(k-major, [HD in][HD out]) . relu(in)   (one ResnetBlockFC linear; C-layout of `in` feeds B directly).
+// RELU_IN = false with w = the ROW-major weight ([out][in] = nn.Linear.weight) gives the backward product W^T . g.
+template <int HD, bool RELU_IN = true>
 __device__ __forceinline__ void hidden_layer(f32x16 (&out)[HD / 32][2], const f32x16 (&in)[HD / 32][2], const float* w, int lane) {
   const int h = lane >> 5, col = lane & 31;
 #pragma unroll
@@ -256,8 +257,8 @@ __device__ __forceinline__ void hidden_layer(f32x16 (&out)[HD / 32][2], const f3
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int kin = it * 32 + mfma_row(r, 0) + 4 * h;
-      const float b0 = fmaxf(in[it][0][r], 0.0f);
-      const float b1 = fmaxf(in[it][1][r], 0.0f);
+      const float b0 = RELU_IN ? fmaxf(in[it][0][r], 0.0f) : in[it][0][r];
+      const float b1 = RELU_IN ? fmaxf(in[it][1][r], 0.0f) : in[it][1][r];
 #pragma unroll
       for (int ot = 0; ot < HD / 32; ++ot) {
         const float a = w[kin * HD + ot * 32 + col];

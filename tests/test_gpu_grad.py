@@ -40,16 +40,21 @@ def _hip_grads(hip, net, renderer, rays, z, sb, loss_fn):
     return [p.grad for p in params]
 
 
-def test_gradients_vs_reference_golden(hip):
+@pytest.mark.parametrize("name", ["kitti_train", "re10k_train"])
+def test_gradients_vs_reference_golden(hip, name):
+    """kitti_train: lin_in -> lin_out; re10k_train: one ResnetBlockFC in between (fc_0 / fc_1 weight and bias gradients too)."""
     from tests._hip_helpers import net_from_case
-    c = Case("kitti_train")
+    c = Case(name)
     net = net_from_case(c, train=True)
     net.encode(c.scene["images"].cuda(), c.scene["projs"].cuda(), c.scene["poses"].cuda(), ids_encoder=[0], ids_render=c.meta["ids_render"])
     renderer = hip.NeRFRenderer(n_coarse=c.meta["K"], lindisp=True, hard_alpha_cap=c.hard_cap).cuda()
     g_rgb, g_depth = c.t["gin_rgb"].cuda(), c.t["gin_depth"].cuda()
     grads = _hip_grads(hip, net, renderer, c.rays.reshape(-1, 8).cuda(), c.z_samp.cuda(), c.rays.shape[0],
                        lambda w, rgb, depth, a: (rgb * g_rgb).sum() + (depth * g_depth).sum())
-    names = ["g_w_in", "g_b_in", "g_w_out", "g_b_out", "g_feat"]
+    nb = c.meta["nb"]
+    names = ["g_w_in", "g_b_in"] + sum([[f"g_blk{i}_w0", f"g_blk{i}_b0", f"g_blk{i}_w1", f"g_blk{i}_b1"] for i in range(nb)], []) \
+        + ["g_w_out", "g_b_out", "g_feat"]
+    assert len(grads) == len(names)
     for g, nme in zip(grads, names):
         assert g is not None, nme
         assert _rel_to_max(g, c.t[nme].view_as(g.cpu())) <= GRAD_RTOL, (nme, _rel_to_max(g, c.t[nme].view_as(g.cpu())))
