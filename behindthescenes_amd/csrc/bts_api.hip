@@ -17,6 +17,7 @@ int gen_rays_launch(const float* poses, const float* projs, int V, int H, int W,
                     hipStream_t s);
 int sample_coarse_launch(const float* rays, const float* u, long B, int K, int lindisp, float* z, hipStream_t s);
 int distance_to_z_launch(const float* depths, const float* invK, int N, int H, int W, float* out, hipStream_t s);
+int invert_small_launch(const float* src, float* dst, int N, int dim, hipStream_t s);
 
 int project_features_impl(int C, int HD, const float* feat, const float* mlp, int N, int HW, float* proj, hipStream_t s);
 int project_features_bwd_impl(int C, int HD, const float* feat, const float* dproj, const float* mlp, int N, int HW, float* dfeat,
@@ -197,6 +198,11 @@ int bts_sample_coarse(const float* rays, const float* u, int64_t B, int32_t K, i
 int bts_distance_to_z(const float* depths, const float* inv_K, int32_t N, int32_t H, int32_t W, float* out, void* stream) {
   BTS_CHECK_LAYOUT(depths && inv_K && out && N > 0 && H > 0 && W > 0, "bts_distance_to_z");
   BTS_RET_LAUNCH(distance_to_z_launch(depths, inv_K, N, H, W, out, (hipStream_t)stream), "bts_distance_to_z");
+}
+
+int bts_invert_small(const float* src, float* dst, int32_t N, int32_t dim, void* stream) {
+  BTS_CHECK_LAYOUT(src && dst && N > 0 && (dim == 3 || dim == 4), "bts_invert_small");
+  BTS_RET_LAUNCH(invert_small_launch(src, dst, N, dim, (hipStream_t)stream), "bts_invert_small");
 }
 
 }  // extern "C"

@@ -173,4 +173,59 @@ int distance_to_z_launch(const float* depths, const float* invK, int N, int H, i
   return hipGetLastError() == hipSuccess ? BTS_OK : BTS_E_LAUNCH;
 }
 
+// ----------------------------------------------------------------------------------------------------------------
+// Batched inverse of 3x3 / 4x4 matrices (torch.inverse at models_bts.py:71 on the c2w poses and at
+// projection_operations.py:9 on the intrinsics): one thread per matrix, Gauss-Jordan with partial pivoting in fp64, rounded once to
+// fp32 -- within 1 ulp of any correctly working fp32 LU, and no hipSOLVER call / host synchronisation on the render path.
+// ----------------------------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(64) void invert_small_kernel(const float* __restrict__ src, float* __restrict__ dst, int N) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= N) return;
+  double a[D][2 * D];
+#pragma unroll
+  for (int r = 0; r < D; ++r)
+#pragma unroll
+    for (int c = 0; c < D; ++c) a[r][c] = (double)src[(long)i * D * D + r * D + c], a[r][D + c] = r == c ? 1.0 : 0.0;
+#pragma unroll
+  for (int col = 0; col < D; ++col) {
+    int piv = col;
+    double best = fabs(a[col][col]);
+#pragma unroll
+    for (int r = col + 1; r < D; ++r)
+      if (fabs(a[r][col]) > best) best = fabs(a[r][col]), piv = r;
+#pragma unroll
+    for (int r = col + 1; r < D; ++r)
+      if (r == piv) {
+#pragma unroll
+        for (int c = 0; c < 2 * D; ++c) {
+          const double t = a[col][c];
+          a[col][c] = a[r][c], a[r][c] = t;
+        }
+      }
+    const double inv = 1.0 / a[col][col];  // singular input -> inf / nan, like torch.inverse's garbage-or-error; callers pass rigid poses
+#pragma unroll
+    for (int c = 0; c < 2 * D; ++c) a[col][c] *= inv;
+#pragma unroll
+    for (int r = 0; r < D; ++r)
+      if (r != col) {
+        const double f = a[r][col];
+#pragma unroll
+        for (int c = 0; c < 2 * D; ++c) a[r][c] -= f * a[col][c];
+      }
+  }
+#pragma unroll
+  for (int r = 0; r < D; ++r)
+#pragma unroll
+    for (int c = 0; c < D; ++c) dst[(long)i * D * D + r * D + c] = (float)a[r][D + c];
+}
+
+int invert_small_launch(const float* src, float* dst, int N, int dim, hipStream_t s) {
+  const int grid = (N + 63) / 64;
+  if (dim == 3) invert_small_kernel<3><<<grid, 64, 0, s>>>(src, dst, N);
+  else if (dim == 4) invert_small_kernel<4><<<grid, 64, 0, s>>>(src, dst, N);
+  else return BTS_E_UNSUPPORTED;
+  return hipGetLastError() == hipSuccess ? BTS_OK : BTS_E_LAUNCH;
+}
+
 }  // namespace bts

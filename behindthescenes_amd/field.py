@@ -73,7 +73,7 @@ class BTSNet(nn.Module):
         """images (n,v,3,H,W) in [-1,1]; Ks (n,v,3,3) normalised intrinsics; poses_c2w (n,v,4,4)  (models_bts.py:65-136)."""
         if combine_ids is not None:
             raise NotImplementedError("combine_ids (waymo multi-encoder-view mode) is not part of the HIP render path")
-        poses_w2c = torch.inverse(poses_c2w)
+        poses_w2c = native.invert_small(poses_c2w)
         if ids_encoder is None:
             ids_encoder = list(range(images.shape[1]))
         images_encoder, Ks_encoder, poses_w2c_encoder = images[:, ids_encoder], Ks[:, ids_encoder], poses_w2c[:, ids_encoder]

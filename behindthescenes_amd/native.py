@@ -113,11 +113,24 @@ def sample_coarse(rays: torch.Tensor, u: torch.Tensor, lindisp: bool) -> torch.T
     return out
 
 
+def invert_small(m: torch.Tensor) -> torch.Tensor:
+    """(..., d, d) with d in {3, 4} -> inverses (bts_invert_small); the stand-in for torch.inverse on poses / intrinsics."""
+    d = m.shape[-1]
+    if m.shape[-2] != d or d not in (3, 4):
+        raise BtsNativeError(f"invert_small: expected (..., 3, 3) or (..., 4, 4), got {tuple(m.shape)}")
+    src = m.float().contiguous()
+    _req(src, "matrices")
+    out = torch.empty_like(src)
+    N = src.numel() // (d * d)
+    _lib.check(_lib.load().bts_invert_small(_ptr(src), _ptr(out), N, d, _stream(src)), "bts_invert_small")
+    return out
+
+
 def distance_to_z(depths: torch.Tensor, projs: torch.Tensor) -> torch.Tensor:
-    """depths (n,nv,H,W), projs (n,nv,3,3) -> z (n,nv,H,W) (bts_distance_to_z).  The 3x3 inverse stays in torch."""
+    """depths (n,nv,H,W), projs (n,nv,3,3) -> z (n,nv,H,W) (bts_invert_small + bts_distance_to_z)."""
     n, nv, H, W = depths.shape
     _req(depths, "depths")
-    inv_K = torch.inverse(projs).reshape(n * nv, 3, 3).contiguous()
+    inv_K = invert_small(projs).reshape(n * nv, 3, 3)
     _req(inv_K, "inv_K", (n * nv, 3, 3))
     out = torch.empty_like(depths)
     _lib.check(_lib.load().bts_distance_to_z(_ptr(depths), _ptr(inv_K), n * nv, H, W, _ptr(out), _stream(out)),

@@ -11,8 +11,10 @@ rays (`renderer(all_rays, want_weights=True, want_alphas=True)`), `reconstruct`,
 resident in HBM before the timed region.  N > 1: every rank renders its own frame (frames are independent -> weak scaling,
 no collective on the data path); value = total rays of all ranks / max-over-ranks time.
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (field_kernel = bts_render_fwd), timed live with HIP
-events on the launch stream; `cpu_baseline` times the CPU oracle port on a bounded sample of the same workload.
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (bts::render_kernel_p = bts_render_fwd), timed live with HIP
+events on the launch stream inside the timed region; `roofline.traffic` is the HBM byte count of the committed rocprofv3 PMC passes
+of the same workload (profiles/<round>/traffic.json, written by tools/profile.sh), null when absent; `cpu_baseline` times the CPU
+oracle port on a bounded sample of the same workload.
 """
 import argparse
 import json
@@ -148,6 +150,14 @@ def main():
         elapsed = t.item()
 
     kernel_ms = sum(a.elapsed_time(b) for a, b in kernel_events) / max(len(kernel_events), 1)
+    traffic = None
+    prof = sorted(d for d in os.listdir(os.path.join(ROOT, "profiles")) if os.path.exists(os.path.join(ROOT, "profiles", d, "traffic.json"))) \
+        if os.path.isdir(os.path.join(ROOT, "profiles")) else []
+    if prof:
+        tj = json.load(open(os.path.join(ROOT, "profiles", prof[-1], "traffic.json")))
+        traffic = {"hbm_bytes_per_launch": tj["fetch_bytes"] + tj["write_bytes"], "fetch_bytes": tj["fetch_bytes"],
+                   "write_bytes": tj["write_bytes"], "source": f"profiles/{prof[-1]}/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
+                   "FETCH_SIZE doubled per MI355X_MICROARCH.md)"}
     step_ms = elapsed * 1e3 / args.steps
     value = world * n_rays * args.steps / elapsed
     if rank == 0:
@@ -161,8 +171,10 @@ def main():
                                    "nv=1, want_weights+alphas, renderer only (feature-map encoder stand-in)",
                        "rays_per_step_per_gpu": n_rays, "samples_per_ray": K, "parallelism": f"frames x{world}"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_MATRIX_TFLOPS, "traffic": None, "kernel": "bts::render_kernel<64,64,0,1,true>",
-                         "kernel_ms": kernel_ms, "algorithmic_flop_per_launch": flop_per_launch},
+                         "frac": achieved / PEAK_FP32_MATRIX_TFLOPS, "traffic": traffic, "kernel": "bts::render_kernel_p<64,64,0,1,true,true>",
+                         "kernel_ms": kernel_ms, "algorithmic_flop_per_launch": flop_per_launch,
+                         "note": "algorithmic FLOP (13 312 / sample, SURVEY 8d); the kernel executes 5 248 / sample (projected features, "
+                                 "DESIGN.md section 3), 36 of its 40 lin_in rows on the f16 matrix pipe (split precision)"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, mlp, cfg, args.cpu_rows)

@@ -159,6 +159,11 @@ int bts_sample_coarse(const float* rays, const float* u, int64_t B, int32_t K, i
 /* distance_to_z (utils/projection_operations.py:4-16): depths (N, H, W), inv_K (N, 3, 3) = inverse(projs) -> z (N, H, W) */
 int bts_distance_to_z(const float* depths, const float* inv_K, int32_t N, int32_t H, int32_t W, float* out, void* stream);
 
+/* Batched inverse of N dim x dim matrices, dim = 3 or 4 (row-major).  Stands in for torch.inverse on the c2w poses in
+ * BTSNet.encode (models/bts/model/models_bts.py:71) and on the intrinsics in distance_to_z (utils/projection_operations.py:9):
+ * fp64 Gauss-Jordan with partial pivoting rounded to fp32, enqueued on the stream (no solver library, no host sync). */
+int bts_invert_small(const float* src, float* dst, int32_t N, int32_t dim, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

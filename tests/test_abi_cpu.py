@@ -1,0 +1,112 @@
+"""CPU (no GPU, no kernel launches): libbts_render.so loads and exports every symbol include/bts_render.h declares, the ctypes
+structs have the C layout (checked against gcc), the host-only entry points answer, errors are loud, and the host mirror of the
+reference interface keeps the reference's constructor keys and state-dict layout."""
+import ctypes as C
+import os
+import re
+import subprocess
+import tempfile
+
+import pytest
+import torch
+
+import behindthescenes_amd as bts
+from behindthescenes_amd import _lib, native
+from behindthescenes_amd.build import build_library
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "bts_render.h")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    build_library()          # hipcc cross-compiles for gfx950 without a GPU
+    return _lib.load()
+
+
+def _declared_symbols():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(bts_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported_and_bound(lib):
+    names = _declared_symbols()
+    assert len(names) >= 17 and "bts_render_fwd" in names and "bts_render_bwd" in names
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/bts_render.h but not exported"
+        assert n in _lib.SYMBOLS, f"{n} has no ctypes signature in _lib.SYMBOLS"
+    assert set(_lib.SYMBOLS) == set(names)
+    assert lib.bts_abi_version() == _lib.ABI_VERSION == 1
+
+
+def test_ctypes_structs_match_the_c_layout():
+    prog = r'''
+#include <stdio.h>
+#include <stddef.h>
+#include "bts_render.h"
+int main(void) {
+  printf("%zu %zu %zu %zu\n", sizeof(BtsFieldCfg), sizeof(BtsFieldTensors), sizeof(BtsRenderArgs), sizeof(BtsRenderGrads));
+  printf("%zu %zu %zu %zu\n", offsetof(BtsFieldCfg, freq_factor), offsetof(BtsFieldTensors, mlp_params), offsetof(BtsRenderArgs, rays),
+         offsetof(BtsRenderArgs, trans));
+  return 0;
+}'''
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "t.c"), "w").write(prog)
+        subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "t.c"), "-o", os.path.join(d, "t")], check=True)
+        out = subprocess.run([os.path.join(d, "t")], capture_output=True, text=True, check=True).stdout.split()
+    sizes = [C.sizeof(_lib.BtsFieldCfg), C.sizeof(_lib.BtsFieldTensors), C.sizeof(_lib.BtsRenderArgs), C.sizeof(_lib.BtsRenderGrads)]
+    offs = [_lib.BtsFieldCfg.freq_factor.offset, _lib.BtsFieldTensors.mlp_params.offset, _lib.BtsRenderArgs.rays.offset,
+            _lib.BtsRenderArgs.trans.offset]
+    assert [int(x) for x in out[:4]] == sizes and [int(x) for x in out[4:]] == offs
+
+
+def test_host_only_entry_points(lib):
+    kitti = native._spec_cfg(native.FieldSpec(C=64, d_hidden=64, n_blocks=0), nv=4)
+    re10k = native._spec_cfg(native.FieldSpec(C=32, d_hidden=32, n_blocks=1), nv=2)
+    assert lib.bts_supported(C.byref(kitti)) == 1 and lib.bts_supported(C.byref(re10k)) == 1
+    assert lib.bts_mlp_param_count(C.byref(kitti)) == 6721 and lib.bts_mlp_param_count(C.byref(re10k)) == 4449
+    odd = native._spec_cfg(native.FieldSpec(C=48, d_hidden=64, n_blocks=0))
+    assert lib.bts_supported(C.byref(odd)) == 0
+    many = native._spec_cfg(native.FieldSpec(C=64, d_hidden=64, n_blocks=0), nv=9)
+    assert lib.bts_supported(C.byref(many)) == 0
+
+
+def test_errors_are_codes_with_messages_never_exceptions(lib):
+    assert lib.bts_render_fwd(None, None, None, None) == -1                       # BTS_E_INVALID
+    assert b"NULL" in lib.bts_last_error()
+    cfg = native._spec_cfg(native.FieldSpec(C=48, d_hidden=64, n_blocks=0), n=1, H=4, W=4)
+    tens = _lib.BtsFieldTensors(*([1] * 9))
+    assert lib.bts_render_fwd(C.byref(cfg), C.byref(tens), None, None) == -2      # BTS_E_UNSUPPORTED before anything is touched
+    assert b"envelope" in lib.bts_last_error()
+    assert lib.bts_invert_small(None, None, 1, 3, None) == -1
+    with pytest.raises(bts.BtsNativeError):
+        native.nchw_to_nhwc(torch.zeros(1, 4, 2, 2))                                # CPU tensor: no CPU path
+    with pytest.raises(bts.BtsNativeError):
+        native.check_supported(native.FieldSpec(C=48, d_hidden=64, n_blocks=0))
+
+
+def test_host_mirror_keeps_reference_interface():
+    conf = dict(z_near=3.0, z_far=80.0, inv_z=True, learn_empty=False, code_mode="z",
+                code=dict(num_freqs=6, freq_factor=1.5, include_input=True), encoder=dict(type="feature_map", size=(8, 16), d_out=64),
+                mlp_coarse=dict(type="resnet", n_blocks=0, d_hidden=64), mlp_fine=dict(type="empty"))
+    net = bts.BTSNet(conf)
+    r = bts.NeRFRenderer.from_conf(dict(n_coarse=64, n_fine=0, lindisp=True, hard_alpha_cap=True, eval_batch_size=100000, sched=[]))
+    w = r.bind_parallel(net)
+    assert w.net is net and w.renderer is r and r.n_coarse == 64 and r.lindisp and not r.using_fine
+    keys = set(w.state_dict())
+    # checkpoint layout of the reference: renderer.net.* / renderer.renderer.* below the task wrapper
+    for k in ("net.code_xyz._freqs", "net.code_xyz._phases", "net.mlp_coarse.lin_in.weight", "net.mlp_coarse.lin_in.bias",
+              "net.mlp_coarse.lin_out.weight", "net.mlp_coarse.lin_out.bias", "renderer.iter_idx", "renderer.last_sched"):
+        assert k in keys, k
+    assert net.mlp_coarse.lin_in.weight.shape == (64, 103) and net.mlp_coarse.packed().numel() == 6721
+    assert net._d_in == 103 and net.get_scale() == 0
+    with pytest.raises(native.BtsNativeError):
+        r.composite(torch.nn.Linear(3, 3), torch.zeros(4, 8), torch.zeros(4, 64), sb=1)
+    # patch sampler draws with torch's CPU generator like the reference (ray_sampler.py:134-140)
+    ps = bts.PatchRaySampler(ray_batch_size=128, z_near=3.0, z_far=80.0, patch_size=8)
+    torch.manual_seed(3)
+    a = ps.draw_patches(2, 4, 32, 64)
+    torch.manual_seed(3)
+    ref = [(torch.randint(0, 4, (2,)), torch.randint(0, 32 - 8, (2,)), torch.randint(0, 64 - 8, (2,))) for _ in range(2)]
+    assert torch.equal(a[0], torch.stack([x[0] for x in ref])) and torch.equal(a[2], torch.stack([x[2] for x in ref]))
