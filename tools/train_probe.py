@@ -1,0 +1,55 @@
+"""Times the renderer's share of a training step on BASELINE configs[2] shapes (exp_kitti_360.yaml: bs 16, 4096 patch rays per
+sample, K = 64, 4 render views; no CNN): hand-over (project), forward with saved activations, backward (render_bwd + project_bwd).
+    python tools/train_probe.py [n] [rounds]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import behindthescenes_amd as bts
+from behindthescenes_amd import native
+from oracle import bts_oracle as O
+from tests._hip_helpers import make_conf, load_mlp
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+H, W, K, C, HD, V = 192, 640, 64, 64, 64, 8
+cfg = O.FieldConfig()
+scene = O.synthetic_scene(n, V, H, W, C, seed=5, intrinsics=O.K_KITTI360, smooth=True)
+mlp = O.init_mlp(C + 39, HD, 0, gen=torch.Generator().manual_seed(7))
+net = bts.BTSNet(make_conf(cfg, C, HD, 0, H, W)); load_mlp(net, mlp)
+net.encoder = bts.FeatureMapEncoder((H, W), C, num_views=n)
+with torch.no_grad():
+    net.encoder.feats[0].data = scene["feat"].clone()
+net = net.cuda().train()
+renderer = bts.NeRFRenderer.from_conf(dict(n_coarse=K, lindisp=True, hard_alpha_cap=True)).cuda().train()
+sampler = bts.PatchRaySampler(ray_batch_size=4096, z_near=cfg.d_min, z_far=cfg.d_max, patch_size=8)
+images, projs, poses = scene["images"].cuda(), scene["projs"].cuda(), scene["poses"].cuda()
+ids_loss, ids_render = [0, 1, 2, 3], [4, 5, 6, 7]
+ev = lambda: torch.cuda.Event(enable_timing=True)
+res = {}
+for r in range(rounds + 1):
+    net.zero_grad(set_to_none=True)
+    t = [ev() for _ in range(5)]
+    t[0].record()
+    net.encode(images, projs, poses, ids_encoder=[0], ids_render=ids_render, images_alt=images * .5 + .5)
+    all_rays, gt = sampler.sample(images[:, ids_loss] * .5 + .5, poses[:, ids_loss], projs[:, ids_loss])
+    t[1].record()
+    ft = net.native_field()                       # project_features (hand-over)
+    t[2].record()
+    out = renderer.composite(net, all_rays.reshape(-1, 8), renderer.sample_coarse(all_rays.reshape(-1, 8)), sb=n)
+    w, rgb, depth, a, inv, _, rs = out
+    t[3].record()
+    loss = (rgb - gt.reshape(-1, 1, 3).repeat(1, 4, 1).reshape(rgb.shape)).abs().mean() + 1e-3 * depth.mean()
+    loss.backward()
+    t[4].record()
+    torch.cuda.synchronize()
+    if r > 0:
+        for name, i in (("encode+sample", 0), ("project", 1), ("render fwd (saved, all outputs)", 2), ("loss + backward (render_bwd, project_bwd)", 3)):
+            res.setdefault(name, []).append(t[i].elapsed_time(t[i + 1]))
+B = n * 4096
+print(f"n={n}: {B} rays x {K} samples, nv=4")
+tot = 0
+for k, v in res.items():
+    v = sorted(v); m = v[len(v) // 2]; tot += m
+    print(f"  {k:45s} {m:8.3f} ms")
+print(f"  renderer share of a step: {tot:.3f} ms -> {B / tot / 1e3:.2f} M rays/s")
