@@ -127,23 +127,27 @@ __global__ __launch_bounds__(256) void project_bwd_feat_kernel(const float* __re
 }
 
 // ---- backward, weight gradient: dW[hid][c] = sum_pix dG[pix][hid] * F[c][pix]  (contraction over pixels).
-// A[i = hid][k = pix] = dG rows (coalesced along hid), B[k = pix][j = c] = F[c][pix].  k-step s of a 64-pixel tile pairs pixel
-// s (lane half 0) with pixel s + 32 (half 1) so that each lane streams 32 consecutive pixels of ITS channel row.
-// Each work-group reduces a slab of pixels into registers, then LDS, then one atomic per (hid, c) into d_mlp.
+// A[i = stored channel s][k = pix] comes straight from dG (32 lanes = 32 consecutive channels of one pixel: a 128-byte row segment);
+// B[k = pix][j = c] = F[c][pix] would be a 4-byte gather with stride H*W from the NCHW map, so every wave first stages its 64-pixel
+// tile of F through LDS: coalesced 256-byte rows in (lane = pixel), [c][pix] with an odd leading dimension out (conflict-free).
+// k-step s of a tile pairs pixel s (lane half 0) with pixel s + 32 (half 1).  Each work-group reduces a slab of pixels into
+// registers, then LDS, then one atomic per (hid, c) into d_mlp.  HBM-bound: reads 4*(C + Hd) bytes per pixel once.
 template <int C, int HD>
 __global__ __launch_bounds__(256) void project_bwd_weight_kernel(const float* __restrict__ feat, const float* __restrict__ dproj,
                                                                  float* __restrict__ d_mlp, int HW, int slabs_per_img, int tiles_per_slab) {
   constexpr int HT = HD / 32, CT = C / 32;
   constexpr int D_IN = C + kPeDim;
-  __shared__ float red[HD * C];
-  for (int i = threadIdx.x; i < HD * C; i += blockDim.x) red[i] = 0.0f;
-  __syncthreads();
+  constexpr int LDF = 65;
+  static_assert(4 * C * LDF >= HD * C, "the reduction buffer aliases the staging tiles");
+  __shared__ float ftile[4 * C * LDF];
+  float* red = ftile;                            // reused after the pixel loop
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int h = lane >> 5, col = lane & 31;
   const int img = blockIdx.x / slabs_per_img;
   const int slab = blockIdx.x - img * slabs_per_img;
   const float* F = feat + (long)img * C * HW;
   const float* dG = dproj + (long)img * HW * HD;
+  float* ft = ftile + wave * C * LDF;
   f32x16 acc[HT][CT];
 #pragma unroll
   for (int ht = 0; ht < HT; ++ht)
@@ -152,27 +156,43 @@ __global__ __launch_bounds__(256) void project_bwd_weight_kernel(const float* __
   for (int t = wave; t < tiles_per_slab; t += 4) {
     const int p0 = (slab * tiles_per_slab + t) * 64;
     if (p0 >= HW) break;
+    // every global load of the tile is issued before the first use (the wave is alone on its SIMD half the time)
+    const int px = min(p0 + lane, HW - 1);
+    const bool okl = p0 + lane < HW;
+    float fv[C], av[32][HT];
+#pragma unroll
+    for (int c = 0; c < C; ++c) fv[c] = F[(long)c * HW + px];   // rows of F: 256-byte coalesced reads
+#pragma unroll
     for (int s = 0; s < 32; ++s) {
-      const int pix = p0 + s + 32 * h;
-      const bool ok = pix < HW;
-      const int pc = ok ? pix : HW - 1;
-      float a[HT], b[CT];
+      const int pix = min(p0 + s + 32 * h, HW - 1);
 #pragma unroll
-      for (int ht = 0; ht < HT; ++ht) a[ht] = ok ? dG[(long)pc * HD + proj_storage_index(ht * 32 + col)] : 0.0f;
+      for (int ht = 0; ht < HT; ++ht) av[s][ht] = dG[(long)pix * HD + ht * 32 + col];   // stored channel ht*32 + col
+    }
 #pragma unroll
-      for (int ct = 0; ct < CT; ++ct) b[ct] = F[(long)(ct * 32 + col) * HW + pc];
+    for (int c = 0; c < C; ++c) ft[c * LDF + lane] = okl ? fv[c] : 0.0f;
+#pragma unroll
+    for (int s = 0; s < 32; ++s) {
+      const int pl = s + 32 * h;                 // pixel of this lane half inside the tile
+      const bool ok = p0 + pl < HW;
+      float b[CT];
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) b[ct] = ft[(ct * 32 + col) * LDF + pl];
 #pragma unroll
       for (int ht = 0; ht < HT; ++ht)
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) acc[ht][ct] = mfma(a[ht], b[ct], acc[ht][ct]);
+        for (int ct = 0; ct < CT; ++ct) acc[ht][ct] = mfma(ok ? av[s][ht] : 0.0f, b[ct], acc[ht][ct]);
     }
   }
+  __syncthreads();
+  for (int i = threadIdx.x; i < HD * C; i += blockDim.x) red[i] = 0.0f;
+  __syncthreads();
+  // accumulator rows are STORED channels: map back to hidden units
 #pragma unroll
   for (int ht = 0; ht < HT; ++ht)
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-      for (int q = 0; q < 16; ++q) atomicAdd(&red[(ht * 32 + mfma_row(q, h)) * C + ct * 32 + col], acc[ht][ct][q]);
+      for (int q = 0; q < 16; ++q) atomicAdd(&red[proj_hidden_of_storage(ht * 32 + mfma_row(q, h)) * C + ct * 32 + col], acc[ht][ct][q]);
   __syncthreads();
   for (int i = threadIdx.x; i < HD * C; i += blockDim.x) {
     const int hid = i / C, c = i % C;

@@ -53,3 +53,17 @@ for k, v in res.items():
     v = sorted(v); m = v[len(v) // 2]; tot += m
     print(f"  {k:45s} {m:8.3f} ms")
 print(f"  renderer share of a step: {tot:.3f} ms -> {B / tot / 1e3:.2f} M rays/s")
+
+# the two projection-backward kernels on their own (dG = the gradient the render backward just produced, in spirit: random here)
+spec = ft.spec if hasattr(ft, "spec") else None
+if spec is not None:
+    feat = net.encoder.feats[0].data.contiguous()
+    dG = torch.randn(n, H, W, HD, device="cuda")
+    mp = net.mlp_coarse.packed()
+    if mp is not None:
+        for name, kw in (("project_bwd feat only", dict(need_feat=True, need_mlp=False)), ("project_bwd weight only", dict(need_feat=False, need_mlp=True))):
+            ts = []
+            for r in range(rounds + 1):
+                a, b = ev(), ev(); a.record(); native.project_features_bwd(spec, feat, dG, mp.detach(), **kw); b.record(); torch.cuda.synchronize()
+                ts.append(a.elapsed_time(b))
+            print(f"  {name:45s} {sorted(ts[1:])[len(ts[1:]) // 2]:8.3f} ms")
