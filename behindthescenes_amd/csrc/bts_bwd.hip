@@ -15,6 +15,7 @@
 //
 // What torch.autograd would do for nerf.py:283-299 + models_bts.py:266-338 + resnetfc.py:132-184 of the reference.
 #include "bts_field_kernel.h"
+#include <cstdlib>
 
 namespace bts {
 
@@ -27,6 +28,7 @@ struct BwdParams {
   float* d_proj;          // (n,H,W,HD)
   float* d_mlp;           // packed
   float* d_empty_proj;    // (HD)
+  float* gh_ws;           // (groups, K, 64, HD) g_h rows for the dG scatter pass, or null: scatter with direct atomics
 };
 
 template <int HD, int NB>
@@ -381,7 +383,26 @@ __global__ __launch_bounds__(256, 1) void render_bwd_kernel(const BwdParams bp) 
     // hidden gradients to the 256 contiguous bytes of a texel row -- 2 cache-line requests per atomic instruction instead of 32
     // (with lane = point, one dword per line: 27 of the 28 ms of the first backward went into those L2 atomics).  g_h comes from
     // the [point][hidden] tile that also feeds the dW_pe contraction; taps and weights of every point from a small LDS table.
-    if (dG) {
+    if (dG && bp.gh_ws) {
+      // two-pass form: the rows go to the workspace ([group of 64 rays][k][ray][channel], 256-byte coalesced stores); the scatter
+      // kernel below merges them per texel in LDS before anything reaches the L2 atomic units
+      if (p.learn_empty) tap_tile[lane * 8 + 4] = use_empty ? -1.0f : 1.0f;
+      constexpr int PPI = 64 / HD;
+      const int ch = lane % HD;
+      const int hid_l = proj_hidden_of_storage(ch);
+      const long grp = (long)wg * 4 + wave;
+      float* wrow = bp.gh_ws + ((grp * K + k) * 64) * HD;
+#pragma unroll 4
+      for (int pnt0 = 0; pnt0 < 64; pnt0 += PPI) {
+        const int pnt = pnt0 + lane / HD;
+        float gv = gh_tile[pnt * L::LDG + hid_l];
+        if (p.learn_empty && tap_tile[pnt * 8 + 4] < 0.0f) {   // the point took the (projected) empty feature
+          if (gv != 0.0f) atomicAdd(&lds[L::D_EMPTY + hid_l], gv);
+          gv = 0.0f;
+        }
+        wrow[pnt * HD + ch] = gv;
+      }
+    } else if (dG) {
       {
         float* row = tap_tile + lane * 8;
         reinterpret_cast<int4*>(row)[0] = make_int4(tp.o00, tp.o01, tp.o10, tp.o11);
@@ -498,6 +519,159 @@ __global__ __launch_bounds__(256, 1) void render_bwd_kernel(const BwdParams bp) 
   }
 }
 
+// ---- dG scatter pass.  One wave per group of 64 rays (one 8x8 patch under PatchRaySampler).  Neighbouring rays and consecutive
+// samples of a patch land on the same few texels of G: the 4 taps x 64 rays of one step cover ~9x9 texels, and the footprint drifts by
+// about a pixel per step.  The wave therefore keeps a CW x CH texel window of dG rows in LDS (slot = (y mod CH, x mod CW): a texel
+// keeps its slot while the window slides), adds tap contributions there with ds_add, and only rows LEAVING the window go to global
+// memory as one 256-byte row of float atomics.  ~5-10 % of the tap updates remain as L2 atomics (measured by simulation on the
+// KITTI-360 training geometry and on the GPU).  A step whose footprint does not fit the window falls back to direct row atomics.
+// lane = channel throughout; the taps of the step are computed lane = ray and broadcast with v_readlane.
+struct ScatterParams {
+  FwdParams f;
+  const float* gh_ws;
+  float* d_proj;
+  int groups_per_sample;
+  int mode;   // probe bits (BTS_SCATTER_MODE): 1 no LDS adds, 2 never move the window, 4 no workspace loads, 8 skip non-fitting steps
+};
+
+__device__ __forceinline__ int wave_min(int v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v = min(v, __shfl_xor(v, off, 64));
+  return __builtin_amdgcn_readfirstlane(v);
+}
+
+template <int HD>
+__global__ __launch_bounds__(64) void scatter_dg_kernel(const ScatterParams sp) {
+#ifndef BTS_SCATTER_RB
+#define BTS_SCATTER_RB 64
+#endif
+  constexpr int CW = 12, CH = 12, RB = BTS_SCATTER_RB;  // window of texels (9x9 footprint of a patch + 3 of drift); g_h rows per register block
+  __shared__ float cache[(CW * CH + 1) * HD];   // + one scratch row: the target of clamped (duplicate, zero-weight) taps
+  const FwdParams& p = sp.f;
+  const int lane = threadIdx.x;
+  const int grp = blockIdx.x;
+  const int sample = grp / sp.groups_per_sample;
+  const int g_in = grp - sample * sp.groups_per_sample;
+  const int Bp = p.Bp, K = p.K, H = p.H, W = p.W;
+  const int r_raw = g_in * 64 + lane;
+  const int r = r_raw < Bp ? r_raw : Bp - 1;
+  const long ray = (long)sample * Bp + r;
+  const bool chan = HD == 64 || lane < HD;
+  const int ch = lane % HD;
+  for (int i = lane; i < (CW * CH + 1) * HD; i += 64) cache[i] = 0.0f;
+  const Cam enc = load_cam(p.w2c_enc + sample * 16, p.K_enc + sample * 9);
+  const float4 r0 = reinterpret_cast<const float4*>(p.rays)[ray * 2];
+  const float4 r1 = reinterpret_cast<const float4*>(p.rays)[ray * 2 + 1];
+  const float* zrow = p.z_samp + ray * K;
+  float* __restrict__ dG = sp.d_proj + (long)sample * H * W * HD;
+  const float* __restrict__ ws = sp.gh_ws + (long)grp * K * 64 * HD;
+  int wx = 0, wy = 0;   // window origin (uniform)
+
+  // evict every slot whose texel lies outside the window at (nwx, nwy)
+  auto flush = [&](int nwx, int nwy, bool all) {
+    const int wxm = ((wx % CW) + CW) % CW, wym = ((wy % CH) + CH) % CH;   // slot column / row of the window origin
+    for (int sy = 0; sy < CH; ++sy) {
+      const int ty = wy + sy - wym + (sy < wym ? CH : 0);
+      const bool row_out = all || ty < nwy || ty >= nwy + CH;
+      for (int sx = 0; sx < CW; ++sx) {
+        const int tx = wx + sx - wxm + (sx < wxm ? CW : 0);
+        if (row_out || tx < nwx || tx >= nwx + CW) {
+          if (chan) {
+            float* c = &cache[(sy * CW + sx) * HD + ch];
+            const float v = *c;
+            if (v != 0.0f) {
+              atomic_add_f32(dG + ((long)ty * W + tx) * HD + ch, v);
+              *c = 0.0f;
+            }
+          }
+        }
+      }
+    }
+  };
+
+  float cur[RB], nxt[RB];
+#pragma unroll
+  for (int i = 0; i < RB; ++i) cur[i] = chan ? ws[((long)(K - 1) * 64 + i) * HD + ch] : 0.0f;
+
+  for (int k = K - 1; k >= 0; --k) {
+    const float z = zrow[k];
+    const Proj pe = project<false>(enc, r0.x + z * r0.w, r0.y + z * r1.x, r0.z + z * r1.y);
+    int x0, y0, x1, y1;
+    const Taps tp = make_taps_xy(pe.x, pe.y, H, W, x0, y0, x1, y1);
+    const int mnx = wave_min(x0), mxx = -wave_min(-x1), mny = wave_min(y0), mxy = -wave_min(-y1);
+    const bool fits = ((mxx - mnx < CW) && (mxy - mny < CH)) || (sp.mode & 2);
+    if (fits && !(sp.mode & 2) && (mnx < wx || mxx >= wx + CW || mny < wy || mxy >= wy + CH)) {
+      const int nwx = mnx - (CW - (mxx - mnx + 1)) / 2, nwy = mny - (CH - (mxy - mny + 1)) / 2;
+      flush(nwx, nwy, false);
+      wx = nwx, wy = nwy;
+    }
+    // LDS slot (float index of the row) of each tap of this lane's point.  A clamped tap (x1 == x0 or y1 == y0 at the far border:
+    // weight exactly 0) would alias its neighbour's slot inside one read-modify-write group; it goes to the scratch row instead.
+    const int rya = (int)((unsigned)y0 % CH) * CW, ryb = (int)((unsigned)y1 % CH) * CW;
+    const int cxa = (int)((unsigned)x0 % CW), cxb = (int)((unsigned)x1 % CW);
+    const bool ddx = x1 != x0, ddy = y1 != y0;
+    const int s00 = (rya + cxa) * HD;
+    const int s01 = ddx ? (rya + cxb) * HD : CW * CH * HD;
+    const int s10 = ddy ? (ryb + cxa) * HD : CW * CH * HD;
+    const int s11 = (ddx && ddy) ? (ryb + cxb) * HD : CW * CH * HD;
+    const float* wk = ws + (long)k * 64 * HD;
+#pragma unroll 1
+    for (int b = 0; b < 64 / RB; ++b) {
+      // prefetch the next block of rows (next step's first block after the last one of this step)
+      {
+        const bool more = b + 1 < 64 / RB || k > 0;
+        const float* nb = b + 1 < 64 / RB ? wk + (long)(b + 1) * RB * HD : wk - (long)64 * HD;
+#pragma unroll
+        for (int i = 0; i < RB; ++i) nxt[i] = (chan && more && !(sp.mode & 4)) ? nb[i * HD + ch] : 0.0f;
+      }
+      auto bc_i = [&](int v, int pnt) { return __builtin_amdgcn_readlane(v, pnt); };
+      auto bc_f = [&](float v, int pnt) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), pnt)); };
+      // NOTE: every v_readlane below sits in wave-uniform control flow.  Reading a lane that is inactive at the readlane is
+      // undefined in LLVM's model (the producer may be sunk into the divergent region): with d_hidden = 32 an `if (chan)` around
+      // this block made lanes >= 32 inactive and points 32..63 picked up stale registers.  Idle lanes aim at the scratch row.
+      if (fits) {
+        if (!(sp.mode & 1)) {
+          // wave-private read-modify-write (LDS operations of one wave execute in order).  ds_add_f32 would be one instruction
+          // per tap but runs at ~100 cycles per wave instruction on gfx950 (measured); plain loads and stores do not.
+#pragma unroll
+          for (int i = 0; i < RB; ++i) {
+            const int pnt = b * RB + i;
+            const float gv = cur[i];
+            float* c00 = &cache[(chan ? bc_i(s00, pnt) : CW * CH * HD) + ch];
+            float* c01 = &cache[(chan ? bc_i(s01, pnt) : CW * CH * HD) + ch];
+            float* c10 = &cache[(chan ? bc_i(s10, pnt) : CW * CH * HD) + ch];
+            float* c11 = &cache[(chan ? bc_i(s11, pnt) : CW * CH * HD) + ch];
+            const float a00 = *c00, a01 = *c01, a10 = *c10, a11 = *c11;
+            *c00 = a00 + bc_f(tp.w00, pnt) * gv;
+            *c01 = a01 + bc_f(tp.w01, pnt) * gv;
+            *c10 = a10 + bc_f(tp.w10, pnt) * gv;
+            *c11 = a11 + bc_f(tp.w11, pnt) * gv;
+          }
+        }
+      } else if (!(sp.mode & 8)) {
+        // rare (a footprint wider than the window: rays nearly through the encoder's centre): every tap a row of L2 atomics.
+        // The rows are re-read from the workspace so that the register block is never indexed dynamically.
+#pragma unroll 1
+        for (int pnt = b * RB; pnt < (b + 1) * RB; ++pnt) {
+          const float gv = chan ? wk[pnt * HD + ch] : 0.0f;
+          const long ya = (long)bc_i(y0, pnt) * W, yb = (long)bc_i(y1, pnt) * W;
+          const int xa = bc_i(x0, pnt), xb = bc_i(x1, pnt);
+          const float w00 = bc_f(tp.w00, pnt), w01 = bc_f(tp.w01, pnt), w10 = bc_f(tp.w10, pnt), w11 = bc_f(tp.w11, pnt);
+          if (gv != 0.0f) {
+            atomic_add_f32(dG + (ya + xa) * HD + ch, w00 * gv);
+            atomic_add_f32(dG + (ya + xb) * HD + ch, w01 * gv);
+            atomic_add_f32(dG + (yb + xa) * HD + ch, w10 * gv);
+            atomic_add_f32(dG + (yb + xb) * HD + ch, w11 * gv);
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < RB; ++i) cur[i] = nxt[i];
+    }
+  }
+  flush(0, 0, true);
+}
+
 template <int C, int HD, int NB>
 static int launch_bwd(const BwdParams& bp, int grid, hipStream_t s) {
   using L = BwdLds<HD, NB>;
@@ -520,10 +694,29 @@ static int launch_bwd(const BwdParams& bp, int grid, hipStream_t s) {
 
 FwdParams make_params(const BtsFieldCfg* cfg, const BtsFieldTensors* t);
 
-size_t render_bwd_workspace_impl(const BtsFieldCfg*, const BtsRenderArgs*) { return 0; }
+// workspace = the g_h rows between the two passes: groups of 64 rays x K x 64 x d_hidden floats
+size_t render_bwd_workspace_impl(const BtsFieldCfg* cfg, const BtsRenderArgs* a) {
+  const size_t groups = (size_t)cfg->n * ((a->rays_per_sample + 255) / 256) * 4;
+  return groups * (size_t)a->K * 64 * (size_t)cfg->d_hidden * sizeof(float);
+}
 
-int render_bwd_impl(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const BtsRenderArgs* a, const BtsRenderGrads* g, void*, size_t,
-                    hipStream_t s) {
+template <int HD>
+static int launch_scatter(const BwdParams& bp, int n, hipStream_t s) {
+  ScatterParams sp;
+  sp.f = bp.f, sp.gh_ws = bp.gh_ws, sp.d_proj = bp.d_proj, sp.groups_per_sample = bp.f.tiles_per_sample * 4;
+  static const int mode = getenv("BTS_SCATTER_MODE") ? atoi(getenv("BTS_SCATTER_MODE")) : 0;
+  sp.mode = mode;
+  scatter_dg_kernel<HD><<<n * sp.groups_per_sample, 64, 0, s>>>(sp);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: dG scatter kernel launch failed (%ld)", hipGetErrorString(e), (long)e);
+    return BTS_E_LAUNCH;
+  }
+  return BTS_OK;
+}
+
+int render_bwd_impl(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const BtsRenderArgs* a, const BtsRenderGrads* g, void* workspace,
+                    size_t, hipStream_t s) {
   if (a->white_bkgd) {
     set_error("%s: white_bkgd has no backward (no shipped config trains with it)", "bts_render_bwd");
     return BTS_E_UNSUPPORTED;
@@ -536,10 +729,15 @@ int render_bwd_impl(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const BtsR
   bp.f.tiles_per_sample = (a->rays_per_sample + 255) / 256;
   bp.g_rgb = g->g_rgb, bp.g_depth = g->g_depth, bp.g_weights = g->g_weights, bp.g_alphas = g->g_alphas;
   bp.d_proj = g->d_proj_nhwc, bp.d_mlp = g->d_mlp_params, bp.d_empty_proj = g->d_empty_proj;
+  static const bool direct = getenv("BTS_BWD_DIRECT_ATOMICS") != nullptr;   // A/B: single pass, every tap update an L2 atomic
+  bp.gh_ws = (bp.d_proj && !direct) ? static_cast<float*>(workspace) : nullptr;
   const int grid = bp.f.tiles_per_sample * cfg->n;
-  if (cfg->C == 64 && cfg->d_hidden == 64 && cfg->n_blocks == 0) return launch_bwd<64, 64, 0>(bp, grid, s);
-  if (cfg->C == 32 && cfg->d_hidden == 32 && cfg->n_blocks == 0) return launch_bwd<32, 32, 0>(bp, grid, s);
-  if (cfg->C == 32 && cfg->d_hidden == 32 && cfg->n_blocks == 1) return launch_bwd<32, 32, 1>(bp, grid, s);
+  int rc = BTS_E_UNSUPPORTED;
+  if (cfg->C == 64 && cfg->d_hidden == 64 && cfg->n_blocks == 0) rc = launch_bwd<64, 64, 0>(bp, grid, s);
+  else if (cfg->C == 32 && cfg->d_hidden == 32 && cfg->n_blocks == 0) rc = launch_bwd<32, 32, 0>(bp, grid, s);
+  else if (cfg->C == 32 && cfg->d_hidden == 32 && cfg->n_blocks == 1) rc = launch_bwd<32, 32, 1>(bp, grid, s);
+  if (rc == BTS_OK && bp.gh_ws) rc = cfg->d_hidden == 64 ? launch_scatter<64>(bp, cfg->n, s) : launch_scatter<32>(bp, cfg->n, s);
+  if (rc != BTS_E_UNSUPPORTED) return rc;
   set_error("%s: unsupported MLP shape C=%ld d_hidden=%ld n_blocks=%ld", "bts_render_bwd", cfg->C, cfg->d_hidden, cfg->n_blocks);
   return BTS_E_UNSUPPORTED;
 }

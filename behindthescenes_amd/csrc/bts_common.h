@@ -128,7 +128,7 @@ struct Taps {
   float w00, w01, w10, w11;
 };
 
-__device__ __forceinline__ Taps make_taps(float x, float y, int H, int W) {
+__device__ __forceinline__ Taps make_taps_xy(float x, float y, int H, int W, int& x0, int& y0, int& x1, int& y1) {
   float ix = ((x + 1.0f) * (float)W - 1.0f) / 2.0f;
   float iy = ((y + 1.0f) * (float)H - 1.0f) / 2.0f;
   ix = fminf((float)(W - 1), fmaxf(ix, 0.0f));
@@ -140,8 +140,8 @@ __device__ __forceinline__ Taps make_taps(float x, float y, int H, int W) {
   t.w01 = (ix - fx) * (ey - iy);
   t.w10 = (ex - ix) * (iy - fy);
   t.w11 = (ix - fx) * (iy - fy);
-  int x0 = (int)fx, y0 = (int)fy;
-  int x1 = min(x0 + 1, W - 1), y1 = min(y0 + 1, H - 1);
+  x0 = (int)fx, y0 = (int)fy;
+  x1 = min(x0 + 1, W - 1), y1 = min(y0 + 1, H - 1);
   // NaN coordinates (never produced by finite inputs) would give x0 = INT_MIN: clamp for memory safety
   x0 = max(0, min(x0, W - 1));
   y0 = max(0, min(y0, H - 1));
@@ -150,6 +150,11 @@ __device__ __forceinline__ Taps make_taps(float x, float y, int H, int W) {
   t.o10 = y1 * W + x0;
   t.o11 = y1 * W + x1;
   return t;
+}
+
+__device__ __forceinline__ Taps make_taps(float x, float y, int H, int W) {
+  int x0, y0, x1, y1;
+  return make_taps_xy(x, y, H, W, x0, y0, x1, y1);
 }
 
 // depth code in [-1,1] (models_bts.py:157-171)

@@ -42,10 +42,14 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(scene, mlp, cfg, rows):
+def cpu_baseline(scene, net, rows):
     """The oracle ("port" of the reference algorithm, same torch CPU ops) on a bounded sample: `rows` full image rows of
-    both views (rows*640*2 rays, K=64), best of 2 after one warm-up."""
+    both views (rows*640*2 rays, K=64), best of 2 after one warm-up.  The only place bench.py touches ``oracle/``."""
     from oracle import bts_oracle as O
+    cfg = O.FieldConfig()                       # z in [3, 80], inv_z, code_mode z (eval_depth.yaml)
+    m = net.mlp_coarse
+    mlp = O.MlpParams(w_in=m.lin_in.weight.detach().cpu().clone(), b_in=m.lin_in.bias.detach().cpu().clone(),
+                      w_out=m.lin_out.weight.detach().cpu().clone(), b_out=m.lin_out.bias.detach().cpu().clone())
     rays = O.image_rays(scene["poses"], scene["projs"], H, W, cfg.d_min, cfg.d_max).view(1, V, H, W, 8)
     r0 = (H - rows) // 2
     rays = rays[:, :, r0:r0 + rows].reshape(1, -1, 8).contiguous()
@@ -82,21 +86,17 @@ def main():
 
     import behindthescenes_amd as bts
     from behindthescenes_amd import _lib
-    from oracle import bts_oracle as O          # synthetic input generator + cpu_baseline leg only
-    from tests._hip_helpers import make_conf, load_mlp
+    from behindthescenes_amd import synthetic as S
 
     _lib.load()
-    cfg = O.FieldConfig()                       # z in [3, 80], inv_z, code_mode z (eval_depth.yaml)
-    scene = O.synthetic_scene(1, V, H, W, C, seed=1000 + rank, intrinsics=O.K_KITTIRAW)
-    g = torch.Generator().manual_seed(7)
-    mlp = O.init_mlp(C + 39, HD, 0, gen=g)
-    net = bts.BTSNet(make_conf(cfg, C, HD, 0, H, W))
-    load_mlp(net, mlp)
-    with torch.no_grad():
-        net.encoder.feats[0].data = scene["feat"].clone()
+    Z_NEAR, Z_FAR = 3.0, 80.0                   # eval_depth.yaml
+    scene = S.synthetic_scene(1, V, H, W, C, seed=1000 + rank, intrinsics=S.K_KITTIRAW)
+    net = bts.BTSNet(S.field_conf(C, HD, 0, H, W, z_near=Z_NEAR, z_far=Z_FAR))
+    S.init_mlp_(net.mlp_coarse, seed=7)
+    S.set_feature_map(net, scene["feat"])
     net = net.to(dev).eval()
     wrapped = bts.NeRFRenderer.from_conf(dict(n_coarse=K, lindisp=True, hard_alpha_cap=True)).bind_parallel(net).eval().to(dev)
-    sampler = bts.ImageRaySampler(cfg.d_min, cfg.d_max)
+    sampler = bts.ImageRaySampler(Z_NEAR, Z_FAR)
     images, projs, poses = scene["images"].to(dev), scene["projs"].to(dev), scene["poses"].to(dev)
     n_rays = V * H * W
 
@@ -150,14 +150,15 @@ def main():
         elapsed = t.item()
 
     kernel_ms = sum(a.elapsed_time(b) for a, b in kernel_events) / max(len(kernel_events), 1)
-    traffic = None
+    traffic, traffic_detail = None, None
     prof = sorted(d for d in os.listdir(os.path.join(ROOT, "profiles")) if os.path.exists(os.path.join(ROOT, "profiles", d, "traffic.json"))) \
         if os.path.isdir(os.path.join(ROOT, "profiles")) else []
     if prof:
         tj = json.load(open(os.path.join(ROOT, "profiles", prof[-1], "traffic.json")))
-        traffic = {"hbm_bytes_per_launch": tj["fetch_bytes"] + tj["write_bytes"], "fetch_bytes": tj["fetch_bytes"],
-                   "write_bytes": tj["write_bytes"], "source": f"profiles/{prof[-1]}/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
-                   "FETCH_SIZE doubled per MI355X_MICROARCH.md)"}
+        traffic = tj["fetch_bytes"] + tj["write_bytes"]          # HBM bytes per launch of the render kernel
+        traffic_detail = {"fetch_bytes": tj["fetch_bytes"], "write_bytes": tj["write_bytes"],
+                          "source": f"profiles/{prof[-1]}/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, "
+                                    "FETCH_SIZE doubled per MI355X_MICROARCH.md)"}
     step_ms = elapsed * 1e3 / args.steps
     value = world * n_rays * args.steps / elapsed
     if rank == 0:
@@ -171,13 +172,13 @@ def main():
                                    "nv=1, want_weights+alphas, renderer only (feature-map encoder stand-in)",
                        "rays_per_step_per_gpu": n_rays, "samples_per_ray": K, "parallelism": f"frames x{world}"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_MATRIX_TFLOPS, "traffic": traffic, "kernel": "bts::render_kernel_p<64,64,0,1,true,true>",
+                         "frac": achieved / PEAK_FP32_MATRIX_TFLOPS, "traffic": traffic, "traffic_detail": traffic_detail, "kernel": "bts::render_kernel_p<64,64,0,1,true,true>",
                          "kernel_ms": kernel_ms, "algorithmic_flop_per_launch": flop_per_launch,
                          "note": "algorithmic FLOP (13 312 / sample, SURVEY 8d); the kernel executes 5 248 / sample (projected features, "
                                  "DESIGN.md section 3), 36 of its 40 lin_in rows on the f16 matrix pipe (split precision)"},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(scene, mlp, cfg, args.cpu_rows)
+            out["cpu_baseline"] = cpu_baseline(scene, net, args.cpu_rows)
         print(json.dumps(out))
     if world > 1:
         torch.distributed.destroy_process_group()

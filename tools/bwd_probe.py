@@ -5,14 +5,12 @@ sys.path.insert(0, ROOT)
 import torch
 import behindthescenes_amd as bts
 from behindthescenes_amd import native
-from oracle import bts_oracle as O
-from tests._hip_helpers import make_conf, load_mlp
+from behindthescenes_amd import synthetic as S
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 H, W, K, C, HD, V = 192, 640, 64, 64, 64, 8
-cfg = O.FieldConfig()
-scene = O.synthetic_scene(n, V, H, W, C, seed=5, intrinsics=O.K_KITTI360, smooth=True)
-mlp = O.init_mlp(C + 39, HD, 0, gen=torch.Generator().manual_seed(7))
-net = bts.BTSNet(make_conf(cfg, C, HD, 0, H, W)); load_mlp(net, mlp)
+Z_NEAR, Z_FAR = 3.0, 80.0
+scene = S.synthetic_scene(n, V, H, W, C, seed=5, intrinsics=S.K_KITTI360, smooth=True)
+net = bts.BTSNet(S.field_conf(C, HD, 0, H, W)); S.init_mlp_(net.mlp_coarse, seed=7)
 net.encoder = bts.FeatureMapEncoder((H, W), C, num_views=n)
 with torch.no_grad():
     net.encoder.feats[0].data = scene["feat"].clone()
@@ -20,7 +18,7 @@ net = net.cuda().eval()
 images, projs, poses = scene["images"].cuda(), scene["projs"].cuda(), scene["poses"].cuda()
 with torch.no_grad():
     net.encode(images, projs, poses, ids_encoder=[0], ids_render=[4, 5, 6, 7], images_alt=images * .5 + .5)
-    sampler = bts.PatchRaySampler(ray_batch_size=4096, z_near=cfg.d_min, z_far=cfg.d_max, patch_size=8)
+    sampler = bts.PatchRaySampler(ray_batch_size=4096, z_near=Z_NEAR, z_far=Z_FAR, patch_size=8)
     rays, _ = sampler.sample(images[:, :4] * .5 + .5, poses[:, :4], projs[:, :4])
     rays = rays.reshape(-1, 8).contiguous()
     z = native.sample_coarse(rays, torch.rand(rays.shape[0], K, device="cuda"), True)

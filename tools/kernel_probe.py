@@ -5,16 +5,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import behindthescenes_amd as bts
 from behindthescenes_amd import native
-from oracle import bts_oracle as O
-from tests._hip_helpers import build_net
+from behindthescenes_amd import synthetic as S
 
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 only = sys.argv[2] if len(sys.argv) > 2 else None
 H, W, K, V = 192, 640, 64, 2
-cfg = O.FieldConfig()
-scene = O.synthetic_scene(1, V, H, W, 64, seed=1, intrinsics=O.K_KITTIRAW)
-mlp = O.init_mlp(103, 64, 0, gen=torch.Generator().manual_seed(7))
-net = build_net(cfg, mlp, scene, [0])
+scene = S.synthetic_scene(1, V, H, W, 64, seed=1, intrinsics=S.K_KITTIRAW)
+net = S.build_net(scene, 64, 0, [0])
 ft = net.native_field()
 feat_nhwc = native.nchw_to_nhwc(net.grid_f_features[0][:, 0].detach().contiguous())
 ft_direct = native.FieldTensors(net.spec, None, ft.K_enc, ft.w2c_enc, ft.imgs_nhwc4, ft.K_r, ft.w2c_r, None, feat_nhwc=feat_nhwc)

@@ -10,14 +10,11 @@ os.environ.setdefault("BTS_RENDER_LIB", os.path.join(ROOT, "behindthescenes_amd"
 import torch
 import behindthescenes_amd as bts
 from behindthescenes_amd import native
-from oracle import bts_oracle as O
-from tests._hip_helpers import build_net
+from behindthescenes_amd import synthetic as S
 
 H, W, K, V = 192, 640, 64, 2
-cfg = O.FieldConfig()
-scene = O.synthetic_scene(1, V, H, W, 64, seed=1, intrinsics=O.K_KITTIRAW)
-mlp = O.init_mlp(103, 64, 0, gen=torch.Generator().manual_seed(7))
-net = build_net(cfg, mlp, scene, [0])
+scene = S.synthetic_scene(1, V, H, W, 64, seed=1, intrinsics=S.K_KITTIRAW)
+net = S.build_net(scene, 64, 0, [0])
 ft = net.native_field()
 params = net.mlp_coarse.packed().detach()
 rays = bts.ImageRaySampler(3.0, 80.0, H, W).sample(None, scene["poses"].cuda(), scene["projs"].cuda())[0].reshape(-1, 8).contiguous()

@@ -4,18 +4,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 import behindthescenes_amd as bts
-from oracle import bts_oracle as O
-from tests._hip_helpers import make_conf, load_mlp
+from behindthescenes_amd import synthetic as S
 H, W, K, C, HD, V = 192, 640, 64, 64, 64, 2
-cfg = O.FieldConfig()
-scene = O.synthetic_scene(1, V, H, W, C, seed=1000, intrinsics=O.K_KITTIRAW)
-mlp = O.init_mlp(C + 39, HD, 0, gen=torch.Generator().manual_seed(7))
-net = bts.BTSNet(make_conf(cfg, C, HD, 0, H, W)); load_mlp(net, mlp)
+Z_NEAR, Z_FAR = 3.0, 80.0
+scene = S.synthetic_scene(1, V, H, W, C, seed=1000, intrinsics=S.K_KITTIRAW)
+net = bts.BTSNet(S.field_conf(C, HD, 0, H, W)); S.init_mlp_(net.mlp_coarse, seed=7)
 with torch.no_grad():
     net.encoder.feats[0].data = scene["feat"].clone()
 net = net.cuda().eval()
 wrapped = bts.NeRFRenderer.from_conf(dict(n_coarse=K, lindisp=True, hard_alpha_cap=True)).bind_parallel(net).eval().cuda()
-sampler = bts.ImageRaySampler(cfg.d_min, cfg.d_max)
+sampler = bts.ImageRaySampler(Z_NEAR, Z_FAR)
 images, projs, poses = scene["images"].cuda(), scene["projs"].cuda(), scene["poses"].cuda()
 stages = {}
 def tick(name, t0):
