@@ -60,6 +60,7 @@ SYMBOLS = {
     "bts_nhwc_to_nchw": (C.c_int, [_P, _P, _I, _I, _I, _I, _P]),
     "bts_pack_rgb": (C.c_int, [_P, _P, _I, _I, _I, C.c_float, C.c_float, _P]),
     "bts_gen_rays": (C.c_int, [_P, _P, _I, _I, _I, C.c_float, C.c_float, _I, _P, _P]),
+    "bts_patch_rays": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, C.c_float, C.c_float, _I, _P, _P, _P]),
     "bts_sample_coarse": (C.c_int, [_P, _P, C.c_int64, _I, _I, _P, _P]),
     "bts_distance_to_z": (C.c_int, [_P, _P, _I, _I, _I, _P, _P]),
     "bts_invert_small": (C.c_int, [_P, _P, _I, _I, _P]),

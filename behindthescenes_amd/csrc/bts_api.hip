@@ -13,6 +13,8 @@ bool shape_supported(int C, int HD, int NB);
 
 int transpose_launch(const float* src, float* dst, int N, int C, int H, int W, bool to_nhwc, hipStream_t s);
 int pack_rgb_launch(const float* src, float* dst, int N, int H, int W, float scale, float shift, hipStream_t s);
+int patch_rays_launch(const float* poses, const float* projs, const float* images, const int* pv, const int* py, const int* px, int n, int v,
+                      int c, int H, int W, int P, int ph, int pw, float zn, float zf, int norm_dir, float* rays, float* gt, hipStream_t s);
 int gen_rays_launch(const float* poses, const float* projs, int V, int H, int W, float zn, float zf, int norm_dir, float* rays,
                     hipStream_t s);
 int sample_coarse_launch(const float* rays, const float* u, long B, int K, int lindisp, float* z, hipStream_t s);
@@ -190,6 +192,16 @@ int bts_gen_rays(const float* poses, const float* projs, int32_t V, int32_t H, i
                  int32_t norm_dir, float* rays, void* stream) {
   BTS_CHECK_LAYOUT(poses && projs && rays && V > 0 && H > 0 && W > 0, "bts_gen_rays");
   BTS_RET_LAUNCH(gen_rays_launch(poses, projs, V, H, W, z_near, z_far, norm_dir, rays, (hipStream_t)stream), "bts_gen_rays");
+}
+int bts_patch_rays(const float* poses, const float* projs, const float* images, const int32_t* patch_v, const int32_t* patch_y,
+                   const int32_t* patch_x, int32_t n, int32_t v, int32_t c, int32_t H, int32_t W, int32_t P, int32_t ph, int32_t pw,
+                   float z_near, float z_far, int32_t norm_dir, float* rays, float* rgb_gt, void* stream) {
+  BTS_CHECK_LAYOUT(poses && projs && patch_v && patch_y && patch_x && rays && n > 0 && v > 0 && H > 0 && W > 0 && P >= 0 && ph > 0 && pw > 0 &&
+                       ph <= H && pw <= W && (!images || (rgb_gt && c > 0)),
+                   "bts_patch_rays");
+  BTS_RET_LAUNCH(patch_rays_launch(poses, projs, images, patch_v, patch_y, patch_x, n, v, c, H, W, P, ph, pw, z_near, z_far, norm_dir, rays,
+                                   rgb_gt, (hipStream_t)stream),
+                 "bts_patch_rays");
 }
 int bts_sample_coarse(const float* rays, const float* u, int64_t B, int32_t K, int32_t lindisp, float* z_samp, void* stream) {
   BTS_CHECK_LAYOUT(rays && u && z_samp && B > 0 && K > 0, "bts_sample_coarse");

@@ -78,7 +78,30 @@ __device__ __forceinline__ float linspace_at(float start, float end, int steps, 
   return i < steps / 2 ? start + step * (float)i : end - step * (float)(steps - i - 1);
 }
 
-// gen_rays: rays (V, H, W, 8) = [c2w translation, R @ unproj(pixel), near, far]
+// the ray of pixel (x, y) of a view: [c2w translation, R @ unproj(pixel), near, far]  (util.py:113-149, 244-273)
+__device__ __forceinline__ void ray_of_pixel(const float* __restrict__ P, const float* __restrict__ Kp, int H, int W, int x, int y,
+                                             float z_near, float z_far, int norm_dir, float4& a, float4& b) {
+  const float fx = Kp[0], fy = Kp[4], cx = Kp[2], cy = Kp[5];
+  const float gx = W > 1 ? linspace_at(-1.0f, 1.0f, W, x) : -1.0f;
+  const float gy = H > 1 ? linspace_at(-1.0f, 1.0f, H, y) : -1.0f;
+  float d0 = (gx - cx) / fx, d1 = (gy - cy) / fy, d2 = 1.0f;
+  if (norm_dir) {
+    const float nrm = sqrtf(d0 * d0 + d1 * d1 + d2 * d2);
+    d0 = d0 / nrm, d1 = d1 / nrm, d2 = d2 / nrm;
+  }
+  float w[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    float t = P[4 * r + 0] * d0;
+    t = __builtin_fmaf(P[4 * r + 1], d1, t);
+    t = __builtin_fmaf(P[4 * r + 2], d2, t);
+    w[r] = t;
+  }
+  a = make_float4(P[3], P[7], P[11], w[0]);
+  b = make_float4(w[1], w[2], z_near, z_far);
+}
+
+// gen_rays: rays (V, H, W, 8)
 __global__ __launch_bounds__(256) void gen_rays_kernel(const float* __restrict__ poses, const float* __restrict__ projs, int V, int H, int W,
                                                        float z_near, float z_far, int norm_dir, float4* __restrict__ rays) {
   const long total = (long)V * H * W;
@@ -86,26 +109,10 @@ __global__ __launch_bounds__(256) void gen_rays_kernel(const float* __restrict__
     const int v = (int)(i / ((long)H * W));
     const int rem = (int)(i - (long)v * H * W);
     const int y = rem / W, x = rem - y * W;
-    const float* P = poses + v * 16;
-    const float* Kp = projs + v * 9;
-    const float fx = Kp[0], fy = Kp[4], cx = Kp[2], cy = Kp[5];
-    const float gx = W > 1 ? linspace_at(-1.0f, 1.0f, W, x) : -1.0f;
-    const float gy = H > 1 ? linspace_at(-1.0f, 1.0f, H, y) : -1.0f;
-    float d0 = (gx - cx) / fx, d1 = (gy - cy) / fy, d2 = 1.0f;
-    if (norm_dir) {
-      const float nrm = sqrtf(d0 * d0 + d1 * d1 + d2 * d2);
-      d0 = d0 / nrm, d1 = d1 / nrm, d2 = d2 / nrm;
-    }
-    float w[3];
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      float a = P[4 * r + 0] * d0;
-      a = __builtin_fmaf(P[4 * r + 1], d1, a);
-      a = __builtin_fmaf(P[4 * r + 2], d2, a);
-      w[r] = a;
-    }
-    rays[2 * i] = make_float4(P[3], P[7], P[11], w[0]);
-    rays[2 * i + 1] = make_float4(w[1], w[2], z_near, z_far);
+    float4 a, b;
+    ray_of_pixel(poses + v * 16, projs + v * 9, H, W, x, y, z_near, z_far, norm_dir, a, b);
+    rays[2 * i] = a;
+    rays[2 * i + 1] = b;
   }
 }
 
@@ -114,6 +121,45 @@ int gen_rays_launch(const float* poses, const float* projs, int V, int H, int W,
   const long total = (long)V * H * W;
   const int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
   gen_rays_kernel<<<grid, 256, 0, s>>>(poses, projs, V, H, W, zn, zf, norm_dir, reinterpret_cast<float4*>(rays));
+  return hipGetLastError() == hipSuccess ? BTS_OK : BTS_E_LAUNCH;
+}
+
+// patch_rays: PatchRaySampler.sample on device (ray_sampler.py:125-162).  Per sample P patches (view, y0, x0) of ph x pw pixels:
+// the rays of exactly those pixels (never the (n, v, H, W, 8) ray volume the reference builds and then slices) and, when frames are
+// given, their ground-truth colours gathered from the NCHW frames.  Output order = the reference's: patch-major, then row, then column.
+__global__ __launch_bounds__(256) void patch_rays_kernel(const float* __restrict__ poses, const float* __restrict__ projs,
+                                                         const float* __restrict__ images, const int* __restrict__ pv,
+                                                         const int* __restrict__ py, const int* __restrict__ px, int n, int v, int c, int H,
+                                                         int W, int P, int ph, int pw, float z_near, float z_far, int norm_dir,
+                                                         float4* __restrict__ rays, float* __restrict__ gt) {
+  const int per = P * ph * pw;
+  const long total = (long)n * per;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int smp = (int)(i / per);
+    int rem = (int)(i - (long)smp * per);
+    const int patch = rem / (ph * pw);
+    rem -= patch * ph * pw;
+    const int dy = rem / pw, dx = rem - dy * pw;
+    const int view = pv[smp * P + patch];
+    const int y = py[smp * P + patch] + dy, x = px[smp * P + patch] + dx;
+    float4 a, b;
+    ray_of_pixel(poses + ((long)smp * v + view) * 16, projs + ((long)smp * v + view) * 9, H, W, x, y, z_near, z_far, norm_dir, a, b);
+    rays[2 * i] = a;
+    rays[2 * i + 1] = b;
+    if (gt) {
+      const float* img = images + (((long)smp * v + view) * c) * H * W + (long)y * W + x;
+      for (int ch = 0; ch < c; ++ch) gt[i * c + ch] = img[(long)ch * H * W];
+    }
+  }
+}
+
+int patch_rays_launch(const float* poses, const float* projs, const float* images, const int* pv, const int* py, const int* px, int n, int v,
+                      int c, int H, int W, int P, int ph, int pw, float zn, float zf, int norm_dir, float* rays, float* gt, hipStream_t s) {
+  const long total = (long)n * P * ph * pw;
+  if (total == 0) return BTS_OK;
+  const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  patch_rays_kernel<<<grid, 256, 0, s>>>(poses, projs, images, pv, py, px, n, v, c, H, W, P, ph, pw, zn, zf, norm_dir,
+                                         reinterpret_cast<float4*>(rays), images ? gt : nullptr);
   return hipGetLastError() == hipSuccess ? BTS_OK : BTS_E_LAUNCH;
 }
 

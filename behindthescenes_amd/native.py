@@ -103,6 +103,29 @@ def gen_rays(poses_c2w: torch.Tensor, projs: torch.Tensor, H: int, W: int, z_nea
     return out
 
 
+def patch_rays(poses_c2w, projs, images, patch_v, patch_y, patch_x, ph: int, pw: int, z_near: float, z_far: float, norm_dir: bool = True):
+    """poses (n,v,4,4), projs (n,v,3,3), images (n,v,c,H,W) | None with (H, W) given via ``images`` or a (H, W) tuple; patch_* (n,P)
+    int32 -> rays (n, P*ph*pw, 8), rgb_gt (n, P*ph*pw, c) | None  (bts_patch_rays)."""
+    n, v = poses_c2w.shape[:2]
+    _req(poses_c2w, "poses_c2w", (n, v, 4, 4)), _req(projs, "projs", (n, v, 3, 3))
+    if isinstance(images, tuple):
+        (H, W), c, images = images, 0, None
+    else:
+        _req(images, "images")
+        c, H, W = images.shape[2:]
+    P = patch_v.shape[1]
+    for t, nme in ((patch_v, "patch_v"), (patch_y, "patch_y"), (patch_x, "patch_x")):
+        if t.dtype != torch.int32 or not t.is_cuda or not t.is_contiguous() or tuple(t.shape) != (n, P):
+            raise BtsNativeError(f"{nme}: expected a contiguous int32 device tensor of shape {(n, P)}")
+    dev = poses_c2w.device
+    rays = torch.empty((n, P * ph * pw, 8), device=dev, dtype=torch.float32)
+    gt = torch.empty((n, P * ph * pw, c), device=dev, dtype=torch.float32) if images is not None else None
+    _lib.check(_lib.load().bts_patch_rays(_ptr(poses_c2w), _ptr(projs), _ptr(images), patch_v.data_ptr(), patch_y.data_ptr(),
+                                          patch_x.data_ptr(), n, v, c, H, W, P, ph, pw, z_near, z_far, int(norm_dir), _ptr(rays),
+                                          _ptr(gt), _stream(rays)), "bts_patch_rays")
+    return rays, gt
+
+
 def sample_coarse(rays: torch.Tensor, u: torch.Tensor, lindisp: bool) -> torch.Tensor:
     """rays (B,8), u (B,K) uniform jitter -> z_samp (B,K) (bts_sample_coarse)."""
     B, K = u.shape

@@ -98,19 +98,16 @@ class PatchRaySampler(RaySampler):
         return torch.stack(pv), torch.stack(py), torch.stack(px)
 
     def sample(self, images, poses, projs, patches=None):
+        """Rays and ground-truth colours of ``ray_batch_size`` / (ph*pw) random patches per sample (ray_sampler.py:125-162).  The patch
+        coordinates come from the CPU RNG in the reference's order; one HIP pass (bts_patch_rays) then produces the rays of exactly
+        those pixels and gathers their colours -- the reference builds all v*H*W rays per sample and slices them in a Python loop."""
         n, v, c, h, w = images.shape
         dev = images.device
-        rays = _all_rays(poses, projs, h, w, self.z_near, self.z_far)               # (n, v, h, w, 8)
         pv, py, px = self.draw_patches(n, v, h, w) if patches is None else patches
-        pv, py, px = pv.to(dev), py.to(dev), px.to(dev)
-        oy = torch.arange(self.patch_size_y, device=dev).view(1, 1, -1, 1)
-        ox = torch.arange(self.patch_size_x, device=dev).view(1, 1, 1, -1)
-        yy = (py.view(n, -1, 1, 1) + oy).expand(-1, -1, -1, self.patch_size_x)     # (n, pc, ph, pw)
-        xx = (px.view(n, -1, 1, 1) + ox).expand(-1, -1, self.patch_size_y, -1)
-        flat = ((pv.view(n, -1, 1, 1) * h + yy) * w + xx).reshape(n, -1)           # index into (v*h*w)
-        all_rays = torch.gather(rays.view(n, -1, 8), 1, flat.unsqueeze(-1).expand(-1, -1, 8))
-        gt = images.permute(0, 1, 3, 4, 2).reshape(n, -1, c)
-        all_rgb_gt = torch.gather(gt, 1, flat.unsqueeze(-1).expand(-1, -1, c))
+        idx = torch.stack((pv, py, px)).to(device=dev, dtype=torch.int32)          # one small host-to-device copy
+        all_rays, all_rgb_gt = native.patch_rays(poses.detach().float().contiguous(), projs.detach().float().contiguous(),
+                                                 images.detach().float().contiguous(), idx[0], idx[1], idx[2],
+                                                 self.patch_size_y, self.patch_size_x, self.z_near, self.z_far)
         return all_rays, all_rgb_gt
 
     def reconstruct(self, render_dict, channels=None):

@@ -152,6 +152,14 @@ int bts_pack_rgb(const float* src_nchw, float* dst_nhwc4, int32_t N, int32_t H, 
 int bts_gen_rays(const float* poses_c2w, const float* projs, int32_t V, int32_t H, int32_t W, float z_near, float z_far,
                  int32_t norm_dir, float* rays, void* stream);
 
+/* PatchRaySampler.sample (models/bts/model/ray_sampler.py:125-162) on device: for each of the n samples, P patches given by
+ * (view, y0, x0) triples (int32, (n, P) each; the caller draws them -- the reference uses the CPU RNG) of ph x pw pixels.
+ * poses_c2w (n, v, 4, 4), projs (n, v, 3, 3), images (n, v, c, H, W) or NULL -> rays (n, P*ph*pw, 8) and, with images,
+ * rgb_gt (n, P*ph*pw, c), in the reference's order (patch, row, column).  Patch pixels must lie inside the frame. */
+int bts_patch_rays(const float* poses_c2w, const float* projs, const float* images, const int32_t* patch_v, const int32_t* patch_y,
+                   const int32_t* patch_x, int32_t n, int32_t v, int32_t c, int32_t H, int32_t W, int32_t P, int32_t ph, int32_t pw,
+                   float z_near, float z_far, int32_t norm_dir, float* rays, float* rgb_gt, void* stream);
+
 /* NeRFRenderer.sample_coarse (nerf.py:103-123) with the uniform jitter u (B, K) in [0,1) supplied by the caller. */
 int bts_sample_coarse(const float* rays, const float* u, int64_t B, int32_t K, int32_t lindisp, float* z_samp,
                       void* stream);

@@ -129,6 +129,21 @@ def test_aux_kernels_vs_reference_golden(hip):
     rays, gt = ps.sample(imgs, poses.unsqueeze(0).expand(2, -1, -1, -1), projs.unsqueeze(0).expand(2, -1, -1, -1))
     torch.testing.assert_close(rays.cpu(), torch.from_numpy(z["patch_rays"]), rtol=0, atol=2e-6)
     assert torch.equal(gt.cpu(), torch.from_numpy(z["patch_rgb"]))
+    # ... and bit-identical to slicing the full ray volume (what the reference does), odd patch shape, explicit draws
+    P2 = poses.unsqueeze(0).expand(2, -1, -1, -1).contiguous()
+    K2 = projs.unsqueeze(0).expand(2, -1, -1, -1).contiguous()
+    v, (h, w) = imgs.shape[1], imgs.shape[-2:]
+    ps2 = hip.PatchRaySampler(ray_batch_size=5 * 3 * 2, z_near=1.0, z_far=50.0, patch_size=(3, 2))
+    draws = ps2.draw_patches(2, v, h, w)
+    rays2, gt2 = ps2.sample(imgs, P2, K2, patches=draws)
+    full = torch.stack([native.gen_rays(P2[i].contiguous(), K2[i], h, w, 1.0, 50.0, True) for i in range(2)])   # (2, v, h, w, 8)
+    k = 0
+    for i in range(2):
+        for pi in range(5):
+            vv, yy, xx = (int(t[i, pi]) for t in draws)
+            blk = full[i, vv, yy:yy + 3, xx:xx + 2].reshape(-1, 8)
+            assert torch.equal(rays2[i, pi * 6:(pi + 1) * 6], blk)
+            assert torch.equal(gt2[i, pi * 6:(pi + 1) * 6], imgs[i, vv, :, yy:yy + 3, xx:xx + 2].permute(1, 2, 0).reshape(-1, 3))
 
 
 def test_layout_kernels_roundtrip(hip):
