@@ -37,6 +37,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", choices=("eval", "train"), default="eval",
+                    help="eval (default): BASELINE configs[1], the headline line.  train: configs[2] (exp_kitti_360.yaml shapes), the "
+                         "renderer's share of a training step, forward + backward")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=24, help="image rows of view 0 rendered by the CPU oracle sample")
     return ap.parse_args()
@@ -70,6 +73,88 @@ def cpu_baseline(scene, net, rows):
                 sample=f"{rows} rows x {W} px x {V} views = {n_rays} rays x {K} samples, renderer only, best of 2")
 
 
+def train_workload(args, world, rank, dev):
+    """BASELINE configs[2] (configs/exp_kitti_360.yaml): bs 16 per GPU, 8 frames per sample (4 loss + 4 render views), 4096 patch rays
+    (64 patches of 8x8) per sample, 64 samples per ray.  One step = the renderer's share of `trainer.py:208-259` + backward: encode
+    hand-over (no CNN), PatchRaySampler.sample, G = project(F), render with saved activations and all training outputs, a scalar loss
+    on rgb / depth, backward through bts_render_bwd and bts_project_features_bwd (gradients for the MLP and the feature map), and
+    under N > 1 the all-reduce of the MLP gradient (the only exchange of the path; the CNN's DDP bucket is not part of it)."""
+    import behindthescenes_amd as bts
+    from behindthescenes_amd import native, parallel, synthetic as S
+    n, Vt, Kt, NV = 16, 8, 64, 4
+    scene = S.synthetic_scene(n, Vt, H, W, C, seed=2000 + rank, intrinsics=S.K_KITTI360, baseline=0.6, smooth=True)
+    net = bts.BTSNet(S.field_conf(C, HD, 0, H, W))
+    S.init_mlp_(net.mlp_coarse, seed=7)
+    net.encoder = bts.FeatureMapEncoder((H, W), C, num_views=n)
+    S.set_feature_map(net, scene["feat"])
+    net = net.to(dev).train()
+    renderer = bts.NeRFRenderer.from_conf(dict(n_coarse=Kt, lindisp=True, hard_alpha_cap=True)).to(dev).train()
+    sampler = bts.PatchRaySampler(ray_batch_size=4096, z_near=3.0, z_far=80.0, patch_size=8)
+    images, projs, poses = scene["images"].to(dev), scene["projs"].to(dev), scene["poses"].to(dev)
+    ids_loss, ids_render = [0, 1, 2, 3], [4, 5, 6, 7]
+    kern = {"fwd": [], "bwd": []}
+    orig_fwd, orig_bwd = native.render_fwd, native.render_bwd
+
+    def timed(fn, key):
+        def f(*a, **kw):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = fn(*a, **kw)
+            e1.record()
+            kern[key].append((e0, e1))
+            return out
+        return f
+
+    def step():
+        net.zero_grad(set_to_none=True)
+        net.encode(images, projs, poses, ids_encoder=[0], ids_render=ids_render, images_alt=images * .5 + .5)
+        all_rays, gt = sampler.sample(images[:, ids_loss] * .5 + .5, poses[:, ids_loss], projs[:, ids_loss])
+        out = renderer.composite(net, all_rays.reshape(-1, 8), renderer.sample_coarse(all_rays.reshape(-1, 8)), sb=n)
+        rgb, depth = out[1], out[2]
+        loss = (rgb - gt.reshape(-1, 1, 3).repeat(1, NV, 1).reshape(rgb.shape)).abs().mean() + 1e-3 * depth.mean()
+        loss.backward()
+        parallel.all_reduce_mean_([p.grad for p in net.mlp_coarse.parameters() if p.grad is not None])
+
+    for _ in range(args.warmup):
+        step()
+    native.render_fwd, native.render_bwd = timed(orig_fwd, "fwd"), timed(orig_bwd, "bwd")
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+        torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+        torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    native.render_fwd, native.render_bwd = orig_fwd, orig_bwd
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = t.item()
+    n_rays = n * 4096
+    ms = {k: sum(a.elapsed_time(b) for a, b in v) / max(len(v), 1) for k, v in kern.items()}
+    if rank == 0:
+        flop = 3 * n_rays * Kt * FLOP_PER_POINT          # SURVEY 8d: training = 3x forward (dX + dW)
+        achieved = flop / ((ms["fwd"] + ms["bwd"]) * 1e-3) / 1e12
+        print(json.dumps({
+            "metric": "renderer forward+backward rays/sec (KITTI-360 training step)", "value": world * n_rays * args.steps / elapsed,
+            "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "exp_kitti_360.yaml shapes: bs=16/GPU, 8 frames (4 loss + 4 render views), 4096 patch rays (8x8) per sample, "
+                                   "64 samples/ray, renderer only (feature-map encoder stand-in, L1 + depth scalar loss), fwd + bwd",
+                       "rays_per_step_per_gpu": n_rays, "samples_per_ray": Kt, "parallelism": f"batch x{world}"},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_FP32_MATRIX_TFLOPS, "traffic": None,
+                         "kernel": "bts_render_fwd + bts_render_bwd (render_kernel_p, render_bwd_kernel, scatter_dg_kernel)",
+                         "kernel_ms": ms["fwd"] + ms["bwd"], "fwd_ms": ms["fwd"], "bwd_ms": ms["bwd"], "algorithmic_flop_per_launch": flop,
+                         "note": "algorithmic 3 x 13 312 FLOP / sample; the backward is bound by L2 float atomics and LDS, not by MFMA"},
+        }))
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -89,6 +174,11 @@ def main():
     from behindthescenes_amd import synthetic as S
 
     _lib.load()
+    if args.workload == "train":
+        train_workload(args, world, rank, dev)
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
     Z_NEAR, Z_FAR = 3.0, 80.0                   # eval_depth.yaml
     scene = S.synthetic_scene(1, V, H, W, C, seed=1000 + rank, intrinsics=S.K_KITTIRAW)
     net = bts.BTSNet(S.field_conf(C, HD, 0, H, W, z_near=Z_NEAR, z_far=Z_FAR))

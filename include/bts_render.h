@@ -120,7 +120,8 @@ int64_t bts_mlp_param_count(const BtsFieldCfg* cfg);
 int bts_render_fwd(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const BtsRenderArgs* a, void* stream);
 
 /* Backward of bts_render_fwd.  `a` must carry sigma_raw written by the forward (weights/alphas are not needed).
- * workspace: bts_render_bwd_workspace(cfg, a) bytes of device scratch. */
+ * workspace: bts_render_bwd_workspace(cfg, a) bytes of device scratch (rays x K x d_hidden floats, rounded up to groups of 64
+ * rays: the gradient rows handed from the per-ray pass to the per-texel scatter pass); contents need no initialisation. */
 size_t bts_render_bwd_workspace(const BtsFieldCfg* cfg, const BtsRenderArgs* a);
 int bts_render_bwd(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const BtsRenderArgs* a, const BtsRenderGrads* g,
                    void* workspace, size_t workspace_bytes, void* stream);
