@@ -18,6 +18,18 @@ from .mlp import make_mlp
 EPS = 1e-3
 
 
+def _take(x, ids):
+    """``x[:, ids]`` for a Python list of frame indices without the host-to-device copy of an index tensor: list indexing makes
+    torch upload the indices from pageable memory, which blocks the host behind whatever the stream is still running (the previous
+    frame's render kernel) and so serialises host and device.  Consecutive ids are a view; anything else a stack of slices."""
+    if torch.is_tensor(ids):
+        return x[:, ids]
+    ids = [int(i) for i in ids]
+    if len(ids) > 0 and ids == list(range(ids[0], ids[0] + len(ids))):
+        return x[:, ids[0]:ids[0] + len(ids)]
+    return torch.stack([x[:, i] for i in ids], dim=1)
+
+
 class BTSNet(nn.Module):
     def __init__(self, conf):
         super().__init__()
@@ -76,7 +88,7 @@ class BTSNet(nn.Module):
         poses_w2c = native.invert_small(poses_c2w)
         if ids_encoder is None:
             ids_encoder = list(range(images.shape[1]))
-        images_encoder, Ks_encoder, poses_w2c_encoder = images[:, ids_encoder], Ks[:, ids_encoder], poses_w2c[:, ids_encoder]
+        images_encoder, Ks_encoder, poses_w2c_encoder = _take(images, ids_encoder), _take(Ks, ids_encoder), _take(poses_w2c, ids_encoder)
         colours = images_alt if images_alt is not None else None
         if ids_render is None:
             ids_render = list(range(images.shape[1]))
@@ -100,10 +112,10 @@ class BTSNet(nn.Module):
         self.grid_f_poses_w2c = poses_w2c_encoder
         self.grid_f_combine = None
         # colours: (x*.5+.5) fused into the rgb0 packing kernel unless the caller supplies processed frames
-        src = (colours if colours is not None else images)[:, ids_render]
+        src = _take(colours if colours is not None else images, ids_render)
         self.grid_c_imgs = src if colours is not None else src * .5 + .5
-        self.grid_c_Ks = Ks[:, ids_render]
-        self.grid_c_poses_w2c = poses_w2c[:, ids_render]
+        self.grid_c_Ks = _take(Ks, ids_render)
+        self.grid_c_poses_w2c = _take(poses_w2c, ids_render)
         self.grid_c_combine = None
 
         # ---- hand-over into the renderer's HBM layouts
