@@ -5,10 +5,11 @@ from . import parallel  # noqa: F401
 from .backbone import FeatureMapEncoder, make_backbone, register_backbone  # noqa: F401
 from .code import PositionalEncoding  # noqa: F401
 from .field import BTSNet  # noqa: F401
+from .loss import ReconstructionLoss  # noqa: F401
 from .mlp import ResnetBlockFC, ResnetFC, make_mlp  # noqa: F401
 from .projection import distance_to_z  # noqa: F401
 from .ray_sampler import ImageRaySampler, PatchRaySampler, RandomRaySampler, gen_rays  # noqa: F401
 from .renderer import NeRFRenderer, _RenderWrapper  # noqa: F401
 
 __all__ = ["BTSNet", "NeRFRenderer", "PositionalEncoding", "ResnetFC", "ResnetBlockFC", "make_mlp", "make_backbone",
-           "ImageRaySampler", "PatchRaySampler", "RandomRaySampler", "gen_rays", "distance_to_z", "BtsNativeError"]
+           "ImageRaySampler", "PatchRaySampler", "RandomRaySampler", "gen_rays", "distance_to_z", "ReconstructionLoss", "BtsNativeError"]

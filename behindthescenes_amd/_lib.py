@@ -41,6 +41,12 @@ class BtsRenderGrads(C.Structure):
                                           "d_empty_proj")]
 
 
+class BtsLossArgs(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("rgb", "depth", "weights", "invalid", "rgb_gt", "parts", "g_rgb", "g_depth")] + \
+               [(k, C.c_int32) for k in ("n_patches", "patch_h", "patch_w", "nv", "K", "invalid_policy", "edge_aware_smoothness")] + \
+               [("scale_rgb", C.c_float), ("scale_eas", C.c_float)]
+
+
 # every symbol include/bts_render.h declares: name -> (restype, argtypes)
 _P = C.c_void_p
 _I = C.c_int32
@@ -61,6 +67,7 @@ SYMBOLS = {
     "bts_pack_rgb": (C.c_int, [_P, _P, _I, _I, _I, C.c_float, C.c_float, _P]),
     "bts_gen_rays": (C.c_int, [_P, _P, _I, _I, _I, C.c_float, C.c_float, _I, _P, _P]),
     "bts_patch_rays": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, C.c_float, C.c_float, _I, _P, _P, _P]),
+    "bts_photometric_loss": (C.c_int, [C.POINTER(BtsLossArgs), _P]),
     "bts_sample_coarse": (C.c_int, [_P, _P, C.c_int64, _I, _I, _P, _P]),
     "bts_distance_to_z": (C.c_int, [_P, _P, _I, _I, _I, _P, _P]),
     "bts_invert_small": (C.c_int, [_P, _P, _I, _I, _P]),

@@ -16,7 +16,7 @@ ROOT = os.path.dirname(PKG)
 LIB = os.path.join(PKG, "libbts_render.so")
 # objects, saved assembly and the digest stamp live outside the repo (they are large and must not travel to the GPU box)
 OBJ = os.path.join(os.environ.get("BTS_OBJ_DIR", "/tmp"), "bts_render_obj")
-SOURCES = ["bts_fwd.hip", "bts_fwd_proj.hip", "bts_bwd.hip", "bts_prep.hip", "bts_aux.hip", "bts_api.hip"]
+SOURCES = ["bts_fwd.hip", "bts_fwd_proj.hip", "bts_bwd.hip", "bts_prep.hip", "bts_aux.hip", "bts_loss.hip", "bts_api.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-fno-gpu-rdc", "-munsafe-fp-atomics"]
 
 

@@ -15,6 +15,7 @@ int transpose_launch(const float* src, float* dst, int N, int C, int H, int W, b
 int pack_rgb_launch(const float* src, float* dst, int N, int H, int W, float scale, float shift, hipStream_t s);
 int patch_rays_launch(const float* poses, const float* projs, const float* images, const int* pv, const int* py, const int* px, int n, int v,
                       int c, int H, int W, int P, int ph, int pw, float zn, float zf, int norm_dir, float* rays, float* gt, hipStream_t s);
+int photometric_loss_impl(const BtsLossArgs* a, hipStream_t s);
 int gen_rays_launch(const float* poses, const float* projs, int V, int H, int W, float zn, float zf, int norm_dir, float* rays,
                     hipStream_t s);
 int sample_coarse_launch(const float* rays, const float* u, long B, int K, int lindisp, float* z, hipStream_t s);
@@ -202,6 +203,14 @@ int bts_patch_rays(const float* poses, const float* projs, const float* images, 
   BTS_RET_LAUNCH(patch_rays_launch(poses, projs, images, patch_v, patch_y, patch_x, n, v, c, H, W, P, ph, pw, z_near, z_far, norm_dir, rays,
                                    rgb_gt, (hipStream_t)stream),
                  "bts_patch_rays");
+}
+int bts_photometric_loss(const BtsLossArgs* a, void* stream) {
+  BTS_CHECK_LAYOUT(a && a->rgb && a->rgb_gt && a->parts && a->n_patches >= 0 && a->patch_h > 0 && a->patch_w > 0 &&
+                       a->patch_h * a->patch_w <= 64 && a->nv > 0 && a->invalid_policy >= 0 && a->invalid_policy <= 2 &&
+                       (a->invalid_policy == 0 || (a->invalid && a->K > 0)) && (a->invalid_policy != 2 || a->weights) &&
+                       (!a->edge_aware_smoothness || a->depth),
+                   "bts_photometric_loss");
+  BTS_RET_LAUNCH(photometric_loss_impl(a, (hipStream_t)stream), "bts_photometric_loss");
 }
 int bts_sample_coarse(const float* rays, const float* u, int64_t B, int32_t K, int32_t lindisp, float* z_samp, void* stream) {
   BTS_CHECK_LAYOUT(rays && u && z_samp && B > 0 && K > 0, "bts_sample_coarse");

@@ -1,0 +1,173 @@
+"""Drop-in for the reference's ``ReconstructionLoss`` (models/bts/model/loss.py:43-293) on the renderer's patch outputs.
+
+For the criterion every shipped config trains with ("l1+ssim") the whole photometric term -- SSIM + L1 per patch, minimum over the
+render views, invalid-ray masking, edge-aware smoothness -- and its gradient with respect to ``rgb`` / ``depth`` come from ONE HIP
+pass per scale (``bts_photometric_loss``, csrc/bts_loss.hip); the ~60 small kernels and nine ``.item()`` synchronisations of the
+reference become one launch, one reduction and one device-to-host copy for the logging dict.  The optional regularisers (depth /
+alpha / surfaceness / depth-smoothness / ray-entropy, all off in the shipped configs) are a few elementwise torch expressions on
+top.  Same constructor keys, same call signature, same ``(loss, loss_dict)`` result as the reference."""
+import math
+
+import torch
+
+from . import native
+
+
+class _PhotometricSums(torch.autograd.Function):
+    """(sum of the rgb term, sum of the smoothness term, number of invalid rays) over all patches; differentiable w.r.t. rgb, depth."""
+
+    @staticmethod
+    def forward(ctx, rgb, depth, weights, invalid, rgb_gt, ph, pw, policy, eas):
+        need = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        parts, g_rgb, g_depth = native.photometric_loss(rgb, depth if eas else None, weights, invalid, rgb_gt, ph, pw, policy, eas, 1.0, 1.0,
+                                                        need_grad=need)
+        ctx.save_for_backward(g_rgb, g_depth)
+        ctx.had_depth = depth is not None
+        return parts.sum(0)[:3]
+
+    @staticmethod
+    def backward(ctx, g):
+        g_rgb, g_depth = ctx.saved_tensors
+        d_rgb = g_rgb * g[0] if (g_rgb is not None and ctx.needs_input_grad[0]) else None
+        d_depth = g_depth * g[1] if (g_depth is not None and ctx.needs_input_grad[1]) else None
+        return d_rgb, d_depth, None, None, None, None, None, None, None
+
+
+def _flat(t, tail):
+    """(n, pc, h, w, *tail) -> contiguous float32 (B, prod(tail))"""
+    return t.reshape((-1,) + tuple(tail)).float().contiguous()
+
+
+class ReconstructionLoss:
+    def __init__(self, config, use_automasking=False) -> None:
+        self.criterion_str = config.get("criterion", "l2")
+        if self.criterion_str not in ("l2", "l1", "l1+ssim"):
+            raise ValueError(f"unknown criterion {self.criterion_str}")
+        self.invalid_policy = config.get("invalid_policy", "strict")
+        assert self.invalid_policy in ["strict", "weight_guided", "weight_guided_diverse", None, "none"]
+        self.ignore_invalid = self.invalid_policy is not None and self.invalid_policy != "none"
+        self.lambda_coarse = config.get("lambda_coarse", 1)
+        self.lambda_fine = config.get("lambda_fine", 1)
+        self.use_automasking = use_automasking
+        self.lambda_entropy = config.get("lambda_entropy", 0)
+        self.lambda_depth_reg = config.get("lambda_depth_reg", 0)
+        self.lambda_alpha_reg = config.get("lambda_alpha_reg", 0)
+        self.lambda_surfaceness_reg = config.get("lambda_surfaceness_reg", 0)
+        self.lambda_edge_aware_smoothness = config.get("lambda_edge_aware_smoothness", 0)
+        self.lambda_depth_smoothness = config.get("lambda_depth_smoothness", 0)
+        self.median_thresholding = config.get("median_thresholding", False)
+        self.alpha_reg_reduction = config.get("alpha_reg_reduction", "ray")
+        self.alpha_reg_fraction = config.get("alpha_reg_fraction", 1 / 8)
+        if self.alpha_reg_reduction not in ("ray", "slice"):
+            raise ValueError(f"Unknown reduction for alpha regularization: {self.alpha_reg_reduction}")
+        if self.criterion_str != "l1+ssim" or use_automasking or self.median_thresholding or self.invalid_policy == "weight_guided_diverse":
+            raise NotImplementedError("the fused HIP loss covers criterion 'l1+ssim' with invalid_policy strict / weight_guided / none, "
+                                      "without automasking / median thresholding (every shipped config); got "
+                                      f"criterion={self.criterion_str}, invalid_policy={self.invalid_policy}, "
+                                      f"automasking={use_automasking}, median_thresholding={self.median_thresholding}")
+
+    @staticmethod
+    def get_loss_metric_names():
+        return ["loss", "loss_rgb_coarse", "loss_rgb_fine", "loss_ray_entropy", "loss_depth_reg"]
+
+    def _photometric(self, level, level0, rgb_gt, eas):
+        """-> (mean rgb term, mean smoothness term, invalid-ray ratio) of one set of renderer outputs in patch layout."""
+        rgb = level["rgb"]                                   # (n, pc, h, w, nv, 3)
+        n, pc, h, w, nv, c = rgb.shape
+        if c != 3:
+            raise NotImplementedError("the fused HIP loss takes 3 colour channels")
+        B = n * pc * h * w
+        K = level0["weights"].shape[-1]
+        sums = _PhotometricSums.apply(_flat(rgb, (nv * 3,)), _flat(level["depth"], ()) if eas else None,
+                                      _flat(level0["weights"], (K,)).detach() if self.invalid_policy == "weight_guided" else None,
+                                      _flat(level0["invalid"], (K, nv)).detach() if self.ignore_invalid else None,
+                                      _flat(rgb_gt, (3,)).detach(), h, w, self.invalid_policy, eas)
+        return sums[0] / B, sums[1] / B, sums[2] / B
+
+    def __call__(self, data):
+        n_scales = len(data["coarse"])
+        coarse_0, fine_0 = data["coarse"][0], data["fine"][0]
+        dev = coarse_0["rgb"].device
+        zero = torch.zeros((), device=dev)
+        loss = zero
+        m = dict(coarse=zero, fine=zero, depth_reg=zero, alpha_reg=zero, surf=zero, eas=zero, dsmooth=zero, inv=zero)
+        keep_cache = None
+
+        def keep():   # 1 - invalid ray mask (n, pc, h, w) for the optional regularisers
+            nonlocal keep_cache
+            if keep_cache is None:
+                inv, wts = coarse_0["invalid"], coarse_0["weights"]
+                if self.invalid_policy == "strict":
+                    bad = torch.all(torch.any(inv > .5, dim=-2), dim=-1)
+                elif self.invalid_policy == "weight_guided":
+                    bad = torch.all((inv.to(torch.float32) * wts.unsqueeze(-1)).sum(-2) > .9, dim=-1)
+                else:
+                    bad = torch.zeros(inv.shape[:-2], dtype=torch.bool, device=dev)
+                keep_cache = 1 - bad.to(torch.float32)
+            return keep_cache
+
+        for scale in range(n_scales):
+            coarse, fine = data["coarse"][scale], data["fine"][scale]
+            eas_on = self.lambda_edge_aware_smoothness > 0
+            rgb_loss, eas, inv_ratio = self._photometric(coarse, coarse_0, data["rgb_gt"], eas_on)
+            if scale == 0:
+                m["inv"] = inv_ratio.detach()
+            m["coarse"] = m["coarse"] + rgb_loss.detach() * self.lambda_coarse
+            if len(fine) > 0:
+                if fine["rgb"] is coarse["rgb"]:           # trainer.py:247-248 aliases fine = dict(coarse)
+                    fine_loss = rgb_loss
+                else:
+                    fine_loss, _, _ = self._photometric(fine, fine_0, data["rgb_gt"], False)
+                m["fine"] = m["fine"] + fine_loss.detach() * self.lambda_fine
+                rgb_loss = rgb_loss * self.lambda_coarse + fine_loss * self.lambda_fine
+            loss = loss + rgb_loss
+
+            if self.lambda_depth_reg > 0:
+                d = coarse["depth"]
+                s = ((d[:, :, 1:, :] - d[:, :, :-1, :]) ** 2).mean() + ((d[:, :, :, 1:] - d[:, :, :, :-1]) ** 2).mean()
+                m["depth_reg"] = m["depth_reg"] + s.detach()
+                loss = loss + s * self.lambda_depth_reg
+            if self.lambda_alpha_reg > 0:
+                a = coarse["alphas"]
+                a_sum = a[..., :-1].sum(-1)
+                cap = torch.ones_like(a_sum) * (a.shape[-1] * self.alpha_reg_fraction)
+                if self.ignore_invalid:
+                    a_sum, cap = a_sum * keep(), cap * keep()
+                if self.alpha_reg_reduction == "ray":
+                    s = (a_sum - cap).clamp_min(0)
+                else:
+                    s = (a_sum.sum(dim=-1) - cap.sum(dim=-1)).clamp_min(0) / a_sum.shape[-1]
+                s = s.mean()
+                m["alpha_reg"] = m["alpha_reg"] + s.detach()
+                loss = loss + s * self.lambda_alpha_reg
+            if self.lambda_surfaceness_reg > 0:
+                a = coarse["alphas"]
+                p = (-torch.log(torch.exp(-a.abs()) + torch.exp(-(1 - a).abs()))).mean(-1)
+                if self.ignore_invalid:
+                    p = p * keep()
+                s = p.mean()
+                m["surf"] = m["surf"] + s.detach()
+                loss = loss + s * self.lambda_surfaceness_reg
+            if eas_on:
+                m["eas"] = m["eas"] + eas.detach()
+                loss = loss + eas * self.lambda_edge_aware_smoothness / (2 ** scale)
+            if self.lambda_depth_smoothness > 0:
+                d = coarse["depth"]
+                s = ((d[..., :-1, :] - d[..., 1:, :]) ** 2).mean() + ((d[..., :, :-1] - d[..., :, 1:]) ** 2).mean()
+                m["dsmooth"] = m["dsmooth"] + s.detach()
+                loss = loss + s * self.lambda_depth_smoothness
+
+        loss = loss / n_scales
+        ent = zero
+        if self.lambda_entropy > 0:
+            a = coarse_0["alphas"] + 1e-5
+            dens = a / a.sum(dim=-1, keepdim=True)
+            ent = (-(dens * torch.log(dens)).sum(-1) / math.log2(a.shape[-1]) * keep()).mean()
+            loss = loss + ent * self.lambda_entropy
+
+        # one device-to-host copy for the whole logging dict (the reference pays one synchronisation per entry)
+        vals = torch.stack([m["coarse"], m["fine"], ent.detach(), m["depth_reg"], m["alpha_reg"], m["eas"], m["dsmooth"], m["inv"],
+                            loss.detach()]).tolist()
+        keys = ["loss_rgb_coarse", "loss_rgb_fine", "loss_ray_entropy", "loss_depth_reg", "loss_alpha_reg", "loss_eas",
+                "loss_depth_smoothness", "loss_invalid_ratio", "loss"]
+        return loss, dict(zip(keys, vals))

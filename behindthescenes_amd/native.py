@@ -126,6 +126,44 @@ def patch_rays(poses_c2w, projs, images, patch_v, patch_y, patch_x, ph: int, pw:
     return rays, gt
 
 
+INVALID_POLICIES = {None: 0, "none": 0, "strict": 1, "weight_guided": 2}
+
+
+def photometric_loss(rgb, depth, weights, invalid, rgb_gt, patch_h: int, patch_w: int, invalid_policy, eas: bool,
+                     scale_rgb: float, scale_eas: float, need_grad: bool = True):
+    """Patch-ordered renderer outputs -> per-patch partial sums and the loss gradients (bts_photometric_loss).
+    rgb (B, nv*3), depth (B) | None, weights (B, K) | None, invalid (B, K, nv) | None, rgb_gt (B, 3)
+    -> parts (B / (ph*pw), 4), g_rgb (B, nv*3) | None, g_depth (B) | None."""
+    B = rgb_gt.shape[0]
+    area = patch_h * patch_w
+    if B % area:
+        raise BtsNativeError(f"{B} rays are not a whole number of {patch_h}x{patch_w} patches")
+    nv = rgb.shape[-1] // 3
+    policy = INVALID_POLICIES[invalid_policy]
+    _req(rgb, "rgb", (B, nv * 3)), _req(rgb_gt, "rgb_gt", (B, 3))
+    K = 0
+    if policy:
+        K = invalid.shape[1]
+        _req(invalid, "invalid", (B, K, nv))
+    if policy == 2:
+        _req(weights, "weights", (B, K))
+    if eas:
+        _req(depth, "depth", (B,))
+    dev = rgb.device
+    parts = torch.empty((B // area, 4), device=dev, dtype=torch.float32)
+    g_rgb = torch.empty_like(rgb) if need_grad else None
+    g_depth = torch.empty((B,), device=dev, dtype=torch.float32) if (need_grad and depth is not None) else None
+    a = _lib.BtsLossArgs(rgb=rgb.data_ptr(), depth=None if depth is None else depth.data_ptr(),
+                         weights=None if (weights is None or policy != 2) else weights.data_ptr(),
+                         invalid=None if (invalid is None or not policy) else invalid.data_ptr(), rgb_gt=rgb_gt.data_ptr(),
+                         parts=parts.data_ptr(), g_rgb=None if g_rgb is None else g_rgb.data_ptr(),
+                         g_depth=None if g_depth is None else g_depth.data_ptr(), n_patches=B // area, patch_h=patch_h, patch_w=patch_w,
+                         nv=nv, K=K, invalid_policy=policy, edge_aware_smoothness=int(bool(eas)), scale_rgb=scale_rgb,
+                         scale_eas=scale_eas)
+    _lib.check(_lib.load().bts_photometric_loss(C.byref(a), _stream(rgb)), "bts_photometric_loss")
+    return parts, g_rgb, g_depth
+
+
 def sample_coarse(rays: torch.Tensor, u: torch.Tensor, lindisp: bool) -> torch.Tensor:
     """rays (B,8), u (B,K) uniform jitter -> z_samp (B,K) (bts_sample_coarse)."""
     B, K = u.shape

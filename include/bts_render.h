@@ -153,6 +153,30 @@ int bts_pack_rgb(const float* src_nchw, float* dst_nhwc4, int32_t N, int32_t H, 
 int bts_gen_rays(const float* poses_c2w, const float* projs, int32_t V, int32_t H, int32_t W, float z_near, float z_far,
                  int32_t norm_dir, float* rays, void* stream);
 
+/* Photometric loss on the renderer's patch outputs, forward AND backward in one pass.  Replaces, for criterion "l1+ssim",
+ * ReconstructionLoss.__call__ (models/bts/model/loss.py:83-293): compute_errors_l1ssim (:10-18) with SSIM
+ * (models/common/model/layers.py:79-150: 3x3 Gaussian window, zero padding, comp_mode), the minimum over the nv render views,
+ * the invalid-ray policy (:100-118) and edge_aware_smoothness (:21-40, masked as in :262-266).
+ * Rays are in PatchRaySampler order: B = n_patches * patch_h * patch_w, patch-major, then row, then column; patch_h*patch_w <= 64.
+ * parts (n_patches, 4) receives per patch [sum of the rgb term, sum of the smoothness term, number of invalid rays, 0]: the caller
+ * forms  loss = scale_rgb * sum(parts[:,0]) + scale_eas * sum(parts[:,1])  (scale_rgb = (lambda_coarse + lambda_fine) / B ...).
+ * g_rgb (B, nv, 3) / g_depth (B), when given, receive d loss / d rgb and d loss / d depth for exactly that loss. */
+typedef struct {
+  const float* rgb;      /* (B, nv, 3) rendered colours per view */
+  const float* depth;    /* (B) expected ray termination depth (may be NULL without edge_aware_smoothness) */
+  const float* weights;  /* (B, K)      needed by invalid_policy 2 */
+  const float* invalid;  /* (B, K, nv)  needed by invalid_policy 1, 2 */
+  const float* rgb_gt;   /* (B, 3) */
+  float* parts;          /* (n_patches, 4) */
+  float* g_rgb;          /* (B, nv, 3) or NULL */
+  float* g_depth;        /* (B) or NULL */
+  int32_t n_patches, patch_h, patch_w, nv, K;
+  int32_t invalid_policy;          /* 0 none, 1 strict, 2 weight_guided */
+  int32_t edge_aware_smoothness;   /* 0 / 1 */
+  float scale_rgb, scale_eas;
+} BtsLossArgs;
+int bts_photometric_loss(const BtsLossArgs* args, void* stream);
+
 /* PatchRaySampler.sample (models/bts/model/ray_sampler.py:125-162) on device: for each of the n samples, P patches given by
  * (view, y0, x0) triples (int32, (n, P) each; the caller draws them -- the reference uses the CPU RNG) of ph x pw pixels.
  * poses_c2w (n, v, 4, 4), projs (n, v, 3, 3), images (n, v, c, H, W) or NULL -> rays (n, P*ph*pw, 8) and, with images,

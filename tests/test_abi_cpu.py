@@ -46,6 +46,7 @@ def test_ctypes_structs_match_the_c_layout():
 #include <stddef.h>
 #include "bts_render.h"
 int main(void) {
+  printf("%zu %zu\n", sizeof(BtsLossArgs), offsetof(BtsLossArgs, scale_rgb));
   printf("%zu %zu %zu %zu\n", sizeof(BtsFieldCfg), sizeof(BtsFieldTensors), sizeof(BtsRenderArgs), sizeof(BtsRenderGrads));
   printf("%zu %zu %zu %zu\n", offsetof(BtsFieldCfg, freq_factor), offsetof(BtsFieldTensors, mlp_params), offsetof(BtsRenderArgs, rays),
          offsetof(BtsRenderArgs, trans));
@@ -58,6 +59,8 @@ int main(void) {
     sizes = [C.sizeof(_lib.BtsFieldCfg), C.sizeof(_lib.BtsFieldTensors), C.sizeof(_lib.BtsRenderArgs), C.sizeof(_lib.BtsRenderGrads)]
     offs = [_lib.BtsFieldCfg.freq_factor.offset, _lib.BtsFieldTensors.mlp_params.offset, _lib.BtsRenderArgs.rays.offset,
             _lib.BtsRenderArgs.trans.offset]
+    assert [int(x) for x in out[:2]] == [C.sizeof(_lib.BtsLossArgs), _lib.BtsLossArgs.scale_rgb.offset]
+    out = out[2:]
     assert [int(x) for x in out[:4]] == sizes and [int(x) for x in out[4:]] == offs
 
 

@@ -15,7 +15,10 @@ from tests._cases import GOLDEN
 pytestmark = pytest.mark.gpu
 
 
-def test_train_step_loss_and_gradients_vs_reference_golden():
+@pytest.mark.parametrize("fused_loss", [False, True], ids=["oracle_loss", "hip_loss"])
+def test_train_step_loss_and_gradients_vs_reference_golden(fused_loss):
+    """fused_loss=False: the oracle's torch restatement of the loss consumes the HIP renderer's outputs (isolates the renderer);
+    fused_loss=True: the drop-in ReconstructionLoss (bts_photometric_loss, one HIP pass) -- the whole step after the CNN is HIP."""
     import behindthescenes_amd as bts
     from behindthescenes_amd import _lib
     from tests._hip_helpers import load_mlp, make_conf
@@ -45,9 +48,16 @@ def test_train_step_loss_and_gradients_vs_reference_golden():
     assert c["rgb"].shape == t["out_rgb"].shape and c["invalid"].shape == t["out_invalid"].shape
     torch.testing.assert_close(c["depth"].detach().cpu(), t["out_depth"], rtol=1e-4, atol=0)
     torch.testing.assert_close(c["rgb"].detach().cpu(), t["out_rgb"], rtol=0, atol=1e-5)
-    loss, parts = OL.reconstruction_loss(c, rd["rgb_gt"])
+    if fused_loss:
+        crit = bts.ReconstructionLoss({"criterion": "l1+ssim", "invalid_policy": "weight_guided", "lambda_edge_aware_smoothness": 0.001})
+        loss, parts = crit(dict(coarse=[c], fine=[rd["fine"]], rgb_gt=rd["rgb_gt"]))
+        assert abs(parts["loss"] - t["loss"].item()) <= 1e-5 and abs(parts["loss_invalid_ratio"] - t["loss_invalid_ratio"].item()) <= 1e-6
+        ref_loss, ref_parts = OL.reconstruction_loss({k: v.detach() for k, v in c.items()}, rd["rgb_gt"])
+        assert abs(parts["loss_eas"] - ref_parts["loss_eas"].item()) <= 1e-6 and abs(parts["loss_rgb_coarse"] - ref_parts["loss_rgb_coarse"].item()) <= 1e-6
+    else:
+        loss, parts = OL.reconstruction_loss(c, rd["rgb_gt"])
+        assert abs(parts["loss_invalid_ratio"].item() - t["loss_invalid_ratio"].item()) <= 1e-6
     assert abs(loss.item() - t["loss"].item()) <= 1e-5, (loss.item(), t["loss"].item())
-    assert abs(parts["loss_invalid_ratio"].item() - t["loss_invalid_ratio"].item()) <= 1e-6
     loss.backward()
     got = dict(g_w_in=net.mlp_coarse.lin_in.weight.grad, g_b_in=net.mlp_coarse.lin_in.bias.grad,
                g_w_out=net.mlp_coarse.lin_out.weight.grad, g_b_out=net.mlp_coarse.lin_out.bias.grad, g_feat=net.encoder.feats[0].grad)
