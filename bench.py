@@ -76,8 +76,9 @@ def cpu_baseline(scene, net, rows):
 def train_workload(args, world, rank, dev):
     """BASELINE configs[2] (configs/exp_kitti_360.yaml): bs 16 per GPU, 8 frames per sample (4 loss + 4 render views), 4096 patch rays
     (64 patches of 8x8) per sample, 64 samples per ray.  One step = the renderer's share of `trainer.py:208-259` + backward: encode
-    hand-over (no CNN), PatchRaySampler.sample, G = project(F), render with saved activations and all training outputs, a scalar loss
-    on rgb / depth, backward through bts_render_bwd and bts_project_features_bwd (gradients for the MLP and the feature map), and
+    hand-over (no CNN), PatchRaySampler.sample, G = project(F), render with saved activations and every output the trainer asks for
+    (weights, alphas, rgb_samps), reconstruct, the photometric loss (l1+ssim, weight-guided invalid mask, edge-aware smoothness: one
+    HIP pass incl. its gradient), backward through bts_render_bwd and bts_project_features_bwd (MLP and feature-map gradients), and
     under N > 1 the all-reduce of the MLP gradient (the only exchange of the path; the CNN's DDP bucket is not part of it)."""
     import behindthescenes_amd as bts
     from behindthescenes_amd import native, parallel, synthetic as S
@@ -105,13 +106,19 @@ def train_workload(args, world, rank, dev):
             return out
         return f
 
-    def step():
+    wrapped = renderer.bind_parallel(net).train()
+    crit = bts.ReconstructionLoss({"criterion": "l1+ssim", "invalid_policy": "weight_guided", "lambda_edge_aware_smoothness": 0.001})
+
+    def step():   # trainer.py:208-259 after the CNN, then base_trainer.py:297
         net.zero_grad(set_to_none=True)
-        net.encode(images, projs, poses, ids_encoder=[0], ids_render=ids_render, images_alt=images * .5 + .5)
-        all_rays, gt = sampler.sample(images[:, ids_loss] * .5 + .5, poses[:, ids_loss], projs[:, ids_loss])
-        out = renderer.composite(net, all_rays.reshape(-1, 8), renderer.sample_coarse(all_rays.reshape(-1, 8)), sb=n)
-        rgb, depth = out[1], out[2]
-        loss = (rgb - gt.reshape(-1, 1, 3).repeat(1, NV, 1).reshape(rgb.shape)).abs().mean() + 1e-3 * depth.mean()
+        images_ip = images * .5 + .5
+        net.encode(images, projs, poses, ids_encoder=[0], ids_render=ids_render, images_alt=images_ip)
+        all_rays, all_rgb_gt = sampler.sample(images_ip[:, :4], poses[:, :4], projs[:, :4])       # ids_loss = first four frames
+        rd = wrapped(all_rays, want_weights=True, want_alphas=True, want_rgb_samps=True)
+        rd["fine"] = dict(rd["coarse"])
+        rd["rgb_gt"], rd["rays"] = all_rgb_gt, all_rays
+        rd = sampler.reconstruct(rd)
+        loss, _ = crit(dict(coarse=[rd["coarse"]], fine=[rd["fine"]], rgb_gt=rd["rgb_gt"]))
         loss.backward()
         parallel.all_reduce_mean_([p.grad for p in net.mlp_coarse.parameters() if p.grad is not None])
 
@@ -141,11 +148,11 @@ def train_workload(args, world, rank, dev):
         flop = 3 * n_rays * Kt * FLOP_PER_POINT          # training = 3x forward (dX + dW)
         achieved = flop / ((ms["fwd"] + ms["bwd"]) * 1e-3) / 1e12
         print(json.dumps({
-            "metric": "renderer forward+backward rays/sec (KITTI-360 training step)", "value": world * n_rays * args.steps / elapsed,
+            "metric": "training-step rays/sec after the CNN: render forward + loss + backward (KITTI-360 shapes)", "value": world * n_rays * args.steps / elapsed,
             "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "exp_kitti_360.yaml shapes: bs=16/GPU, 8 frames (4 loss + 4 render views), 4096 patch rays (8x8) per sample, "
-                                   "64 samples/ray, renderer only (feature-map encoder stand-in, L1 + depth scalar loss), fwd + bwd",
+                                   "64 samples/ray, everything after the CNN (feature-map encoder stand-in): sample, render, photometric loss, backward",
                        "rays_per_step_per_gpu": n_rays, "samples_per_ray": Kt, "parallelism": f"batch x{world}"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_MATRIX_TFLOPS, "traffic": None,

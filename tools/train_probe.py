@@ -20,6 +20,7 @@ with torch.no_grad():
     net.encoder.feats[0].data = scene["feat"].clone()
 net = net.cuda().train()
 renderer = bts.NeRFRenderer.from_conf(dict(n_coarse=K, lindisp=True, hard_alpha_cap=True)).cuda().train()
+crit = bts.ReconstructionLoss({"criterion": "l1+ssim", "invalid_policy": "weight_guided", "lambda_edge_aware_smoothness": 0.001})
 sampler = bts.PatchRaySampler(ray_batch_size=4096, z_near=Z_NEAR, z_far=Z_FAR, patch_size=8)
 images, projs, poses = scene["images"].cuda(), scene["projs"].cuda(), scene["poses"].cuda()
 ids_loss, ids_render = [0, 1, 2, 3], [4, 5, 6, 7]
@@ -27,7 +28,7 @@ ev = lambda: torch.cuda.Event(enable_timing=True)
 res = {}
 for r in range(rounds + 1):
     net.zero_grad(set_to_none=True)
-    t = [ev() for _ in range(5)]
+    t = [ev() for _ in range(6)]
     t[0].record()
     net.encode(images, projs, poses, ids_encoder=[0], ids_render=ids_render, images_alt=images * .5 + .5)
     all_rays, gt = sampler.sample(images[:, ids_loss] * .5 + .5, poses[:, ids_loss], projs[:, ids_loss])
@@ -37,12 +38,15 @@ for r in range(rounds + 1):
     out = renderer.composite(net, all_rays.reshape(-1, 8), renderer.sample_coarse(all_rays.reshape(-1, 8)), sb=n)
     w, rgb, depth, a, inv, _, rs = out
     t[3].record()
-    loss = (rgb - gt.reshape(-1, 1, 3).repeat(1, 4, 1).reshape(rgb.shape)).abs().mean() + 1e-3 * depth.mean()
-    loss.backward()
+    pch = lambda x, *tail: x.reshape(n, 64, 8, 8, *tail)      # PatchRaySampler.reconstruct layout
+    level = dict(rgb=pch(rgb, 4, 3), depth=pch(depth), weights=pch(w, K), invalid=pch(inv, K, 4), alphas=pch(a, K))
+    loss, _ = crit(dict(coarse=[level], fine=[dict(level)], rgb_gt=pch(gt, 3)))
     t[4].record()
+    loss.backward()
+    t[5].record()
     torch.cuda.synchronize()
     if r > 0:
-        for name, i in (("encode+sample", 0), ("project", 1), ("render fwd (saved, all outputs)", 2), ("loss + backward (render_bwd, project_bwd)", 3)):
+        for name, i in (("encode+sample", 0), ("project", 1), ("render fwd (saved, all outputs)", 2), ("photometric loss (fused, incl. its gradient)", 3), ("backward (render_bwd, project_bwd)", 4)):
             res.setdefault(name, []).append(t[i].elapsed_time(t[i + 1]))
 B = n * 4096
 print(f"n={n}: {B} rays x {K} samples, nv=4")
