@@ -41,11 +41,14 @@ def parse():
                     help="eval (default): BASELINE configs[1], the headline line.  train: configs[2] (exp_kitti_360.yaml shapes), the "
                          "renderer's share of a training step, forward + backward")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gpu-eager-baseline", action="store_true",
+                    help="also time the oracle's torch ops eagerly on the GPU (the reference's own code path on this device) -> "
+                         "cpu_baseline.gpu_eager_port; off by default")
     ap.add_argument("--cpu-rows", type=int, default=24, help="image rows of view 0 rendered by the CPU oracle sample")
     return ap.parse_args()
 
 
-def cpu_baseline(scene, net, rows):
+def cpu_baseline(scene, net, rows, device="cpu"):
     """The oracle ("port" of the reference algorithm, same torch CPU ops) on a bounded sample: `rows` full image rows of
     both views (rows*640*2 rays, K=64), best of 2 after one warm-up.  The only place bench.py touches ``oracle/``."""
     from oracle import bts_oracle as O
@@ -59,16 +62,25 @@ def cpu_baseline(scene, net, rows):
     g = torch.Generator().manual_seed(1)
     u = torch.rand(rays.shape[1], K, generator=g)
     st = O.make_state(scene, [0], cfg)
+    if device != "cpu":   # the same torch ops, eagerly, on the GPU: what the reference's own code path costs on this device
+        rays, u = rays.to(device), u.to(device)
+        st = O.FieldState(*[None if t is None else t.to(device) for t in (st.feat, st.K_enc, st.w2c_enc, st.imgs, st.K_r, st.w2c_r, st.empty_feature)])
+        mlp = O.MlpParams(mlp.w_in.to(device), mlp.b_in.to(device), [], mlp.w_out.to(device), mlp.b_out.to(device))
     best = float("inf")
     with torch.no_grad():
         for i in range(3):
             t0 = time.perf_counter()
             z = O.sample_coarse(rays.reshape(-1, 8), K, True, u)
             O.composite(rays.reshape(-1, 8), z, 1, st, mlp, cfg, hard_alpha_cap=True)
+            if device != "cpu":
+                torch.cuda.synchronize()
             dt = time.perf_counter() - t0
             if i > 0:
                 best = min(best, dt)
     n_rays = rays.shape[1]
+    if device != "cpu":
+        return dict(value=n_rays / best, unit="rays/s", kind="port", device="MI355X, PyTorch-ROCm eager (the oracle's torch ops on cuda:0)",
+                    sample=f"{rows} rows x {W} px x {V} views = {n_rays} rays x {K} samples, renderer only, best of 2")
     return dict(value=n_rays / best, unit="rays/s", cores=torch.get_num_threads(), kind="port",
                 sample=f"{rows} rows x {W} px x {V} views = {n_rays} rays x {K} samples, renderer only, best of 2")
 
@@ -276,6 +288,8 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, net, args.cpu_rows)
+            if args.gpu_eager_baseline:
+                out["cpu_baseline"]["gpu_eager_port"] = cpu_baseline(scene, net, 4 * args.cpu_rows, device=dev)
         print(json.dumps(out))
     if world > 1:
         torch.distributed.destroy_process_group()

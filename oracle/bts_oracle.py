@@ -144,7 +144,7 @@ def sample_coarse(rays: torch.Tensor, n_coarse: int, lindisp: bool, u: torch.Ten
     reference's in-place ``rand_like`` (nerf.py:116) so that the jitter can be injected."""
     near, far = rays[:, 6:7], rays[:, 7:8]
     step = 1.0 / n_coarse
-    s = torch.linspace(0, 1 - step, n_coarse, dtype=torch.float32).unsqueeze(0).repeat(rays.shape[0], 1)
+    s = torch.linspace(0, 1 - step, n_coarse, dtype=torch.float32).to(rays.device).unsqueeze(0).repeat(rays.shape[0], 1)
     s = s + u * step
     if not lindisp:
         return near * (1 - s) + far * s
@@ -157,9 +157,9 @@ def sample_coarse(rays: torch.Tensor, n_coarse: int, lindisp: bool, u: torch.Ten
 def positional_encoding(x: torch.Tensor, num_freqs: int = 6, freq_factor: float = 1.5, include_input: bool = True):
     """x (N, 3) -> (N, 3 + 6*num_freqs).  Output order: [x, then per octave k: sin(f_k x)(3), sin(f_k x + pi/2)(3)],
     where the "cos" is evaluated as sin(phase + x*f) with phase = fl32(pi/2) through addcmul (code.py:25-28, 38)."""
-    freqs = freq_factor * 2.0 ** torch.arange(0, num_freqs)
+    freqs = (freq_factor * 2.0 ** torch.arange(0, num_freqs)).to(x.device)
     f = torch.repeat_interleave(freqs, 2).view(1, -1, 1).to(torch.float32)
-    ph = torch.zeros(2 * num_freqs)
+    ph = torch.zeros(2 * num_freqs, device=x.device)
     ph[1::2] = math.pi * 0.5
     ph = ph.view(1, -1, 1)
     e = x.unsqueeze(1).repeat(1, 2 * num_freqs, 1)
@@ -251,7 +251,7 @@ def field_forward(xyz: torch.Tensor, st: FieldState, mlp: MlpParams, cfg: FieldC
         sigma = torch.where(inv_f, torch.zeros_like(sigma), sigma)
     nv = st.imgs.shape[1]
     if only_density:
-        return torch.zeros(n, P, nv * 3), inv_f.to(sigma.dtype), sigma
+        return torch.zeros(n, P, nv * 3, device=sigma.device), inv_f.to(sigma.dtype), sigma
     c, inv_c = sample_colors(xyz, st)
     rgb = c.permute(0, 2, 1, 3).reshape(n, P, nv * 3)
     invalid = (inv_c.permute(0, 2, 1, 3).reshape(n, P, nv) | inv_f).to(rgb.dtype)
@@ -267,7 +267,7 @@ def composite(rays: torch.Tensor, z_samp: torch.Tensor, sb: int, st: FieldState,
     invalid (B,K,nv), z_samp (B,K), rgb_samps (B,K,nv*3)).  Point queries are chunked like nerf.py:238-268 (chunking does
     not change any value, only peak memory)."""
     B, K = z_samp.shape
-    deltas = torch.cat((z_samp[:, 1:] - z_samp[:, :-1], torch.full((B, 1), 1e10)), dim=-1)
+    deltas = torch.cat((z_samp[:, 1:] - z_samp[:, :-1], torch.full((B, 1), 1e10, device=z_samp.device, dtype=z_samp.dtype)), dim=-1)
     pts = (rays[:, None, :3] + z_samp.unsqueeze(2) * rays[:, None, 3:6]).reshape(sb, -1, 3)
     per = (chunk - 1) // sb + 1
     rgbs, invs, sigs = [], [], []
