@@ -142,7 +142,8 @@ __device__ __forceinline__ void octave_seq(f32x16 (&acc)[HD / 32][2], GBuf& ba, 
 // accumulation in the MFMA).  tools/ubench/f16split_gemm.hip: max error 3.8e-7 / rms 8e-8 against fp64 at K = 48, |D| ~ 2 -- slightly
 // better than the fp32-input MFMA (6.1e-7 / 9.3e-8).  Weights are pre-split once per work-group and scaled by 2^S (S chosen from
 // max |w| so that the low halves stay normal f16 numbers); everything else that enters the accumulators carries the same 2^S
-// (exact), removed again after lin_out.  The raw inputs x, y, code and the bias row stay on the fp32 path (x, y are unbounded).
+// (exact), removed again after lin_out.  The raw inputs x, y, code use the spare k rows of the slices (bounded on this path: larger
+// arguments take the exact routine); the bias row is the fp32 C operand of each accumulator tile's first MFMA.
 // ---------------------------------------------------------------------------------------------------------------
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -170,7 +171,7 @@ __device__ __forceinline__ void stage_weights_h(float* lh, const float* lds_old,
   if (threadIdx.x == 0) *mx = 0;
   __syncthreads();
   float m = 0.0f;
-  for (int i = threadIdx.x; i < 36 * HD; i += blockDim.x) m = fmaxf(m, fabsf(mlp[ml.w_in() + (i % HD) * D_IN + C + 3 + i / HD]));
+  for (int i = threadIdx.x; i < 39 * HD; i += blockDim.x) m = fmaxf(m, fabsf(mlp[ml.w_in() + (i % HD) * D_IN + C + i / HD]));  // x, y, code + 36 trig rows
   atomicMax(mx, __float_as_int(m));  // non-negative floats order like their bit patterns
   __syncthreads();
   const float wmax = __int_as_float(*mx);
@@ -189,6 +190,8 @@ __device__ __forceinline__ void stage_weights_h(float* lh, const float* lds_old,
     const int slot = 8 * (lane >> 5) + e, hid = ht * 32 + (lane & 31);
     float w = 0.0f;
     if (slot < 12) w = mlp[ml.w_in() + hid * D_IN + C + 3 + 6 * (2 * r + slot / 6) + slot % 6] * scale;
+    else if (r == 0 && slot < 14) w = mlp[ml.w_in() + hid * D_IN + C + (slot - 12)] * scale;   // spare rows of region 0: raw x, y
+    else if (r == 1 && slot == 12) w = mlp[ml.w_in() + hid * D_IN + C + 2] * scale;             // spare row of region 1: raw depth code
     const _Float16 hi = (_Float16)w;
     wf[i] = hi;
     wf[i + LH::TERM_STRIDE * 2] = (_Float16)(w - (float)hi);  // TERM_STRIDE floats = 2 x halves
@@ -210,22 +213,23 @@ __device__ __forceinline__ unsigned pack_h2(_Float16 a, _Float16 b) {
 }
 
 // 12 encoding entries (two octaves) of this lane's sample -> both point tiles' B operands (high and low halves) -> 12 f16 MFMAs
-template <int HD>
+template <int HD, int NE = 12, bool FIRST = false>
 __device__ __forceinline__ void f16_region(f32x16 (&acc)[HD / 32][2], const float* wf /* lane-resolved, this region */, int term_stride,
-                                           const float (&e)[12]) {
+                                           const float (&e)[NE], const f32x16* bias = nullptr) {
+  static_assert(NE >= 8 && NE <= 16, "one 16-row k-slice");
   constexpr int HT = HD / 32;
-  _Float16 hi[12], lo[12];
+  _Float16 hi[16], lo[16];
 #pragma unroll
-  for (int i = 0; i < 12; ++i) {
-    hi[i] = (_Float16)e[i];
-    lo[i] = (_Float16)(e[i] - (float)hi[i]);
+  for (int i = 0; i < 16; ++i) {
+    hi[i] = i < NE ? (_Float16)e[i < NE ? i : 0] : (_Float16)0.0f;
+    lo[i] = i < NE ? (_Float16)(e[i < NE ? i : 0] - (float)hi[i]) : (_Float16)0.0f;
   }
   unsigned ph[4], qh[4], pl[4], ql[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     ph[j] = pack_h2(hi[2 * j], hi[2 * j + 1]), pl[j] = pack_h2(lo[2 * j], lo[2 * j + 1]);
-    qh[j] = j < 2 ? pack_h2(hi[8 + 2 * j], hi[9 + 2 * j]) : 0u;
-    ql[j] = j < 2 ? pack_h2(lo[8 + 2 * j], lo[9 + 2 * j]) : 0u;
+    qh[j] = 8 + 2 * j < NE ? pack_h2(hi[8 + 2 * j], hi[9 + 2 * j]) : 0u;
+    ql[j] = 8 + 2 * j < NE ? pack_h2(lo[8 + 2 * j], lo[9 + 2 * j]) : 0u;
     swap32u(ph[j], qh[j]);  // p*: point tile 0 (k 0-7 from its own lanes, k 8-15 from the partner half), q*: point tile 1
     swap32u(pl[j], ql[j]);
   }
@@ -241,8 +245,10 @@ __device__ __forceinline__ void f16_region(f32x16 (&acc)[HD / 32][2], const floa
   }
 #pragma unroll
   for (int ht = 0; ht < HT; ++ht) {
-    acc[ht][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ht], b0h, acc[ht][0], 0, 0, 0);
-    acc[ht][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ht], b1h, acc[ht][1], 0, 0, 0);
+    // FIRST: the accumulators are born here, from the bias row (both point tiles share it).  The destination is a fresh value, so
+    // the sources are kept alive below -- hipcc may otherwise place it on top of this MFMA's own A / B registers (see kstep_first).
+    acc[ht][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ht], b0h, FIRST ? bias[ht] : acc[ht][0], 0, 0, 0);
+    acc[ht][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ht], b1h, FIRST ? bias[ht] : acc[ht][1], 0, 0, 0);
   }
 #pragma unroll
   for (int ht = 0; ht < HT; ++ht) {
@@ -261,11 +267,12 @@ __device__ __forceinline__ void f16_region(f32x16 (&acc)[HD / 32][2], const floa
 template <int HD, int R>
 __device__ __forceinline__ void region_seq(f32x16 (&acc)[HD / 32][2], GBuf& ba, GBuf& bb, const float4* __restrict__ G,
                                            const int (&o)[2][4], const float (&wq)[2][4], int h, const float* wf, int term_stride,
-                                           SinCos3& raw, const float (&v3)[3], float ff) {
+                                           SinCos3& raw, const float (&v3)[3], float ff, const f32x16* bias) {
   constexpr int HT = HD / 32;
   constexpr int NS = 4 * HT;
   if constexpr (R < 3) {
-    float e[12];
+    constexpr int NE = R == 0 ? 14 : (R == 1 ? 13 : 12);   // + raw x, y (region 0) / raw depth code (region 1) in the spare k rows
+    float e[NE];
     {
       float t[6];
       pe_entries(t, raw, v3, ff);
@@ -277,8 +284,10 @@ __device__ __forceinline__ void region_seq(f32x16 (&acc)[HD / 32][2], GBuf& ba, 
 #pragma unroll
       for (int i = 0; i < 6; ++i) e[6 + i] = t[i];
     }
+    if constexpr (R == 0) e[12] = v3[0], e[13] = v3[1];
+    if constexpr (R == 1) e[12] = v3[2];
     if constexpr (R + 1 < 3) pe_direct(raw, v3, ff * 4.0f);
-    f16_region<HD>(acc, wf + R * HT * 256, term_stride, e);
+    f16_region<HD, NE, R == 0>(acc, wf + R * HT * 256, term_stride, e, bias);
     if constexpr (2 * R < NS) {
       stage_blend<HD, 2 * R>(acc, ba, wq);
       if constexpr (2 * R + 2 < NS) stage_load<HD, 2 * R + 2>(ba, G, o, h);
@@ -286,7 +295,7 @@ __device__ __forceinline__ void region_seq(f32x16 (&acc)[HD / 32][2], GBuf& ba, 
       if constexpr (2 * R + 3 < NS) stage_load<HD, 2 * R + 3>(bb, G, o, h);
     }
     __builtin_amdgcn_sched_barrier(0);
-    region_seq<HD, R + 1>(acc, ba, bb, G, o, wq, h, wf, term_stride, raw, v3, ff * 4.0f);
+    region_seq<HD, R + 1>(acc, ba, bb, G, o, wq, h, wf, term_stride, raw, v3, ff * 4.0f, bias);
   }
 }
 
@@ -467,15 +476,26 @@ __global__ __launch_bounds__(256, 2) void render_kernel_p(const FwdParams p) {
         stage_load<HD, 1>(bb, G, o, h);
       }
       if constexpr (F16) {
-        const float* wl = lh + LH::W_RAW + lane_off;
-        kstep_first<HD>(acc, wl, 0, v3[0], v3[1]);
-        kstep<HD>(acc, wl + 2 * HD, 0, v3[2], 1.0f);
+        // bias row (times 2^S, fp32): the C operand of the first MFMA of every accumulator tile.  The raw inputs x, y, code ride in
+        // the spare k rows of the f16 slices (|x|, |y| <= 2083 here -- beyond that the wave took the exact path above), so the
+        // fp32-input MFMAs, which block the VALU for 64 cycles each, are gone from this path.
+        f32x16 bias[HT];
+        {
+          const float* bl = lh + LH::W_RAW + 3 * HD + 4 * h;
+#pragma unroll
+          for (int ht = 0; ht < HT; ++ht)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const float4 v = *reinterpret_cast<const float4*>(bl + ht * 32 + 8 * j);
+              bias[ht][4 * j + 0] = v.x, bias[ht][4 * j + 1] = v.y, bias[ht][4 * j + 2] = v.z, bias[ht][4 * j + 3] = v.w;
+            }
+        }
         SinCos3 raw;
         pe_direct(raw, v3, p.freq_factor);
         __builtin_amdgcn_sched_barrier(0);
         int lane4 = lane * 4;
         asm volatile("" : "+v"(lane4));  // keep the A-operand reads inside the loop (see lane_off above)
-        region_seq<HD, 0>(acc, ba, bb, G, o, wq, h, lh + LH::W_F16 + lane4, LH::TERM_STRIDE, raw, v3, p.freq_factor);
+        region_seq<HD, 0>(acc, ba, bb, G, o, wq, h, lh + LH::W_F16 + lane4, LH::TERM_STRIDE, raw, v3, p.freq_factor, bias);
       } else {
         const float* wl = lds + L::W_IN + lane_off;
         kstep_first<HD>(acc, wl, 0, v3[0], v3[1]);

@@ -284,7 +284,7 @@ def main():
                          "frac": achieved / PEAK_FP32_MATRIX_TFLOPS, "traffic": traffic, "traffic_detail": traffic_detail, "kernel": "bts::render_kernel_p<64,64,0,1,true,true>",
                          "kernel_ms": kernel_ms, "algorithmic_flop_per_launch": flop_per_launch,
                          "note": "algorithmic FLOP (13 312 / sample, SURVEY 8d); the kernel executes 5 248 / sample (projected features, "
-                                 "DESIGN.md section 3), 36 of its 40 lin_in rows on the f16 matrix pipe (split precision)"},
+                                 "DESIGN.md section 3), 39 of its 40 lin_in rows on the f16 matrix pipe in split precision, the bias row as the fp32 C operand"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, net, args.cpu_rows)
