@@ -531,7 +531,8 @@ struct ScatterParams {
   const float* gh_ws;
   float* d_proj;
   int groups_per_sample;
-  int mode;   // probe bits (BTS_SCATTER_MODE): 1 no LDS adds, 2 never move the window, 4 no workspace loads, 8 skip non-fitting steps
+  int mode;   // probe builds only (-DBTS_PROBE, env BTS_SCATTER_MODE): 1 no LDS adds, 2 never move the window, 4 no workspace loads,
+              // 8 skip non-fitting steps -- how the pass was taken apart in profiles/README.md; always 0 in the product
 };
 
 __device__ __forceinline__ int wave_min(int v) {
@@ -539,6 +540,12 @@ __device__ __forceinline__ int wave_min(int v) {
   for (int off = 32; off >= 1; off >>= 1) v = min(v, __shfl_xor(v, off, 64));
   return __builtin_amdgcn_readfirstlane(v);
 }
+
+#ifdef BTS_PROBE
+#define BTS_SCATTER_ABL(bit) ((sp.mode & (bit)) != 0)
+#else
+#define BTS_SCATTER_ABL(bit) false
+#endif
 
 template <int HD>
 __global__ __launch_bounds__(64) void scatter_dg_kernel(const ScatterParams sp) {
@@ -599,8 +606,8 @@ __global__ __launch_bounds__(64) void scatter_dg_kernel(const ScatterParams sp) 
     int x0, y0, x1, y1;
     const Taps tp = make_taps_xy(pe.x, pe.y, H, W, x0, y0, x1, y1);
     const int mnx = wave_min(x0), mxx = -wave_min(-x1), mny = wave_min(y0), mxy = -wave_min(-y1);
-    const bool fits = ((mxx - mnx < CW) && (mxy - mny < CH)) || (sp.mode & 2);
-    if (fits && !(sp.mode & 2) && (mnx < wx || mxx >= wx + CW || mny < wy || mxy >= wy + CH)) {
+    const bool fits = ((mxx - mnx < CW) && (mxy - mny < CH)) || BTS_SCATTER_ABL(2);
+    if (fits && !BTS_SCATTER_ABL(2) && (mnx < wx || mxx >= wx + CW || mny < wy || mxy >= wy + CH)) {
       const int nwx = mnx - (CW - (mxx - mnx + 1)) / 2, nwy = mny - (CH - (mxy - mny + 1)) / 2;
       flush(nwx, nwy, false);
       wx = nwx, wy = nwy;
@@ -622,7 +629,7 @@ __global__ __launch_bounds__(64) void scatter_dg_kernel(const ScatterParams sp) 
         const bool more = b + 1 < 64 / RB || k > 0;
         const float* nb = b + 1 < 64 / RB ? wk + (long)(b + 1) * RB * HD : wk - (long)64 * HD;
 #pragma unroll
-        for (int i = 0; i < RB; ++i) nxt[i] = (chan && more && !(sp.mode & 4)) ? nb[i * HD + ch] : 0.0f;
+        for (int i = 0; i < RB; ++i) nxt[i] = (chan && more && !BTS_SCATTER_ABL(4)) ? nb[i * HD + ch] : 0.0f;
       }
       auto bc_i = [&](int v, int pnt) { return __builtin_amdgcn_readlane(v, pnt); };
       auto bc_f = [&](float v, int pnt) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), pnt)); };
@@ -630,7 +637,7 @@ __global__ __launch_bounds__(64) void scatter_dg_kernel(const ScatterParams sp) 
       // undefined in LLVM's model (the producer may be sunk into the divergent region): with d_hidden = 32 an `if (chan)` around
       // this block made lanes >= 32 inactive and points 32..63 picked up stale registers.  Idle lanes aim at the scratch row.
       if (fits) {
-        if (!(sp.mode & 1)) {
+        if (!BTS_SCATTER_ABL(1)) {
           // wave-private read-modify-write (LDS operations of one wave execute in order).  ds_add_f32 would be one instruction
           // per tap but runs at ~100 cycles per wave instruction on gfx950 (measured); plain loads and stores do not.
 #pragma unroll
@@ -648,7 +655,7 @@ __global__ __launch_bounds__(64) void scatter_dg_kernel(const ScatterParams sp) 
             *c11 = a11 + bc_f(tp.w11, pnt) * gv;
           }
         }
-      } else if (!(sp.mode & 8)) {
+      } else if (!BTS_SCATTER_ABL(8)) {
         // rare (a footprint wider than the window: rays nearly through the encoder's centre): every tap a row of L2 atomics.
         // The rows are re-read from the workspace so that the register block is never indexed dynamically.
 #pragma unroll 1
@@ -704,8 +711,10 @@ template <int HD>
 static int launch_scatter(const BwdParams& bp, int n, hipStream_t s) {
   ScatterParams sp;
   sp.f = bp.f, sp.gh_ws = bp.gh_ws, sp.d_proj = bp.d_proj, sp.groups_per_sample = bp.f.tiles_per_sample * 4;
-  static const int mode = getenv("BTS_SCATTER_MODE") ? atoi(getenv("BTS_SCATTER_MODE")) : 0;
-  sp.mode = mode;
+  sp.mode = 0;
+#ifdef BTS_PROBE
+  if (const char* e = getenv("BTS_SCATTER_MODE")) sp.mode = atoi(e);
+#endif
   scatter_dg_kernel<HD><<<n * sp.groups_per_sample, 64, 0, s>>>(sp);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
