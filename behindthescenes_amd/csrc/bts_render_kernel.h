@@ -157,7 +157,13 @@ struct LdsH {  // in floats, placed behind Lds<C, HD, NB, true>
   static constexpr int BIAS = W_F16 + 2 * TERM_STRIDE;         // per block: b0 [HD], b1 [HD] -- times 2^S
   static constexpr int EMPTY = BIAS + NB * 2 * HD;             // projected empty feature -- times 2^S
   static constexpr int SCALE = EMPTY + HD;                     // [0] 2^S, [1] 2^-S, [2] max |w| (as int bits)
-  static constexpr int TOTAL = SCALE + 4;
+  // ResnetBlockFC linears on the f16 pipe (d_hidden = 32): per layer [term hi/lo][k-slice 2][64 lanes][8 halves] -- times 2^S.
+  // k slot (slice s, lane half h, i) is the hidden row mfma_row(8 s + i, h): exactly the 8 accumulator values a lane holds for it,
+  // so the C layout of one layer feeds the next layer's B operand from the lane's own registers.
+  static constexpr int W_BLK = SCALE + 4;
+  static constexpr int BLK_TERM_STRIDE = 2 * 64 * 4;
+  static constexpr int BLK_LAYER_STRIDE = 2 * BLK_TERM_STRIDE;
+  static constexpr int TOTAL = W_BLK + NB * 2 * BLK_LAYER_STRIDE;
 };
 
 template <int C, int HD, int NB>
@@ -172,6 +178,10 @@ __device__ __forceinline__ void stage_weights_h(float* lh, const float* lds_old,
   __syncthreads();
   float m = 0.0f;
   for (int i = threadIdx.x; i < 39 * HD; i += blockDim.x) m = fmaxf(m, fabsf(mlp[ml.w_in() + (i % HD) * D_IN + C + i / HD]));  // x, y, code + 36 trig rows
+  for (int i = threadIdx.x; i < NB * 2 * HD * HD; i += blockDim.x) {   // fc_0 / fc_1 weights share the scale (same f16 range)
+    const int b = i / (2 * HD * HD), j = i % (2 * HD * HD);
+    m = fmaxf(m, fabsf(mlp[(j < HD * HD ? ml.blk_w0(b) : ml.blk_w1(b)) + j % (HD * HD)]));
+  }
   atomicMax(mx, __float_as_int(m));  // non-negative floats order like their bit patterns
   __syncthreads();
   const float wmax = __int_as_float(*mx);
@@ -195,6 +205,19 @@ __device__ __forceinline__ void stage_weights_h(float* lh, const float* lds_old,
     const _Float16 hi = (_Float16)w;
     wf[i] = hi;
     wf[i + LH::TERM_STRIDE * 2] = (_Float16)(w - (float)hi);  // TERM_STRIDE floats = 2 x halves
+  }
+  if constexpr (NB > 0) {
+    static_assert(HD == 32, "f16 ResnetBlockFC layers are laid out for d_hidden = 32");
+    _Float16* wb = reinterpret_cast<_Float16*>(lh + LH::W_BLK);
+    for (int i = threadIdx.x; i < NB * 2 * 2 * 64 * 8; i += blockDim.x) {
+      const int e = i & 7, lane = (i >> 3) & 63, sl = (i >> 9) & 1, layer = i >> 10;   // layer = 2 * block + {0: fc_0, 1: fc_1}
+      const int kin = mfma_row(8 * sl + e, lane >> 5), out = lane & 31;
+      const float w = mlp[((layer & 1) ? ml.blk_w1(layer >> 1) : ml.blk_w0(layer >> 1)) + out * HD + kin] * scale;
+      const _Float16 hi = (_Float16)w;
+      _Float16* dst = wb + layer * LH::BLK_LAYER_STRIDE * 2 + (sl * 64 + lane) * 8 + e;
+      dst[0] = hi;
+      dst[LH::BLK_TERM_STRIDE * 2] = (_Float16)(w - (float)hi);
+    }
   }
   for (int i = threadIdx.x; i < NB * 2 * HD; i += blockDim.x) {
     const int b = i / (2 * HD), j = i % (2 * HD);
@@ -259,6 +282,35 @@ __device__ __forceinline__ void f16_region(f32x16 (&acc)[HD / 32][2], const floa
   for (int ht = 0; ht < HT; ++ht) {
     acc[ht][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ht], b0l, acc[ht][0], 0, 0, 0);
     acc[ht][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ht], b1l, acc[ht][1], 0, 0, 0);
+  }
+}
+
+// out[pt] += (W 2^S) . relu(in[pt]) 2^-S for one ResnetBlockFC linear of width 32 on the f16 pipe (split precision, as lin_in):
+// the lane's own 16 accumulator values of a point tile are the B operand of two 16-row k-slices -- no data movement between layers.
+// `in` carries 2^S (like every accumulator of this path); it is unscaled on the way into f16 and the pre-scaled weights put 2^S back.
+__device__ __forceinline__ void hidden_layer_h(f32x16 (&out)[1][2], const f32x16 (&in)[1][2], const float* wl /* lane-resolved, this layer */,
+                                               int term_stride, float inv_scale) {
+#pragma unroll
+  for (int sl = 0; sl < 2; ++sl) {
+    const h8 ah = *reinterpret_cast<const h8*>(wl + sl * 256);
+    const h8 al = *reinterpret_cast<const h8*>(wl + term_stride + sl * 256);
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt) {
+      _Float16 hi[8], lo[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        // relu, then back to the true magnitude; the upper clamp only keeps a (never observed) 6e4 activation from turning into inf
+        const float v = __builtin_amdgcn_fmed3f(in[0][pt][8 * sl + i], 0.0f, 3.4028234663852886e38f) * inv_scale;
+        const float vc = fminf(v, 6.0e4f);
+        hi[i] = (_Float16)vc;
+        lo[i] = (_Float16)(vc - (float)hi[i]);
+      }
+      const h8 bh = __builtin_bit_cast(h8, (u32x4){pack_h2(hi[0], hi[1]), pack_h2(hi[2], hi[3]), pack_h2(hi[4], hi[5]), pack_h2(hi[6], hi[7])});
+      const h8 bl = __builtin_bit_cast(h8, (u32x4){pack_h2(lo[0], lo[1]), pack_h2(lo[2], lo[3]), pack_h2(lo[4], lo[5]), pack_h2(lo[6], lo[7])});
+      out[0][pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, out[0][pt], 0, 0, 0);
+      out[0][pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, out[0][pt], 0, 0, 0);
+      out[0][pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, out[0][pt], 0, 0, 0);
+    }
   }
 }
 
@@ -524,6 +576,8 @@ __global__ __launch_bounds__(256, 2) void render_kernel_p(const FwdParams p) {
       }
 
       // ---------------- ResnetBlockFC layers: h = h + fc_1(relu(fc_0(relu(h))))   (resnetfc.py:53-62)
+      int lane4b = lane * 4;
+      asm volatile("" : "+v"(lane4b));   // keep the weight reads inside the persistent loop (see lane_off)
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
         const float* base = lds + L::BLK + b * L::BLK_STRIDE;
@@ -536,7 +590,8 @@ __global__ __launch_bounds__(256, 2) void render_kernel_p(const FwdParams p) {
             const float bias = F16 ? lh[LH::BIAS + b * 2 * HD + row] : base[HD * HD + row];
             net[ot][0][q] = bias, net[ot][1][q] = bias;
           }
-        hidden_layer<HD>(net, acc, base, lane);
+        if constexpr (F16 && HD == 32) hidden_layer_h(net, acc, lh + LH::W_BLK + (2 * b) * LH::BLK_LAYER_STRIDE + lane4b, LH::BLK_TERM_STRIDE, inv_scale);
+        else hidden_layer<HD>(net, acc, base, lane);
 #pragma unroll
         for (int ot = 0; ot < HT; ++ot)
 #pragma unroll
@@ -545,7 +600,8 @@ __global__ __launch_bounds__(256, 2) void render_kernel_p(const FwdParams p) {
             const float bias = F16 ? lh[LH::BIAS + b * 2 * HD + HD + row] : base[2 * HD * HD + HD + row];
             acc[ot][0][q] += bias, acc[ot][1][q] += bias;
           }
-        hidden_layer<HD>(acc, net, base + HD * HD + HD, lane);
+        if constexpr (F16 && HD == 32) hidden_layer_h(acc, net, lh + LH::W_BLK + (2 * b + 1) * LH::BLK_LAYER_STRIDE + lane4b, LH::BLK_TERM_STRIDE, inv_scale);
+        else hidden_layer<HD>(acc, net, base + HD * HD + HD, lane);
       }
 
       BTS_TICK(1)
