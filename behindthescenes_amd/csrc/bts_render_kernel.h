@@ -315,7 +315,8 @@ __device__ __forceinline__ void hidden_layer_h(f32x16 (&out)[1][2], const f32x16
 }
 
 // Region R = octaves 2R (sines computed directly, one region ahead) and 2R+1 (by angle doubling), with gather stages 2R and 2R+1
-// blended behind the region's MFMAs and stages 2R+2, 2R+3 issued.  One scheduling region each (see octave_seq).
+// blended behind the region's MFMAs and stages 2R+2, 2R+3 issued.  The regions are no longer fenced from each other: the scheduler
+// may pull the next region's trigonometry under this region's MFMAs (3 % faster, +3 spilled VGPRs).
 template <int HD, int R>
 __device__ __forceinline__ void region_seq(f32x16 (&acc)[HD / 32][2], GBuf& ba, GBuf& bb, const float4* __restrict__ G,
                                            const int (&o)[2][4], const float (&wq)[2][4], int h, const float* wf, int term_stride,
@@ -346,7 +347,9 @@ __device__ __forceinline__ void region_seq(f32x16 (&acc)[HD / 32][2], GBuf& ba, 
       stage_blend<HD, 2 * R + 1>(acc, bb, wq);
       if constexpr (2 * R + 3 < NS) stage_load<HD, 2 * R + 3>(bb, G, o, h);
     }
+#ifdef BTS_REGION_BARRIER   // one scheduling region per encoding region: was needed against spills in r01c, costs 3 % now (r01g A/B)
     __builtin_amdgcn_sched_barrier(0);
+#endif
     region_seq<HD, R + 1>(acc, ba, bb, G, o, wq, h, wf, term_stride, raw, v3, ff * 4.0f, bias);
   }
 }
@@ -372,7 +375,11 @@ __global__ __launch_bounds__(256, 2) void render_kernel_p(const FwdParams p) {
   using LH = LdsH<C, HD, NB>;
   constexpr int HT = HD / 32;
   constexpr int NS = 4 * HT;
-  constexpr bool EARLY_COL = NVMAX <= 2;  // colour taps issued before the MFMA phase (16 VGPRs per view)
+#ifdef BTS_EARLY_COL
+  constexpr bool EARLY_COL = NVMAX <= 2;  // colour taps issued before the MFMA phase (16 VGPRs per view): r01c default
+#else
+  constexpr bool EARLY_COL = false;       // r01g A/B: issuing them after lin_out frees 20 VGPRs in the MFMA phase (0 spills), 3 % faster
+#endif
   __shared__ __attribute__((aligned(16))) float lds[L::TOTAL + (F16 ? LH::TOTAL + 4 : 0)];
   float* const lh = lds + ((L::TOTAL + 3) & ~3);  // 16-byte aligned: the f16 A operands are read as ds_read_b128
   stage_weights<C, HD, NB, true>(lds, p.mlp, p.empty_feature);
