@@ -5,6 +5,7 @@ import ctypes as C
 import os
 import re
 import subprocess
+import sys
 import tempfile
 
 import pytest
@@ -136,3 +137,18 @@ def test_synthetic_generators_match_oracle():
         assert torch.equal(m.lin_in.weight, ref.w_in) and torch.equal(m.lin_out.weight, ref.w_out)
         for blk, (w0, b0, w1, b1) in zip(m.blocks, ref.blocks):
             assert torch.equal(blk.fc_0.weight, w0) and torch.equal(blk.fc_1.weight, w1)
+
+
+def test_mfma_overlap_lint_catches_the_hazard(tmp_path):
+    """The build refuses assembly in which an MFMA destination overlaps its own A / B source registers ("What the
+    hardware taught us"): the lint must flag the pattern hipcc produced and stay quiet on the safe forms."""
+    bad = tmp_path / "bad.s"
+    bad.write_text("_Zk:\n\tv_mfma_f32_32x32x2_f32 v[34:49], v35, v36, 0\n\tv_mfma_f32_32x32x16_f16 v[0:15], v[4:7], v[20:23], v[0:15]\n")
+    ok = tmp_path / "ok.s"
+    ok.write_text("_Zk:\n\tv_mfma_f32_32x32x2_f32 v[34:49], v50, v51, 0\n\tv_mfma_f32_32x32x16_f16 v[0:15], v[16:19], v[20:23], v[0:15]\n"
+                  "\tv_mfma_f32_32x32x16_f16 a[0:15], v[0:3], v[4:7], a[0:15]\n")
+    tool = os.path.join(ROOT, "tools", "check_mfma_overlap.py")
+    r_bad = subprocess.run([sys.executable, tool, str(bad)], capture_output=True, text=True)
+    r_ok = subprocess.run([sys.executable, tool, str(ok)], capture_output=True, text=True)
+    assert r_bad.returncode == 1 and "2 MFMA(s)" in r_bad.stdout, r_bad.stdout
+    assert r_ok.returncode == 0 and "0 MFMA(s)" in r_ok.stdout, r_ok.stdout
