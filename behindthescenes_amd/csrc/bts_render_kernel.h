@@ -377,7 +377,8 @@ __global__ __launch_bounds__(256, 2) void render_kernel_p(const FwdParams p) {
   constexpr int NS = 4 * HT;
 #ifdef BTS_LATE_COL
   // r01g A/B: issuing the colour taps after lin_out frees 20 VGPRs in the MFMA phase (0 spills) and is 3 % faster, but the NVMAX <= 2
-  // instantiations then FAIL parity (rgb off by up to 2.7e-3, test_fp64_arbiter) -- cause not found yet; not the default.
+  // instantiations then FAIL parity (rgb only, weights stay exact; the error changes with the schedule -- 2.7e-3, 3e-2, 6e-2 in three
+  // builds -- so a hazard, not arithmetic; test_fp64_arbiter) -- cause not found yet; not the default.
   constexpr bool EARLY_COL = false;
 #else
   constexpr bool EARLY_COL = NVMAX <= 2;  // colour taps issued before the MFMA phase (16 VGPRs per view)
