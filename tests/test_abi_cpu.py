@@ -152,3 +152,22 @@ def test_mfma_overlap_lint_catches_the_hazard(tmp_path):
     r_ok = subprocess.run([sys.executable, tool, str(ok)], capture_output=True, text=True)
     assert r_bad.returncode == 1 and "2 MFMA(s)" in r_bad.stdout, r_bad.stdout
     assert r_ok.returncode == 0 and "0 MFMA(s)" in r_ok.stdout, r_ok.stdout
+
+
+def test_loss_module_keeps_the_reference_interface_and_is_loud_outside_its_envelope():
+    """ReconstructionLoss mirrors models/bts/model/loss.py:43-81 (constructor keys, metric names); what the fused pass does not
+    cover is rejected at construction, not silently served by something else."""
+    crit = bts.ReconstructionLoss({"criterion": "l1+ssim", "invalid_policy": "weight_guided", "lambda_edge_aware_smoothness": 0.001})
+    assert (crit.lambda_coarse, crit.lambda_fine, crit.lambda_edge_aware_smoothness, crit.alpha_reg_fraction) == (1, 1, 0.001, 1 / 8)
+    assert crit.get_loss_metric_names() == ["loss", "loss_rgb_coarse", "loss_rgb_fine", "loss_ray_entropy", "loss_depth_reg"]
+    for conf in ({"criterion": "l2"}, {"criterion": "l1+ssim", "median_thresholding": True},
+                 {"criterion": "l1+ssim", "invalid_policy": "weight_guided_diverse"}):
+        with pytest.raises(NotImplementedError):
+            bts.ReconstructionLoss(conf)
+    with pytest.raises(NotImplementedError):
+        bts.ReconstructionLoss({"criterion": "l1+ssim"}, use_automasking=True)
+    with pytest.raises(ValueError):
+        bts.ReconstructionLoss({"criterion": "l1+ssim", "alpha_reg_reduction": "batch"})
+    with pytest.raises(bts.BtsNativeError):   # CPU tensors: no fallback
+        crit(dict(coarse=[dict(rgb=torch.zeros(1, 1, 8, 8, 1, 3), depth=torch.ones(1, 1, 8, 8), weights=torch.zeros(1, 1, 8, 8, 4),
+                               invalid=torch.zeros(1, 1, 8, 8, 4, 1))], fine=[{}], rgb_gt=torch.zeros(1, 1, 8, 8, 3)))

@@ -73,11 +73,3 @@ def test_regularisers_and_multiscale_vs_oracle():
     cu = [{k: v.cuda() for k, v in level.items()} for level in lv]
     loss, parts = crit(dict(coarse=cu, fine=[dict(c) for c in cu], rgb_gt=gt.cuda()))
     assert abs(loss.item() - want.item()) <= 2e-5, (loss.item(), want.item())
-
-
-def test_unsupported_options_are_loud():
-    import behindthescenes_amd as bts
-    for conf in ({"criterion": "l2"}, {"criterion": "l1+ssim", "median_thresholding": True},
-                 {"criterion": "l1+ssim", "invalid_policy": "weight_guided_diverse"}):
-        with pytest.raises(NotImplementedError):
-            bts.ReconstructionLoss(conf)
