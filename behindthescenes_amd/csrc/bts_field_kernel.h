@@ -364,6 +364,16 @@ __device__ __forceinline__ void pe_entries(float (&o)[6], const SinCos3& r, cons
     o[3 + i] = __builtin_fmaf(-d, r.s[i], r.c[i]);
   }
 }
+// scalar form of pe_entries: one argument's pair (sin, reference "cos" = sin(fl(arg + P)))
+__device__ __forceinline__ void pe_entry1(float arg, float s, float c, float& es, float& ec) {
+  constexpr float P = 1.57079637050628662109375f;
+  const float sm = arg + P;
+  const float bb = sm - arg;
+  const float err = (arg - (sm - bb)) + (P - bb);   // arg + P = sm + err exactly
+  const float d = 4.371139000186241e-08f - err;     // (P - pi/2) - err
+  es = s;
+  ec = __builtin_fmaf(-d, s, c);
+}
 // pe_octave_fast: branch-free (valid while every |argument| <= 1e5); pe_octave_exact: libm range reduction for any argument.
 __device__ __forceinline__ void pe_octave_fast(float (&o)[6], const float (&v)[3], float f) {
   SinCos3 r;

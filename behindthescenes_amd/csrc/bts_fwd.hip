@@ -73,8 +73,11 @@ int render_fwd_impl(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const BtsR
     if (p.proj) return launch_field<false, true>(p, cfg->C, cfg->d_hidden, cfg->n_blocks, p.tiles_per_sample * cfg->n, s);
     return launch_field<false, false>(p, cfg->C, cfg->d_hidden, cfg->n_blocks, p.tiles_per_sample * cfg->n, s);
   }
+#ifdef BTS_ENC_RAY
+  if (getenv("BTS_RENDER_NO_ENCRAY")) p.ablate |= 64;   // experimental build only: A/B switch for the encoder-camera ray path
+#endif
 #ifdef BTS_PROBE
-  if (const char* e = getenv("BTS_ABLATE")) p.ablate = atoi(e);
+  if (const char* e = getenv("BTS_ABLATE")) p.ablate |= atoi(e);
   if (const char* e = getenv("BTS_DBG_PTR")) p.dbg = (unsigned long long*)strtoull(e, nullptr, 0);
 #endif
   render_geometry(p, cfg->n);

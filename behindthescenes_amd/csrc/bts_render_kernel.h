@@ -163,7 +163,17 @@ struct LdsH {  // in floats, placed behind Lds<C, HD, NB, true>
   static constexpr int W_BLK = SCALE + 4;
   static constexpr int BLK_TERM_STRIDE = 2 * 64 * 4;
   static constexpr int BLK_LAYER_STRIDE = 2 * BLK_TERM_STRIDE;
+#ifdef BTS_ENC_RAY   // experimental: not part of the shipped library
+  static constexpr int W_Z = W_BLK + NB * 2 * BLK_LAYER_STRIDE;   // [term hi/lo][HT][64 lanes][8 halves]: 12 depth-code trig rows + raw code
+  static constexpr int WZ_TERM_STRIDE = HT * 64 * 4;
+  static constexpr int UBUF = W_Z + 2 * WZ_TERM_STRIDE;           // per wave [term][HT][64 lanes][8 halves]: the six per-ray rows
+  static constexpr int UBUF_TERM_STRIDE = HT * 64 * 4;
+  static constexpr int UBUF_WAVE_STRIDE = 2 * UBUF_TERM_STRIDE;
+  static constexpr int BASE = UBUF + 4 * UBUF_WAVE_STRIDE;        // per wave [HD]: ray-constant part of lin_in's output (times 2^S)
+  static constexpr int TOTAL = BASE + 4 * HD;
+#else
   static constexpr int TOTAL = W_BLK + NB * 2 * BLK_LAYER_STRIDE;
+#endif
 };
 
 template <int C, int HD, int NB>
@@ -219,6 +229,22 @@ __device__ __forceinline__ void stage_weights_h(float* lh, const float* lds_old,
       dst[LH::BLK_TERM_STRIDE * 2] = (_Float16)(w - (float)hi);
     }
   }
+#ifdef BTS_ENC_RAY
+  {
+    _Float16* wz = reinterpret_cast<_Float16*>(lh + LH::W_Z);
+    for (int i = threadIdx.x; i < HT * 64 * 8; i += blockDim.x) {
+      const int e = i & 7, lane = (i >> 3) & 63, ht = i >> 9;
+      const int slot = 8 * (lane >> 5) + e, hid = ht * 32 + (lane & 31);
+      float w = 0.0f;   // slot 2*oct + {0: sin, 1: "cos"} of the depth code, slot 12: the raw depth code
+      if (slot < 12) w = mlp[ml.w_in() + hid * D_IN + C + 3 + 6 * (slot >> 1) + 3 * (slot & 1) + 2] * scale;
+      else if (slot == 12) w = mlp[ml.w_in() + hid * D_IN + C + 2] * scale;
+      const _Float16 hi = (_Float16)w;
+      wz[i] = hi;
+      wz[i + LH::WZ_TERM_STRIDE * 2] = (_Float16)(w - (float)hi);
+    }
+    for (int i = threadIdx.x; i < 4 * LH::UBUF_WAVE_STRIDE; i += blockDim.x) lh[LH::UBUF + i] = 0.0f;   // k rows 6..15 stay zero
+  }
+#endif
   for (int i = threadIdx.x; i < NB * 2 * HD; i += blockDim.x) {
     const int b = i / (2 * HD), j = i % (2 * HD);
     lh[LH::BIAS + i] = (j < HD ? mlp[ml.blk_b0(b) + j] : mlp[ml.blk_b1(b) + j - HD]) * scale;
@@ -353,6 +379,184 @@ __device__ __forceinline__ void region_seq(f32x16 (&acc)[HD / 32][2], GBuf& ba, 
     region_seq<HD, R + 1>(acc, ba, bb, G, o, wq, h, wf, term_stride, raw, v3, ff * 4.0f, bias);
   }
 }
+
+#ifdef BTS_ENC_RAY
+// ---------------------------------------------------------------------------------------------------------------
+// EXPERIMENTAL (not in the shipped library; build with -DBTS_ENC_RAY): encoder-camera rays, exact to first order.
+//
+// A ray through the encoder camera's centre projects to one pixel of the encoder view at every depth.  Its samples' image
+// coordinates x_k, y_k (and the pixel coordinates ix_k, iy_k derived from them) agree to a few ulp -- the reference's own rounding
+// noise -- but that noise matters at the 1e-5 bar ("Not taken"), so the per-ray constant is corrected per sample
+// with the first-order terms:
+//   h_k = [ f(ix0, iy0) + W_xy . PE(x_r, y_r) + b ]                                    (per ray, lane = hidden unit)
+//       + dix-_k u_x- + dix+_k u_x+ + diy-_k u_y- + diy+_k u_y+ + da_x,k v_x + da_y,k v_y   (six k rows, A operand per ray)
+//       + W_z . PE(zn_k) + w_code zn_k                                                 (13 k rows, constant A operand)
+// dix = ix_k - ix0 split by sign: rays through pixel centres sit exactly on a texel boundary, where the bilinear interpolant has
+// different one-sided slopes u_x-, u_x+; ix0 is then the boundary itself.  da = fl(x_k ff) - fl(x_r ff): every octave's argument is
+// an exact power-of-two multiple of fl(x ff), so ONE scalar per axis carries the argument jitter of all six octaves
+// (v_x = sum_oct 2^oct (W_sin cos(arg) - W_cos sin(arg)) + W_raw / ff).  Second-order terms are below 3e-7 under the entry
+// condition (|dix| <= 2^-11 px, |dx| <= 2^-18).  Per sample that leaves 6 sincos and 2 k-slices (24 f16 MFMAs) and no gather.
+__device__ __forceinline__ void wave_lds_fence_r() {   // lanes exchange data through LDS without a barrier: pin the order for the compiler
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ float bcast_lane(float v, int l) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+
+// pixel coordinates as make_taps computes them (GridSampler unnormalize + border clip)
+__device__ __forceinline__ void pixel_coords(float x, float y, int H, int W, float& ix, float& iy) {
+  ix = ((x + 1.0f) * (float)W - 1.0f) / 2.0f;
+  iy = ((y + 1.0f) * (float)H - 1.0f) / 2.0f;
+  ix = fminf((float)(W - 1), fmaxf(ix, 0.0f));
+  iy = fminf((float)(H - 1), fmaxf(iy, 0.0f));
+}
+
+// one axis of the reference point: first texel c0 of a 3-texel window, value weights V and one-sided slope weights DL / DR on it
+struct AxisRef {
+  int c0;
+  float p0;          // reference coordinate (the texel boundary itself when the samples straddle one)
+  float V[3], DL[3], DR[3];
+};
+__device__ __forceinline__ AxisRef axis_ref(float pr) {
+  AxisRef a;
+  const float nb = rintf(pr);
+  const bool near = fabsf(pr - nb) <= 0.0009765625f;   // 2^-10 px: the cluster (radius <= 2^-11) may straddle boundary nb
+  if (near) {
+    a.c0 = (int)nb - 1, a.p0 = nb;
+    a.V[0] = 0.0f, a.V[1] = 1.0f, a.V[2] = 0.0f;
+    a.DL[0] = -1.0f, a.DL[1] = 1.0f, a.DL[2] = 0.0f;     // slope in cell [nb-1, nb]
+    a.DR[0] = 0.0f, a.DR[1] = -1.0f, a.DR[2] = 1.0f;     // slope in cell [nb, nb+1]
+  } else {
+    const float fl = floorf(pr), fr = pr - fl;
+    a.c0 = (int)fl, a.p0 = pr;
+    a.V[0] = 1.0f - fr, a.V[1] = fr, a.V[2] = 0.0f;
+    a.DL[0] = -1.0f, a.DL[1] = 1.0f, a.DL[2] = 0.0f;
+    a.DR[0] = -1.0f, a.DR[1] = 1.0f, a.DR[2] = 0.0f;
+  }
+  return a;
+}
+
+// returns false (wave-uniform) when the per-ray rows would leave the f16 range: the caller then takes the ordinary path
+template <int C, int HD, int NB>
+__device__ __forceinline__ bool enc_ray_lin_in(f32x16 (&acc)[HD / 32][2], const float* lds, float* lh, const float4* __restrict__ G, int W,
+                                               int lane, int h, int wave, float ixr, float iyr, float xr, float yr, float ix, float iy,
+                                               float x, float y, float zn, float ff, float scale, int lane4) {
+  using L = Lds<C, HD, NB, true>;
+  using LH = LdsH<C, HD, NB>;
+  constexpr int HT = HD / 32;
+  constexpr float kDelScale = 4096.0f, kArgScale = 1048576.0f;   // 2^12, 2^20: the per-sample corrections as normal f16 numbers
+  const AxisRef ax = axis_ref(ixr), ay = axis_ref(iyr);            // wave-uniform
+  int hs = lane % HD;                              // stored channel of G handled by this lane ...
+  asm volatile("" : "+v"(hs));                     // (opaque per ray: keeps the weight reads below out of the persistent loop's preheader)
+  const int hid = proj_hidden_of_storage(hs);      // ... which is this hidden unit
+  const float* __restrict__ Gf = reinterpret_cast<const float*>(G);
+
+  // ---- per ray, lane = hidden unit: value and one-sided slopes of the bilinear interpolant at the reference point (9 texel rows)
+  float f0 = 0.0f, uxm = 0.0f, uxp = 0.0f, uym = 0.0f, uyp = 0.0f;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    float rv = 0.0f, rl = 0.0f, rr = 0.0f;
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      const float g = Gf[((long)(ay.c0 + a) * W + (ax.c0 + b)) * HD + hs];
+      rv = __builtin_fmaf(ax.V[b], g, rv);
+      rl = __builtin_fmaf(ax.DL[b], g, rl);
+      rr = __builtin_fmaf(ax.DR[b], g, rr);
+    }
+    f0 = __builtin_fmaf(ay.V[a], rv, f0);
+    uxm = __builtin_fmaf(ay.V[a], rl, uxm);
+    uxp = __builtin_fmaf(ay.V[a], rr, uxp);
+    uym = __builtin_fmaf(ay.DL[a], rv, uym);
+    uyp = __builtin_fmaf(ay.DR[a], rv, uyp);
+  }
+  // ---- x, y encoding at the representative coordinates: lane l < 12 evaluates octave l >> 1 of axis l & 1
+  float es, ec, sn2, cs2;
+  {
+    const int oct = (lane >> 1) % kNumFreqs;
+    const float po = (float)(1 << oct);
+    const float arg = ((lane & 1) ? yr : xr) * (ff * po);
+    float sn, cs;
+    sincos_small(arg, sn, cs);
+    pe_entry1(arg, sn, cs, es, ec);
+    sn2 = sn * po, cs2 = cs * po;                  // d/d(x ff) of sin / cos at this octave
+  }
+  const float* wl = lds + L::W_IN + hid;
+  float p0 = wl[3 * HD];                           // bias row
+  p0 = __builtin_fmaf(wl[0], xr, p0);
+  p0 = __builtin_fmaf(wl[HD], yr, p0);
+  float vx = wl[0] / ff, vy = wl[HD] / ff;         // raw rows: d(w x)/d(x ff)
+#pragma unroll 1   // once per ray: keep it compact (unrolled, its 24 weight reads and 48 broadcasts cost ~100 spilled VGPRs around it)
+  for (int l = 0; l < 12; ++l) {
+    const float w_s = wl[(4 + 6 * (l >> 1) + (l & 1)) * HD], w_c = wl[(4 + 6 * (l >> 1) + 3 + (l & 1)) * HD];
+    p0 = __builtin_fmaf(w_s, bcast_lane(es, l), p0);
+    p0 = __builtin_fmaf(w_c, bcast_lane(ec, l), p0);
+    // d/da [w_s sin(a 2^oct) + w_c sin(a 2^oct + P)] = 2^oct (w_s cos - w_c sin)
+    const float dv = __builtin_fmaf(w_s, bcast_lane(cs2, l), -(w_c * bcast_lane(sn2, l)));
+    vy += (l & 1) ? dv : 0.0f;
+    vx += (l & 1) ? 0.0f : dv;
+  }
+  // ---- the six per-ray k rows (times 2^S and the inverse of the B scale), range check, split, per-wave LDS
+  const float r0 = uxm * (scale / kDelScale), r1 = uxp * (scale / kDelScale), r2 = uym * (scale / kDelScale), r3 = uyp * (scale / kDelScale);
+  const float r4 = vx * (scale / kArgScale), r5 = vy * (scale / kArgScale);
+  const float big = fmaxf(fmaxf(fmaxf(fabsf(r0), fabsf(r1)), fmaxf(fabsf(r2), fabsf(r3))), fmaxf(fabsf(r4), fabsf(r5)));
+  if (!__all(big < 3.0e4f)) return false;
+  float* bl = lh + LH::BASE + wave * HD;
+  bl[hid] = (f0 + p0) * scale;
+  {
+    unsigned* ub = reinterpret_cast<unsigned*>(lh + LH::UBUF + wave * LH::UBUF_WAVE_STRIDE) + ((hid >> 5) * 64 + (hid & 31)) * 4;
+    const float rows[6] = {r0, r1, r2, r3, r4, r5};
+    _Float16 hi[6], lo[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) hi[i] = (_Float16)rows[i], lo[i] = (_Float16)(rows[i] - (float)hi[i]);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      ub[j] = pack_h2(hi[2 * j], hi[2 * j + 1]);
+      ub[LH::UBUF_TERM_STRIDE + j] = pack_h2(lo[2 * j], lo[2 * j + 1]);
+    }
+  }
+  wave_lds_fence_r();
+  // ---- per sample: accumulators start from the ray constant (rows ht*32 + 8j + 4h + {0..3} of this lane, both point tiles)
+#pragma unroll
+  for (int ht = 0; ht < HT; ++ht)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float4 v = *reinterpret_cast<const float4*>(bl + ht * 32 + 8 * j + 4 * h);
+      acc[ht][0][4 * j + 0] = v.x, acc[ht][0][4 * j + 1] = v.y, acc[ht][0][4 * j + 2] = v.z, acc[ht][0][4 * j + 3] = v.w;
+      acc[ht][1][4 * j + 0] = v.x, acc[ht][1][4 * j + 1] = v.y, acc[ht][1][4 * j + 2] = v.z, acc[ht][1][4 * j + 3] = v.w;
+    }
+  // depth-code slice: octaves 0, 2, 4 direct, 1, 3, 5 by angle doubling (as region_seq), then the raw code
+  {
+    float e[13];
+    float f = ff;
+#pragma unroll
+    for (int o2 = 0; o2 < kNumFreqs; o2 += 2) {
+      float sn, cs;
+      sincos_small(zn * f, sn, cs);
+      pe_entry1(zn * f, sn, cs, e[2 * o2], e[2 * o2 + 1]);
+      const float tt = sn + sn;
+      pe_entry1(zn * (f * 2.0f), tt * cs, __builtin_fmaf(-tt, sn, 1.0f), e[2 * o2 + 2], e[2 * o2 + 3]);
+      f = f * 4.0f;
+    }
+    e[12] = zn;
+    f16_region<HD, 13>(acc, lh + LH::W_Z + lane4, LH::WZ_TERM_STRIDE, e);
+  }
+  // correction slice: this sample's offsets from the reference point
+  {
+    const float dx = ix - ax.p0, dy = iy - ay.p0;                   // exact (Sterbenz)
+    const float dax = x * ff - xr * ff, day = y * ff - yr * ff;     // fl(x ff) - fl(x_r ff): contraction is off, both products round
+    float e[8];
+    e[0] = fminf(dx, 0.0f) * kDelScale, e[1] = fmaxf(dx, 0.0f) * kDelScale;
+    e[2] = fminf(dy, 0.0f) * kDelScale, e[3] = fmaxf(dy, 0.0f) * kDelScale;
+    e[4] = dax * kArgScale, e[5] = day * kArgScale, e[6] = 0.0f, e[7] = 0.0f;
+    f16_region<HD, 8>(acc, lh + LH::UBUF + wave * LH::UBUF_WAVE_STRIDE + lane4, LH::UBUF_TERM_STRIDE, e);
+  }
+  wave_lds_fence_r();   // the next ray's rows must not overtake these reads
+  return true;
+}
+#endif  // BTS_ENC_RAY
 
 // Cold path: a wave in which some sample's encoding argument leaves the fast sincos range (|arg| > 1e5: points within millimetres
 // of the encoder's camera plane) evaluates that iteration with the compact lane = point routine (libm range reduction inside).
@@ -523,6 +727,21 @@ __global__ __launch_bounds__(256, 2) void render_kernel_p(const FwdParams p) {
         bcast_tiles(use_empty ? 1u : 0u, t0, t1), emp[0] = t0 != 0, emp[1] = t1 != 0;
       }
 
+#ifdef BTS_ENC_RAY
+      // encoder-camera ray?  wave-uniform: every sample inside the frustum, away from the border texels, and all of them within
+      // 2^-11 px / 2^-18 of lane 0's coordinates
+      bool enc_ray = false;
+      float ixk = 0.0f, iyk = 0.0f, ixr = 0.0f, iyr = 0.0f, xr = 0.0f, yr = 0.0f;
+      if constexpr (ONE_RAY && F16) {
+        pixel_coords(pe.x, pe.y, H, W, ixk, iyk);
+        ixr = bcast_lane(ixk, 0), iyr = bcast_lane(iyk, 0), xr = bcast_lane(pe.x, 0), yr = bcast_lane(pe.y, 0);
+        const bool ok = !pe.invalid & (fabsf(ixk - ixr) <= 0.00048828125f) & (fabsf(iyk - iyr) <= 0.00048828125f) &
+                        (fabsf(pe.x - xr) <= 3.814697265625e-6f) & (fabsf(pe.y - yr) <= 3.814697265625e-6f) &
+                        (ixr >= 1.5f) & (ixr <= (float)W - 2.5f) & (iyr >= 1.5f) & (iyr <= (float)H - 2.5f);
+        enc_ray = __all(ok) && !(p.ablate & 64);
+      }
+#endif
+
       float s_raw;
       if (__builtin_expect(__any(pe_needs_exact(v3, p.freq_factor)), 0)) {
         s_raw = eval_point_exact<C, HD, NB>(lds, G, p.w2c_enc + sample * 16, p.K_enc + sample * 9, H, W, p.code_mode, p.inv_z, p.inv_dmax,
@@ -531,6 +750,18 @@ __global__ __launch_bounds__(256, 2) void render_kernel_p(const FwdParams p) {
       BTS_TICK(0)
       // ---------------- h = bilinear(G) + W_pe . PE + b: gather two stages ahead, blend between the octaves
       f32x16 acc[HT][2];
+#ifdef BTS_ENC_RAY
+      bool done = false;
+      if constexpr (ONE_RAY && F16) {
+        if (enc_ray) {
+          int lane4e = lane * 4;
+          asm volatile("" : "+v"(lane4e));
+          done = enc_ray_lin_in<C, HD, NB>(acc, lds, lh, G, W, lane, h, wave, ixr, iyr, xr, yr, ixk, iyk, pe.x, pe.y, v3[2], p.freq_factor,
+                                           scale, lane4e);
+        }
+      }
+      if (!done) {
+#endif
       GBuf ba, bb;
       const bool nogather = BTS_ABL(1);
       if (!nogather) {
@@ -574,6 +805,9 @@ __global__ __launch_bounds__(256, 2) void render_kernel_p(const FwdParams p) {
           stage_blend<HD, 7>(acc, bb, wq);
         }
       }
+#ifdef BTS_ENC_RAY
+      }
+#endif
       if (p.learn_empty && __any(use_empty)) {
 #pragma unroll
         for (int ht = 0; ht < HT; ++ht)
