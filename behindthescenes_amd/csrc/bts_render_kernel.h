@@ -758,6 +758,9 @@ __global__ __launch_bounds__(256, 2) void render_kernel_p(const FwdParams p) {
           asm volatile("" : "+v"(lane4e));
           done = enc_ray_lin_in<C, HD, NB>(acc, lds, lh, G, W, lane, h, wave, ixr, iyr, xr, yr, ixk, iyk, pe.x, pe.y, v3[2], p.freq_factor,
                                            scale, lane4e);
+#ifdef BTS_PROBE
+          if (done && lane == 0 && p.dbg) atomicAdd(p.dbg + 63, 1ull);   // how many rays took the path (BTS_DBG_PTR buffer, slot 63)
+#endif
         }
       }
       if (!done) {
