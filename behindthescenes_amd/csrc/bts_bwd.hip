@@ -738,7 +738,11 @@ int render_bwd_impl(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const BtsR
   bp.f.tiles_per_sample = (a->rays_per_sample + 255) / 256;
   bp.g_rgb = g->g_rgb, bp.g_depth = g->g_depth, bp.g_weights = g->g_weights, bp.g_alphas = g->g_alphas;
   bp.d_proj = g->d_proj_nhwc, bp.d_mlp = g->d_mlp_params, bp.d_empty_proj = g->d_empty_proj;
-  static const bool direct = getenv("BTS_BWD_DIRECT_ATOMICS") != nullptr;   // A/B: single pass, every tap update an L2 atomic
+#ifdef BTS_PROBE
+  static const bool direct = getenv("BTS_BWD_DIRECT_ATOMICS") != nullptr;   // A/B (probe build): single pass, every tap update an L2 atomic
+#else
+  constexpr bool direct = false;
+#endif
   bp.gh_ws = (bp.d_proj && !direct) ? static_cast<float*>(workspace) : nullptr;
   const int grid = bp.f.tiles_per_sample * cfg->n;
   int rc = BTS_E_UNSUPPORTED;

@@ -225,26 +225,19 @@ __device__ __forceinline__ void kstep(f32x16 (&acc)[HD / 32][2], const float* wl
   }
 }
 
-// First k-pair of a FRESH accumulator set: acc = W . x (srcC = inline 0, saves zero-filling 64 registers per sample).  With srcC = 0 the
-// destination is a new value and hipcc may allocate it on top of the instruction's own A / B registers, which MI355X does not
-// tolerate (see zero_acc in bts_common.h): the sources are therefore kept alive past the last MFMA of the step.
+// First k-pair of a FRESH accumulator set: acc = W . x (srcC = inline 0, saves zero-filling 64 registers per sample)
 template <int HD>
 __device__ __forceinline__ void kstep_first(f32x16 (&acc)[HD / 32][2], const float* wl, int lane_off, float a, float b) {
   swap32(a, b);
-  float w[HD / 32];
   f32x16 zero;
 #pragma unroll
   for (int q = 0; q < 16; ++q) zero[q] = 0.0f;
 #pragma unroll
   for (int ht = 0; ht < HD / 32; ++ht) {
-    w[ht] = wl[lane_off + ht * 32];
-    acc[ht][0] = mfma(w[ht], a, zero);
-    acc[ht][1] = mfma(w[ht], b, zero);
+    const float w = wl[lane_off + ht * 32];
+    acc[ht][0] = mfma(w, a, zero);
+    acc[ht][1] = mfma(w, b, zero);
   }
-  __builtin_amdgcn_sched_barrier(0);
-  if constexpr (HD == 64) asm volatile("" ::"v"(w[0]), "v"(w[HD / 32 - 1]), "v"(a), "v"(b));
-  else asm volatile("" ::"v"(w[0]), "v"(a), "v"(b));
-  __builtin_amdgcn_sched_barrier(0);
 }
 
 // out[ot][pt] += W^T(k-major, [HD in][HD out]) . relu(in)   (one ResnetBlockFC linear; C-layout of `in` feeds B directly).

@@ -54,10 +54,19 @@ void render_geometry(FwdParams& p, int n) {
   p.groups = (long)n * p.Bp / (64 / lpr);
 }
 
-// persistent grid: 2 work-groups (8 waves) per CU, multiple of 8 so that every XCD owns an equal contiguous share of the rays
+// persistent grid: 2 work-groups (8 waves) per CU of the current device, multiple of 8 so that every XCD owns an equal contiguous
+// share of the rays
 int render_grid(const FwdParams& p) {
+  static thread_local int cus[16] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+  if (!cus[dev]) {
+    hipDeviceProp_t prop;
+    cus[dev] = hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  const long cap = 2L * cus[dev];
   const long want = (p.groups + 3) / 4;
-  long g = want < 512 ? want : 512;
+  long g = want < cap ? want : cap;
   g = (g + 7) / 8 * 8;
   return (int)g;
 }
@@ -69,10 +78,12 @@ int render_fwd_impl(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const BtsR
   p.rgb = a->rgb, p.depth = a->depth, p.weights = a->weights, p.alphas = a->alphas, p.invalid = a->invalid;
   p.rgb_samps = a->rgb_samps, p.sigma_raw = a->sigma_raw, p.trans = a->trans;
   p.tiles_per_sample = (a->rays_per_sample + 255) / 256;
-  if (getenv("BTS_LANE_IS_RAY")) {  // previous mapping (one lane = one ray), kept for A/B measurements
+#ifdef BTS_PROBE   // A/B switches exist only in the probe build (python -m behindthescenes_amd.build --probe); the product has one path
+  if (getenv("BTS_LANE_IS_RAY")) {  // round-1a mapping (one lane = one ray)
     if (p.proj) return launch_field<false, true>(p, cfg->C, cfg->d_hidden, cfg->n_blocks, p.tiles_per_sample * cfg->n, s);
     return launch_field<false, false>(p, cfg->C, cfg->d_hidden, cfg->n_blocks, p.tiles_per_sample * cfg->n, s);
   }
+#endif
 #ifdef BTS_ENC_RAY
   if (getenv("BTS_RENDER_NO_ENCRAY")) p.ablate |= 64;   // experimental build only: A/B switch for the encoder-camera ray path
 #endif
@@ -82,7 +93,9 @@ int render_fwd_impl(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const BtsR
 #endif
   render_geometry(p, cfg->n);
   const int grid = render_grid(p);
-  if (p.proj && getenv("BTS_RENDER_V1")) return launch_render<true>(p, cfg->C, cfg->d_hidden, cfg->n_blocks, grid, s);  // A/B only
+#ifdef BTS_PROBE
+  if (p.proj && getenv("BTS_RENDER_V1")) return launch_render<true>(p, cfg->C, cfg->d_hidden, cfg->n_blocks, grid, s);  // compact lane = sample kernel
+#endif
   if (p.proj) return launch_render_pipelined(p, cfg->C, cfg->d_hidden, cfg->n_blocks, grid, s);
   return launch_render<false>(p, cfg->C, cfg->d_hidden, cfg->n_blocks, grid, s);
 }
