@@ -212,6 +212,7 @@ __device__ __forceinline__ void stage_weights_h(float* lh, const float* lds_old,
     if (slot < 12) w = mlp[ml.w_in() + hid * D_IN + C + 3 + 6 * (2 * r + slot / 6) + slot % 6] * scale;
     else if (r == 0 && slot < 14) w = mlp[ml.w_in() + hid * D_IN + C + (slot - 12)] * scale;   // spare rows of region 0: raw x, y
     else if (r == 1 && slot == 12) w = mlp[ml.w_in() + hid * D_IN + C + 2] * scale;             // spare row of region 1: raw depth code
+    asm("" : "+v"(w));
     const _Float16 hi = (_Float16)w;
     wf[i] = hi;
     wf[i + LH::TERM_STRIDE * 2] = (_Float16)(w - (float)hi);  // TERM_STRIDE floats = 2 x halves
@@ -222,7 +223,8 @@ __device__ __forceinline__ void stage_weights_h(float* lh, const float* lds_old,
     for (int i = threadIdx.x; i < NB * 2 * 2 * 64 * 8; i += blockDim.x) {
       const int e = i & 7, lane = (i >> 3) & 63, sl = (i >> 9) & 1, layer = i >> 10;   // layer = 2 * block + {0: fc_0, 1: fc_1}
       const int kin = mfma_row(8 * sl + e, lane >> 5), out = lane & 31;
-      const float w = mlp[((layer & 1) ? ml.blk_w1(layer >> 1) : ml.blk_w0(layer >> 1)) + out * HD + kin] * scale;
+      float w = mlp[((layer & 1) ? ml.blk_w1(layer >> 1) : ml.blk_w0(layer >> 1)) + out * HD + kin] * scale;
+      asm("" : "+v"(w));
       const _Float16 hi = (_Float16)w;
       _Float16* dst = wb + layer * LH::BLK_LAYER_STRIDE * 2 + (sl * 64 + lane) * 8 + e;
       dst[0] = hi;
@@ -270,8 +272,14 @@ __device__ __forceinline__ void f16_region(f32x16 (&acc)[HD / 32][2], const floa
   _Float16 hi[16], lo[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
-    hi[i] = i < NE ? (_Float16)e[i < NE ? i : 0] : (_Float16)0.0f;
-    lo[i] = i < NE ? (_Float16)(e[i < NE ? i : 0] - (float)hi[i]) : (_Float16)0.0f;
+    // The entry as an opaque fp32 VALUE.  Otherwise hipcc folds the producing fma / multiply into ONE of the two conversions below
+    // (v_fma_mixlo_f16: a single rounding of the exact result) while the other goes through v_cvt_pk_f16_f32 of the rounded fp32
+    // value; in the 2^-13 of cases where double rounding matters the MFMA operand hi and the hi inside lo then differ by one f16
+    // ulp and hi + lo misses e by 5e-4 |e| (tools/ubench/f16_split_fusion.hip; seen as 1e-4 jumps of the MLP output).
+    float ev = e[i < NE ? i : 0];
+    asm("" : "+v"(ev));
+    hi[i] = i < NE ? (_Float16)ev : (_Float16)0.0f;
+    lo[i] = i < NE ? (_Float16)(ev - (float)hi[i]) : (_Float16)0.0f;
   }
   unsigned ph[4], qh[4], pl[4], ql[4];
 #pragma unroll
@@ -326,7 +334,8 @@ __device__ __forceinline__ void hidden_layer_h(f32x16 (&out)[1][2], const f32x16
       for (int i = 0; i < 8; ++i) {
         // relu, then back to the true magnitude; the upper clamp only keeps a (never observed) 6e4 activation from turning into inf
         const float v = __builtin_amdgcn_fmed3f(in[0][pt][8 * sl + i], 0.0f, 3.4028234663852886e38f) * inv_scale;
-        const float vc = fminf(v, 6.0e4f);
+        float vc = fminf(v, 6.0e4f);
+        asm("" : "+v"(vc));   // opaque fp32 value: both conversions below must see the same rounding (see f16_region)
         hi[i] = (_Float16)vc;
         lo[i] = (_Float16)(vc - (float)hi[i]);
       }

@@ -55,6 +55,9 @@ CASES = {  # name: (n, v, H, W, C, Hd, nb, K, ids_render, n_rays, conf)      one
     "nv1_shared_wave": (2, 2, 96, 320, 64, 64, 0, 32, [1], 16384, {}),                 # K = 32: two rays per wave
     "nv2_shared_wave": (2, 3, 96, 320, 64, 64, 0, 16, [1, 2], 16384, {}),              # K = 16: four rays per wave
     "nv4_shared_wave": (1, 5, 96, 320, 64, 64, 0, 8, [1, 2, 3, 4], 16384, {}),         # K = 8: eight rays per wave
+    "k24_idle_lanes": (1, 2, 96, 320, 64, 64, 0, 24, [1], 16384, {}),                 # K = 24: 8 idle lanes per ray (two rays per wave)
+    "k12_idle_lanes_re10k": (2, 3, 64, 96, 32, 32, 1, 12, [1, 2], 4096, dict(z_near=1.0, z_far=100.0, code_mode="distance")),
+    "k48_idle_lanes": (1, 2, 96, 320, 64, 64, 0, 48, [0], 8192, {}),                   # K = 48: 16 idle lanes (one ray per wave)
     "re10k_nv2": (2, 3, 256, 384, 32, 32, 1, 48, [1, 2], 24576, dict(z_near=1.0, z_far=100.0, code_mode="distance")),
     "re10k_k128": (1, 3, 256, 384, 32, 32, 1, 128, [1, 2], 8192, dict(z_near=1.0, z_far=100.0, code_mode="distance")),
 }

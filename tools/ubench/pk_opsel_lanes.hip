@@ -100,6 +100,12 @@ __global__ __launch_bounds__(512) void k(int mode, int partner, unsigned long lo
       case 19: asm volatile(PRE_ "v_pk_mov_b32 v[2:3], v[12:13], v[28:29] op_sel:[1,0]\n" POST_ OPS_); e0 = s0[1], e1 = s1[0]; break;
       case 20: asm volatile(PRE_ "v_pk_mov_b32 v[2:3], v[12:13], v[28:29] op_sel:[0,1]\n" POST_ OPS_); e0 = s0[0], e1 = s1[1]; break;
       case 21: asm volatile(PRE_ "v_pk_mul_f32 v[2:3], v[12:13], v[28:29] op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1]\n" POST_ OPS_); e0 = s0[0] * -s1[1], e1 = s0[1] * s1[1]; break;
+      // mixed-precision FMAs (VOP3P encoded as well): f16(a * b + c) from fp32 sources, low / high half of the destination
+      case 22: asm volatile(PRE_ "v_fma_mixlo_f16 v2, v12, v28, v30\n v_cvt_f32_f16 v2, v2\n v_mov_b32 v3, 0\n" POST_ OPS_); e0 = (float)(_Float16)__builtin_fmaf(s0[0], s1[0], s2[0]), e1 = 0.0f; break;
+      case 23: asm volatile(PRE_ "v_mov_b32 v2, 0\n v_fma_mixhi_f16 v2, v12, v28, v30\n v_lshrrev_b32 v2, 16, v2\n v_cvt_f32_f16 v2, v2\n v_mov_b32 v3, 0\n" POST_ OPS_); e0 = (float)(_Float16)__builtin_fmaf(s0[0], s1[0], s2[0]), e1 = 0.0f; break;
+      case 24: asm volatile(PRE_ "v_fma_mixlo_f16 v2, -v12, v28, v30\n v_cvt_f32_f16 v2, v2\n v_mov_b32 v3, 0\n" POST_ OPS_); e0 = (float)(_Float16)__builtin_fmaf(-s0[0], s1[0], s2[0]), e1 = 0.0f; break;
+      case 25: asm volatile(PRE_ "v_fma_mixlo_f16 v2, v12, v28, 0\n v_cvt_f32_f16 v2, v2\n v_mov_b32 v3, 0\n" POST_ OPS_); e0 = (float)(_Float16)(s0[0] * s1[0]), e1 = 0.0f; break;
+      case 26: asm volatile(PRE_ "v_cvt_pk_f16_f32 v2, v12, v28\n v_lshrrev_b32 v3, 16, v2\n v_cvt_f32_f16 v2, v2\n v_cvt_f32_f16 v3, v3\n" POST_ OPS_); e0 = (float)(_Float16)s0[0], e1 = (float)(_Float16)s1[0]; break;
       // 100 + d: the probe wave's OWN wide MFMA issued, then d idle cycles, then the packed multiply (partners idle)
       case 100: asm volatile(PRE_ "v_mfma_f32_32x32x16_f16 v[40:55], v[32:35], v[36:39], 0\n v_pk_mul_f32 v[2:3], v[12:13], v[28:29] op_sel:[0,1]\n" POST_ OPS2_); e0 = s0[0] * s1[1], e1 = s0[1] * s1[1]; break;
       case 104: asm volatile(PRE_ "v_mfma_f32_32x32x16_f16 v[40:55], v[32:35], v[36:39], 0\n s_nop 3\n v_pk_mul_f32 v[2:3], v[12:13], v[28:29] op_sel:[0,1]\n" POST_ OPS2_); e0 = s0[0] * s1[1], e1 = s0[1] * s1[1]; break;
@@ -122,7 +128,7 @@ __global__ __launch_bounds__(512) void k(int mode, int partner, unsigned long lo
   done = 1;
 }
 
-static const char* kNames[] = {"v_pk_mul_f32 op_sel:[0,0] op_sel_hi:[0,0]", "v_pk_mul_f32 op_sel:[0,0] op_sel_hi:[0,1]", "v_pk_mul_f32 op_sel:[0,0] op_sel_hi:[1,0]", "v_pk_mul_f32 op_sel:[0,0] op_sel_hi:[1,1]", "v_pk_mul_f32 op_sel:[0,1] op_sel_hi:[0,0]", "v_pk_mul_f32 op_sel:[0,1] op_sel_hi:[0,1]", "v_pk_mul_f32 op_sel:[0,1] op_sel_hi:[1,0]", "v_pk_mul_f32 op_sel:[0,1] op_sel_hi:[1,1]", "v_pk_mul_f32 op_sel:[1,0] op_sel_hi:[0,0]", "v_pk_mul_f32 op_sel:[1,0] op_sel_hi:[0,1]", "v_pk_mul_f32 op_sel:[1,0] op_sel_hi:[1,0]", "v_pk_mul_f32 op_sel:[1,0] op_sel_hi:[1,1]", "v_pk_mul_f32 op_sel:[1,1] op_sel_hi:[0,0]", "v_pk_mul_f32 op_sel:[1,1] op_sel_hi:[0,1]", "v_pk_mul_f32 op_sel:[1,1] op_sel_hi:[1,0]", "v_pk_mul_f32 op_sel:[1,1] op_sel_hi:[1,1]", "v_pk_add_f32 op_sel:[0,1]", "v_pk_fma_f32 op_sel:[0,1,0]", "v_pk_fma_f32 op_sel:[0,0,1]", "v_pk_mov_b32 op_sel:[1,0]", "v_pk_mov_b32 op_sel:[0,1]", "v_pk_mul_f32 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1]"};
+static const char* kNames[] = {/*22..26 appended below*/"v_pk_mul_f32 op_sel:[0,0] op_sel_hi:[0,0]", "v_pk_mul_f32 op_sel:[0,0] op_sel_hi:[0,1]", "v_pk_mul_f32 op_sel:[0,0] op_sel_hi:[1,0]", "v_pk_mul_f32 op_sel:[0,0] op_sel_hi:[1,1]", "v_pk_mul_f32 op_sel:[0,1] op_sel_hi:[0,0]", "v_pk_mul_f32 op_sel:[0,1] op_sel_hi:[0,1]", "v_pk_mul_f32 op_sel:[0,1] op_sel_hi:[1,0]", "v_pk_mul_f32 op_sel:[0,1] op_sel_hi:[1,1]", "v_pk_mul_f32 op_sel:[1,0] op_sel_hi:[0,0]", "v_pk_mul_f32 op_sel:[1,0] op_sel_hi:[0,1]", "v_pk_mul_f32 op_sel:[1,0] op_sel_hi:[1,0]", "v_pk_mul_f32 op_sel:[1,0] op_sel_hi:[1,1]", "v_pk_mul_f32 op_sel:[1,1] op_sel_hi:[0,0]", "v_pk_mul_f32 op_sel:[1,1] op_sel_hi:[0,1]", "v_pk_mul_f32 op_sel:[1,1] op_sel_hi:[1,0]", "v_pk_mul_f32 op_sel:[1,1] op_sel_hi:[1,1]", "v_pk_add_f32 op_sel:[0,1]", "v_pk_fma_f32 op_sel:[0,1,0]", "v_pk_fma_f32 op_sel:[0,0,1]", "v_pk_mov_b32 op_sel:[1,0]", "v_pk_mov_b32 op_sel:[0,1]", "v_pk_mul_f32 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1]", "v_fma_mixlo_f16 a, b, c (fp32 sources)", "v_fma_mixhi_f16 a, b, c", "v_fma_mixlo_f16 -a, b, c", "v_fma_mixlo_f16 a, b, 0", "v_cvt_pk_f16_f32"};
 static const char* kPartners[] = {"idle (s_sleep)", "v_mfma_f32_32x32x16_f16", "v_pk_fma_f32", "ds_read_b128", "v_fma_f32", "v_mfma_f32_32x32x2_f32", "f16 MFMA + v_pk_fma + ds_read",
                                   "v_mfma_f32_16x16x32_f16", "v_mfma_f32_32x32x16_bf16", "v_mfma_f32_32x32x8_f16", "v_mfma_f32_16x16x16_f16", "v_mfma_i32_32x32x32_i8"};
 
@@ -148,7 +154,7 @@ int main(int argc, char** argv) {
   };
   const int only = argc > 1 ? atoi(argv[1]) : -1;
   // 1. every selection of v_pk_mul_f32 (and the other packed instructions) next to the full partner load
-  for (int m = 0; m < 22; ++m) {
+  for (int m = 0; m < 27; ++m) {
     if (only >= 0 && only != m) continue;
     printf("%s\n", kNames[m]);
     cell(m, 6);
