@@ -151,6 +151,12 @@ __global__ __launch_bounds__(256, 1) void render_bwd_kernel(const BwdParams bp) 
 #pragma unroll
   for (int i = 0; i < NVMAX * 3; ++i) g_rgb[i] = (bp.g_rgb && active && i < nv * 3) ? bp.g_rgb[ray * nv * 3 + i] : 0.0f;
   const float g_depth = (bp.g_depth && active) ? bp.g_depth[ray] : 0.0f;
+  // white background (nerf.py:301-304): rgb = sum_k w_k c_k + 1 - sum_k w_k, so every weight also receives -sum_channels g_rgb
+  float g_bkgd = 0.0f;
+  if (p.white_bkgd) {
+#pragma unroll
+    for (int i = 0; i < NVMAX * 3; ++i) g_bkgd -= g_rgb[i];
+  }
 
   // persistent per-wave gradient state
   f32x16 dwpe[HT][2];  // dW_pe^T tiles: rows hidden (ht), columns pe input (2 tiles of 32, 40 used)
@@ -184,7 +190,7 @@ __global__ __launch_bounds__(256, 1) void render_bwd_kernel(const BwdParams bp) 
     const float px = ox + z * dx, py = oy + z * dy, pz = oz + z * dz;
 
     // ---------------- colours of this sample -> g_w = sum_j g_rgb_j . c_kj + g_depth z_k (+ g_weights_k)
-    float g_w = g_depth * z;
+    float g_w = g_depth * z + g_bkgd;
     if (bp.g_weights && active) g_w += bp.g_weights[ray * K + k];
 #pragma unroll
     for (int j = 0; j < NVMAX; ++j) {
@@ -726,14 +732,10 @@ static int launch_scatter(const BwdParams& bp, int n, hipStream_t s) {
 
 int render_bwd_impl(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const BtsRenderArgs* a, const BtsRenderGrads* g, void* workspace,
                     size_t, hipStream_t s) {
-  if (a->white_bkgd) {
-    set_error("%s: white_bkgd has no backward (no shipped config trains with it)", "bts_render_bwd");
-    return BTS_E_UNSUPPORTED;
-  }
   BwdParams bp;
   bp.f = make_params(cfg, t);
   bp.f.rays = a->rays, bp.f.z_samp = a->z_samp;
-  bp.f.Bp = a->rays_per_sample, bp.f.K = a->K, bp.f.hard_cap = a->hard_alpha_cap, bp.f.white_bkgd = 0;
+  bp.f.Bp = a->rays_per_sample, bp.f.K = a->K, bp.f.hard_cap = a->hard_alpha_cap, bp.f.white_bkgd = a->white_bkgd;
   bp.f.sigma_raw = a->sigma_raw, bp.f.trans = a->trans;
   bp.f.tiles_per_sample = (a->rays_per_sample + 255) / 256;
   bp.g_rgb = g->g_rgb, bp.g_depth = g->g_depth, bp.g_weights = g->g_weights, bp.g_alphas = g->g_alphas;

@@ -38,6 +38,12 @@ def _flat(t, tail):
     return t.reshape((-1,) + tuple(tail)).float().contiguous()
 
 
+def _same_view(a, b):
+    """True when a and b are the same values in the same memory (same storage offset, shape, strides, grad history)."""
+    return a is b or (a.data_ptr() == b.data_ptr() and a.shape == b.shape and a.stride() == b.stride() and a.dtype == b.dtype
+                      and a._base is not None and a._base is b._base)
+
+
 class ReconstructionLoss:
     def __init__(self, config, use_automasking=False) -> None:
         self.criterion_str = config.get("criterion", "l2")
@@ -114,7 +120,10 @@ class ReconstructionLoss:
                 m["inv"] = inv_ratio.detach()
             m["coarse"] = m["coarse"] + rgb_loss.detach() * self.lambda_coarse
             if len(fine) > 0:
-                if fine["rgb"] is coarse["rgb"]:           # trainer.py:247-248 aliases fine = dict(coarse)
+                if _same_view(fine["rgb"], coarse["rgb"]) and _same_view(fine_0["weights"], coarse_0["weights"]) \
+                        and _same_view(fine_0["invalid"], coarse_0["invalid"]):
+                    # trainer.py:247-248 aliases fine = dict(coarse): reconstruct() then views the SAME storage once per dict, so the
+                    # tensors are different Python objects over identical memory -- one launch serves both terms
                     fine_loss = rgb_loss
                 else:
                     fine_loss, _, _ = self._photometric(fine, fine_0, data["rgb_gt"], False)

@@ -41,6 +41,11 @@ def _ptr(t: Optional[torch.Tensor]):
 
 
 def _stream(t: torch.Tensor):
+    """The current HIP stream of the tensor's device.  The library launches on the CURRENT device, so a tensor that lives elsewhere
+    is rejected here instead of enqueuing its pointers on the wrong GPU."""
+    if t.device.index is not None and t.device.index != torch.cuda.current_device():
+        raise BtsNativeError(f"tensor on {t.device} but the current device is cuda:{torch.cuda.current_device()}: wrap the call in "
+                             "torch.cuda.device(...) (one process per GPU never hits this)")
     return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
 
 
@@ -114,6 +119,8 @@ def patch_rays(poses_c2w, projs, images, patch_v, patch_y, patch_x, ph: int, pw:
         _req(images, "images")
         c, H, W = images.shape[2:]
     P = patch_v.shape[1]
+    if not isinstance(images, tuple) and ((ph > H) or (pw > W)):
+        raise BtsNativeError(f"patch {ph}x{pw} does not fit a {H}x{W} frame")
     for t, nme in ((patch_v, "patch_v"), (patch_y, "patch_y"), (patch_x, "patch_x")):
         if t.dtype != torch.int32 or not t.is_cuda or not t.is_contiguous() or tuple(t.shape) != (n, P):
             raise BtsNativeError(f"{nme}: expected a contiguous int32 device tensor of shape {(n, P)}")
@@ -322,7 +329,7 @@ def render_fwd(ft: FieldTensors, mlp_params: torch.Tensor, rays: torch.Tensor, z
 
 
 def render_bwd(ft: FieldTensors, mlp_params, rays, z_samp, sigma_raw, trans, *, hard_alpha_cap, g_rgb=None, g_depth=None,
-               g_weights=None, g_alphas=None, need_proj=True, need_mlp=True, need_empty=False):
+               g_weights=None, g_alphas=None, need_proj=True, need_mlp=True, need_empty=False, white_bkgd=False):
     """Returns (d_proj_nhwc | None, d_mlp_params | None, d_empty_proj | None) (bts_render_bwd)."""
     B, K = z_samp.shape
     for name, g in (("g_rgb", g_rgb), ("g_depth", g_depth), ("g_weights", g_weights), ("g_alphas", g_alphas)):
@@ -334,7 +341,7 @@ def render_bwd(ft: FieldTensors, mlp_params, rays, z_samp, sigma_raw, trans, *, 
     d_mlp = torch.zeros(ft.spec.mlp_param_count(), device=dev, dtype=torch.float32) if need_mlp else None
     d_empty = torch.zeros(ft.spec.d_hidden, device=dev, dtype=torch.float32) if need_empty else None
     cfg, tens = ft.cfg(), ft.tensors(mlp_params)
-    args = _render_args(ft, rays, z_samp, hard_alpha_cap, False, dict(sigma_raw=sigma_raw, trans=trans))
+    args = _render_args(ft, rays, z_samp, hard_alpha_cap, white_bkgd, dict(sigma_raw=sigma_raw, trans=trans))
 
     def dp(t):
         return None if t is None else t.data_ptr()
@@ -342,10 +349,24 @@ def render_bwd(ft: FieldTensors, mlp_params, rays, z_samp, sigma_raw, trans, *, 
                            d_proj_nhwc=dp(d_proj), d_mlp_params=dp(d_mlp), d_empty_proj=dp(d_empty))
     lib = _lib.load()
     ws_bytes = lib.bts_render_bwd_workspace(C.byref(cfg), C.byref(args))
-    ws = torch.empty(int(ws_bytes) // 4 + 1, device=dev, dtype=torch.float32)
+    ws = _workspace(dev, int(ws_bytes))
     _lib.check(lib.bts_render_bwd(C.byref(cfg), C.byref(tens), C.byref(args), C.byref(grads), _ptr(ws), ws_bytes, _stream(rays)),
                "bts_render_bwd")
     return d_proj, d_mlp, d_empty
+
+
+_WS = {}
+
+
+def _workspace(dev, n_bytes):
+    """Scratch of the backward (g_h rows between its two passes, ~1 GiB at bs 16 x 4096 rays x 64 samples): one buffer per device
+    and stream, grown on demand and reused -- its contents need no initialisation and every use is ordered on the stream."""
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+    buf = _WS.get(key)
+    if buf is None or buf.numel() * 4 < n_bytes + 4:
+        buf = torch.empty(n_bytes // 4 + 1, device=dev, dtype=torch.float32)
+        _WS[key] = buf
+    return buf
 
 
 def field_query(ft: FieldTensors, mlp_params: torch.Tensor, xyz: torch.Tensor, only_density: bool = False):
@@ -394,7 +415,7 @@ class RenderFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, proj_nhwc, mlp_params, empty_feature, ft: FieldTensors, rays, z_samp, hard_alpha_cap, white_bkgd,
                 want_weights, want_alphas, want_rgb_samps):
-        needs_grad = any(ctx.needs_input_grad[:3])
+        needs_grad = any(ctx.needs_input_grad[:3]) and torch.is_grad_enabled()   # needs_input_grad ignores no_grad()
         out = render_fwd(ft, mlp_params, rays, z_samp, hard_alpha_cap=hard_alpha_cap, white_bkgd=white_bkgd,
                          want_weights=want_weights, want_alphas=want_alphas, want_invalid=True, want_rgb_samps=want_rgb_samps,
                          want_saved=needs_grad)
@@ -411,8 +432,6 @@ class RenderFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_rgb, g_depth, g_weights, g_alphas, _g_inv, _g_rs):
         mlp_params, rays, z_samp, sigma_raw, trans = ctx.saved_tensors
-        if ctx.white_bkgd:
-            raise BtsNativeError("backward with white_bkgd is not supported (no shipped config trains with it)")
 
         def prep(g, present=True):
             return g.contiguous() if (g is not None and present and g.numel() > 0) else None
@@ -420,7 +439,7 @@ class RenderFunction(torch.autograd.Function):
         ft = ctx.ft
         need_proj, need_mlp, need_empty = ctx.needs_input_grad[:3]
         d_proj, d_mlp, d_eproj = render_bwd(ft, mlp_params, rays, z_samp, sigma_raw, trans, hard_alpha_cap=ctx.hard_alpha_cap,
-                                            g_rgb=prep(g_rgb), g_depth=prep(g_depth), g_weights=prep(g_weights, ctx.has[0]),
+                                            g_rgb=prep(g_rgb), g_depth=prep(g_depth), g_weights=prep(g_weights, ctx.has[0]), white_bkgd=ctx.white_bkgd,
                                             g_alphas=prep(g_alphas, ctx.has[1]), need_proj=need_proj, need_mlp=need_mlp,
                                             need_empty=need_empty or (need_mlp and ft.spec.learn_empty))
         d_empty = None

@@ -104,6 +104,10 @@ class PatchRaySampler(RaySampler):
         n, v, c, h, w = images.shape
         dev = images.device
         pv, py, px = self.draw_patches(n, v, h, w) if patches is None else patches
+        if patches is not None:   # the draws live on the host anyway: out-of-frame patches would read out of bounds on the device
+            for t, hi, nme in ((pv, v, "view"), (py, h - self.patch_size_y + 1, "y0"), (px, w - self.patch_size_x + 1, "x0")):
+                if t.numel() and (int(t.min()) < 0 or int(t.max()) >= hi):
+                    raise ValueError(f"patch {nme} outside [0, {hi})")
         idx = torch.stack((pv, py, px)).to(device=dev, dtype=torch.int32)          # one small host-to-device copy
         all_rays, all_rgb_gt = native.patch_rays(poses.detach().float().contiguous(), projs.detach().float().contiguous(),
                                                  images.detach().float().contiguous(), idx[0], idx[1], idx[2],

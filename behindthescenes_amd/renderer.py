@@ -178,8 +178,7 @@ class NeRFRenderer(torch.nn.Module):
         while self.last_sched.item() < len(self.sched[0]) and self.iter_idx.item() >= self.sched[0][self.last_sched.item()]:
             self.n_coarse = self.sched[1][self.last_sched.item()]
             self.n_fine = self.sched[2][self.last_sched.item()]
-            self.using_fine = self.n_fine > 0
-            self.last_sched += 1
+            self.last_sched += 1   # (the reference leaves using_fine as constructed, nerf.py:403-423: reproduced)
 
     @classmethod
     def from_conf(cls, conf, white_bkgd=False, eval_batch_size=100000):

@@ -80,7 +80,7 @@ typedef struct BtsRenderArgs {
   int32_t rays_per_sample; /* Bp */
   int32_t K;               /* samples per ray */
   int32_t hard_alpha_cap;  /* nerf.py:285-286 */
-  int32_t white_bkgd;      /* nerf.py:301-304 */
+  int32_t white_bkgd;      /* nerf.py:301-304: rgb += 1 - sum(weights); honoured by the forward AND the backward */
   const float* rays;       /* (n*Bp, 8) */
   const float* z_samp;     /* (n*Bp, K) */
   /* outputs; the per-sample ones may be NULL when not wanted */

@@ -84,31 +84,81 @@ def _oracle_grads(scene, mlp, cfg, ids_render, rays, z, n, hard_cap, loss_fn, em
     return torch.autograd.grad(loss_fn(w, rgb, depth, a), wanted)
 
 
+def _gate_safe_rays(scene, mlp, cfg, ids_render, rays, z, empty, margin):
+    """Rays none of whose samples has a hidden pre-activation within its fp32 uncertainty of the relu kink (fp64 evaluation).  On
+    every other ray two correct fp32 evaluations may gate a unit differently, and ONE flipped gate moves a few gradient entries by
+    ~1e-4..1e-3 of the largest entry -- an effect of the test point, not of either implementation.  Measured on the KITTI-360
+    training shape against an fp64 evaluation: the fp32 ORACLE is 4e-4 off at one such point (sample 4), the HIP path 2e-3 at
+    another (sample 14, ray 1573, k = 17: unit 63 has h = -3.3e-5 there), every other ray agrees to 1e-6.
+    What makes h uncertain in ANY fp32 evaluation:
+      * the tap position: ix = ((x + 1) W - 1) / 2 carries a few ulp of (x + 1) W / 2, i.e. ~4e-5 px at W = 640, and h moves by
+        |dh / d ix| times that -- the dominant term wherever the feature map has a slope (3e-5 at the point above);
+      * the encoding: sin(f x) up to f = 48 with x = q.x / q.z good to ~2e-7 |x|: ~6e-6 |x|, large only far outside the frustum.
+    margin_unit = margin * (1 + max(|x|, |y|, |code|)) + |W_f (f(ix + e, iy) - f(ix, iy))| + |W_f (f(ix, iy + e) - f)|, e = 6e-5 px,
+    pushed (in quadrature) through the ResnetBlockFC layers.   Returns (mask (n, B'), #rays excluded)."""
+    import torch.nn.functional as F
+    torch.set_default_dtype(torch.float64)
+    try:
+        st = O.make_state({k: v.double() for k, v in scene.items()}, ids_render, cfg, None if empty is None else empty.double())
+        n, Bp = rays.shape[:2]
+        C, Hh, Ww = st.feat.shape[1:]
+        r = rays.double().reshape(-1, 8)
+        pts = (r[:, None, :3] + z.double().unsqueeze(2) * r[:, None, 3:6]).reshape(n, -1, 3)
+        x, _ = O.sample_features(pts, st, cfg)
+        xy = O.project(pts, st.w2c_enc.unsqueeze(1), st.K_enc.unsqueeze(1))[0][:, 0]   # (n, P, 2)
+        e_px = 6e-5
+        f0 = O._bilinear_border(st.feat, xy)
+        w_f = mlp.w_in.double()[:, :C]
+        dh = F.linear(O._bilinear_border(st.feat, xy + torch.tensor([2 * e_px / Ww, 0.0])) - f0, w_f).abs() \
+            + F.linear(O._bilinear_border(st.feat, xy + torch.tensor([0.0, 2 * e_px / Hh])) - f0, w_f).abs()
+        m = margin * (1.0 + x[..., C:C + 3].abs().amax(-1, keepdim=True)) + dh          # (n, B'*K, Hd)
+        h = F.linear(x, mlp.w_in.double(), mlp.b_in.double())
+        near = torch.zeros(h.shape[:-1], dtype=torch.bool)
+        for (w0, b0, w1, b1) in mlp.blocks:
+            t = F.linear(torch.relu(h), w0.double(), b0.double())
+            mt = F.linear(m * m, w0.double() ** 2).sqrt() + margin      # independent errors add in quadrature
+            near |= (h.abs() < m).any(-1) | (t.abs() < mt).any(-1)
+            h = h + F.linear(torch.relu(t), w1.double(), b1.double())
+            m = (m * m + F.linear(mt * mt, w1.double() ** 2)).sqrt()
+        near |= (h.abs() < m).any(-1)
+    finally:
+        torch.set_default_dtype(torch.float32)
+    safe = ~near.view(n, Bp, -1).any(-1)
+    return safe, int((~safe).sum())
+
+
 @pytest.mark.parametrize("learn_empty", [False, True])
 def test_gradients_vs_oracle_autograd(hip, learn_empty):
     """Training-like shape in the small (n=3, nv=4, K=64, ragged ray count), a loss that also feeds gradient into `weights` and
-    `alphas` (the alpha / entropy regularisers of loss.py use them), with and without learn_empty."""
+    `alphas` (the alpha / entropy regularisers of loss.py use them), with and without learn_empty.  The strict bound -- every
+    entry within 1e-4 of the largest one -- is asserted against an fp64 evaluation on rays that keep a margin from every relu kink
+    (round 1 had ratcheted this test to 20e-4 "because of gate flips"; with those rays identified and set aside, and the two
+    round-2 root causes fixed, the strict bound holds)."""
     from tests._hip_helpers import build_net
+    from tests._cases import robust_ray_mask
     cfg = O.FieldConfig(learn_empty=learn_empty)
     g = torch.Generator().manual_seed(77)
-    n, v, H, W, K = 3, 5, 48, 160, 64
+    n, v, H, W, K, NR = 3, 5, 48, 160, 64, 700
     scene = O.synthetic_scene(n, v, H, W, 64, seed=77, intrinsics=O.K_KITTI360, smooth=True)
     mlp = O.init_mlp(103, 64, 0, gen=g)
     mlp.b_in = torch.randn(64, generator=g) * 0.1
     empty = torch.randn(64, generator=g) if learn_empty else None
     rays = O.image_rays(scene["poses"], scene["projs"], H, W, 3.0, 80.0)
-    rays = rays[:, torch.randperm(rays.shape[1], generator=g)[:1400].sort().values].contiguous()
-    z = O.sample_coarse(rays.reshape(-1, 8), K, True, torch.rand(n * 1400, K, generator=g))
-    # keep rays whose samples stay clear of every frustum border: with learn_empty a flipped `invalid` flag (1-ulp effect on
-    # exact-border pixels, see test_gpu_parity) swaps the whole feature vector of that sample, i.e. reroutes gradient
-    from tests._cases import robust_ray_mask
+    rays = rays[:, torch.randperm(rays.shape[1], generator=g)[:1600].sort().values].contiguous()
+    z = O.sample_coarse(rays.reshape(-1, 8), K, True, torch.rand(n * 1600, K, generator=g))
+    # keep rays whose samples stay clear of every frustum border (a flipped `invalid` flag -- 1-ulp effect on exact-border pixels,
+    # see test_gpu_parity -- swaps the whole feature vector of that sample with learn_empty) and of every relu kink
     keep = robust_ray_mask(O.make_state(scene, [1, 2, 3, 4], cfg, empty), rays, z).view(n, -1)
-    idx = torch.stack([torch.nonzero(keep[i])[:700, 0] for i in range(n)])
-    assert idx.shape == (n, 700)
+    safe, n_gate = _gate_safe_rays(scene, mlp, cfg, [1, 2, 3, 4], rays, z, empty, margin=2e-5)
+    print(f"rays excluded for a hidden unit within 2e-5 of the relu kink: {n_gate} of {n * 1600}")
+    assert n_gate <= 0.5 * n * 1600
+    keep = keep & safe
+    idx = torch.stack([torch.nonzero(keep[i])[:NR, 0] for i in range(n)])
+    assert idx.shape == (n, NR)
     rays = torch.gather(rays, 1, idx.unsqueeze(-1).expand(-1, -1, 8)).contiguous()
     z = torch.gather(z.view(n, -1, K), 1, idx.unsqueeze(-1).expand(-1, -1, K)).reshape(-1, K).contiguous()
-    c_rgb = torch.randn(n * 700, 12, generator=g)
-    c_w = torch.randn(n * 700, K, generator=g) * 0.1
+    c_rgb = torch.randn(n * NR, 12, generator=g)
+    c_w = torch.randn(n * NR, K, generator=g) * 0.1
 
     def loss_fn(w, rgb, depth, a):
         dev, dt = rgb.device, rgb.dtype
@@ -120,26 +170,99 @@ def test_gradients_vs_oracle_autograd(hip, learn_empty):
     renderer = hip.NeRFRenderer(n_coarse=K, lindisp=True, hard_alpha_cap=True).cuda()
     ours = _hip_grads(hip, net, renderer, rays.reshape(-1, 8).cuda(), z.cuda(), n, loss_fn)
     names = ["w_in", "b_in", "w_out", "b_out", "feat"] + (["empty_feature"] if learn_empty else [])
-    # Weight gradients are sums over ~10^5 samples x 64 hidden units of terms gated by relu'(h): where |h| is within rounding of 0
-    # two fp32 evaluations gate differently, and one flipped term moves one gradient entry by ~1e-4 of the largest entry (measured:
-    # the fp32 oracle itself is 6e-5 .. 2e-4 away from an fp64 evaluation in the max norm).  So: max-norm within 1e-3 of the fp32
-    # oracle, and in the L2 norm -- which single flips barely move -- as close to the fp64 evaluation as the fp32 oracle is.
     for a, b, t, nme in zip(ours, ref, truth, names):
         assert a is not None, nme
         t = t.view_as(a.cpu())
-        l2_hip = ((a.cpu().double() - t).norm() / t.norm()).item()
-        l2_ref = ((b.view_as(a.cpu()).double() - t).norm() / t.norm()).item()
-        assert l2_hip <= max(3.0 * l2_ref, 3 * GRAD_RTOL), (nme, l2_hip, l2_ref)
         mx_hip = (a.cpu().double() - t).abs().max().item() / t.abs().max().item()
         mx_ref = (b.view_as(a.cpu()).double() - t).abs().max().item() / t.abs().max().item()
-        # a single flipped gate moves a handful of entries by up to ~1e-3 of the largest entry (the fp32 oracle's own worst
-        # entry is 3.4e-4 off the fp64 evaluation on this seed, the HIP path's 1.2e-3 -- deterministic, not an atomics effect):
-        # bound the max loosely and hold the 99.99th percentile of the entry errors to the strict tolerance
-        assert mx_hip <= max(5.0 * mx_ref, 20 * GRAD_RTOL), (nme, mx_hip, mx_ref)
-        err = ((a.cpu().double() - t).abs() / t.abs().max()).flatten()
-        if err.numel() >= 10000:
-            q = err.kthvalue(int(0.9999 * err.numel())).values.item()
-            assert q <= 10 * GRAD_RTOL, (nme, q)
+        l2_hip = ((a.cpu().double() - t).norm() / t.norm()).item()
+        l2_ref = ((b.view_as(a.cpu()).double() - t).norm() / t.norm()).item()
+        print(f"{nme}: max err / max entry  HIP {mx_hip:.2e}  fp32 oracle {mx_ref:.2e};  L2  HIP {l2_hip:.2e}  fp32 oracle {l2_ref:.2e}")
+        assert mx_hip <= 0.2 * GRAD_RTOL, (nme, mx_hip, mx_ref)     # measured: 4e-7 .. 6e-6 (the fp32 oracle: 1e-7 .. 6e-6)
+        assert l2_hip <= max(2.0 * l2_ref, 0.1 * GRAD_RTOL), (nme, l2_hip, l2_ref)
+
+
+def _patch_rays_with_kink_mask(scene, mlp, cfg, ids_loss, ids_render, n_patches, K, g, margin):
+    """`n_patches` random 8x8 patches per sample in PatchRaySampler order (the backward's dG scatter relies on a 64-ray group being
+    one patch) + a per-ray mask that is 0 where some sample of the ray has a hidden unit within `margin` of the relu kink in an fp64
+    evaluation (see _gate_safe_rays).  The tests multiply each ray's upstream gradient by the mask, so such rays contribute to
+    NEITHER path's gradient while the kernels still run on the full, real ray layout.
+    -> rays (n, n_patches*64, 8), z (n*n_patches*64, K), mask (n*n_patches*64,)"""
+    n, v, _, H, W = scene["images"].shape
+    nl = len(ids_loss)
+    all_rays = O.image_rays(scene["poses"][:, ids_loss], scene["projs"][:, ids_loss], H, W, cfg.d_min, cfg.d_max).view(n, nl, H, W, 8)
+    pv = torch.randint(0, nl, (n, n_patches), generator=g)
+    py = torch.randint(0, H - 8, (n, n_patches), generator=g)
+    px = torch.randint(0, W - 8, (n, n_patches), generator=g)
+    rays = torch.stack([torch.cat([all_rays[i, pv[i, j], py[i, j]:py[i, j] + 8, px[i, j]:px[i, j] + 8].reshape(64, 8) for j in range(n_patches)])
+                        for i in range(n)]).contiguous()                               # (n, n_patches*64, 8)
+    z = O.sample_coarse(rays.reshape(-1, 8), K, True, torch.rand(n * n_patches * 64, K, generator=g))
+    masks = []
+    for i in range(n):   # one sample at a time: fp64 activations
+        sc = {k: t[i:i + 1] for k, t in scene.items()}
+        safe, _ = _gate_safe_rays(sc, mlp, cfg, ids_render, rays[i:i + 1], z.view(n, -1, K)[i], None, margin)
+        masks.append(safe.view(-1))
+    mask = torch.cat(masks).float()
+    print(f"rays whose upstream gradient is zeroed (hidden unit within {margin:g} of the relu kink): {int((1 - mask).sum())} of {mask.numel()}")
+    return rays, z.contiguous(), mask
+
+
+def test_gradients_at_the_kitti360_training_shape(hip):
+    """BASELINE configs[2] at its real shape: bs 16, 8 frames (4 loss + 4 render views), 64 patches of 8x8 = 4096 rays per sample,
+    64 samples per ray, nv = 4 -- 4.19 M field queries through bts_render_bwd (two-pass dG scatter, one work-group per 256 rays) and
+    bts_project_features_bwd, against torch.autograd through the CPU oracle.  Bound: 1e-4 of the largest entry."""
+    from tests._hip_helpers import build_net
+    cfg = O.FieldConfig()
+    g = torch.Generator().manual_seed(303)
+    n, v, H, W, K = 16, 8, 192, 640, 64
+    ids_loss, ids_render = [0, 1, 2, 3], [4, 5, 6, 7]
+    scene = O.synthetic_scene(n, v, H, W, 64, seed=303, intrinsics=O.K_KITTI360, baseline=0.6, smooth=True)
+    mlp = O.init_mlp(103, 64, 0, gen=g)
+    mlp.b_in = torch.randn(64, generator=g) * 0.1
+    rays, z, mask = _patch_rays_with_kink_mask(scene, mlp, cfg, ids_loss, ids_render, 64, K, g, margin=2e-5)
+    assert rays.shape == (n, 4096, 8) and mask.mean() > 0.4
+    c_rgb = torch.randn(n * 4096, 12, generator=g) * mask.unsqueeze(-1)
+
+    def loss_fn(w, rgb, depth, a):
+        return (rgb * c_rgb.to(rgb.device, rgb.dtype)).sum() + 0.05 * (depth * mask.to(depth.device, depth.dtype)).sum()
+
+    ref = _oracle_grads(scene, mlp, cfg, ids_render, rays, z, n, True, loss_fn)
+    net = build_net(cfg, mlp, scene, ids_render, train=True)
+    renderer = hip.NeRFRenderer(n_coarse=K, lindisp=True, hard_alpha_cap=True).cuda()
+    ours = _hip_grads(hip, net, renderer, rays.reshape(-1, 8).cuda(), z.cuda(), n, loss_fn)
+    for a, b, nme in zip(ours, ref, ["w_in", "b_in", "w_out", "b_out", "feat"]):
+        err = _rel_to_max(a, b.view_as(a.cpu()))
+        print(f"{nme}: max err / max entry {err:.2e}")
+        assert err <= GRAD_RTOL, (nme, err)
+
+
+@pytest.mark.parametrize("K", [48, 128])
+def test_gradients_re10k_shape(hip, K):
+    """exp_re10k.yaml field (C = 32, one ResnetBlockFC of width 32, distance code, no alpha cap) at its ray-march lengths: K = 48 (the
+    yaml) and 128 (BASELINE.json), 256x384 frames, 1024 patch rays per sample, nv = 2; all ten parameter gradients + the feature map."""
+    from tests._hip_helpers import build_net
+    cfg = O.FieldConfig(d_min=1.0, d_max=100.0, code_mode="distance")
+    g = torch.Generator().manual_seed(500 + K)
+    n, v, H, W = 3, 3, 256, 384
+    scene = O.synthetic_scene(n, v, H, W, 32, seed=500 + K, intrinsics=O.K_RE10K, baseline=0.2, smooth=True)
+    mlp = O.init_mlp(71, 32, 1, gen=g)
+    rays, z, mask = _patch_rays_with_kink_mask(scene, mlp, cfg, [0], [1, 2], 16, K, g, margin=2e-5)
+    assert mask.mean() > 0.25
+    c_rgb = torch.randn(n * 1024, 6, generator=g) * mask.unsqueeze(-1)
+
+    def loss_fn(w, rgb, depth, a):
+        return (rgb * c_rgb.to(rgb.device, rgb.dtype)).sum() + 0.05 * (depth * mask.to(depth.device, depth.dtype)).sum()
+
+    ref = _oracle_grads(scene, mlp, cfg, [1, 2], rays, z, n, False, loss_fn)
+    net = build_net(cfg, mlp, scene, [1, 2], train=True)
+    renderer = hip.NeRFRenderer(n_coarse=K, lindisp=True, hard_alpha_cap=False).cuda()
+    ours = _hip_grads(hip, net, renderer, rays.reshape(-1, 8).cuda(), z.cuda(), n, loss_fn)
+    names = ["w_in", "b_in", "fc_0.w", "fc_0.b", "fc_1.w", "fc_1.b", "w_out", "b_out", "feat"]
+    assert len(ours) == len(ref) == len(names)
+    for a, b, nme in zip(ours, ref, names):
+        err = _rel_to_max(a, b.view_as(a.cpu()))
+        print(f"K={K} {nme}: max err / max entry {err:.2e}")
+        assert err <= GRAD_RTOL, (nme, err)
 
 
 def test_projection_kernels_vs_torch(hip):
