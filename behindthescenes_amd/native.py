@@ -414,8 +414,10 @@ class RenderFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, proj_nhwc, mlp_params, empty_feature, ft: FieldTensors, rays, z_samp, hard_alpha_cap, white_bkgd,
-                want_weights, want_alphas, want_rgb_samps):
-        needs_grad = any(ctx.needs_input_grad[:3]) and torch.is_grad_enabled()   # needs_input_grad ignores no_grad()
+                want_weights, want_alphas, want_rgb_samps, grad_mode=True):
+        # needs_input_grad reflects requires_grad even under torch.no_grad(), and inside forward() grad mode is always off: the
+        # caller passes the mode it was invoked in, so that evaluation does not allocate / write the 8 B per sample of saved state
+        needs_grad = any(ctx.needs_input_grad[:3]) and grad_mode
         out = render_fwd(ft, mlp_params, rays, z_samp, hard_alpha_cap=hard_alpha_cap, white_bkgd=white_bkgd,
                          want_weights=want_weights, want_alphas=want_alphas, want_invalid=True, want_rgb_samps=want_rgb_samps,
                          want_saved=needs_grad)
@@ -451,4 +453,4 @@ class RenderFunction(torch.autograd.Function):
                 d_empty = w_f.t() @ d_eproj
             if need_mlp:
                 d_mlp[:spec.d_hidden * spec.d_in].view(spec.d_hidden, spec.d_in)[:, :spec.C] += torch.outer(d_eproj, ft.empty_feature.detach())
-        return (d_proj, d_mlp, d_empty) + (None,) * 8
+        return (d_proj, d_mlp, d_empty) + (None,) * 9

@@ -117,7 +117,7 @@ class NeRFRenderer(torch.nn.Module):
         empty = model.empty_feature if model.learn_empty else None
         rgb, depth, weights, alphas, invalid, rgb_samps = native.RenderFunction.apply(
             ft.proj_nhwc, mlp_params, empty, ft, rays, z_samp, bool(self.hard_alpha_cap), bool(self.white_bkgd),
-            bool(want_weights), bool(want_alphas), bool(want_rgb_samps))
+            bool(want_weights), bool(want_alphas), bool(want_rgb_samps), torch.is_grad_enabled())
         return (weights if want_weights else None, rgb, depth, alphas if want_alphas else None, invalid, z_samp,
                 rgb_samps if want_rgb_samps else None)
 
