@@ -13,9 +13,12 @@ def register_backbone(name, factory):
 
 
 class FeatureMapEncoder(nn.Module):
-    def __init__(self, size, feat_dim, num_views=1, n_scales=1):
+    def __init__(self, size, feat_dim, num_views=1, n_scales=1, pyramid=False):
+        """pyramid=True halves the resolution per scale, like the decoder outputs of the reference's Monodepth2 (BTSNet.encode
+        resizes every scale back to scale 0's size, models_bts.py:111-119)."""
         super().__init__()
-        self.feats = nn.ParameterList([nn.Parameter(torch.randn(num_views, feat_dim, *size)) for _ in range(n_scales)])
+        sizes = [tuple(max(1, d >> s) for d in size) if pyramid else tuple(size) for s in range(n_scales)]
+        self.feats = nn.ParameterList([nn.Parameter(torch.randn(num_views, feat_dim, *sz)) for sz in sizes])
         self.latent_size = feat_dim
         self.scales = list(range(n_scales))
 
@@ -28,7 +31,7 @@ class FeatureMapEncoder(nn.Module):
 
     @classmethod
     def from_conf(cls, conf, **kw):
-        return cls(tuple(conf["size"]), conf.get("d_out", 64), conf.get("num_views", 1), conf.get("n_scales", 1))
+        return cls(tuple(conf["size"]), conf.get("d_out", 64), conf.get("num_views", 1), conf.get("n_scales", 1), conf.get("pyramid", False))
 
 
 register_backbone("feature_map", FeatureMapEncoder.from_conf)
@@ -42,6 +45,7 @@ def make_backbone(conf, **kwargs):
         try:
             from .monodepth2 import Monodepth2
         except ImportError as e:  # pragma: no cover
-            raise NotImplementedError("encoder type 'monodepth2' needs behindthescenes_amd.monodepth2") from e
+            raise NotImplementedError("encoder type 'monodepth2' needs behindthescenes_amd.monodepth2; alternatively register the "
+                                      "reference's own module with behindthescenes_amd.register_backbone (INTEGRATION.md)") from e
         return Monodepth2.from_conf(conf, **kwargs)
     raise NotImplementedError(f"Unsupported encoder type: {enc_type}")

@@ -10,6 +10,7 @@ from tests._cases import Case
 
 pytestmark = pytest.mark.gpu
 GRAD_RTOL = 1e-4
+DEPTH_RTOL_MS = 1e-4
 
 
 @pytest.fixture(scope="module")
@@ -263,6 +264,67 @@ def test_gradients_re10k_shape(hip, K):
         err = _rel_to_max(a, b.view_as(a.cpu()))
         print(f"K={K} {nme}: max err / max entry {err:.2e}")
         assert err <= GRAD_RTOL, (nme, err)
+
+
+def test_multiscale_render_and_backward_vs_oracle(hip):
+    """trainer.py:220-242 with prediction_mode "multiscale" (the default exp_re10k.yaml runs with): the encoder returns four feature
+    maps, full to 1/8 resolution; BTSNet.encode resizes them to scale 0's size (nearest, models_bts.py:111-119) and every training
+    step renders once per scale after net.set_scale(i).  Each scale's outputs and gradients (w.r.t. the MLP and w.r.t. that
+    scale's OWN low-resolution feature map, through the resize) against the oracle on the resized map."""
+    import torch.nn.functional as F
+    import behindthescenes_amd as bts
+    from tests._hip_helpers import make_conf, load_mlp
+    cfg = O.FieldConfig(d_min=1.0, d_max=100.0, code_mode="distance")
+    g = torch.Generator().manual_seed(91)
+    n, v, H, W, C, Hd, K = 2, 3, 64, 96, 32, 32, 24
+    scene = O.synthetic_scene(n, v, H, W, C, seed=91, intrinsics=O.K_RE10K, baseline=0.2, smooth=True)
+    mlp = O.init_mlp(C + 39, Hd, 1, gen=g)
+    feats = [F.avg_pool2d(torch.randn(n, C, H >> s, W >> s, generator=g), 3, 1, 1) * 2 for s in range(4)]
+    conf = make_conf(cfg, C, Hd, 1, H, W)
+    conf["encoder"].update(n_scales=4, pyramid=True, num_views=n)
+    net = bts.BTSNet(conf)
+    load_mlp(net, mlp)
+    assert [tuple(f.shape[-2:]) for f in net.encoder.feats] == [(H >> s, W >> s) for s in range(4)] and list(net.encoder.scales) == [0, 1, 2, 3]
+    with torch.no_grad():
+        for f_dst, f_src in zip(net.encoder.feats, feats):
+            f_dst.copy_(f_src)
+    net = net.cuda().train()
+    renderer = hip.NeRFRenderer(n_coarse=K, lindisp=True, hard_alpha_cap=False).cuda()
+    net.encode(scene["images"].cuda(), scene["projs"].cuda(), scene["poses"].cuda(), ids_encoder=[0], ids_render=[1, 2])
+    for s_i in range(4):
+        up = F.interpolate(feats[s_i], (H, W))                     # what the reference renders from at this scale
+        sc = dict(scene, feat=up)
+        rays, z, mask = _patch_rays_with_kink_mask(sc, mlp, cfg, [0], [1, 2], 8, K, g, margin=2e-5)
+        c_rgb = torch.randn(n * 512, 6, generator=g) * mask.unsqueeze(-1)
+
+        def loss_fn(w, rgb, depth, a):
+            return (rgb * c_rgb.to(rgb.device, rgb.dtype)).sum() + 0.05 * (depth * mask.to(depth.device, depth.dtype)).sum()
+
+        # oracle: gradients w.r.t. the MLP and w.r.t. the LOW-RESOLUTION map through the resize
+        params = [t.clone().requires_grad_(True) for t in mlp.tensors()]
+        lo = feats[s_i].clone().requires_grad_(True)
+        m = O.MlpParams(params[0], params[1], [tuple(params[2:6])], params[-2], params[-1])
+        st = O.make_state(dict(scene, feat=F.interpolate(lo, (H, W))), [1, 2], cfg)
+        ow, orgb, odepth, oa, *_ = O.composite(rays.reshape(-1, 8), z, n, st, m, cfg, hard_alpha_cap=False)
+        ref = torch.autograd.grad(loss_fn(ow, orgb, odepth, oa), params + [lo])
+        # HIP path at this scale
+        net.set_scale(s_i)
+        assert net.get_scale() == s_i
+        net.zero_grad(set_to_none=True)
+        w, rgb, depth, a, inv, _, _ = renderer.composite(net, rays.reshape(-1, 8).cuda(), z.cuda(), sb=n)
+        torch.testing.assert_close(depth.detach().cpu(), odepth.detach(), rtol=DEPTH_RTOL_MS, atol=1e-5)
+        torch.testing.assert_close(rgb.detach().cpu(), orgb.detach(), rtol=0, atol=1e-5)
+        loss_fn(w, rgb, depth, a).backward()
+        mc = net.mlp_coarse
+        ours = [mc.lin_in.weight.grad, mc.lin_in.bias.grad, mc.blocks[0].fc_0.weight.grad, mc.blocks[0].fc_0.bias.grad,
+                mc.blocks[0].fc_1.weight.grad, mc.blocks[0].fc_1.bias.grad, mc.lin_out.weight.grad, mc.lin_out.bias.grad,
+                net.encoder.feats[s_i].grad]
+        for a_, b_, nme in zip(ours, ref, ["w_in", "b_in", "fc_0.w", "fc_0.b", "fc_1.w", "fc_1.b", "w_out", "b_out", f"feat[{s_i}]"]):
+            err = _rel_to_max(a_, b_.view_as(a_.cpu()))
+            assert err <= GRAD_RTOL, (s_i, nme, err)
+        for j in range(4):   # the other scales' maps received nothing from this render
+            if j != s_i:
+                assert net.encoder.feats[j].grad is None or float(net.encoder.feats[j].grad.abs().max()) == 0.0
 
 
 def test_projection_kernels_vs_torch(hip):

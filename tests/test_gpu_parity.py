@@ -160,45 +160,68 @@ def test_layout_kernels_roundtrip(hip):
     assert torch.equal(p[..., :3], (im * 0.5 + 0.5).permute(0, 1, 3, 4, 2)) and float(p[..., 3].abs().max()) == 0.0
 
 
-def _oracle_vs_hip(hip, *, n, v, H, W, C, Hd, nb, K, ids_render, cfg, hard_cap, intr, n_rays, seed, norm_dir=True, smooth=False):
+def _oracle_vs_hip(hip, *, n, v, H, W, C, Hd, nb, K, ids_render, cfg, hard_cap, intr, n_rays, seed, norm_dir=True, smooth=False,
+                   want_fp64=False):
     from tests._cases import robust_ray_mask
     from tests._hip_helpers import build_net
     g = torch.Generator().manual_seed(seed)
     scene = O.synthetic_scene(n, v, H, W, C, seed=seed, intrinsics=intr, smooth=smooth)
     mlp = O.init_mlp(C + 39, Hd, nb, gen=g)
+    empty = torch.randn(C, generator=g) if cfg.learn_empty else None
     rays = O.image_rays(scene["poses"], scene["projs"], H, W, cfg.d_min, cfg.d_max, norm_dir)
     if n_rays is not None:
         idx = torch.randperm(rays.shape[1], generator=g)[:n_rays].sort().values
         rays = rays[:, idx].contiguous()
     u = torch.rand(rays.shape[0] * rays.shape[1], K, generator=g)
     z = O.sample_coarse(rays.reshape(-1, 8), K, True, u)
-    st = O.make_state(scene, ids_render, cfg)
+    st = O.make_state(scene, ids_render, cfg, empty)
     with torch.no_grad():
         ow, orgb, odepth, oa, oinv, _, _ = O.composite(rays.reshape(-1, 8), z, n, st, mlp, cfg, hard_alpha_cap=hard_cap)
-    net = build_net(cfg, mlp, scene, ids_render)
+    net = build_net(cfg, mlp, scene, ids_render, empty_feature=empty)
     renderer = hip.NeRFRenderer(n_coarse=K, lindisp=True, hard_alpha_cap=hard_cap).cuda().eval()
     with torch.no_grad():
         w, rgb, depth, a, inv, _, _ = renderer.composite(net, rays.reshape(-1, 8).cuda(), z.cuda(), sb=n)
     flips = (inv.cpu() != oinv).any(-1).any(-1)
     robust = robust_ray_mask(st, rays, z)
     assert not flips[robust].any(), "invalid flag differs on a ray that keeps a 1e-4 margin from every frustum border"
-    return dict(depth=(depth.cpu(), odepth), rgb=(rgb.cpu(), orgb), w=(w.cpu(), ow), a=(a.cpu(), oa), flips=flips, robust=robust)
+    # rays with a sample within a few fp32 ulps of a border test: the only place where a flag CAN legitimately differ
+    on_border = ~robust_ray_mask(st, rays, z, margin=3e-6)
+    out = dict(depth=(depth.cpu(), odepth), rgb=(rgb.cpu(), orgb), w=(w.cpu(), ow), a=(a.cpu(), oa), flips=flips, robust=robust,
+               on_border=on_border)
+    if want_fp64:   # the same formulas in double: the arbiter between two fp32 evaluations
+        dd = lambda t: None if t is None else t.double()
+        torch.set_default_dtype(torch.float64)
+        try:
+            st64 = O.FieldState(dd(st.feat), dd(st.K_enc), dd(st.w2c_enc), dd(st.imgs), dd(st.K_r), dd(st.w2c_r), dd(st.empty_feature))
+            mlp64 = O.MlpParams(dd(mlp.w_in), dd(mlp.b_in), [tuple(dd(t) for t in b) for b in mlp.blocks], dd(mlp.w_out), dd(mlp.b_out))
+            with torch.no_grad():
+                out["a64"] = O.composite(dd(rays.reshape(-1, 8)), dd(z), n, st64, mlp64, cfg, hard_alpha_cap=hard_cap)[3]
+        finally:
+            torch.set_default_dtype(torch.float32)
+    return out
 
 
 NOISE_FLOOR = 5e-5   # max |fp32 reference - fp64 evaluation| of weights / colours on the full-size scene (alphas: 1.3e-4)
 
 
-def _check(r, min_ok=0.9, depth_floor=0.0, max_tol=NOISE_FLOOR):
-    ok = ~r["flips"]
-    assert ok.float().mean() > min_ok, ok.float().mean()
+def _check(r, depth_floor=0.0, max_tol=NOISE_FLOOR, alpha_frac=2e-4):
+    """Rays with a flipped `invalid` flag leave the comparison (a flipped flag swaps the feature vector with learn_empty, and is a
+    1-ulp event of a pixel that projects exactly onto a frustum border) -- but only as many of them as there are such pixels: every
+    flip must sit on a ray within 3e-6 of a border test, and at most that many rays may be set aside.  Reported, not hidden."""
+    flips, border = r["flips"], r["on_border"]
+    assert not (flips & ~border).any(), "flag differs on a ray that is not within 3e-6 of any frustum border"
+    print(f"rays set aside for a flipped invalid flag: {int(flips.sum())} of {flips.numel()} (rays within 3e-6 of a border: {int(border.sum())})")
+    ok = ~flips
     d, od = r["depth"]
     rel = ((d - od).abs() / od.abs().clamp_min(depth_floor))[ok]
     assert rel.max().item() <= DEPTH_RTOL, rel.max().item()
     for key in ("rgb", "w", "a"):
         e = (r[key][0] - r[key][1]).abs()[ok].flatten()
         big = e[e > ABS_TOL]
-        # 99.99 % within 1e-5; alphas amplify a sigma error by delta*exp(-delta*sigma) (delta up to ~15 m): 99 %
-        assert big.numel() <= (1e-2 if key == "a" else 1e-4) * e.numel(), (key, big.numel(), e.numel())
+        print(f"  {key}: max |err| {e.max().item():.2e}, entries above 1e-5: {big.numel()} of {e.numel()}")
+        # 99.99 % within 1e-5; alphas = 1 - exp(-delta sigma) amplify a sigma difference by delta exp(-delta sigma) with delta up to
+        # 15 m between the far samples, so a 1e-6 difference in sigma already shows as 1.5e-5: 99.98 % (measured 99.985 % at full size)
+        assert big.numel() <= (alpha_frac if key == "a" else 1e-4) * e.numel(), (key, big.numel(), e.numel())
         assert e.max().item() <= (3 * max_tol if key == "a" else max_tol), (key, e.max().item())
 
 
@@ -207,7 +230,7 @@ def test_full_size_frame_vs_oracle(hip):
     Frames are low-passed noise (like real frames, neighbouring pixels correlate): colour tolerance 1e-5."""
     r = _oracle_vs_hip(hip, n=1, v=2, H=192, W=640, C=64, Hd=64, nb=0, K=64, ids_render=[0], cfg=O.FieldConfig(), hard_cap=True,
                        intr=O.K_KITTIRAW, n_rays=None, seed=21, smooth=True)
-    _check(r, min_ok=0.98)
+    _check(r)
     d, od = r["depth"]
     # Abs-Rel against synthetic sparse ground truth (evaluator.py:96-151 formula), both z-depth maps
     g = torch.Generator().manual_seed(3)
@@ -219,12 +242,30 @@ def test_full_size_frame_vs_oracle(hip):
     assert abs(O.abs_rel(ours, gt) - O.abs_rel(theirs, gt)) <= 1e-4
 
 
+def test_full_size_frame_learn_empty_vs_oracle(hip):
+    """The EFFECTIVE eval_depth.yaml field: the yaml does not set learn_empty, so BTSNet runs with its default learn_empty=True
+    (models_bts.py:24): samples outside the encoder frustum -- half of the stereo partner's rays leave it -- take the learnt empty
+    feature.  Full BASELINE configs[1] size."""
+    r = _oracle_vs_hip(hip, n=1, v=2, H=192, W=640, C=64, Hd=64, nb=0, K=64, ids_render=[0], cfg=O.FieldConfig(learn_empty=True),
+                       hard_cap=True, intr=O.K_KITTIRAW, n_rays=None, seed=23, smooth=True)
+    _check(r)
+
+
 def test_white_noise_frames_vs_oracle(hip):
-    """Worst-case conditioning for the colour taps: iid-uniform pixels (|dI/dpx| up to 1) at W = 640.  A 1-ulp difference in the
-    projected x (6e-8) moves the tap by W/2 * 6e-8 = 2e-5 px, i.e. up to 2e-5 in colour per ulp."""
+    """Worst-case conditioning: iid pixels AND iid feature texels (slopes of order 1 per pixel) at W = 640.  The tap position
+    ix = ((x + 1) W - 1) / 2 carries ~4e-5 px of fp32 rounding in ANY implementation, so colours move by up to 2e-5 and the hidden
+    activations by ~1e-4 per ulp of x -- and alphas amplify that by delta exp(-delta sigma).  Colours and weights are still held to
+    1e-5 at 99.99 %; for the alphas the fp64 evaluation arbitrates: the HIP path may not have more samples beyond 1e-5 of the truth
+    than the fp32 reference restatement has (x 1.25)."""
     r = _oracle_vs_hip(hip, n=1, v=2, H=192, W=640, C=64, Hd=64, nb=0, K=64, ids_render=[0], cfg=O.FieldConfig(), hard_cap=True,
-                       intr=O.K_KITTIRAW, n_rays=40000, seed=22)
-    _check(r, min_ok=0.98)
+                       intr=O.K_KITTIRAW, n_rays=40000, seed=22, want_fp64=True)
+    _check(r, alpha_frac=1.0)
+    ok = ~r["flips"]
+    a_hip, a_ref, a_64 = r["a"][0][ok].double(), r["a"][1][ok].double(), r["a64"][ok]
+    n_hip, n_ref = int(((a_hip - a_64).abs() > ABS_TOL).sum()), int(((a_ref - a_64).abs() > ABS_TOL).sum())
+    print(f"alphas beyond 1e-5 of the fp64 evaluation: HIP {n_hip}, fp32 reference restatement {n_ref} of {a_64.numel()}")
+    assert n_hip <= 1.25 * n_ref + 10, (n_hip, n_ref)
+    assert (a_hip - a_64).abs().max().item() <= 1.5 * (a_ref - a_64).abs().max().item() + 1e-7
 
 
 def test_fp64_arbiter(hip):

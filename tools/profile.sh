@@ -1,15 +1,18 @@
 #!/bin/bash
-# rocprofv3 passes over the forward kernel on the BASELINE configs[1] workload.  Run on the GPU box via gpurun:
-#   gpurun -- bash tools/profile.sh <tag>
-# Writes raw output under gpurun_out/prof_<tag>/ ; copy the summaries you want judged into profiles/.
+# rocprofv3 passes over the render kernels.  Run on the GPU box via gpurun:
+#   gpurun -- bash tools/profile.sh <tag> [fwd|train]
+# fwd (default): tools/kernel_probe.py = the bench.py kernel (BASELINE configs[1]); train: tools/train_probe.py = configs[2] shapes.
+# Writes raw output under gpurun_out/prof_<tag>/ and a summary (traffic.json with the derived fractions bench.py reports);
+# copy what you want judged into profiles/<tag>/.  Counters are collected in separate --pmc passes with --kernel-trace only.
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
+MODE=${2:-fwd}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-CMD="python $REPO/tools/kernel_probe.py 3 proj__all"
+if [ "$MODE" = train ]; then CMD="python $REPO/tools/train_probe.py 16 3"; else CMD="python $REPO/tools/kernel_probe.py 5"; fi
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $CMD > $OUT/trace.log 2>&1 || tail -5 $OUT/trace.log
 for i in 0 1 2 3 4; do
   case $i in
@@ -21,27 +24,51 @@ for i in 0 1 2 3 4; do
   esac
   rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d $OUT/pmc$i -o pmc$i -- $CMD > $OUT/pmc$i.log 2>&1 || tail -5 $OUT/pmc$i.log
 done
-rocprofv3 -L > $OUT/counters.txt 2>&1
 cd $REPO
 find $OUT -type f ! -name "*.csv" ! -name "*.log" ! -name "*.txt" -delete
-du -sh $OUT; tail -3 $OUT/trace.log; find $OUT -name "*.csv" | head -30
+du -sh $OUT; tail -2 $OUT/trace.log
 python - <<PY
-import csv, glob, collections
-allc = {}
-for f in sorted(glob.glob("$OUT/**/*kernel_stats.csv", recursive=True)):
-    print("==", f)
-    for i, row in enumerate(csv.reader(open(f))):
-        if i < 8: print(row)
-for f in sorted(glob.glob("$OUT/**/*counter_collection.csv", recursive=True)):
-    agg = collections.defaultdict(list)
+import csv, glob, collections, json, re
+mode = "$MODE"
+# kernels of interest and their average duration (ns) from the stats pass
+dur = {}
+for f in sorted(glob.glob("$OUT/trace/**/*kernel_stats.csv", recursive=True)):
     for row in csv.DictReader(open(f)):
-        if "render_kernel" in row.get("Kernel_Name", ""):
-            agg[row["Counter_Name"]].append(float(row["Counter_Value"]))
-    print("==", f.split("/")[-3:], {k: sum(v) / len(v) for k, v in agg.items()}, "n=", {k: len(v) for k, v in agg.items()})
-    allc.update({k: sum(v) / len(v) for k, v in agg.items()})
-import json
-if "FETCH_SIZE" in allc and "WRITE_SIZE" in allc:
-    # rocprofv3 reports KB; on gfx950 FETCH_SIZE counts 64 B per 128-B request of a wide coalesced read -> doubled (MI355X_MICROARCH.md, HBM)
-    json.dump({"fetch_bytes": 2 * allc["FETCH_SIZE"] * 1024, "write_bytes": allc["WRITE_SIZE"] * 1024, "fetch_size_kb_raw": allc["FETCH_SIZE"],
-               "write_size_kb_raw": allc["WRITE_SIZE"], "counters": allc}, open("$OUT/traffic.json", "w"), indent=1)
+        dur[row["Name"]] = (float(row["AverageNs"]), int(row["Calls"]))
+        if len(dur) <= 10:
+            print(f"{float(row['AverageNs']) / 1e6:9.4f} ms x {row['Calls']:>4s}  {row['Name'][:110]}")
+pats = {"fwd": ["render_kernel_p"], "train": ["render_bwd_kernel", "scatter_dg_kernel", "render_kernel_p", "project_kernel", "project_bwd_feat_kernel",
+                                               "project_bwd_weight_kernel", "photometric_loss_kernel"]}[mode]
+per = {p: collections.defaultdict(list) for p in pats}
+for f in sorted(glob.glob("$OUT/pmc*/**/*counter_collection.csv", recursive=True)):
+    for row in csv.DictReader(open(f)):
+        for p in pats:
+            if p in row.get("Kernel_Name", ""):
+                per[p][row["Counter_Name"]].append(float(row["Counter_Value"]))
+summary = {}
+for p, agg in per.items():
+    c = {k: sum(v) / len(v) for k, v in agg.items()}
+    if not c:
+        continue
+    ns = next((d[0] for n, d in dur.items() if p in n), None)
+    s = {"counters": c, "kernel_ms_rocprof": None if ns is None else ns / 1e6}
+    if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+        # rocprofv3 reports KB; on gfx950 FETCH_SIZE counts 64 B per 128-B request of a wide coalesced read -> doubled (MI355X_MICROARCH.md, HBM)
+        s.update(fetch_bytes=2 * c["FETCH_SIZE"] * 1024, write_bytes=c["WRITE_SIZE"] * 1024, fetch_size_kb_raw=c["FETCH_SIZE"], write_size_kb_raw=c["WRITE_SIZE"])
+    if "SQ_WAVE_CYCLES" in c:
+        s.update(valu_busy=c.get("SQ_ACTIVE_INST_VALU", 0) / c["SQ_WAVE_CYCLES"], wait_frac=c.get("SQ_WAIT_ANY", 0) / c["SQ_WAVE_CYCLES"])
+    if ns and "SQ_VALU_MFMA_BUSY_CYCLES" in c:
+        s["mfma_busy"] = c["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * ns * 2.4)      # 1024 SIMDs x kernel cycles at 2.4 GHz
+    if "TCC_HIT_sum" in c and "TCC_MISS_sum" in c:
+        s["l2_hit"] = c["TCC_HIT_sum"] / max(c["TCC_HIT_sum"] + c["TCC_MISS_sum"], 1)
+    summary[p] = s
+    print(p, {k: (round(v, 4) if isinstance(v, float) else v) for k, v in s.items() if k != "counters"})
+if mode == "fwd" and "render_kernel_p" in summary:
+    s = summary["render_kernel_p"]
+    rays = 245760
+    s["valu_insts_per_ray"] = s["counters"].get("SQ_INSTS_VALU", 0) / rays
+    s["mfma_insts_per_ray"] = s["counters"].get("SQ_INSTS_MFMA", 0) / rays
+    json.dump(s, open("$OUT/traffic.json", "w"), indent=1)
+else:
+    json.dump(summary, open("$OUT/traffic_train.json", "w"), indent=1)
 PY
