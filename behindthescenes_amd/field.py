@@ -63,6 +63,11 @@ class BTSNet(nn.Module):
             self.empty_feature = nn.Parameter(torch.randn((self.encoder.latent_size,), requires_grad=True))
         self._scale = 0
         self._native = {}   # scale -> native.FieldTensors
+        self._proj_ms = None
+        # an encoder that can compose the feature half of lin_in into its last convolution hands the
+        # renderer its projected, channels-last map G directly (monodepth2.Monodepth2.forward_projected); `fused_handover: false`
+        # keeps the generic route (encoder -> F (NCHW) -> bts_project_features)
+        self.fused_handover = bool(conf.get("fused_handover", True)) and hasattr(self.encoder, "forward_projected")
         self.spec = native.FieldSpec(C=self.encoder.latent_size, d_hidden=self.mlp_coarse.d_hidden,
                                      n_blocks=self.mlp_coarse.n_blocks, num_freqs=self.code_xyz.num_freqs,
                                      freq_factor=self.code_xyz.freq_factor, d_min=float(self.d_min), d_max=float(self.d_max),
@@ -100,12 +105,25 @@ class BTSNet(nn.Module):
         do_flip = bool(self.flip_augmentation and self.training and (torch.rand(1) > .5).item())
         if do_flip:
             images_encoder = torch.flip(images_encoder, dims=(-1,))
-        image_latents_ms = self.encoder(images_encoder.reshape(n * nv_enc, c, h, w))
-        if do_flip:
-            image_latents_ms = [torch.flip(il, dims=(-1,)) for il in image_latents_ms]
-        _, _, h_, w_ = image_latents_ms[0].shape
-        image_latents_ms = [(il if il.shape[-2:] == (h_, w_) else F.interpolate(il, (h_, w_))).view(n, nv_enc, c_l, h_, w_)
-                            for il in image_latents_ms]
+        enc_in = images_encoder.reshape(n * nv_enc, c, h, w)
+        self._proj_ms = None
+        if self.fused_handover:
+            # G_s = F_s . w_in[:, :C]^T straight out of the decoder's last convolutions, channels-last (no F in HBM, no projection pass)
+            order = native.proj_storage_order(self.spec.d_hidden).to(images.device)
+            g_ms = self.encoder.forward_projected(enc_in, self.mlp_coarse.lin_in.weight[:, :c_l][order])
+            if do_flip:
+                g_ms = [torch.flip(g, dims=(2,)) for g in g_ms]
+            h_, w_ = g_ms[0].shape[1:3]
+            self._proj_ms = [(g if g.shape[1:3] == (h_, w_) else F.interpolate(g.permute(0, 3, 1, 2), (h_, w_)).permute(0, 2, 3, 1)).contiguous()
+                             for g in g_ms]
+            image_latents_ms = None    # the feature map itself is never materialised on this route
+        else:
+            image_latents_ms = self.encoder(enc_in)
+            if do_flip:
+                image_latents_ms = [torch.flip(il, dims=(-1,)) for il in image_latents_ms]
+            _, _, h_, w_ = image_latents_ms[0].shape
+            image_latents_ms = [(il if il.shape[-2:] == (h_, w_) else F.interpolate(il, (h_, w_))).view(n, nv_enc, c_l, h_, w_)
+                                for il in image_latents_ms]
 
         self.grid_f_features = image_latents_ms
         self.grid_f_Ks = Ks_encoder
@@ -139,8 +157,11 @@ class BTSNet(nn.Module):
         version = (self.mlp_coarse.lin_in.weight._version, torch.is_grad_enabled())
         hit = self._native.get(s)
         if hit is None or hit[1] != version:
-            f = self.grid_f_features[s][:, 0].float()              # (n, C, H, W)
-            proj = native.ProjectFunction.apply(f, self.mlp_coarse.packed(), self.spec)
+            if self._proj_ms is not None:                          # fused hand-over: G came out of the encoder
+                proj = self._proj_ms[s].float()
+            else:
+                f = self.grid_f_features[s][:, 0].float()          # (n, C, H, W)
+                proj = native.ProjectFunction.apply(f, self.mlp_coarse.packed(), self.spec)
             ft = native.FieldTensors(self.spec, proj, self._K_enc, self._w2c_enc, self._imgs_nhwc4, self._K_r, self._w2c_r,
                                      self.empty_feature if self.learn_empty else None)
             self._native[s] = (ft, version)

@@ -1,0 +1,229 @@
+"""``Monodepth2`` -- the reference's image encoder (ResNet + skip decoder emitting four scales of ``d_out``-channel features,
+models/common/backbones/monodepth2.py:71-302) with the reference's / torchvision's state-dict keys, so that reference checkpoints
+load unchanged:  ``encoder.encoder.{conv1,bn1,layer1..4.*,fc}``, ``decoder.decoder.{0..9}.conv.conv.{weight,bias}`` (the ten
+ConvBlocks, scale 4 down to 0) and ``decoder.decoder.{10..13}.conv.{weight,bias}`` (the per-scale output convolutions).
+
+The CNN is NOT part of the render path and stays PyTorch-ROCm (MIOpen) -- written here without torchvision, which the image lacks.
+What IS on the path is the hand-over: the renderer does not consume the feature map F but the projected
+map  G = F . w_in[:, :C]^T  in channels-last order.  F is the output of a 3x3 convolution and G a per-pixel linear map of it, so
+G is itself a 3x3 convolution of the decoder's last activation with the COMPOSED weights  W' = w_f . W_conv,  b' = w_f . b_conv:
+``forward_projected`` runs the network in ``torch.channels_last`` and lets that last convolution write G directly -- no F in HBM, no
+projection pass, no projection backward (autograd differentiates the composition, a 64 x 64 x 576 GEMM, for lin_in and the conv).
+"""
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# ResNet (parameter names of torchvision.models.resnet, which monodepth2.py:86-101 instantiates)
+# ---------------------------------------------------------------------------------------------------------------
+class BasicBlock(nn.Module):
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 3, stride, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.downsample = downsample
+
+    def forward(self, x):
+        identity = x if self.downsample is None else self.downsample(x)
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.bn2(self.conv2(out))
+        return self.relu(out + identity)
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride, 1, bias=False)      # stride on the 3x3 (torchvision's "v1.5")
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+
+    def forward(self, x):
+        identity = x if self.downsample is None else self.downsample(x)
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.relu(self.bn2(self.conv2(out)))
+        out = self.bn3(self.conv3(out))
+        return self.relu(out + identity)
+
+
+_RESNETS = {18: (BasicBlock, [2, 2, 2, 2]), 34: (BasicBlock, [3, 4, 6, 3]), 50: (Bottleneck, [3, 4, 6, 3]),
+            101: (Bottleneck, [3, 4, 23, 3]), 152: (Bottleneck, [3, 8, 36, 3])}
+
+
+class ResNet(nn.Module):
+    def __init__(self, block, layers, num_classes=1000):
+        super().__init__()
+        self.inplanes = 64
+        self.conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(3, 2, 1)
+        self.layer1 = self._make_layer(block, 64, layers[0])
+        self.layer2 = self._make_layer(block, 128, layers[1], 2)
+        self.layer3 = self._make_layer(block, 256, layers[2], 2)
+        self.layer4 = self._make_layer(block, 512, layers[3], 2)
+        self.avgpool = nn.AdaptiveAvgPool2d((1, 1))
+        self.fc = nn.Linear(512 * block.expansion, num_classes)     # unused by the encoder; present so that checkpoints load strictly
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1), nn.init.constant_(m.bias, 0)
+
+    def _make_layer(self, block, planes, blocks, stride=1):
+        downsample = None
+        if stride != 1 or self.inplanes != planes * block.expansion:
+            downsample = nn.Sequential(nn.Conv2d(self.inplanes, planes * block.expansion, 1, stride, bias=False),
+                                       nn.BatchNorm2d(planes * block.expansion))
+        layers = [block(self.inplanes, planes, stride, downsample)]
+        self.inplanes = planes * block.expansion
+        layers += [block(self.inplanes, planes) for _ in range(1, blocks)]
+        return nn.Sequential(*layers)
+
+
+class ResnetEncoder(nn.Module):
+    """monodepth2.py:71-107: five feature maps, strides 2..32."""
+
+    def __init__(self, num_layers, pretrained=False, num_input_images=1):
+        super().__init__()
+        if num_layers not in _RESNETS:
+            raise ValueError(f"{num_layers} is not a valid number of resnet layers")
+        if num_input_images != 1:
+            raise NotImplementedError("multi-image input is not used by BehindTheScenes")
+        block, layers = _RESNETS[num_layers]
+        self.encoder = ResNet(block, layers)
+        self.num_ch_enc = [64, 64, 128, 256, 512] if num_layers <= 34 else [64, 256, 512, 1024, 2048]
+        # `pretrained`: the reference downloads ImageNet weights here (monodepth2.py:258 passes True unconditionally); there is no
+        # network in this environment -- load them, or a BTS checkpoint, through load_state_dict (same keys).
+
+    def forward(self, input_image):
+        e = self.encoder
+        x = (input_image - 0.45) / 0.225
+        f0 = e.relu(e.bn1(e.conv1(x)))
+        f1 = e.layer1(e.maxpool(f0))
+        f2 = e.layer2(f1)
+        f3 = e.layer3(f2)
+        f4 = e.layer4(f3)
+        return [f0, f1, f2, f3, f4]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# decoder (models/common/model/layers.py:11-41, monodepth2.py:172-239)
+# ---------------------------------------------------------------------------------------------------------------
+class Conv3x3(nn.Module):
+    def __init__(self, in_channels, out_channels, use_refl=True):
+        super().__init__()
+        self.pad = nn.ReflectionPad2d(1) if use_refl else nn.ZeroPad2d(1)
+        self.conv = nn.Conv2d(int(in_channels), int(out_channels), 3)
+
+    def forward(self, x, weight=None, bias=None):
+        """weight / bias override the module's own (the composed projection weights of ``forward_projected``)."""
+        x = self.pad(x)
+        return self.conv(x) if weight is None else F.conv2d(x, weight, bias)
+
+
+class ConvBlock(nn.Module):
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.conv = Conv3x3(in_channels, out_channels)
+        self.nonlin = nn.ELU(inplace=True)
+
+    def forward(self, x):
+        return self.nonlin(self.conv(x))
+
+
+class Decoder(nn.Module):
+    def __init__(self, num_ch_enc, num_ch_dec=None, d_out=1, scales=range(4), use_skips=True):
+        super().__init__()
+        self.use_skips, self.num_ch_enc, self.d_out, self.scales = use_skips, list(num_ch_enc), d_out, list(scales)
+        num_ch_dec = [128, 128, 256, 256, 512] if num_ch_dec is None else list(num_ch_dec)
+        self.num_ch_dec = [max(d_out, c) for c in num_ch_dec]
+        convs, keys = [], {}
+        for i in range(4, -1, -1):
+            cin = self.num_ch_enc[-1] if i == 4 else self.num_ch_dec[i + 1]
+            keys[("upconv", i, 0)] = len(convs)
+            convs.append(ConvBlock(cin, self.num_ch_dec[i]))
+            cin = self.num_ch_dec[i] + (self.num_ch_enc[i - 1] if use_skips and i > 0 else 0)
+            keys[("upconv", i, 1)] = len(convs)
+            convs.append(ConvBlock(cin, self.num_ch_dec[i]))
+        for s in self.scales:
+            keys[("dispconv", s)] = len(convs)
+            convs.append(Conv3x3(self.num_ch_dec[s], d_out))
+        self.decoder_keys = keys
+        self.decoder = nn.ModuleList(convs)
+
+    def trunk(self, input_features):
+        """The activations feeding the per-scale output convolutions: {scale: (N, num_ch_dec[scale], h, w)}."""
+        feats, x = {}, input_features[-1]
+        for i in range(4, -1, -1):
+            x = self.decoder[self.decoder_keys[("upconv", i, 0)]](x)
+            x = [F.interpolate(x, scale_factor=(2, 2), mode="nearest")]
+            if self.use_skips and i > 0:
+                skip = input_features[i - 1]
+                x[0] = x[0][:, :, :skip.shape[2], :skip.shape[3]]
+                x.append(skip)
+            x = self.decoder[self.decoder_keys[("upconv", i, 1)]](torch.cat(x, 1))
+            if i in self.scales:
+                feats[i] = x
+        return feats
+
+    def forward(self, input_features):
+        feats = self.trunk(input_features)
+        return {("disp", s): self.decoder[self.decoder_keys[("dispconv", s)]](feats[s]) for s in self.scales}
+
+
+class Monodepth2(nn.Module):
+    def __init__(self, resnet_layers=18, cp_location=None, freeze=False, num_ch_dec=None, d_out=128, scales=range(4), pretrained=True):
+        super().__init__()
+        self.encoder = ResnetEncoder(resnet_layers, pretrained, 1)
+        self.num_ch_enc = self.encoder.num_ch_enc
+        self.d_out, self.scales = d_out, list(scales)
+        self.decoder = Decoder(num_ch_enc=self.num_ch_enc, d_out=d_out, num_ch_dec=num_ch_dec, scales=self.scales)
+        self.num_ch_dec = self.decoder.num_ch_dec
+        self.latent_size = d_out
+        if cp_location is not None:
+            self.load_state_dict(torch.load(cp_location, map_location="cpu")["model"])
+        if freeze:
+            for p in self.parameters(True):
+                p.requires_grad = False
+
+    def _trunk(self, x):
+        x = (x * .5 + .5).contiguous(memory_format=torch.channels_last)     # MIOpen NHWC kernels; the outputs come out channels-last
+        return self.decoder.trunk(self.encoder(x))
+
+    def forward(self, x):
+        """images (B, 3, H, W) in [-1, 1] -> [features (B, d_out, H / 2^s, W / 2^s) for s in scales]  (monodepth2.py:279-291)."""
+        feats = self._trunk(x)
+        return [self.decoder.decoder[self.decoder.decoder_keys[("dispconv", s)]](feats[s]) for s in self.scales]
+
+    def forward_projected(self, x, w_rows):
+        """The renderer's hand-over fused into the decoder tail: w_rows (R, d_out) -- the feature columns of lin_in in the
+        renderer's storage order -- composed into each scale's output convolution.  -> [G_s (B, h_s, w_s, R) channels-last
+        CONTIGUOUS for s in scales], G_s = F_s . w_rows^T with F_s what forward() returns.  Differentiable w.r.t. everything."""
+        feats = self._trunk(x)
+        out = []
+        for s in self.scales:
+            conv = self.decoder.decoder[self.decoder.decoder_keys[("dispconv", s)]]
+            w = torch.einsum("rc,cikl->rikl", w_rows, conv.conv.weight)
+            b = w_rows @ conv.conv.bias
+            g = conv(feats[s], w.contiguous(memory_format=torch.channels_last), b)
+            out.append(g.permute(0, 2, 3, 1))          # channels-last storage -> (B, h, w, R), a contiguous view
+        return out
+
+    @classmethod
+    def from_conf(cls, conf, **kw):
+        return cls(cp_location=conf.get("cp_location", None), freeze=conf.get("freeze", False), num_ch_dec=conf.get("num_ch_dec", None),
+                   d_out=conf.get("d_out", 128), resnet_layers=conf.get("resnet_layers", 18), pretrained=conf.get("pretrained", True))

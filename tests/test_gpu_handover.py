@@ -1,0 +1,75 @@
+"""GPU: the encoder hand-over with the shipped Monodepth2 encoder: the fused route -- the decoder's
+last convolution writes the projected channels-last map G itself -- against the generic route (feature map F in NCHW ->
+bts_project_features), forward and backward, with and without flip augmentation, all four scales."""
+import copy
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import behindthescenes_amd as bts
+    from behindthescenes_amd import _lib
+    assert torch.cuda.is_available()
+    _lib.load()
+    return bts
+
+
+def _conf(fused, flip):
+    return dict(code=dict(num_freqs=6, freq_factor=1.5, include_input=True),
+                encoder=dict(type="monodepth2", resnet_layers=18, num_ch_dec=[32, 32, 64, 128, 256], d_out=64, pretrained=False),
+                mlp_coarse=dict(type="resnet", n_blocks=0, d_hidden=64), mlp_fine=dict(type="empty"), z_near=3, z_far=80, inv_z=True,
+                learn_empty=False, code_mode="z", flip_augmentation=flip, fused_handover=fused)
+
+
+@pytest.mark.parametrize("flip", [False, True])
+def test_fused_handover_matches_the_generic_route(hip, flip):
+    from behindthescenes_amd import synthetic as S
+    torch.manual_seed(5)
+    n, v, H, W, K = 2, 3, 64, 96, 16
+    net_f = hip.BTSNet(_conf(True, flip))
+    S.init_mlp_(net_f.mlp_coarse, seed=3)
+    for m in net_f.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.1), m.running_var.uniform_(0.5, 1.5)
+    net_g = hip.BTSNet(_conf(False, flip))
+    net_g.load_state_dict(copy.deepcopy(net_f.state_dict()))
+    assert net_f.fused_handover and not net_g.fused_handover
+    # train(): flip augmentation is live; the batch-norm layers use batch statistics in both nets alike
+    net_f, net_g = net_f.cuda().train(), net_g.cuda().train()
+    scene = S.synthetic_scene(n, v, H, W, 64, seed=9, intrinsics=S.K_KITTI360, smooth=True)
+    images, projs, poses = scene["images"].cuda(), scene["projs"].cuda(), scene["poses"].cuda()
+    renderer = hip.NeRFRenderer(n_coarse=K, lindisp=True, hard_alpha_cap=True).cuda()
+    sampler = hip.PatchRaySampler(ray_batch_size=256, z_near=3.0, z_far=80.0, patch_size=8)
+    torch.manual_seed(77)
+    rays, _ = sampler.sample(images[:, :1] * .5 + .5, poses[:, :1], projs[:, :1])
+    z = renderer.sample_coarse(rays.reshape(-1, 8), torch.rand(rays.shape[0] * rays.shape[1], K, device="cuda"))
+    c_rgb = torch.randn(rays.shape[0] * rays.shape[1], 6, device="cuda")
+    outs, grads = [], []
+    for net in (net_f, net_g):
+        net.zero_grad(set_to_none=True)
+        torch.manual_seed(123)                         # the flip decision comes from the CPU generator (models_bts.py:96)
+        net.encode(images, projs, poses, ids_encoder=[0], ids_render=[1, 2])
+        total, per_scale = 0.0, []
+        for s in range(4):                             # trainer.py:220-242: one render per scale
+            net.set_scale(s)
+            w, rgb, depth, *_ = renderer.composite(net, rays.reshape(-1, 8), z, sb=n)
+            per_scale.append((rgb.detach(), depth.detach(), w.detach()))
+            total = total + (rgb * c_rgb).sum() + 0.05 * depth.sum()
+        total.backward()
+        outs.append(per_scale)
+        head = net.encoder.decoder.decoder[net.encoder.decoder.decoder_keys[("dispconv", 0)]].conv
+        grads.append([net.mlp_coarse.lin_in.weight.grad, net.mlp_coarse.lin_out.weight.grad, head.weight.grad, head.bias.grad,
+                      net.encoder.encoder.encoder.conv1.weight.grad,
+                      net.encoder.decoder.decoder[net.encoder.decoder.decoder_keys[("dispconv", 3)]].conv.weight.grad])
+    assert net_f.grid_f_features is None and net_g.grid_f_features is not None
+    for s, (a, b) in enumerate(zip(*outs)):
+        for x, y, tol in zip(a, b, (1e-5, 1e-4, 1e-5)):
+            assert (x - y).abs().max().item() <= tol * max(1.0, y.abs().max().item()), (s, (x - y).abs().max().item())
+    for i, (a, b) in enumerate(zip(*grads)):
+        assert a is not None and b is not None, i
+        err = (a - b).abs().max().item() / b.abs().max().item()
+        assert err <= 2e-4, (i, err)

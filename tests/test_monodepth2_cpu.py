@@ -1,0 +1,79 @@
+"""CPU: the shipped Monodepth2 encoder (behindthescenes_amd/monodepth2.py): state-dict layout of the reference / torchvision so that
+reference checkpoints load, numerical identity with the reference's own Decoder (when the reference tree is present), and the fused
+hand-over: forward_projected(x, w) == forward(x) . w^T without ever forming F."""
+import pytest
+import torch
+
+import behindthescenes_amd as bts
+from behindthescenes_amd.monodepth2 import Decoder, Monodepth2
+
+KITTI360_MODEL_CONF = dict(   # configs/exp_kitti_360.yaml model_conf (the keys BTSNet reads)
+    arch="BTSNet", use_code=True, prediction_mode="default",
+    code=dict(num_freqs=6, freq_factor=1.5, include_input=True),
+    encoder=dict(type="monodepth2", freeze=False, pretrained=True, resnet_layers=50, num_ch_dec=[32, 32, 64, 128, 256], d_out=64),
+    mlp_coarse=dict(type="resnet", n_blocks=0, d_hidden=64), mlp_fine=dict(type="empty", n_blocks=1, d_hidden=128),
+    z_near=3, z_far=80, inv_z=True, n_frames_encoder=1, n_frames_render=2, frame_sample_mode="kitti360-mono", sample_mode="patch",
+    patch_size=8, ray_batch_size=4096, flip_augmentation=True, learn_empty=False, code_mode="z")
+
+
+def test_btsnet_builds_from_the_shipped_kitti360_config_with_reference_state_dict_keys():
+    net = bts.BTSNet(KITTI360_MODEL_CONF)
+    assert isinstance(net.encoder, Monodepth2) and net.encoder.latent_size == 64 and list(net.encoder.scales) == [0, 1, 2, 3]
+    assert net.fused_handover
+    sd = net.state_dict()
+    for k in ("encoder.encoder.encoder.conv1.weight", "encoder.encoder.encoder.bn1.running_mean", "encoder.encoder.encoder.layer1.0.conv3.weight",
+              "encoder.encoder.encoder.layer1.0.downsample.0.weight", "encoder.encoder.encoder.layer4.2.bn3.weight", "encoder.encoder.encoder.fc.weight",
+              "encoder.decoder.decoder.0.conv.conv.weight", "encoder.decoder.decoder.9.conv.conv.bias", "encoder.decoder.decoder.10.conv.weight",
+              "encoder.decoder.decoder.13.conv.bias", "code_xyz._freqs", "code_xyz._phases", "mlp_coarse.lin_in.weight", "mlp_coarse.lin_out.bias"):
+        assert k in sd, k
+    # ResNet-50 of torchvision: 25 557 032 parameters; decoder of this config: channels [64, 64, 64, 128, 256] (max(d_out, num_ch_dec))
+    assert sum(p.numel() for p in net.encoder.encoder.encoder.parameters()) == 25557032
+    assert net.encoder.num_ch_dec == [64, 64, 64, 128, 256] and net.encoder.num_ch_enc == [64, 256, 512, 1024, 2048]
+    assert sd["encoder.decoder.decoder.0.conv.conv.weight"].shape == (256, 2048, 3, 3)          # upconv 4, 0
+    assert sd["encoder.decoder.decoder.9.conv.conv.weight"].shape == (64, 64, 3, 3)             # upconv 0, 1 (no skip at scale 0)
+    assert sd["encoder.decoder.decoder.10.conv.weight"].shape == (64, 64, 3, 3) and sd["encoder.decoder.decoder.13.conv.weight"].shape == (64, 128, 3, 3)
+    assert sum(p.numel() for p in bts.BTSNet(dict(KITTI360_MODEL_CONF, encoder=dict(type="monodepth2", resnet_layers=18, d_out=64))
+                                             ).encoder.encoder.encoder.parameters()) == 11689512
+
+
+def test_forward_shapes_and_fused_handover_equals_projection_of_the_feature_map():
+    torch.manual_seed(0)
+    enc = Monodepth2(resnet_layers=18, num_ch_dec=[32, 32, 64, 128, 256], d_out=64).eval()
+    for m in enc.modules():   # make the batch-norm statistics non-trivial
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.1), m.running_var.uniform_(0.5, 1.5)
+    x = torch.rand(2, 3, 64, 96) * 2 - 1
+    w = torch.randn(64, 64) * 0.2
+    with torch.no_grad():
+        feats = enc(x)
+        proj = enc.forward_projected(x, w)
+    assert [tuple(f.shape) for f in feats] == [(2, 64, 64 >> s, 96 >> s) for s in range(4)]
+    for f, g in zip(feats, proj):
+        assert g.shape == (f.shape[0], f.shape[2], f.shape[3], 64) and g.is_contiguous()
+        want = torch.einsum("nchw,rc->nhwr", f, w)
+        assert (g - want).abs().max().item() <= 2e-5 * want.abs().max().item()
+    # gradients reach the projection rows and the composed convolution alike
+    x.requires_grad_(False)
+    w2 = w.clone().requires_grad_(True)
+    enc.forward_projected(x, w2)[0].square().mean().backward()
+    head = enc.decoder.decoder[enc.decoder.decoder_keys[("dispconv", 0)]].conv
+    assert w2.grad is not None and head.weight.grad is not None and float(w2.grad.abs().sum()) > 0 and float(head.weight.grad.abs().sum()) > 0
+
+
+@pytest.mark.needs_reference
+def test_decoder_matches_the_reference_decoder_bit_for_bit():
+    from oracle.ref_shim import load_reference
+    load_reference()
+    from models.common.backbones.monodepth2 import Decoder as RefDecoder
+    import numpy as np
+    torch.manual_seed(1)
+    num_ch_enc = np.array([64, 64, 128, 256, 512])
+    ref = RefDecoder(num_ch_enc=num_ch_enc, d_out=64, num_ch_dec=[32, 32, 64, 128, 256], scales=range(4))
+    ours = Decoder(num_ch_enc=list(num_ch_enc), d_out=64, num_ch_dec=[32, 32, 64, 128, 256], scales=range(4))
+    assert list(ours.state_dict().keys()) == list(ref.state_dict().keys())
+    ours.load_state_dict(ref.state_dict())
+    feats = [torch.randn(2, c, 32 >> i, 48 >> i) for i, c in enumerate(num_ch_enc)]
+    with torch.no_grad():
+        a, b = ours(feats), ref([f.clone() for f in feats])
+    for s in range(4):
+        assert torch.equal(a[("disp", s)], b[("disp", s)]), s
