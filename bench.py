@@ -131,8 +131,8 @@ def train_workload(args, world, rank, dev):
     (64 patches of 8x8) per sample, 64 samples per ray.  One step = the renderer's share of `trainer.py:208-259` + backward: encode
     hand-over (no CNN), PatchRaySampler.sample, G = project(F), render with saved activations and every output the trainer asks for
     (weights, alphas, rgb_samps), reconstruct, the photometric loss (l1+ssim, weight-guided invalid mask, edge-aware smoothness: one
-    HIP pass incl. its gradient), backward through bts_render_bwd and bts_project_features_bwd (MLP and feature-map gradients), and
-    under N > 1 the all-reduce of the MLP gradient (the only exchange of the path; the CNN's DDP bucket is not part of it)."""
+    HIP pass incl. its gradient), backward through bts_render_bwd and bts_project_features_bwd (MLP and feature-map gradients); under
+    N > 1 the task is wrapped in DistributedDataParallel (parallel.wrap_ddp) and the gradient all-reduce is DDP's own RCCL bucket."""
     import behindthescenes_amd as bts
     from behindthescenes_amd import native, parallel, synthetic as S
     n, Vt, Kt, NV = 16, 8, 64, 4
@@ -162,18 +162,35 @@ def train_workload(args, world, rank, dev):
     wrapped = renderer.bind_parallel(net).train()
     crit = bts.ReconstructionLoss({"criterion": "l1+ssim", "invalid_policy": "weight_guided", "lambda_edge_aware_smoothness": 0.001})
 
-    def step():   # trainer.py:208-259 after the CNN, then base_trainer.py:297
+    class Task(torch.nn.Module):
+        """trainer.py:208-259 after the CNN, as ONE module so that DistributedDataParallel wraps it exactly as idist.auto_model wraps
+        the reference's BTSWrapper (trainer.py:418): the gradient all-reduce of its parameters (MLP + feature maps here; + the CNN in
+        a real run) is DDP's bucketed RCCL all-reduce, overlapped with the backward."""
+
+        def __init__(self):
+            super().__init__()
+            self.wrapped = wrapped
+
+        def forward(self, images, projs, poses):
+            images_ip = images * .5 + .5
+            net.encode(images, projs, poses, ids_encoder=[0], ids_render=ids_render, images_alt=images_ip)
+            all_rays, all_rgb_gt = sampler.sample(images_ip[:, :4], poses[:, :4], projs[:, :4])       # ids_loss = first four frames
+            rd = self.wrapped(all_rays, want_weights=True, want_alphas=True, want_rgb_samps=True)
+            rd["fine"] = dict(rd["coarse"])
+            rd["rgb_gt"], rd["rays"] = all_rgb_gt, all_rays
+            rd = sampler.reconstruct(rd)
+            return crit(dict(coarse=[rd["coarse"]], fine=[rd["fine"]], rgb_gt=rd["rgb_gt"]))[0]
+
+    task = Task()
+    # the stand-in feature maps are per-sample DATA (what the CNN would output), not shared weights: their gradient stays on the rank
+    # (in a real run it flows on into the local CNN backward); the all-reduce carries the MLP here and MLP + CNN in a real run
+    torch.nn.parallel.DistributedDataParallel._set_params_and_buffers_to_ignore_for_model(
+        task, [k for k, _ in task.named_parameters() if ".encoder.feats." in k])
+    model = parallel.wrap_ddp(task, dev)
+
+    def step():   # base_trainer.py:287-297
         net.zero_grad(set_to_none=True)
-        images_ip = images * .5 + .5
-        net.encode(images, projs, poses, ids_encoder=[0], ids_render=ids_render, images_alt=images_ip)
-        all_rays, all_rgb_gt = sampler.sample(images_ip[:, :4], poses[:, :4], projs[:, :4])       # ids_loss = first four frames
-        rd = wrapped(all_rays, want_weights=True, want_alphas=True, want_rgb_samps=True)
-        rd["fine"] = dict(rd["coarse"])
-        rd["rgb_gt"], rd["rays"] = all_rgb_gt, all_rays
-        rd = sampler.reconstruct(rd)
-        loss, _ = crit(dict(coarse=[rd["coarse"]], fine=[rd["fine"]], rgb_gt=rd["rgb_gt"]))
-        loss.backward()
-        parallel.all_reduce_mean_([p.grad for p in net.mlp_coarse.parameters() if p.grad is not None])
+        model(images, projs, poses).backward()
 
     for _ in range(args.warmup):
         step()
