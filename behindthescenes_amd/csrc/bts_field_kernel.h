@@ -60,6 +60,7 @@ struct FwdParams {
   unsigned long long* dbg;  // probe builds only: per-wave section cycle counters (bit 128 of ablate)
   int ablate;    // probe builds only (-DBTS_PROBE): bit mask of kernel sections to skip (tools/ablate_probe.py)
   int lpr;       // lanes per ray: 8, 16, 32 or 64 (>= min(K, 64)); 64 / lpr rays share one wave iteration
+  int chunk_log2;  // pipelined kernel: ray groups per chunk of the XCD interleave (log2), see render_kernel_p
   long groups;   // number of ray groups (= n * Bp * lpr / 64)
 };
 

@@ -93,6 +93,11 @@ int render_fwd_impl(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const BtsR
 #endif
   render_geometry(p, cfg->n);
   const int grid = render_grid(p);
+  {  // chunk = twice the waves an XCD runs at once (one round of the resident waves covers half a chunk), at least 64 groups
+    int waves_per_xcd = grid / 8 * 4, l = 6;
+    while ((1 << l) < 2 * waves_per_xcd) ++l;
+    p.chunk_log2 = l;
+  }
 #ifdef BTS_PROBE
   if (p.proj && getenv("BTS_RENDER_V1")) return launch_render<true>(p, cfg->C, cfg->d_hidden, cfg->n_blocks, grid, s);  // compact lane = sample kernel
 #endif

@@ -354,13 +354,17 @@ __device__ __forceinline__ void hidden_layer_h(f32x16 (&out)[1][2], const f32x16
 template <int HD, int R>
 __device__ __forceinline__ void region_seq(f32x16 (&acc)[HD / 32][2], GBuf& ba, GBuf& bb, const float4* __restrict__ G,
                                            const int (&o)[2][4], const float (&wq)[2][4], int h, const float* wf, int term_stride,
-                                           SinCos3& raw, const float (&v3)[3], float ff, const f32x16* bias) {
+                                           SinCos3& raw, const float (&v3)[3], float ff, const f32x16* bias, bool nosin = false,
+                                           bool nomfma = false) {
   constexpr int HT = HD / 32;
   constexpr int NS = 4 * HT;
   if constexpr (R < 3) {
     constexpr int NE = R == 0 ? 14 : (R == 1 ? 13 : 12);   // + raw x, y (region 0) / raw depth code (region 1) in the spare k rows
     float e[NE];
-    {
+    if (nosin) {   // probe builds only: no trigonometry
+#pragma unroll
+      for (int i = 0; i < 12; ++i) e[i] = v3[i % 3] * ff;
+    } else {
       float t[6];
       pe_entries(t, raw, v3, ff);
 #pragma unroll
@@ -373,8 +377,19 @@ __device__ __forceinline__ void region_seq(f32x16 (&acc)[HD / 32][2], GBuf& ba, 
     }
     if constexpr (R == 0) e[12] = v3[0], e[13] = v3[1];
     if constexpr (R == 1) e[12] = v3[2];
-    if constexpr (R + 1 < 3) pe_direct(raw, v3, ff * 4.0f);
-    f16_region<HD, NE, R == 0>(acc, wf + R * HT * 256, term_stride, e, bias);
+    if constexpr (R + 1 < 3) {
+      if (!nosin) pe_direct(raw, v3, ff * 4.0f);
+    }
+    if (nomfma) {  // probe builds only: no split, no MFMAs
+#pragma unroll
+      for (int i = 0; i < NE; ++i) acc[0][0][i] += e[i];
+      if constexpr (R == 0) {
+#pragma unroll
+        for (int ht = 0; ht < HT; ++ht) acc[ht][0] += bias[ht], acc[ht][1] = bias[ht];
+      }
+    } else {
+      f16_region<HD, NE, R == 0>(acc, wf + R * HT * 256, term_stride, e, bias);
+    }
     if constexpr (2 * R < NS) {
       stage_blend<HD, 2 * R>(acc, ba, wq);
       if constexpr (2 * R + 2 < NS) stage_load<HD, 2 * R + 2>(ba, G, o, h);
@@ -384,7 +399,7 @@ __device__ __forceinline__ void region_seq(f32x16 (&acc)[HD / 32][2], GBuf& ba, 
 #ifdef BTS_REGION_BARRIER   // one scheduling region per encoding region: was needed against spills in r01c, costs 3 % now (r01g A/B)
     __builtin_amdgcn_sched_barrier(0);
 #endif
-    region_seq<HD, R + 1>(acc, ba, bb, G, o, wq, h, wf, term_stride, raw, v3, ff * 4.0f, bias);
+    region_seq<HD, R + 1>(acc, ba, bb, G, o, wq, h, wf, term_stride, raw, v3, ff * 4.0f, bias, nosin, nomfma);
   }
 }
 
@@ -610,8 +625,18 @@ __global__ __launch_bounds__(256, 2) void render_kernel_p(const FwdParams p) {
   const int waves_per_xcd = wg_per_xcd * 4;
   const int lpr = ONE_RAY ? 64 : p.lpr, R = 64 / lpr;
   const int kl = lane & (lpr - 1);
-  const long gx = (p.groups + 7) >> 3;
-  const long g_end = min(p.groups, (xcd + 1) * gx);
+  // Work distribution.  Ray groups are cut into chunks of 2^chunk_log2 consecutive groups; chunk c belongs to XCD c % 8, and the
+  // waves of an XCD walk its chunks in order (consecutive waves = consecutive rays, so the texel footprints of the waves resident
+  // on an XCD still overlap in its L2).  Round 1 gave every XCD ONE contiguous eighth of the rays: with the two stereo views of
+  // eval_depth in one launch, XCDs 0-3 got the encoder camera's own rays (0.56 ms for all of them alone) and XCDs 4-7 the partner's
+  // (0.86 ms alone) -- the launch took 1.69 ms, the slower half's 2 x 0.86, instead of 1.42.
+  const int CHL = p.chunk_log2;
+  const long n_chunks = (p.groups + (1L << CHL) - 1) >> CHL;
+  auto group_of = [&](long idx) -> long {   // idx-th group of this XCD's chunk list, or -1 past the end
+    const long c = ((idx >> CHL) << 3) + xcd;
+    const long gg = (c << CHL) + (idx & ((1L << CHL) - 1));
+    return (c < n_chunks && gg < p.groups) ? gg : -1L;
+  };
   const int Bp = p.Bp, K = p.K, H = p.H, W = p.W, nv = p.nv;
   const float b_out = as_const(p.mlp)[MlpLayout{C + kPeDim, HD, NB}.b_out()];
   const int lane_off0 = h0 * HD + (lane & 31);
@@ -622,18 +647,24 @@ __global__ __launch_bounds__(256, 2) void render_kernel_p(const FwdParams p) {
   unsigned long long t_last = __builtin_readcyclecounter();
   const unsigned long long t_begin = t_last;
 #endif
-  long g = xcd * gx + lw;
+  const long groups_per_sample = Bp / R;   // Bp % R == 0 (render_geometry)
+  long sample_end = groups_per_sample;
+  int sample = 0;
+  long idx = lw;
+  long g = group_of(idx);
   // z of the first ray group
   float z_pre = 0.0f, zn_pre = 0.0f;
-  if (g < g_end) {
+  if (g >= 0) {
     const float* zr = p.z_samp + (g * R + lane / lpr) * K;
     const int kk = min(kl, K - 1);
     z_pre = zr[kk], zn_pre = zr[min(kk + 1, K - 1)];
   }
 
-  for (; g < g_end; g += waves_per_xcd) {
+  for (; g >= 0; idx += waves_per_xcd, g = group_of(idx)) {
     const long ray = g * R + lane / lpr;
-    const int sample = __builtin_amdgcn_readfirstlane((int)((g * R) / Bp));  // all rays of a group belong to one batch element
+    // all rays of a group belong to one batch element; g only grows along a wave's chunk list, so the element is tracked by a
+    // running boundary (the 64-bit division this replaces was ~140 dependent scalar instructions at the top of every iteration)
+    while (g >= sample_end) ++sample, sample_end += groups_per_sample;
     const Cam enc = load_cam(p.w2c_enc + sample * 16, p.K_enc + sample * 9);
     const float4* __restrict__ G = reinterpret_cast<const float4*>(p.proj) + (long)sample * H * W * (HD / 4);
     float ox, oy, oz, dx, dy, dz;
@@ -648,8 +679,8 @@ __global__ __launch_bounds__(256, 2) void render_kernel_p(const FwdParams p) {
     const float* zrow = p.z_samp + ray * K;
     float z_cur = z_pre, zn_cur = zn_pre;
     {  // prefetch the next group's samples; they land while this group is evaluated
-      const long gn = g + waves_per_xcd;
-      if (gn < g_end) {
+      const long gn = group_of(idx + waves_per_xcd);
+      if (gn >= 0) {
         const float* zr = p.z_samp + (gn * R + lane / lpr) * K;
         const int kk = min(kl, K - 1);
         z_pre = zr[kk], zn_pre = zr[min(kk + 1, K - 1)];
@@ -770,7 +801,7 @@ __global__ __launch_bounds__(256, 2) void render_kernel_p(const FwdParams p) {
         __builtin_amdgcn_sched_barrier(0);
         int lane4 = lane * 4;
         asm volatile("" : "+v"(lane4));  // keep the A-operand reads inside the loop (see lane_off above)
-        region_seq<HD, 0>(acc, ba, bb, G, o, wq, h, lh + LH::W_F16 + lane4, LH::TERM_STRIDE, raw, v3, p.freq_factor, bias);
+        region_seq<HD, 0>(acc, ba, bb, G, o, wq, h, lh + LH::W_F16 + lane4, LH::TERM_STRIDE, raw, v3, p.freq_factor, bias, nosin, nomfma);
       } else {
         const float* wl = lds + L::W_IN + lane_off;
         kstep_first<HD>(acc, wl, 0, v3[0], v3[1]);

@@ -21,15 +21,21 @@ rays = bts.ImageRaySampler(3.0, 80.0, H, W).sample(None, scene["poses"].cuda(), 
 z = native.sample_coarse(rays, torch.rand(rays.shape[0], K, device="cuda"), True)
 dbg = torch.zeros(512 * 4 * 8, dtype=torch.int64, device="cuda")
 os.environ["BTS_DBG_PTR"] = str(dbg.data_ptr())
-for extra in (0,):
-    os.environ["BTS_ABLATE"] = str(128 | extra)
-    for _ in range(2):
-        dbg.zero_()
-        native.render_fwd(ft, params, rays, z, hard_alpha_cap=True, want_weights=True, want_alphas=True, want_invalid=True)
-        torch.cuda.synchronize()
-    d = dbg.view(-1, 8).double().cpu()
-    d = d[d[:, 6] > 0]
-    iters = rays.shape[0] / d.shape[0]
-    per = d[:, :6].mean(0) / iters
-    print(f"ablate={extra}: waves {d.shape[0]}, iterations/wave {iters:.1f}, wave lifetime {d[:,6].mean():.0f} cyc (s_memtime ticks @100MHz?)")
-    print("   cycles per iteration by section:", " ".join(f"{x:8.1f}" for x in per.tolist()), " sum", f"{per.sum():.1f}")
+half = rays.shape[0] // 2
+sets = {"both": (rays, z), "view0": (rays[:half].contiguous(), z[:half].contiguous()), "view1": (rays[half:].contiguous(), z[half:].contiguous())}
+for name, (r_, z_) in sets.items():
+    for extra in ((0, 2, 4, 1, 2 | 4 | 1) if name != "both" else (0,)):
+        os.environ["BTS_ABLATE"] = str(128 | extra)
+        for _ in range(2):
+            dbg.zero_()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            native.render_fwd(ft, params, r_, z_, hard_alpha_cap=True, want_weights=True, want_alphas=True, want_invalid=True)
+            e1.record()
+            torch.cuda.synchronize()
+        d = dbg.view(-1, 8).double().cpu()
+        d = d[d[:, 6] > 0]
+        iters = r_.shape[0] / d.shape[0]
+        per = d[:, :6].mean(0) / iters
+        print(f"{name} ablate={extra}: {e0.elapsed_time(e1):.3f} ms, waves {d.shape[0]}, iterations/wave {iters:.1f}, wave lifetime {d[:,6].mean():.0f} ticks (max {d[:,6].max():.0f})")
+        print("   ticks per iteration by section:", " ".join(f"{x:8.1f}" for x in per.tolist()), " sum", f"{per.sum():.1f}")
