@@ -192,6 +192,14 @@ __global__ __launch_bounds__(256, 1) void render_bwd_kernel(const BwdParams bp) 
     // ---------------- colours of this sample -> g_w = sum_j g_rgb_j . c_kj + g_depth z_k (+ g_weights_k)
     float g_w = g_depth * z + g_bkgd;
     if (bp.g_weights && active) g_w += bp.g_weights[ray * K + k];
+    if (p.rgb_samps) {
+      // the forward's per-sample colours, when the caller kept them (training asks for rgb_samps anyway): 12 B per view instead of a
+      // projection, four taps and a blend per view
+      const float* cs = p.rgb_samps + (ray * K + k) * (long)(nv * 3);
+#pragma unroll
+      for (int j = 0; j < NVMAX; ++j)
+        if (j < nv) g_w += g_rgb[3 * j] * cs[3 * j] + g_rgb[3 * j + 1] * cs[3 * j + 1] + g_rgb[3 * j + 2] * cs[3 * j + 2];
+    } else
 #pragma unroll
     for (int j = 0; j < NVMAX; ++j) {
       if (j < nv) {
@@ -737,6 +745,7 @@ int render_bwd_impl(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const BtsR
   bp.f.rays = a->rays, bp.f.z_samp = a->z_samp;
   bp.f.Bp = a->rays_per_sample, bp.f.K = a->K, bp.f.hard_cap = a->hard_alpha_cap, bp.f.white_bkgd = a->white_bkgd;
   bp.f.sigma_raw = a->sigma_raw, bp.f.trans = a->trans;
+  bp.f.rgb_samps = a->rgb_samps;   // optional INPUT here: the forward's per-sample colours (else they are recomputed)
   bp.f.tiles_per_sample = (a->rays_per_sample + 255) / 256;
   bp.g_rgb = g->g_rgb, bp.g_depth = g->g_depth, bp.g_weights = g->g_weights, bp.g_alphas = g->g_alphas;
   bp.d_proj = g->d_proj_nhwc, bp.d_mlp = g->d_mlp_params, bp.d_empty_proj = g->d_empty_proj;

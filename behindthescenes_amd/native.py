@@ -329,7 +329,7 @@ def render_fwd(ft: FieldTensors, mlp_params: torch.Tensor, rays: torch.Tensor, z
 
 
 def render_bwd(ft: FieldTensors, mlp_params, rays, z_samp, sigma_raw, trans, *, hard_alpha_cap, g_rgb=None, g_depth=None,
-               g_weights=None, g_alphas=None, need_proj=True, need_mlp=True, need_empty=False, white_bkgd=False):
+               g_weights=None, g_alphas=None, need_proj=True, need_mlp=True, need_empty=False, white_bkgd=False, rgb_samps=None):
     """Returns (d_proj_nhwc | None, d_mlp_params | None, d_empty_proj | None) (bts_render_bwd)."""
     B, K = z_samp.shape
     for name, g in (("g_rgb", g_rgb), ("g_depth", g_depth), ("g_weights", g_weights), ("g_alphas", g_alphas)):
@@ -341,7 +341,9 @@ def render_bwd(ft: FieldTensors, mlp_params, rays, z_samp, sigma_raw, trans, *, 
     d_mlp = torch.zeros(ft.spec.mlp_param_count(), device=dev, dtype=torch.float32) if need_mlp else None
     d_empty = torch.zeros(ft.spec.d_hidden, device=dev, dtype=torch.float32) if need_empty else None
     cfg, tens = ft.cfg(), ft.tensors(mlp_params)
-    args = _render_args(ft, rays, z_samp, hard_alpha_cap, white_bkgd, dict(sigma_raw=sigma_raw, trans=trans))
+    if rgb_samps is not None:
+        _req(rgb_samps, "rgb_samps", (B, K, ft.nv * 3))
+    args = _render_args(ft, rays, z_samp, hard_alpha_cap, white_bkgd, dict(sigma_raw=sigma_raw, trans=trans, rgb_samps=rgb_samps))
 
     def dp(t):
         return None if t is None else t.data_ptr()
@@ -423,7 +425,8 @@ class RenderFunction(torch.autograd.Function):
                          want_saved=needs_grad)
         ctx.ft, ctx.hard_alpha_cap, ctx.white_bkgd = ft, hard_alpha_cap, white_bkgd
         if needs_grad:
-            ctx.save_for_backward(mlp_params, rays, z_samp, out["sigma_raw"], out["trans"])
+            # rgb_samps is non-differentiable output the caller asked for: kept for the backward too (it then skips the colour taps)
+            ctx.save_for_backward(mlp_params, rays, z_samp, out["sigma_raw"], out["trans"], *([out["rgb_samps"]] if want_rgb_samps else []))
         empty = rays.new_empty(0)
         res = (out["rgb"], out["depth"], out["weights"] if want_weights else empty, out["alphas"] if want_alphas else empty,
                out["invalid"], out["rgb_samps"] if want_rgb_samps else empty)
@@ -433,7 +436,8 @@ class RenderFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_rgb, g_depth, g_weights, g_alphas, _g_inv, _g_rs):
-        mlp_params, rays, z_samp, sigma_raw, trans = ctx.saved_tensors
+        mlp_params, rays, z_samp, sigma_raw, trans, *rest = ctx.saved_tensors
+        rgb_samps = rest[0] if rest else None
 
         def prep(g, present=True):
             return g.contiguous() if (g is not None and present and g.numel() > 0) else None
@@ -441,7 +445,7 @@ class RenderFunction(torch.autograd.Function):
         ft = ctx.ft
         need_proj, need_mlp, need_empty = ctx.needs_input_grad[:3]
         d_proj, d_mlp, d_eproj = render_bwd(ft, mlp_params, rays, z_samp, sigma_raw, trans, hard_alpha_cap=ctx.hard_alpha_cap,
-                                            g_rgb=prep(g_rgb), g_depth=prep(g_depth), g_weights=prep(g_weights, ctx.has[0]), white_bkgd=ctx.white_bkgd,
+                                            g_rgb=prep(g_rgb), g_depth=prep(g_depth), g_weights=prep(g_weights, ctx.has[0]), white_bkgd=ctx.white_bkgd, rgb_samps=rgb_samps,
                                             g_alphas=prep(g_alphas, ctx.has[1]), need_proj=need_proj, need_mlp=need_mlp,
                                             need_empty=need_empty or (need_mlp and ft.spec.learn_empty))
         d_empty = None

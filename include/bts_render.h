@@ -119,7 +119,9 @@ int64_t bts_mlp_param_count(const BtsFieldCfg* cfg);
  * PositionalEncoding.forward (nerf.py:210-313, models_bts.py:138-338, resnetfc.py:132-184, code.py:30-42). */
 int bts_render_fwd(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const BtsRenderArgs* a, void* stream);
 
-/* Backward of bts_render_fwd.  `a` must carry sigma_raw written by the forward (weights/alphas are not needed).
+/* Backward of bts_render_fwd.  `a` must carry sigma_raw and trans written by the forward (weights/alphas are not needed).  When
+ * a->rgb_samps is non-NULL it is READ here: the forward's per-sample colours, which spare the backward one projection + four taps
+ * per view and sample (training requests rgb_samps anyway); NULL = recompute them.
  * workspace: bts_render_bwd_workspace(cfg, a) bytes of device scratch (rays x K x d_hidden floats, rounded up to groups of 64
  * rays: the gradient rows handed from the per-ray pass to the per-texel scatter pass); contents need no initialisation. */
 size_t bts_render_bwd_workspace(const BtsFieldCfg* cfg, const BtsRenderArgs* a);

@@ -27,7 +27,7 @@ def _rel_to_max(a, b):
     return ((a - b).abs().max() / b.abs().max().clamp_min(1e-20)).item()
 
 
-def _hip_grads(hip, net, renderer, rays, z, sb, loss_fn):
+def _hip_grads(hip, net, renderer, rays, z, sb, loss_fn, want_rgb_samps=True):
     params = [net.mlp_coarse.lin_in.weight, net.mlp_coarse.lin_in.bias]
     for blk in net.mlp_coarse.blocks:
         params += [blk.fc_0.weight, blk.fc_0.bias, blk.fc_1.weight, blk.fc_1.bias]
@@ -36,13 +36,15 @@ def _hip_grads(hip, net, renderer, rays, z, sb, loss_fn):
         params.append(net.empty_feature)
     for p in params:
         p.grad = None
-    w, rgb, depth, a, inv, _, rs = renderer.composite(net, rays, z, sb=sb)
+    # want_rgb_samps: the backward then reads the forward's per-sample colours instead of re-tapping the colour frames
+    w, rgb, depth, a, inv, _, rs = renderer.composite(net, rays, z, sb=sb, want_rgb_samps=want_rgb_samps)
     loss_fn(w, rgb, depth, a).backward()
     return [p.grad for p in params]
 
 
+@pytest.mark.parametrize("keep_colours", [True, False])
 @pytest.mark.parametrize("name", ["kitti_train", "re10k_train"])
-def test_gradients_vs_reference_golden(hip, name):
+def test_gradients_vs_reference_golden(hip, name, keep_colours):
     """kitti_train: lin_in -> lin_out; re10k_train: one ResnetBlockFC in between (fc_0 / fc_1 weight and bias gradients too)."""
     from tests._hip_helpers import net_from_case
     c = Case(name)
@@ -51,7 +53,7 @@ def test_gradients_vs_reference_golden(hip, name):
     renderer = hip.NeRFRenderer(n_coarse=c.meta["K"], lindisp=True, hard_alpha_cap=c.hard_cap).cuda()
     g_rgb, g_depth = c.t["gin_rgb"].cuda(), c.t["gin_depth"].cuda()
     grads = _hip_grads(hip, net, renderer, c.rays.reshape(-1, 8).cuda(), c.z_samp.cuda(), c.rays.shape[0],
-                       lambda w, rgb, depth, a: (rgb * g_rgb).sum() + (depth * g_depth).sum())
+                       lambda w, rgb, depth, a: (rgb * g_rgb).sum() + (depth * g_depth).sum(), want_rgb_samps=keep_colours)
     nb = c.meta["nb"]
     names = ["g_w_in", "g_b_in"] + sum([[f"g_blk{i}_w0", f"g_blk{i}_b0", f"g_blk{i}_w1", f"g_blk{i}_b1"] for i in range(nb)], []) \
         + ["g_w_out", "g_b_out", "g_feat"]
