@@ -14,22 +14,10 @@
 // The feature-map / w_in[:, :C] gradients follow from dG in bts_prep.hip (per-pixel GEMMs).
 //
 // What torch.autograd would do for nerf.py:283-299 + models_bts.py:266-338 + resnetfc.py:132-184 of the reference.
-#include "bts_field_kernel.h"
+#include "bts_bwd.h"
 #include <cstdlib>
 
 namespace bts {
-
-struct BwdParams {
-  FwdParams f;            // field + rays (+ sigma_raw, trans as inputs)
-  const float* g_rgb;     // (B, nv*3)
-  const float* g_depth;   // (B)
-  const float* g_weights; // (B, K)
-  const float* g_alphas;  // (B, K)
-  float* d_proj;          // (n,H,W,HD)
-  float* d_mlp;           // packed
-  float* d_empty_proj;    // (HD)
-  float* gh_ws;           // (groups, K, 64, HD) g_h rows for the dG scatter pass, or null: scatter with direct atomics
-};
 
 template <int HD, int NB>
 struct BwdLds {
@@ -55,10 +43,6 @@ struct BwdLds {
   static constexpr int TILE_STRIDE = ((TAP + 64 * 8 + 3) & ~3) + 4;
   static constexpr int TOTAL = TILES + 4 * TILE_STRIDE;
 };
-
-__device__ __forceinline__ void atomic_add_f32(float* p, float v) {
-  __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 
 // dW[i][j] += sum over the wave's 64 points of A[p][i] * B[p][j], both operands staged as [point][channel] LDS tiles (k-step s pairs
 // points s and s + 32); i, j < 32: one 32x32 accumulator tile
@@ -714,11 +698,22 @@ static int launch_bwd(const BwdParams& bp, int grid, hipStream_t s) {
 }
 
 FwdParams make_params(const BtsFieldCfg* cfg, const BtsFieldTensors* t);
+int render_grid(const FwdParams& p);
+int render_chunk_log2(int grid);
+int launch_bwd_rows(const BwdParams& bp, int C, int HD, int n, int grid, hipStream_t s);
 
-// workspace = the g_h rows between the two passes: groups of 64 rays x K x 64 x d_hidden floats
+// plain MLP and at most one wave of samples per ray: the lane = sample passes of bts_bwd_rows.hip; ResnetBlockFC layers (RE10K) and
+// K > 64 keep the lane = ray pass of this file
+static bool rows_path(const BtsFieldCfg* cfg, const BtsRenderArgs* a) { return cfg->n_blocks == 0 && a->K <= 64; }
+
+// workspace = the rows between the passes.  lane = ray path: groups of 64 rays x K x 64 x d_hidden floats (g_h); lane = sample path:
+// rays x K x d_hidden (u = relu(h) g_s) + rays x K (g_s).  The larger of the two, so that either path can serve the call.
 size_t render_bwd_workspace_impl(const BtsFieldCfg* cfg, const BtsRenderArgs* a) {
   const size_t groups = (size_t)cfg->n * ((a->rays_per_sample + 255) / 256) * 4;
-  return groups * (size_t)a->K * 64 * (size_t)cfg->d_hidden * sizeof(float);
+  const size_t v1 = groups * (size_t)a->K * 64 * (size_t)cfg->d_hidden * sizeof(float);
+  const size_t rays = (size_t)cfg->n * (size_t)a->rays_per_sample;
+  const size_t v2 = ((rays + 64) * (size_t)a->K * (size_t)cfg->d_hidden + rays * (size_t)a->K) * sizeof(float);   // rows padded by 64 rays
+  return v1 > v2 ? v1 : v2;
 }
 
 template <int HD>
@@ -754,7 +749,24 @@ int render_bwd_impl(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const BtsR
 #else
   constexpr bool direct = false;
 #endif
+#ifdef BTS_PROBE
+  static const bool v1 = getenv("BTS_BWD_V1") != nullptr;   // A/B (probe build): the lane = ray pass for every shape
+#else
+  constexpr bool v1 = false;
+#endif
+  if (rows_path(cfg, a) && !direct && !v1 && bp.f.proj) {
+    bp.f.lpr = 64, bp.f.groups = (long)cfg->n * a->rays_per_sample;
+    const int grid = render_grid(bp.f);
+    bp.f.chunk_log2 = render_chunk_log2(grid);
+    bp.gh_ws = static_cast<float*>(workspace);
+    bp.gs_ws = bp.gh_ws + ((size_t)cfg->n * a->rays_per_sample + 64) * a->K * cfg->d_hidden;
+    const int rc = launch_bwd_rows(bp, cfg->C, cfg->d_hidden, cfg->n, grid, s);
+    if (rc != BTS_E_UNSUPPORTED) return rc;
+    set_error("%s: unsupported MLP shape C=%ld d_hidden=%ld n_blocks=%ld", "bts_render_bwd", cfg->C, cfg->d_hidden, cfg->n_blocks);
+    return rc;
+  }
   bp.gh_ws = (bp.d_proj && !direct) ? static_cast<float*>(workspace) : nullptr;
+  bp.gs_ws = nullptr;
   const int grid = bp.f.tiles_per_sample * cfg->n;
   int rc = BTS_E_UNSUPPORTED;
   if (cfg->C == 64 && cfg->d_hidden == 64 && cfg->n_blocks == 0) rc = launch_bwd<64, 64, 0>(bp, grid, s);

@@ -1,0 +1,850 @@
+// Backward of the fused renderer, lane = SAMPLE form: three passes for the plain MLP (no ResnetBlockFC layers) with K <= 64.
+//
+// The round-1 backward (bts_bwd.hip) walks 64 rays per wave back to front, lane = ray: 392 registers and 138 KB of LDS tiles pin it at one
+// wave per SIMD with every latency exposed (1.5 ms of the 2.3 ms backward at 65 536 x 64).  Here the work is cut along the data
+// instead:
+//   pass A  rows_kernel      one ray per wave iteration, lane = sample -- the FORWARD's pipeline (f16-split lin_in on the matrix pipe,
+//                            gather blended between the encoding regions, 2 waves / SIMD), so h and with it every relu gate is
+//                            bit-identical to what the forward evaluated.  The compositing gradient is a suffix scan across the
+//                            lanes.  Output per sample: g_s (the gradient at the pre-softplus density) and the row
+//                            u[ch] = relu(h[ch]) * g_s in G's channel order, straight from the accumulator registers
+//                            (16 contiguous channels per lane and tile: 64-byte pieces, no LDS transposition).
+//   pass B  scatter_rows_kernel   one wave per 8x8 patch (64 rays), lane = channel: g_h = [u != 0] w_out g_s, tap updates merged per
+//                            texel in a sliding LDS window (as scatter_dg_kernel), plus the three sums that need no second operand:
+//                            dw_out = sum u, db_out = sum g_s, d_empty = sum over empty-feature points of g_h.
+//   pass C  dwpe_kernel      dW_pe^T[ch][kin] = sum_p [u != 0] w_out[ch] * (g_s pe)[p][kin]: one ray per wave iteration, the A operand
+//                            read straight from the rows (lanes 0-31 / 32-63 = 128-byte pieces of two rows), the encoding recomputed
+//                            lane = sample, scaled by g_s and transposed through a per-wave LDS tile.
+// u instead of g_h in the rows lets pass B produce dw_out (which needs relu(h)) without pass A holding gradient accumulators.
+// What torch.autograd would do for nerf.py:283-299 + models_bts.py:266-338 + resnetfc.py:132-184 of the reference.
+#define BTS_NO_LAUNCH_GLUE
+#include "bts_render_kernel.h"
+#include "bts_bwd.h"
+#include <cstdlib>
+
+namespace bts {
+
+// exclusive suffix sum over the wave: out[l] = sum_{m > l} x[m]
+__device__ __forceinline__ float wave_suffix_excl(float x, int lane) {
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const float y = __shfl_down(x, off, 64);
+    x += (lane + off < 64) ? y : 0.0f;
+  }
+  const float s = __shfl_down(x, 1, 64);
+  return lane == 63 ? 0.0f : s;
+}
+
+// u rows of one accumulator set: acc[ht][pt][i] is channel ht*32 + 16h + i (storage order of G) of point pt*32 + (lane & 31)
+template <int HD>
+__device__ __forceinline__ void store_rows(const f32x16 (&acc)[HD / 32][2], const float (&gs_t)[2], float* __restrict__ urow, int K, int lane) {
+  const int h = lane >> 5, col = lane & 31;
+#pragma unroll
+  for (int pt = 0; pt < 2; ++pt) {
+    const int pnt = pt * 32 + col;
+    if (pnt < K) {
+#pragma unroll
+      for (int ht = 0; ht < HD / 32; ++ht) {
+        float4* dst = reinterpret_cast<float4*>(urow + (long)pnt * HD + ht * 32 + 16 * h);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          dst[j] = make_float4(relu1(acc[ht][pt][4 * j + 0]) * gs_t[pt], relu1(acc[ht][pt][4 * j + 1]) * gs_t[pt],
+                               relu1(acc[ht][pt][4 * j + 2]) * gs_t[pt], relu1(acc[ht][pt][4 * j + 3]) * gs_t[pt]);
+      }
+    }
+  }
+}
+
+// Cold path of pass A (see eval_point_exact): some sample's encoding argument leaves the fast sincos range.  The forward evaluated
+// this ray with eval_point (fp32-input MFMAs, libm sines); the same here, rows written from inside so that no accumulator array
+// crosses the call.
+template <int C, int HD>
+__device__ __attribute__((noinline)) void rows_exact(const float* lds, const float4* G, const float* w2c, const float* Kc, int H, int W,
+                                                     int code_mode, int inv_z, float inv_dmax, float inv_range, float d_min, float range,
+                                                     float freq_factor, int learn_empty, float px, float py, float pz, float gs,
+                                                     float* urow, int K) {
+  using L = Lds<C, HD, 0, true>;
+  constexpr int HT = HD / 32;
+  const int lane = threadIdx.x & 63, h = lane >> 5;
+  const Cam enc = load_cam(w2c, Kc);
+  const Proj pe = code_mode == 1 ? project<true>(enc, px, py, pz) : project<false>(enc, px, py, pz);
+  const Taps tp = make_taps(pe.x, pe.y, H, W);
+  float v3[3];
+  v3[0] = pe.x, v3[1] = pe.y;
+  v3[2] = depth_code(code_mode == 1 ? pe.dist : pe.z, inv_z != 0, inv_dmax, inv_range, d_min, range);
+  const bool use_empty = (learn_empty != 0) & pe.invalid;
+  f32x16 acc[HT][2];
+#pragma unroll
+  for (int ht = 0; ht < HT; ++ht)
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt) acc[ht][pt] = zero_acc();
+  int o[2][4];
+  float wq[2][4];
+  bool emp[2];
+  unsigned t0, t1;
+  bcast_tiles((unsigned)tp.o00, t0, t1), o[0][0] = (int)t0, o[1][0] = (int)t1;
+  bcast_tiles((unsigned)tp.o01, t0, t1), o[0][1] = (int)t0, o[1][1] = (int)t1;
+  bcast_tiles((unsigned)tp.o10, t0, t1), o[0][2] = (int)t0, o[1][2] = (int)t1;
+  bcast_tiles((unsigned)tp.o11, t0, t1), o[0][3] = (int)t0, o[1][3] = (int)t1;
+  bcast_tiles(__float_as_uint(tp.w00), t0, t1), wq[0][0] = __uint_as_float(t0), wq[1][0] = __uint_as_float(t1);
+  bcast_tiles(__float_as_uint(tp.w01), t0, t1), wq[0][1] = __uint_as_float(t0), wq[1][1] = __uint_as_float(t1);
+  bcast_tiles(__float_as_uint(tp.w10), t0, t1), wq[0][2] = __uint_as_float(t0), wq[1][2] = __uint_as_float(t1);
+  bcast_tiles(__float_as_uint(tp.w11), t0, t1), wq[0][3] = __uint_as_float(t0), wq[1][3] = __uint_as_float(t1);
+  bcast_tiles(use_empty ? 1u : 0u, t0, t1), emp[0] = t0 != 0, emp[1] = t1 != 0;
+  {
+    GBuf ga, gb;
+    gload<HD>(ga, G, o[0], 0, 4 * h);
+    gather_seq<HD, 0>(acc, ga, gb, G, o, wq, h);
+  }
+  if (learn_empty && __any(use_empty)) apply_empty<HD>(acc, emp, lds + L::EMPTY, h);
+  const float* wl = lds + L::W_IN + h * HD + (lane & 31);
+  kstep<HD>(acc, wl, 0, v3[0], v3[1]);
+  kstep<HD>(acc, wl + 2 * HD, 0, v3[2], 1.0f);
+  wl += 4 * HD;
+  float ff = freq_factor;
+#pragma unroll 1
+  for (int oct = 0; oct < kNumFreqs; ++oct) {
+    float sc[6];
+    pe_octave(sc, v3, ff);
+    kstep<HD>(acc, wl, 0, sc[0], sc[1]);
+    kstep<HD>(acc, wl + 2 * HD, 0, sc[2], sc[3]);
+    kstep<HD>(acc, wl + 4 * HD, 0, sc[4], sc[5]);
+    wl += 6 * HD;
+    ff = ff * 2.0f;
+  }
+  float gs_t[2];
+  bcast_tiles(__float_as_uint(gs), t0, t1);
+  gs_t[0] = __uint_as_float(t0), gs_t[1] = __uint_as_float(t1);
+  store_rows<HD>(acc, gs_t, urow, K, lane);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// pass A
+// ---------------------------------------------------------------------------------------------------------------
+template <int C, int HD, int NVMAX>
+__global__ __launch_bounds__(256, 2) void rows_kernel(const BwdParams bp) {
+  const FwdParams& p = bp.f;
+  using L = Lds<C, HD, 0, true>;
+  using LH = LdsH<C, HD, 0>;
+  constexpr int HT = HD / 32;
+  constexpr int NS = 4 * HT;
+  __shared__ __attribute__((aligned(16))) float lds[L::TOTAL + LH::TOTAL + 4];
+  float* const lh = lds + ((L::TOTAL + 3) & ~3);
+  stage_weights<C, HD, 0, true>(lds, p.mlp, p.empty_feature);
+  __syncthreads();
+  stage_weights_h<C, HD, 0>(lh, lds, p.mlp);
+  __syncthreads();
+  const float scale = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, lh[LH::SCALE])));
+  const float inv_scale = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, lh[LH::SCALE + 1])));
+
+  const int lane = threadIdx.x & 63;
+  const int h0 = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nwg = gridDim.x;  // multiple of 8
+  const int wg = xcd_remap(blockIdx.x, nwg);
+  const int wg_per_xcd = nwg >> 3;
+  const int xcd = wg / wg_per_xcd;
+  const int lw = (wg - xcd * wg_per_xcd) * 4 + wave;
+  const int waves_per_xcd = wg_per_xcd * 4;
+  // chunk-interleaved ray distribution over the XCDs, as render_kernel_p (one group = one ray here)
+  const int CHL = p.chunk_log2;
+  const long n_chunks = (p.groups + (1L << CHL) - 1) >> CHL;
+  auto group_of = [&](long idx) -> long {
+    const long c = ((idx >> CHL) << 3) + xcd;
+    const long gg = (c << CHL) + (idx & ((1L << CHL) - 1));
+    return (c < n_chunks && gg < p.groups) ? gg : -1L;
+  };
+  const int Bp = p.Bp, K = p.K, H = p.H, W = p.W, nv = p.nv;
+  const int k = lane;
+  const bool valid = k < K;
+  const int kk = valid ? k : K - 1;
+  const bool last = k == K - 1;
+
+  long sample_end = Bp;
+  int sample = 0;
+  long idx = lw;
+  long g = group_of(idx);
+  float z_pre = 0.0f, zn_pre = 0.0f, s_pre = 0.0f, t_pre = 0.0f;
+  if (g >= 0) {
+    const long pk = g * K + kk;
+    z_pre = p.z_samp[pk], zn_pre = p.z_samp[g * K + min(kk + 1, K - 1)];
+    s_pre = p.sigma_raw[pk], t_pre = p.trans[pk];
+  }
+
+  for (; g >= 0; idx += waves_per_xcd, g = group_of(idx)) {
+    const long ray = g;
+    while (g >= sample_end) ++sample, sample_end += Bp;
+    const Cam enc = load_cam(p.w2c_enc + sample * 16, p.K_enc + sample * 9);
+    const float4* __restrict__ G = reinterpret_cast<const float4*>(p.proj) + (long)sample * H * W * (HD / 4);
+    const cfp rp = as_const(p.rays) + ray * 8;
+    const float ox = rp[0], oy = rp[1], oz = rp[2], dx = rp[3], dy = rp[4], dz = rp[5];
+    const float z = z_pre, z_nx = zn_pre, s_raw = s_pre, T = t_pre;
+    {  // the next ray's per-sample state lands while this ray is evaluated
+      const long gn = group_of(idx + waves_per_xcd);
+      if (gn >= 0) {
+        const long pk = gn * K + kk;
+        z_pre = p.z_samp[pk], zn_pre = p.z_samp[gn * K + min(kk + 1, K - 1)];
+        s_pre = p.sigma_raw[pk], t_pre = p.trans[pk];
+      }
+    }
+    int lane_off = h0 * HD + (lane & 31), h = h0;
+    asm volatile("" : "+v"(lane_off), "+v"(h));   // keep the weight reads inside the persistent loop (see render_kernel_p)
+    const float px = ox + z * dx, py = oy + z * dy, pz = oz + z * dz;
+    const long pk = ray * K + kk;
+
+    // ---------------- upstream gradient of this sample's weight: g_w = g_depth z + sum_j g_rgb_j . c_kj (+ g_weights_k)
+    float g_w = 0.0f;
+    {
+      const cfp gr = as_const(bp.g_rgb) + ray * (long)(nv * 3);
+      float g_rgb[NVMAX * 3];
+      float g_bkgd = 0.0f;
+#pragma unroll
+      for (int i = 0; i < NVMAX * 3; ++i) {
+        g_rgb[i] = (bp.g_rgb && i < nv * 3) ? gr[i] : 0.0f;
+        g_bkgd -= g_rgb[i];
+      }
+      if (bp.g_depth) g_w = as_const(bp.g_depth)[ray] * z;
+      if (p.white_bkgd) g_w += g_bkgd;   // nerf.py:301-304: rgb = sum_k w_k c_k + 1 - sum_k w_k
+      if (bp.g_weights) g_w += bp.g_weights[pk];
+      if (p.rgb_samps) {
+        const float* cs = p.rgb_samps + pk * (long)(nv * 3);
+#pragma unroll
+        for (int j = 0; j < NVMAX; ++j)
+          if (j < nv) g_w += g_rgb[3 * j] * cs[3 * j] + g_rgb[3 * j + 1] * cs[3 * j + 1] + g_rgb[3 * j + 2] * cs[3 * j + 2];
+      } else {
+#pragma unroll
+        for (int j = 0; j < NVMAX; ++j) {
+          if (j < nv) {
+            const Cam cj = load_cam(p.w2c_r + ((long)sample * nv + j) * 16, p.K_r + ((long)sample * nv + j) * 9);
+            const Proj pc = project<false>(cj, px, py, pz);
+            const Taps tc = make_taps(pc.x, pc.y, H, W);
+            const float4* img = reinterpret_cast<const float4*>(p.imgs) + ((long)sample * nv + j) * H * W;
+            const float4 a = img[tc.o00], b = img[tc.o01], cc = img[tc.o10], d = img[tc.o11];
+            const float c0 = ((a.x * tc.w00 + b.x * tc.w01) + cc.x * tc.w10) + d.x * tc.w11;
+            const float c1 = ((a.y * tc.w00 + b.y * tc.w01) + cc.y * tc.w10) + d.y * tc.w11;
+            const float c2 = ((a.z * tc.w00 + b.z * tc.w01) + cc.z * tc.w10) + d.z * tc.w11;
+            g_w += g_rgb[3 * j] * c0 + g_rgb[3 * j + 1] * c1 + g_rgb[3 * j + 2] * c2;
+          }
+        }
+      }
+    }
+
+    // ---------------- encoder view
+    const Proj pe = p.code_mode == 1 ? project<true>(enc, px, py, pz) : project<false>(enc, px, py, pz);
+    Taps tp = make_taps(pe.x, pe.y, H, W);
+    float v3[3];
+    v3[0] = pe.x, v3[1] = pe.y;
+    v3[2] = depth_code(p.code_mode == 1 ? pe.dist : pe.z, p.inv_z != 0, p.inv_dmax, p.inv_range, p.d_min, p.range);
+    const bool use_empty = (p.learn_empty != 0) & pe.invalid;
+    if (use_empty) tp.w00 = tp.w01 = tp.w10 = tp.w11 = 0.0f;
+    tp.w00 *= scale, tp.w01 *= scale, tp.w10 *= scale, tp.w11 *= scale;
+
+    // ---------------- compositing gradient (nerf.py:283-299):  g_alpha_k = g_w_k T_k - (sum_{m>k} g_w_m w_m) / (1 - alpha_k + 1e-10)
+    float g_s = 0.0f;
+    {
+      float sigma = softplus(s_raw);
+      const bool dead = (p.empty_empty != 0) & pe.invalid;   // sigma forced to 0: no gradient
+      if (dead) sigma = 0.0f;
+      const float delta = last ? 1e10f : (z_nx - z);
+      const float ex = expf(-fabsf(delta) * fmaxf(sigma, 0.0f));
+      const bool capped = (p.hard_cap != 0) & last;
+      const float alpha = capped ? 1.0f : 1.0f - ex;
+      const float S = wave_suffix_excl(valid ? g_w * (alpha * T) : 0.0f, lane);
+      float g_alpha = g_w * T - S / (capped ? 1e-10f : ex + 1e-10f);
+      if (bp.g_alphas) g_alpha += bp.g_alphas[pk];
+      if (!capped && !dead && valid) g_s = g_alpha * fabsf(delta) * ex * (s_raw > 20.0f ? 1.0f : sigmoidf(s_raw));
+      if (valid) bp.gs_ws[pk] = g_s;
+    }
+    float* __restrict__ urow = bp.gh_ws + ray * (long)K * HD;
+
+    if (__builtin_expect(__any(pe_needs_exact(v3, p.freq_factor)), 0)) {
+      rows_exact<C, HD>(lds, G, p.w2c_enc + sample * 16, p.K_enc + sample * 9, H, W, p.code_mode, p.inv_z, p.inv_dmax, p.inv_range, p.d_min,
+                        p.range, p.freq_factor, p.learn_empty, px, py, pz, g_s, urow, K);
+      continue;
+    }
+
+    // ---------------- h = bilinear(G) + W_pe . PE + b, exactly as render_kernel_p evaluates it (accumulators carry 2^S)
+    int o[2][4];
+    float wq[2][4];
+    bool emp[2];
+    {
+      unsigned t0, t1;
+      bcast_tiles((unsigned)tp.o00, t0, t1), o[0][0] = (int)t0, o[1][0] = (int)t1;
+      bcast_tiles((unsigned)tp.o01, t0, t1), o[0][1] = (int)t0, o[1][1] = (int)t1;
+      bcast_tiles((unsigned)tp.o10, t0, t1), o[0][2] = (int)t0, o[1][2] = (int)t1;
+      bcast_tiles((unsigned)tp.o11, t0, t1), o[0][3] = (int)t0, o[1][3] = (int)t1;
+      bcast_tiles(__float_as_uint(tp.w00), t0, t1), wq[0][0] = __uint_as_float(t0), wq[1][0] = __uint_as_float(t1);
+      bcast_tiles(__float_as_uint(tp.w01), t0, t1), wq[0][1] = __uint_as_float(t0), wq[1][1] = __uint_as_float(t1);
+      bcast_tiles(__float_as_uint(tp.w10), t0, t1), wq[0][2] = __uint_as_float(t0), wq[1][2] = __uint_as_float(t1);
+      bcast_tiles(__float_as_uint(tp.w11), t0, t1), wq[0][3] = __uint_as_float(t0), wq[1][3] = __uint_as_float(t1);
+      bcast_tiles(use_empty ? 1u : 0u, t0, t1), emp[0] = t0 != 0, emp[1] = t1 != 0;
+    }
+    f32x16 acc[HT][2];
+    {
+      GBuf ba, bb;
+      stage_load<HD, 0>(ba, G, o, h);
+      stage_load<HD, 1>(bb, G, o, h);
+      f32x16 bias[HT];
+      {
+        const float* bl = lh + LH::W_RAW + 3 * HD + 4 * h;
+#pragma unroll
+        for (int ht = 0; ht < HT; ++ht)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float4 v = *reinterpret_cast<const float4*>(bl + ht * 32 + 8 * j);
+            bias[ht][4 * j + 0] = v.x, bias[ht][4 * j + 1] = v.y, bias[ht][4 * j + 2] = v.z, bias[ht][4 * j + 3] = v.w;
+          }
+      }
+      SinCos3 raw;
+      pe_direct(raw, v3, p.freq_factor);
+      __builtin_amdgcn_sched_barrier(0);
+      int lane4 = lane * 4;
+      asm volatile("" : "+v"(lane4));
+      region_seq<HD, 0>(acc, ba, bb, G, o, wq, h, lh + LH::W_F16 + lane4, LH::TERM_STRIDE, raw, v3, p.freq_factor, bias);
+      if constexpr (NS > kNumFreqs) {
+        stage_blend<HD, 6>(acc, ba, wq);
+        stage_blend<HD, 7>(acc, bb, wq);
+      }
+    }
+    if (p.learn_empty && __any(use_empty)) {
+#pragma unroll
+      for (int ht = 0; ht < HT; ++ht)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const float ev = lh[LH::EMPTY + ht * 32 + mfma_row(q, 0) + 4 * h];
+#pragma unroll
+          for (int pt = 0; pt < 2; ++pt) acc[ht][pt][q] += emp[pt] ? ev : 0.0f;
+        }
+    }
+
+    // ---------------- rows: u = relu(h) g_s (2^S removed through g_s)
+    float gs_t[2];
+    {
+      unsigned t0, t1;
+      bcast_tiles(__float_as_uint(g_s * inv_scale), t0, t1);
+      gs_t[0] = __uint_as_float(t0), gs_t[1] = __uint_as_float(t1);
+    }
+    store_rows<HD>(acc, gs_t, urow, K, lane);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// pass B: dG scatter (the sliding LDS window of scatter_dg_kernel) + dw_out, db_out, d_empty
+// ---------------------------------------------------------------------------------------------------------------
+struct RowsScatterParams {
+  FwdParams f;
+  const float* u_ws;    // (n*Bp, K, HD)
+  const float* gs_ws;   // (n*Bp, K)
+  float* d_proj;        // or null: only the sums
+  float* d_mlp;         // or null
+  float* d_empty_proj;  // or null
+  int groups_per_sample;
+  int w_out_off, b_out_off;   // offsets of w_out / b_out in the packed parameter vector
+};
+
+__device__ __forceinline__ int wave_min_i(int v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v = min(v, __shfl_xor(v, off, 64));
+  return __builtin_amdgcn_readfirstlane(v);
+}
+
+template <int HD>
+__global__ __launch_bounds__(64) void scatter_rows_kernel(const RowsScatterParams sp) {
+  constexpr int CW = 12, CH = 12, RB = 64;
+  __shared__ float cache[(CW * CH + 1) * HD];   // + one scratch row: the target of clamped (duplicate, zero-weight) taps
+  const FwdParams& p = sp.f;
+  const int lane = threadIdx.x;
+  const int grp = blockIdx.x;
+  const int sample = grp / sp.groups_per_sample;
+  const int g_in = grp - sample * sp.groups_per_sample;
+  const int Bp = p.Bp, K = p.K, H = p.H, W = p.W;
+  const int r_raw = g_in * 64 + lane;
+  const bool ray_ok = r_raw < Bp;
+  const int r = ray_ok ? r_raw : Bp - 1;
+  const long ray = (long)sample * Bp + r;
+  const int n_pts = min(64, Bp - g_in * 64);   // rays of this group (uniform)
+  const bool chan = HD == 64 || lane < HD;
+  const int ch = lane % HD;
+  const bool scatter = sp.d_proj != nullptr;
+  for (int i = lane; i < (CW * CH + 1) * HD; i += 64) cache[i] = 0.0f;
+  const Cam enc = load_cam(p.w2c_enc + sample * 16, p.K_enc + sample * 9);
+  const float4 r0 = reinterpret_cast<const float4*>(p.rays)[ray * 2];
+  const float4 r1 = reinterpret_cast<const float4*>(p.rays)[ray * 2 + 1];
+  const float* zrow = p.z_samp + ray * K;
+  const float* gsrow = sp.gs_ws + ray * K;
+  float* __restrict__ dG = sp.d_proj + (long)sample * H * W * HD;
+  // rows of the group's first ray; ray i of the group is i * K rows further
+  const float* __restrict__ ws = sp.u_ws + ((long)sample * Bp + (long)g_in * 64) * K * HD;
+  const float w_out_ch = p.mlp[sp.w_out_off + proj_hidden_of_storage(ch)];
+  float dw_out = 0.0f, d_empty = 0.0f, db_out = 0.0f;
+  int wx = 0, wy = 0;   // window origin (uniform)
+
+  auto flush = [&](int nwx, int nwy, bool all) {
+    const int wxm = ((wx % CW) + CW) % CW, wym = ((wy % CH) + CH) % CH;
+    for (int sy = 0; sy < CH; ++sy) {
+      const int ty = wy + sy - wym + (sy < wym ? CH : 0);
+      const bool row_out = all || ty < nwy || ty >= nwy + CH;
+      for (int sx = 0; sx < CW; ++sx) {
+        const int tx = wx + sx - wxm + (sx < wxm ? CW : 0);
+        if (row_out || tx < nwx || tx >= nwx + CW) {
+          if (chan) {
+            float* c = &cache[(sy * CW + sx) * HD + ch];
+            const float v = *c;
+            if (v != 0.0f) {
+              atomic_add_f32(dG + ((long)ty * W + tx) * HD + ch, v);
+              *c = 0.0f;
+            }
+          }
+        }
+      }
+    }
+  };
+
+  auto row_of = [&](int k, int i) -> const float* { return ws + ((long)min(i, n_pts - 1) * K + k) * HD + ch; };
+  float cur[RB], nxt[RB];
+#pragma unroll
+  for (int i = 0; i < RB; ++i) cur[i] = (chan && i < n_pts) ? *row_of(K - 1, i) : 0.0f;
+
+  for (int k = K - 1; k >= 0; --k) {
+    const float z = zrow[k];
+    const float gs = ray_ok ? gsrow[k] : 0.0f;
+    db_out += gs;
+    const Proj pe = project<false>(enc, r0.x + z * r0.w, r0.y + z * r1.x, r0.z + z * r1.y);
+    int x0, y0, x1, y1;
+    Taps tp = make_taps_xy(pe.x, pe.y, H, W, x0, y0, x1, y1);
+    const bool use_empty = (p.learn_empty != 0) & pe.invalid;
+    // g_h = [u != 0] w_out g_s: the sample's g_s rides in the tap weights (and, for points that took the empty feature, in ge)
+    const float ge = use_empty ? gs : 0.0f;
+    const float gt = use_empty ? 0.0f : gs;
+    tp.w00 *= gt, tp.w01 *= gt, tp.w10 *= gt, tp.w11 *= gt;
+    bool fits = false;
+    if (scatter) {
+      const int mnx = wave_min_i(x0), mxx = -wave_min_i(-x1), mny = wave_min_i(y0), mxy = -wave_min_i(-y1);
+      fits = (mxx - mnx < CW) && (mxy - mny < CH);
+      if (fits && (mnx < wx || mxx >= wx + CW || mny < wy || mxy >= wy + CH)) {
+        const int nwx = mnx - (CW - (mxx - mnx + 1)) / 2, nwy = mny - (CH - (mxy - mny + 1)) / 2;
+        flush(nwx, nwy, false);
+        wx = nwx, wy = nwy;
+      }
+    }
+    const int rya = (int)((unsigned)y0 % CH) * CW, ryb = (int)((unsigned)y1 % CH) * CW;
+    const int cxa = (int)((unsigned)x0 % CW), cxb = (int)((unsigned)x1 % CW);
+    const bool ddx = x1 != x0, ddy = y1 != y0;
+    const int s00 = (rya + cxa) * HD;
+    const int s01 = ddx ? (rya + cxb) * HD : CW * CH * HD;
+    const int s10 = ddy ? (ryb + cxa) * HD : CW * CH * HD;
+    const int s11 = (ddx && ddy) ? (ryb + cxb) * HD : CW * CH * HD;
+    // prefetch the next step's rows
+#pragma unroll
+    for (int i = 0; i < RB; ++i) nxt[i] = (chan && k > 0 && i < n_pts) ? *row_of(k - 1, i) : 0.0f;
+    auto bc_i = [&](int v, int pnt) { return __builtin_amdgcn_readlane(v, pnt); };
+    auto bc_f = [&](float v, int pnt) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), pnt)); };
+    // every v_readlane below sits in wave-uniform control flow (see scatter_dg_kernel); idle lanes aim at the scratch row
+    if (fits) {
+#pragma unroll
+      for (int i = 0; i < RB; ++i) {
+        const float uv = cur[i];
+        dw_out += uv;
+        const float gv = uv != 0.0f ? w_out_ch : 0.0f;
+        d_empty = __builtin_fmaf(bc_f(ge, i), gv, d_empty);
+        float* c00 = &cache[(chan ? bc_i(s00, i) : CW * CH * HD) + ch];
+        float* c01 = &cache[(chan ? bc_i(s01, i) : CW * CH * HD) + ch];
+        float* c10 = &cache[(chan ? bc_i(s10, i) : CW * CH * HD) + ch];
+        float* c11 = &cache[(chan ? bc_i(s11, i) : CW * CH * HD) + ch];
+        const float a00 = *c00, a01 = *c01, a10 = *c10, a11 = *c11;
+        *c00 = a00 + bc_f(tp.w00, i) * gv;
+        *c01 = a01 + bc_f(tp.w01, i) * gv;
+        *c10 = a10 + bc_f(tp.w10, i) * gv;
+        *c11 = a11 + bc_f(tp.w11, i) * gv;
+        // the broadcasts of later points must not be hoisted up here (unfenced: ~300 SGPRs spilled to VGPR lanes)
+        if (i % 4 == 3) __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+      // no scatter wanted, or (rare) a footprint wider than the window: every tap a row of L2 atomics.  The rows are re-read from
+      // the workspace so that the register block is never indexed dynamically
+#pragma unroll 1
+      for (int i = 0; i < n_pts; ++i) {
+        const float uv = chan ? *row_of(k, i) : 0.0f;
+        dw_out += uv;
+        const float gv = uv != 0.0f ? w_out_ch : 0.0f;
+        d_empty = __builtin_fmaf(bc_f(ge, i), gv, d_empty);
+        if (scatter) {
+          const long ya = (long)bc_i(y0, i) * W, yb = (long)bc_i(y1, i) * W;
+          const int xa = bc_i(x0, i), xb = bc_i(x1, i);
+          const float w00 = bc_f(tp.w00, i), w01 = bc_f(tp.w01, i), w10 = bc_f(tp.w10, i), w11 = bc_f(tp.w11, i);
+          if (gv != 0.0f && chan) {
+            atomic_add_f32(dG + (ya + xa) * HD + ch, w00 * gv);
+            atomic_add_f32(dG + (ya + xb) * HD + ch, w01 * gv);
+            atomic_add_f32(dG + (yb + xa) * HD + ch, w10 * gv);
+            atomic_add_f32(dG + (yb + xb) * HD + ch, w11 * gv);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < RB; ++i) cur[i] = nxt[i];
+  }
+  if (scatter) flush(0, 0, true);
+  if (sp.d_mlp) {
+    if (chan && dw_out != 0.0f) atomic_add_f32(sp.d_mlp + sp.w_out_off + proj_hidden_of_storage(ch), dw_out);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) db_out += __shfl_xor(db_out, off, 64);
+    if (lane == 0 && db_out != 0.0f) atomic_add_f32(sp.d_mlp + sp.b_out_off, db_out);
+  }
+  if (sp.d_empty_proj && chan && d_empty != 0.0f) atomic_add_f32(sp.d_empty_proj + proj_hidden_of_storage(ch), d_empty);
+}
+
+// pass B, second form: one wave per (patch, 32-channel half of the row).  Lanes 0-31 and 32-63 work on DIFFERENT points of the
+// step (points i and i + 32: four patch rows apart, their footprints almost never share a texel), so one read-modify-write round of
+// the window serves two points; the taps of every point come from a small per-wave LDS table (two broadcast reads per pair) instead
+// of twelve v_readlane per point; and at 20 KB of LDS per wave eight waves fit a CU (two per SIMD) where the 64-channel window
+// allowed four.  Pairs whose points do share a window slot (found by comparing the partner's slots, lane = ray) are taken apart:
+// the upper half skips its round and is served afterwards on its own.  Points that took the empty feature aim at a dedicated row of
+// the window, so d_empty falls out of the same rounds.
+template <int HD>
+__global__ __launch_bounds__(64) void scatter_rows2_kernel(const RowsScatterParams sp) {
+  constexpr int CW = 12, CH = 12, NSLOT = CW * CH, SCRATCH = NSLOT * 128, EMPTY = (NSLOT + 1) * 128;   // slot offsets in bytes
+  constexpr int NW = HD / 32;
+  __shared__ __attribute__((aligned(128))) float cache[(NSLOT + 2) * 32];   // aligned: see round()
+  __shared__ float4 tab_w[65];   // + one entry: the upper point of a pair served on its own
+  __shared__ uint2 tab_s[65];
+  const FwdParams& p = sp.f;
+  const int lane = threadIdx.x;
+  const int h = lane >> 5, c = lane & 31;
+  const unsigned c4 = (unsigned)c * 4u;
+  const int grp = blockIdx.x / NW, wv = blockIdx.x - grp * NW;
+  const int chg = wv * 32 + c;   // this lane's channel of the row
+  const int sample = grp / sp.groups_per_sample;
+  const int g_in = grp - sample * sp.groups_per_sample;
+  const int Bp = p.Bp, K = p.K, H = p.H, W = p.W;
+  const int r_raw = g_in * 64 + lane;
+  const bool ray_ok = r_raw < Bp;
+  const int r = ray_ok ? r_raw : Bp - 1;
+  const long ray = (long)sample * Bp + r;
+  const int n_pts = min(64, Bp - g_in * 64);
+  const bool scatter = sp.d_proj != nullptr;
+  for (int i = lane; i < (NSLOT + 2) * 32; i += 64) cache[i] = 0.0f;
+  const Cam enc = load_cam(p.w2c_enc + sample * 16, p.K_enc + sample * 9);
+  const float4 r0 = reinterpret_cast<const float4*>(p.rays)[ray * 2];
+  const float4 r1 = reinterpret_cast<const float4*>(p.rays)[ray * 2 + 1];
+  const float* zrow = p.z_samp + ray * K;
+  const float* gsrow = sp.gs_ws + ray * K;
+  float* __restrict__ dG = sp.d_proj + (long)sample * H * W * HD + chg;
+  const float* __restrict__ ws = sp.u_ws + ((long)sample * Bp + (long)g_in * 64) * K * HD + chg;
+  const float w_out_ch = p.mlp[sp.w_out_off + proj_hidden_of_storage(chg)];
+  float dw_out = 0.0f, db_out = 0.0f;
+  int wx = 0, wy = 0;   // window origin (uniform)
+
+  // evict every slot whose texel lies outside the window at (nwx, nwy); the two lane halves take alternate slots
+  auto flush = [&](int nwx, int nwy, bool all) {
+    const int wxm = ((wx % CW) + CW) % CW, wym = ((wy % CH) + CH) % CH;
+#pragma unroll 1
+    for (int s0 = 0; s0 < NSLOT; s0 += 2) {
+      const int sl = s0 + h, sy = sl / CW, sx = sl - sy * CW;
+      const int ty = wy + sy - wym + (sy < wym ? CH : 0), tx = wx + sx - wxm + (sx < wxm ? CW : 0);
+      if (all || ty < nwy || ty >= nwy + CH || tx < nwx || tx >= nwx + CW) {
+        float* cc = &cache[sl * 32 + c];
+        const float v = *cc;
+        if (v != 0.0f) {
+          atomic_add_f32(dG + ((long)ty * W + tx) * HD, v);
+          *cc = 0.0f;
+        }
+      }
+    }
+  };
+
+  // row of point pnt (0..63) of the group at step k, this lane's channel.  Rows of points past the end of a partial group are
+  // read too (the workspace is padded by 64 rays) and masked: unconditional loads keep the prefetch one straight block
+  auto row_of = [&](int k, int pnt) -> const float* { return ws + ((long)pnt * K + k) * HD; };
+  const int lim = n_pts - 32 * h;   // pair i of this lane half exists iff i < lim
+  float cur[32], nxt[32];
+#pragma unroll
+  for (int i = 0; i < 32; ++i) {
+    const float v = *row_of(K - 1, i + 32 * h);
+    cur[i] = i < lim ? v : 0.0f;
+  }
+
+  // one read-modify-write round: this lane's point takes its four taps from the table
+  auto round = [&](int pnt, float gv) {
+    const float4 ww = tab_w[pnt];
+    const uint2 ss = tab_s[pnt];
+    // slot offsets are multiples of 128 bytes: the lane's channel is or-ed in
+    char* const cb = reinterpret_cast<char*>(cache);
+    float* c00 = reinterpret_cast<float*>(cb + ((ss.x & 0xFFFFu) | c4));
+    float* c01 = reinterpret_cast<float*>(cb + ((ss.x >> 16) | c4));
+    float* c10 = reinterpret_cast<float*>(cb + ((ss.y & 0xFFFFu) | c4));
+    float* c11 = reinterpret_cast<float*>(cb + ((ss.y >> 16) | c4));
+    const float a00 = *c00, a01 = *c01, a10 = *c10, a11 = *c11;
+    *c00 = a00 + ww.x * gv;
+    *c01 = a01 + ww.y * gv;
+    *c10 = a10 + ww.z * gv;
+    *c11 = a11 + ww.w * gv;
+  };
+
+  for (int k = K - 1; k >= 0; --k) {
+    const float z = zrow[k];
+    const float gs = ray_ok ? gsrow[k] : 0.0f;
+    db_out += gs;
+    const Proj pe = project<false>(enc, r0.x + z * r0.w, r0.y + z * r1.x, r0.z + z * r1.y);
+    int x0, y0, x1, y1;
+    Taps tp = make_taps_xy(pe.x, pe.y, H, W, x0, y0, x1, y1);
+    const bool use_empty = (p.learn_empty != 0) & pe.invalid;
+    tp.w00 *= gs, tp.w01 *= gs, tp.w10 *= gs, tp.w11 *= gs;   // g_h = [u != 0] w_out g_s: the sample's g_s rides in the tap weights
+    bool fits = false;
+    if (scatter) {
+      const int mnx = wave_min_i(x0), mxx = -wave_min_i(-x1), mny = wave_min_i(y0), mxy = -wave_min_i(-y1);
+      fits = (mxx - mnx < CW) && (mxy - mny < CH);
+      if (fits && (mnx < wx || mxx >= wx + CW || mny < wy || mxy >= wy + CH)) {
+        const int nwx = mnx - (CW - (mxx - mnx + 1)) / 2, nwy = mny - (CH - (mxy - mny + 1)) / 2;
+        flush(nwx, nwy, false);
+        wx = nwx, wy = nwy;
+      }
+    }
+    // window slots of the four taps (float offsets).  A clamped tap (x1 == x0 or y1 == y0 at the far border: weight exactly 0) would
+    // alias its neighbour's slot inside one round; it goes to the scratch row.  An empty-feature point sends g_s to the EMPTY row.
+    const int rya = (int)((unsigned)y0 % CH) * CW, ryb = (int)((unsigned)y1 % CH) * CW;
+    const int cxa = (int)((unsigned)x0 % CW), cxb = (int)((unsigned)x1 % CW);
+    const bool ddx = x1 != x0, ddy = y1 != y0;
+    int s00 = (rya + cxa) * 128;
+    int s01 = ddx ? (rya + cxb) * 128 : SCRATCH;
+    int s10 = ddy ? (ryb + cxa) * 128 : SCRATCH;
+    int s11 = (ddx && ddy) ? (ryb + cxb) * 128 : SCRATCH;
+    if (use_empty) s00 = EMPTY, s01 = s10 = s11 = SCRATCH, tp.w00 = gs, tp.w01 = tp.w10 = tp.w11 = 0.0f;
+    if (!fits && !use_empty) s00 = s01 = s10 = s11 = SCRATCH;   // handled with direct atomics below
+    // pairs (i, i + 32) whose points share a slot: the upper point waits
+    unsigned amask;
+    {
+      unsigned a[4], b[4];
+      bcast_tiles((unsigned)s00, a[0], b[0]), bcast_tiles((unsigned)s01, a[1], b[1]);
+      bcast_tiles((unsigned)s10, a[2], b[2]), bcast_tiles((unsigned)s11, a[3], b[3]);
+      bool al = false;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) al |= (a[i] == b[j]) & (a[i] != (unsigned)SCRATCH);
+      amask = (unsigned)__ballot(al);
+    }
+    const float4 my_w = make_float4(tp.w00, tp.w01, tp.w10, tp.w11);
+    const uint2 my_s = make_uint2((unsigned)s00 | ((unsigned)s01 << 16), (unsigned)s10 | ((unsigned)s11 << 16));
+    const bool wait = h == 1 && ((amask >> c) & 1u);   // lane = ray here: this ray is the upper point of a pair that shares a slot
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    tab_w[lane] = wait ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : my_w;
+    tab_s[lane] = wait ? make_uint2((unsigned)SCRATCH | ((unsigned)SCRATCH << 16), (unsigned)SCRATCH | ((unsigned)SCRATCH << 16)) : my_s;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // prefetch the next step's rows
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      const float v = *row_of(max(k - 1, 0), i + 32 * h);
+      nxt[i] = i < lim ? v : 0.0f;
+    }
+    // one straight block: the table reads of later pairs may run ahead of the window's read-modify-write rounds
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      const float uv = cur[i];
+      dw_out += uv;
+      round(i + 32 * h, uv != 0.0f ? w_out_ch : 0.0f);
+    }
+    // the upper points of the pairs that shared a slot (rows re-read: the register block is never indexed dynamically)
+    while (amask) {
+      const int i = __builtin_ctz(amask);
+      amask &= amask - 1;
+      if (lane == i + 32) tab_w[64] = my_w, tab_s[64] = my_s;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      if (h == 1) {
+        const float uv = (i + 32 < n_pts) ? *row_of(k, i + 32) : 0.0f;
+        round(64, uv != 0.0f ? w_out_ch : 0.0f);
+      }
+    }
+    if (scatter && !fits) {
+      // rare (a footprint wider than the window: rays nearly through the encoder's centre): every tap a row of L2 atomics
+      auto bc_i = [&](int v, int pnt) { return __builtin_amdgcn_readlane(v, pnt); };
+      auto bc_f = [&](float v, int pnt) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), pnt)); };
+#pragma unroll 1
+      for (int i = 0; i < n_pts; ++i) {
+        const float uv = *row_of(k, i);
+        const float gv = uv != 0.0f ? w_out_ch : 0.0f;
+        const long ya = (long)bc_i(y0, i) * W, yb = (long)bc_i(y1, i) * W;
+        const int xa = bc_i(x0, i), xb = bc_i(x1, i);
+        const float w00 = bc_f(tp.w00, i), w01 = bc_f(tp.w01, i), w10 = bc_f(tp.w10, i), w11 = bc_f(tp.w11, i);
+        const bool em = bc_i(use_empty ? 1 : 0, i) != 0;
+        if (gv != 0.0f && h == 0 && !em) {
+          atomic_add_f32(dG + (ya + xa) * HD, w00 * gv);
+          atomic_add_f32(dG + (ya + xb) * HD, w01 * gv);
+          atomic_add_f32(dG + (yb + xa) * HD, w10 * gv);
+          atomic_add_f32(dG + (yb + xb) * HD, w11 * gv);
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 32; ++i) cur[i] = nxt[i];
+  }
+  if (scatter) flush(0, 0, true);
+  if (sp.d_mlp) {
+    dw_out += __shfl_xor(dw_out, 32, 64);
+    if (h == 0 && dw_out != 0.0f) atomic_add_f32(sp.d_mlp + sp.w_out_off + proj_hidden_of_storage(chg), dw_out);
+    if (wv == 0) {
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) db_out += __shfl_xor(db_out, off, 64);
+      if (lane == 0 && db_out != 0.0f) atomic_add_f32(sp.d_mlp + sp.b_out_off, db_out);
+    }
+  }
+  if (sp.d_empty_proj && h == 0) {
+    const float v = cache[EMPTY / 4 + c];
+    if (v != 0.0f) atomic_add_f32(sp.d_empty_proj + proj_hidden_of_storage(chg), v);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// pass C: dW_pe (and db_in: the constant-1 row of the encoding)
+// ---------------------------------------------------------------------------------------------------------------
+struct DwpeParams {
+  FwdParams f;
+  const float* u_ws;
+  const float* gs_ws;
+  float* d_mlp;
+  long rays;   // n * Bp
+};
+
+template <int C, int HD>
+__global__ __launch_bounds__(256) void dwpe_kernel(const DwpeParams dp) {
+  constexpr int HT = HD / 32;
+  constexpr int PE_ROWS = kPeDim + 1, LDX = PE_ROWS + 1;
+  constexpr int D_IN = C + kPeDim;
+  const FwdParams& p = dp.f;
+  __shared__ float d_wpe[PE_ROWS * HD];       // work-group accumulator [kin][channel]
+  __shared__ float pe_tiles[4][64 * LDX];     // per wave [sample][kin]: g_s * encoding
+  const MlpLayout ml{D_IN, HD, 0};
+  for (int i = threadIdx.x; i < PE_ROWS * HD; i += blockDim.x) d_wpe[i] = 0.0f;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int h = lane >> 5, col = lane & 31;
+  float* tile = pe_tiles[wave];
+  const int Bp = p.Bp, K = p.K;
+  float w_out_ch[HT];
+#pragma unroll
+  for (int ht = 0; ht < HT; ++ht) w_out_ch[ht] = p.mlp[ml.w_out() + proj_hidden_of_storage(ht * 32 + col)];
+  f32x16 dw[HT][2];
+#pragma unroll
+  for (int ht = 0; ht < HT; ++ht)
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) dw[ht][kt] = zero_acc();
+  const int k = lane, kk = min(k, K - 1);
+  const long stride = (long)gridDim.x * 4;
+  for (long ray = (long)blockIdx.x * 4 + wave; ray < dp.rays; ray += stride) {
+    const int sample = (int)(ray / Bp);
+    const Cam enc = load_cam(p.w2c_enc + sample * 16, p.K_enc + sample * 9);
+    const cfp rp = as_const(p.rays) + ray * 8;
+    const float z = p.z_samp[ray * K + kk];
+    const float gs = k < K ? dp.gs_ws[ray * K + k] : 0.0f;
+    const float px = rp[0] + z * rp[3], py = rp[1] + z * rp[4], pz = rp[2] + z * rp[5];
+    const Proj pe = p.code_mode == 1 ? project<true>(enc, px, py, pz) : project<false>(enc, px, py, pz);
+    float v3[3];
+    v3[0] = pe.x, v3[1] = pe.y;
+    v3[2] = depth_code(p.code_mode == 1 ? pe.dist : pe.z, p.inv_z != 0, p.inv_dmax, p.inv_range, p.d_min, p.range);
+    // per-wave tile: the LDS accesses of one wave are performed in order, the fences below only pin the compiler's order
+    float* my = tile + lane * LDX;
+    my[0] = v3[0] * gs, my[1] = v3[1] * gs, my[2] = v3[2] * gs, my[3] = gs;
+    float ff = p.freq_factor;
+#pragma unroll 1
+    for (int oct = 0; oct < kNumFreqs; ++oct) {
+      float sc[6];
+      pe_octave(sc, v3, ff);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) my[4 + 6 * oct + i] = sc[i] * gs;
+      ff = ff * 2.0f;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // k-step s pairs samples s (lanes 0-31) and s + 32 (lanes 32-63); rows past K do not exist: their tile rows are zero
+    const float* __restrict__ urow = dp.u_ws + ray * (long)K * HD + col;
+#pragma unroll 8
+    for (int s = 0; s < 32; ++s) {
+      const int pnt = s + 32 * h;
+      const int pr = min(pnt, K - 1);
+      float a[HT];
+#pragma unroll
+      for (int ht = 0; ht < HT; ++ht) a[ht] = urow[(long)pr * HD + ht * 32] != 0.0f ? w_out_ch[ht] : 0.0f;
+      const float b0 = tile[pnt * LDX + col];
+      const float b1 = col < PE_ROWS - 32 ? tile[pnt * LDX + 32 + col] : 0.0f;
+#pragma unroll
+      for (int ht = 0; ht < HT; ++ht) {
+        dw[ht][0] = mfma(a[ht], b0, dw[ht][0]);
+        dw[ht][1] = mfma(a[ht], b1, dw[ht][1]);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+  // D[i = channel in tile][j = kin in tile]: register q of a lane of half h holds row mfma_row(q, h), column col
+#pragma unroll
+  for (int ht = 0; ht < HT; ++ht)
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int chn = ht * 32 + mfma_row(q, h), kin = kt * 32 + col;
+        if (kin < PE_ROWS) atomicAdd(&d_wpe[kin * HD + chn], dw[ht][kt][q]);
+      }
+  __syncthreads();
+  for (int i = threadIdx.x; i < PE_ROWS * HD; i += blockDim.x) {
+    const int kin = i / HD, hid = proj_hidden_of_storage(i % HD);
+    const int src = kernel_to_ref_input<C>(kin + C);
+    const float v = d_wpe[i];
+    if (v != 0.0f) atomic_add_f32(dp.d_mlp + (src >= 0 ? ml.w_in() + hid * D_IN + src : ml.b_in() + hid), v);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// launch
+// ---------------------------------------------------------------------------------------------------------------
+template <int C, int HD>
+static int launch_rows(const BwdParams& bp, int n, int grid, hipStream_t s) {
+  const FwdParams& p = bp.f;
+  if (p.nv <= 1) rows_kernel<C, HD, 1><<<grid, 256, 0, s>>>(bp);
+  else if (p.nv <= 2) rows_kernel<C, HD, 2><<<grid, 256, 0, s>>>(bp);
+  else if (p.nv <= 4) rows_kernel<C, HD, 4><<<grid, 256, 0, s>>>(bp);
+  else rows_kernel<C, HD, 8><<<grid, 256, 0, s>>>(bp);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) {
+    const MlpLayout ml{C + kPeDim, HD, 0};
+    RowsScatterParams sp;
+    sp.f = p, sp.u_ws = bp.gh_ws, sp.gs_ws = bp.gs_ws, sp.d_proj = bp.d_proj, sp.d_mlp = bp.d_mlp, sp.d_empty_proj = bp.d_empty_proj;
+    sp.groups_per_sample = (p.Bp + 63) / 64, sp.w_out_off = ml.w_out(), sp.b_out_off = ml.b_out();
+#ifdef BTS_PROBE
+    static const bool one_wave = getenv("BTS_SCATTER_V1") != nullptr;   // A/B (probe build): the one-wave-per-patch form of pass B
+#else
+    constexpr bool one_wave = false;
+#endif
+    if (one_wave) scatter_rows_kernel<HD><<<n * sp.groups_per_sample, 64, 0, s>>>(sp);
+    else scatter_rows2_kernel<HD><<<n * sp.groups_per_sample * (HD / 32), 64, 0, s>>>(sp);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess && bp.d_mlp) {
+    DwpeParams dp;
+    dp.f = p, dp.u_ws = bp.gh_ws, dp.gs_ws = bp.gs_ws, dp.d_mlp = bp.d_mlp, dp.rays = (long)n * p.Bp;
+    const long wgs = (dp.rays + 3) / 4;
+    dwpe_kernel<C, HD><<<(int)(wgs < 3L * grid / 2 ? wgs : 3L * grid / 2), 256, 0, s>>>(dp);
+    e = hipGetLastError();
+  }
+  if (e != hipSuccess) {
+    set_error("%s: backward kernel launch failed (%ld)", hipGetErrorString(e), (long)e);
+    return BTS_E_LAUNCH;
+  }
+  return BTS_OK;
+}
+
+// bp.gh_ws: (n*Bp, K, HD) floats, bp.gs_ws: (n*Bp, K) floats; p.groups / chunk_log2 / lpr set for one ray per wave iteration
+int launch_bwd_rows(const BwdParams& bp, int C, int HD, int n, int grid, hipStream_t s) {
+  if (C == 64 && HD == 64) return launch_rows<64, 64>(bp, n, grid, s);
+  if (C == 32 && HD == 32) return launch_rows<32, 32>(bp, n, grid, s);
+  return BTS_E_UNSUPPORTED;
+}
+
+}  // namespace bts

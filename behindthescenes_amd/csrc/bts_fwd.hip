@@ -71,6 +71,14 @@ int render_grid(const FwdParams& p) {
   return (int)g;
 }
 
+// chunk of the XCD interleave = twice the waves an XCD runs at once (one round of the resident waves covers half a chunk), at least
+// 64 groups
+int render_chunk_log2(int grid) {
+  int waves_per_xcd = grid / 8 * 4, l = 6;
+  while ((1 << l) < 2 * waves_per_xcd) ++l;
+  return l;
+}
+
 int render_fwd_impl(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const BtsRenderArgs* a, hipStream_t s) {
   FwdParams p = make_params(cfg, t);
   p.rays = a->rays, p.z_samp = a->z_samp;
@@ -93,11 +101,7 @@ int render_fwd_impl(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const BtsR
 #endif
   render_geometry(p, cfg->n);
   const int grid = render_grid(p);
-  {  // chunk = twice the waves an XCD runs at once (one round of the resident waves covers half a chunk), at least 64 groups
-    int waves_per_xcd = grid / 8 * 4, l = 6;
-    while ((1 << l) < 2 * waves_per_xcd) ++l;
-    p.chunk_log2 = l;
-  }
+  p.chunk_log2 = render_chunk_log2(grid);
 #ifdef BTS_PROBE
   if (p.proj && getenv("BTS_RENDER_V1")) return launch_render<true>(p, cfg->C, cfg->d_hidden, cfg->n_blocks, grid, s);  // compact lane = sample kernel
 #endif
