@@ -14,8 +14,8 @@ struct BwdParams {
   float* d_mlp;           // packed
   float* d_empty_proj;    // (HD)
   float* gh_ws;           // lane = ray path: (groups, K, 64, HD) g_h rows for the dG scatter pass, or null: scatter with direct atomics
-                          // lane = sample path (bts_bwd_rows.hip): (n*Bp, K, HD) rows u = relu(h) g_s
-  float* gs_ws;           // lane = sample path: (n*Bp, K) gradient at the pre-softplus density
+  float* gs_ws;           // lane = sample path (bts_bwd_rows.hip): (n*Bp, K) gradient at the pre-softplus density
+  unsigned* mask_ws;      //                    (n*Bp, HD/32, K) relu gates of lin_in's output, one bit per channel
 };
 
 __device__ __forceinline__ void atomic_add_f32(float* p, float v) {

@@ -706,14 +706,18 @@ int launch_bwd_rows(const BwdParams& bp, int C, int HD, int n, int grid, hipStre
 // K > 64 keep the lane = ray pass of this file
 static bool rows_path(const BtsFieldCfg* cfg, const BtsRenderArgs* a) { return cfg->n_blocks == 0 && a->K <= 64; }
 
-// workspace = the rows between the passes.  lane = ray path: groups of 64 rays x K x 64 x d_hidden floats (g_h); lane = sample path:
-// rays x K x d_hidden (u = relu(h) g_s) + rays x K (g_s).  The larger of the two, so that either path can serve the call.
+// workspace = what the passes hand each other.  lane = ray path: groups of 64 rays x K x 64 x d_hidden floats (g_h rows); lane =
+// sample path: rays x K floats (g_s) + rays x K x d_hidden / 32 dwords (relu gates) -- 12 bytes per sample instead of 256.
 size_t render_bwd_workspace_impl(const BtsFieldCfg* cfg, const BtsRenderArgs* a) {
+  const size_t rays = (size_t)cfg->n * (size_t)a->rays_per_sample;
+  const size_t v2 = rays * (size_t)a->K * (1 + (size_t)cfg->d_hidden / 32) * sizeof(float);
   const size_t groups = (size_t)cfg->n * ((a->rays_per_sample + 255) / 256) * 4;
   const size_t v1 = groups * (size_t)a->K * 64 * (size_t)cfg->d_hidden * sizeof(float);
-  const size_t rays = (size_t)cfg->n * (size_t)a->rays_per_sample;
-  const size_t v2 = ((rays + 64) * (size_t)a->K * (size_t)cfg->d_hidden + rays * (size_t)a->K) * sizeof(float);   // rows padded by 64 rays
+#ifdef BTS_PROBE   // either path may serve the call (BTS_BWD_V1)
   return v1 > v2 ? v1 : v2;
+#else
+  return rows_path(cfg, a) ? v2 : v1;
+#endif
 }
 
 template <int HD>
@@ -754,19 +758,20 @@ int render_bwd_impl(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const BtsR
 #else
   constexpr bool v1 = false;
 #endif
-  if (rows_path(cfg, a) && !direct && !v1 && bp.f.proj) {
+  if (rows_path(cfg, a) && !direct && !v1) {
     bp.f.lpr = 64, bp.f.groups = (long)cfg->n * a->rays_per_sample;
     const int grid = render_grid(bp.f);
     bp.f.chunk_log2 = render_chunk_log2(grid);
-    bp.gh_ws = static_cast<float*>(workspace);
-    bp.gs_ws = bp.gh_ws + ((size_t)cfg->n * a->rays_per_sample + 64) * a->K * cfg->d_hidden;
+    bp.gh_ws = nullptr;
+    bp.gs_ws = static_cast<float*>(workspace);
+    bp.mask_ws = reinterpret_cast<unsigned*>(bp.gs_ws + (size_t)cfg->n * a->rays_per_sample * a->K);
     const int rc = launch_bwd_rows(bp, cfg->C, cfg->d_hidden, cfg->n, grid, s);
     if (rc != BTS_E_UNSUPPORTED) return rc;
     set_error("%s: unsupported MLP shape C=%ld d_hidden=%ld n_blocks=%ld", "bts_render_bwd", cfg->C, cfg->d_hidden, cfg->n_blocks);
     return rc;
   }
   bp.gh_ws = (bp.d_proj && !direct) ? static_cast<float*>(workspace) : nullptr;
-  bp.gs_ws = nullptr;
+  bp.gs_ws = nullptr, bp.mask_ws = nullptr;
   const int grid = bp.f.tiles_per_sample * cfg->n;
   int rc = BTS_E_UNSUPPORTED;
   if (cfg->C == 64 && cfg->d_hidden == 64 && cfg->n_blocks == 0) rc = launch_bwd<64, 64, 0>(bp, grid, s);

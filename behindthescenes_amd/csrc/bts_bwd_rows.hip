@@ -1,21 +1,18 @@
 // Backward of the fused renderer, lane = SAMPLE form: three passes for the plain MLP (no ResnetBlockFC layers) with K <= 64.
 //
-// The round-1 backward (bts_bwd.hip) walks 64 rays per wave back to front, lane = ray: 392 registers and 138 KB of LDS tiles pin it at one
-// wave per SIMD with every latency exposed (1.5 ms of the 2.3 ms backward at 65 536 x 64).  Here the work is cut along the data
-// instead:
+// The round-1 backward (bts_bwd.hip) walks 64 rays per wave back to front, lane = ray: 392 registers and 138 KB of LDS tiles pin it at
+// one wave per SIMD with every latency exposed, and 1 GB of g_h rows travels between its two passes (2.3 ms at 65 536 x 64).  The
+// gradient at lin_in's output factorises,  g_h[p][ch] = [h[p][ch] > 0] * w_out[ch] * g_s[p],  so what the passes have to hand each
+// other per sample is ONE float (g_s, the gradient at the pre-softplus density) and ONE BIT per channel (the relu gate):
 //   pass A  rows_kernel      one ray per wave iteration, lane = sample -- the FORWARD's pipeline (f16-split lin_in on the matrix pipe,
 //                            gather blended between the encoding regions, 2 waves / SIMD), so h and with it every relu gate is
 //                            bit-identical to what the forward evaluated.  The compositing gradient is a suffix scan across the
-//                            lanes.  Output per sample: g_s (the gradient at the pre-softplus density) and the row
-//                            u[ch] = relu(h[ch]) * g_s in G's channel order, straight from the accumulator registers
-//                            (16 contiguous channels per lane and tile: 64-byte pieces, no LDS transposition).
-//   pass B  scatter_rows_kernel   one wave per 8x8 patch (64 rays), lane = channel: g_h = [u != 0] w_out g_s, tap updates merged per
-//                            texel in a sliding LDS window (as scatter_dg_kernel), plus the three sums that need no second operand:
-//                            dw_out = sum u, db_out = sum g_s, d_empty = sum over empty-feature points of g_h.
-//   pass C  dwpe_kernel      dW_pe^T[ch][kin] = sum_p [u != 0] w_out[ch] * (g_s pe)[p][kin]: one ray per wave iteration, the A operand
-//                            read straight from the rows (lanes 0-31 / 32-63 = 128-byte pieces of two rows), the encoding recomputed
-//                            lane = sample, scaled by g_s and transposed through a per-wave LDS tile.
-// u instead of g_h in the rows lets pass B produce dw_out (which needs relu(h)) without pass A holding gradient accumulators.
+//                            lanes.  Writes g_s and the gate masks (12 bytes per sample instead of a 256-byte row), and reduces
+//                            dw_out = sum relu(h) g_s (the one term that needs h itself) and db_out = sum g_s on the spot.
+//   pass B  scatter_kernel   one wave per (8x8 patch, 32-channel half): tap updates w_tap * g_s * [gate] * w_out merged per texel in a
+//                            sliding LDS window, two points per read-modify-write round; d_empty from a dedicated window row.
+//   pass C  dwpe_kernel      dW_pe^T[ch][kin] = sum_p [gate] w_out[ch] * (g_s pe)[p][kin]: one ray per wave iteration, the encoding
+//                            recomputed lane = sample, scaled by g_s and transposed through a per-wave LDS tile; fp32 MFMA.
 // What torch.autograd would do for nerf.py:283-299 + models_bts.py:266-338 + resnetfc.py:132-184 of the reference.
 #define BTS_NO_LAUNCH_GLUE
 #include "bts_render_kernel.h"
@@ -35,34 +32,61 @@ __device__ __forceinline__ float wave_suffix_excl(float x, int lane) {
   return lane == 63 ? 0.0f : s;
 }
 
-// u rows of one accumulator set: acc[ht][pt][i] is channel ht*32 + 16h + i (storage order of G) of point pt*32 + (lane & 31)
-template <int HD>
-__device__ __forceinline__ void store_rows(const f32x16 (&acc)[HD / 32][2], const float (&gs_t)[2], float* __restrict__ urow, int K, int lane) {
-  const int h = lane >> 5, col = lane & 31;
+// sum over the 32 lanes of each wave half of 16 registers at once (butterfly with register halving: 2 selects, one shuffle and one
+// add per surviving register and step).  Afterwards both lanes of the pair (col, col ^ 1) hold the total of register col >> 1
+__device__ __forceinline__ float half_transpose_reduce16(float (&w)[16], int col) {
+  int d = 16;
 #pragma unroll
-  for (int pt = 0; pt < 2; ++pt) {
-    const int pnt = pt * 32 + col;
-    if (pnt < K) {
+  for (int n = 16; n > 1; n >>= 1) {
+    const bool up = (col & d) != 0;
 #pragma unroll
-      for (int ht = 0; ht < HD / 32; ++ht) {
-        float4* dst = reinterpret_cast<float4*>(urow + (long)pnt * HD + ht * 32 + 16 * h);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          dst[j] = make_float4(relu1(acc[ht][pt][4 * j + 0]) * gs_t[pt], relu1(acc[ht][pt][4 * j + 1]) * gs_t[pt],
-                               relu1(acc[ht][pt][4 * j + 2]) * gs_t[pt], relu1(acc[ht][pt][4 * j + 3]) * gs_t[pt]);
-      }
+    for (int j = 0; j < n / 2; ++j) {
+      // opaque values: otherwise the two selects become w[up ? .. : ..], a dynamically indexed array (16-deep select chains)
+      float lo = w[j], hi = w[n / 2 + j];
+      asm("" : "+v"(lo), "+v"(hi));
+      const float keep = up ? hi : lo;
+      const float give = up ? lo : hi;
+      w[j] = keep + __shfl_xor(give, d, 64);
     }
+    d >>= 1;
+  }
+  return w[0] + __shfl_xor(w[0], 1, 64);
+}
+
+// End of a ray in pass A.  acc[ht][pt][i] is channel ht*32 + 16h + i (storage order of G) of point pt*32 + (lane & 31), gs_t the g_s
+// of those two points.  Stores the gate masks of the lane's OWN sample (mrow: [HD/32][K] dwords of this ray) and adds the lane's
+// share of dw_out = sum relu(h) g_s: dw[ht] belongs to channel ht*32 + 16h + (col >> 1), on both lanes of the pair.
+template <int HD>
+__device__ __forceinline__ void gates_and_dwout(const f32x16 (&acc)[HD / 32][2], const float (&gs_t)[2], unsigned* __restrict__ mrow, int K,
+                                                int lane, float (&dw)[HD / 32]) {
+  constexpr int HT = HD / 32;
+  const int col = lane & 31;
+#pragma unroll
+  for (int ht = 0; ht < HT; ++ht) {
+    float r[16];
+    unsigned x = 0, y = 0;   // gate bits of the lane's 16 channels: point tile 0 / 1
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const float a0 = acc[ht][0][i], a1 = acc[ht][1][i];
+      x |= (a0 > 0.0f ? 1u : 0u) << i;
+      y |= (a1 > 0.0f ? 1u : 0u) << i;
+      r[i] = __builtin_fmaf(relu1(a1), gs_t[1], relu1(a0) * gs_t[0]);
+    }
+    // x' = {tile 0 channels 0-15 | tile 1 channels 0-15}, y' = {tile 0 channels 16-31 | tile 1 channels 16-31}: lane l = sample l
+    swap32u(x, y);
+    if (lane < K) mrow[ht * K + lane] = x | (y << 16);
+    dw[ht] += half_transpose_reduce16(r, col);
   }
 }
 
 // Cold path of pass A (see eval_point_exact): some sample's encoding argument leaves the fast sincos range.  The forward evaluated
-// this ray with eval_point (fp32-input MFMAs, libm sines); the same here, rows written from inside so that no accumulator array
-// crosses the call.
+// this ray with eval_point (fp32-input MFMAs, libm sines); the same here, masks written from inside so that no accumulator
+// array crosses the call.
 template <int C, int HD>
 __device__ __attribute__((noinline)) void rows_exact(const float* lds, const float4* G, const float* w2c, const float* Kc, int H, int W,
                                                      int code_mode, int inv_z, float inv_dmax, float inv_range, float d_min, float range,
                                                      float freq_factor, int learn_empty, float px, float py, float pz, float gs,
-                                                     float* urow, int K) {
+                                                     unsigned* mrow, int K, float* dw_out /* [HD/32], per lane */) {
   using L = Lds<C, HD, 0, true>;
   constexpr int HT = HD / 32;
   const int lane = threadIdx.x & 63, h = lane >> 5;
@@ -115,7 +139,12 @@ __device__ __attribute__((noinline)) void rows_exact(const float* lds, const flo
   float gs_t[2];
   bcast_tiles(__float_as_uint(gs), t0, t1);
   gs_t[0] = __uint_as_float(t0), gs_t[1] = __uint_as_float(t1);
-  store_rows<HD>(acc, gs_t, urow, K, lane);
+  float dw[HT];
+#pragma unroll
+  for (int ht = 0; ht < HT; ++ht) dw[ht] = 0.0f;
+  gates_and_dwout<HD>(acc, gs_t, mrow, K, lane, dw);
+#pragma unroll
+  for (int ht = 0; ht < HT; ++ht) dw_out[ht] = dw[ht];
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -160,6 +189,9 @@ __global__ __launch_bounds__(256, 2) void rows_kernel(const BwdParams bp) {
   const int kk = valid ? k : K - 1;
   const bool last = k == K - 1;
 
+  float dw_acc[HT], db_acc = 0.0f;   // this lane's share of dw_out (see gates_and_dwout) and of db_out
+#pragma unroll
+  for (int ht = 0; ht < HT; ++ht) dw_acc[ht] = 0.0f;
   long sample_end = Bp;
   int sample = 0;
   long idx = lw;
@@ -255,11 +287,15 @@ __global__ __launch_bounds__(256, 2) void rows_kernel(const BwdParams bp) {
       if (!capped && !dead && valid) g_s = g_alpha * fabsf(delta) * ex * (s_raw > 20.0f ? 1.0f : sigmoidf(s_raw));
       if (valid) bp.gs_ws[pk] = g_s;
     }
-    float* __restrict__ urow = bp.gh_ws + ray * (long)K * HD;
+    db_acc += g_s;
+    unsigned* __restrict__ mrow = bp.mask_ws + ray * (long)(HT * K);
 
     if (__builtin_expect(__any(pe_needs_exact(v3, p.freq_factor)), 0)) {
+      float dwx[HT];   // through memory: no accumulator array may cross the call (it would be demoted to scratch on the hot path)
       rows_exact<C, HD>(lds, G, p.w2c_enc + sample * 16, p.K_enc + sample * 9, H, W, p.code_mode, p.inv_z, p.inv_dmax, p.inv_range, p.d_min,
-                        p.range, p.freq_factor, p.learn_empty, px, py, pz, g_s, urow, K);
+                        p.range, p.freq_factor, p.learn_empty, px, py, pz, g_s, mrow, K, dwx);
+#pragma unroll
+      for (int ht = 0; ht < HT; ++ht) dw_acc[ht] += dwx[ht];
       continue;
     }
 
@@ -317,29 +353,59 @@ __global__ __launch_bounds__(256, 2) void rows_kernel(const BwdParams bp) {
         }
     }
 
-    // ---------------- rows: u = relu(h) g_s (2^S removed through g_s)
+    // ---------------- gate masks; dw_out += relu(h) g_s (2^S removed through g_s)
     float gs_t[2];
     {
       unsigned t0, t1;
       bcast_tiles(__float_as_uint(g_s * inv_scale), t0, t1);
       gs_t[0] = __uint_as_float(t0), gs_t[1] = __uint_as_float(t1);
     }
-    store_rows<HD>(acc, gs_t, urow, K, lane);
+    gates_and_dwout<HD>(acc, gs_t, mrow, K, lane, dw_acc);
+  }
+
+  // ---------------- dw_out, db_out: wave registers -> work-group LDS -> one atomic per parameter
+  if (bp.d_mlp) {
+    __shared__ float red[HD + 1];
+    for (int i = threadIdx.x; i <= HD; i += blockDim.x) red[i] = 0.0f;
+    __syncthreads();
+    if ((lane & 1) == 0) {
+#pragma unroll
+      for (int ht = 0; ht < HT; ++ht) atomicAdd(&red[proj_hidden_of_storage(ht * 32 + 16 * h0 + ((lane & 31) >> 1))], dw_acc[ht]);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) db_acc += __shfl_xor(db_acc, off, 64);
+    if (lane == 0) atomicAdd(&red[HD], db_acc);
+    __syncthreads();
+    const MlpLayout ml{C + kPeDim, HD, 0};
+    for (int i = threadIdx.x; i <= HD; i += blockDim.x) {
+      const float v = red[i];
+      if (v != 0.0f) atomic_add_f32(bp.d_mlp + (i < HD ? ml.w_out() + i : ml.b_out()), v);
+    }
   }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// pass B: dG scatter (the sliding LDS window of scatter_dg_kernel) + dw_out, db_out, d_empty
+// pass B: dG scatter + d_empty.
+// One wave per (patch of 64 rays, 32-channel half of the row).  Neighbouring rays and consecutive samples of a patch land on the same
+// few texels of G (the 4 taps x 64 rays of one step cover ~9x9 texels, the footprint drifts by about a pixel per step), so the wave
+// keeps a CW x CH texel window of dG rows in LDS (slot = (y mod CH, x mod CW): a texel keeps its slot while the window slides), adds
+// the tap contributions there with plain read-modify-write rounds, and only rows LEAVING the window go to global memory as rows of
+// float atomics (~5-10 % of the tap updates).  Lanes 0-31 and 32-63 work on DIFFERENT points of the step (points i and i + 32: four
+// patch rows apart, their footprints almost never share a texel), so one round serves two points; the taps and the gate mask of
+// every point come from a small per-wave LDS table (two broadcast reads per pair); at 20 KB of LDS per wave eight waves fit a CU.
+// Pairs whose points do share a window slot (found by comparing the partner's slots, lane = ray) are taken apart: the upper point's
+// table entry is neutralised for the main rounds and served afterwards on its own.  Points that took the empty feature aim at a
+// dedicated row of the window, so d_empty falls out of the same rounds.  A step whose footprint does not fit the window falls back to
+// direct row atomics.
 // ---------------------------------------------------------------------------------------------------------------
-struct RowsScatterParams {
+struct ScatterMaskParams {
   FwdParams f;
-  const float* u_ws;    // (n*Bp, K, HD)
-  const float* gs_ws;   // (n*Bp, K)
-  float* d_proj;        // or null: only the sums
-  float* d_mlp;         // or null
-  float* d_empty_proj;  // or null
+  const unsigned* mask_ws;   // (n*Bp, HD/32, K) relu gates of lin_in's output, bit j of dword ht = channel ht*32 + j (storage order of G)
+  const float* gs_ws;        // (n*Bp, K)
+  float* d_proj;             // or null: only d_empty
+  float* d_empty_proj;       // or null
   int groups_per_sample;
-  int w_out_off, b_out_off;   // offsets of w_out / b_out in the packed parameter vector
+  int w_out_off;             // offset of w_out in the packed parameter vector
 };
 
 __device__ __forceinline__ int wave_min_i(int v) {
@@ -349,169 +415,16 @@ __device__ __forceinline__ int wave_min_i(int v) {
 }
 
 template <int HD>
-__global__ __launch_bounds__(64) void scatter_rows_kernel(const RowsScatterParams sp) {
-  constexpr int CW = 12, CH = 12, RB = 64;
-  __shared__ float cache[(CW * CH + 1) * HD];   // + one scratch row: the target of clamped (duplicate, zero-weight) taps
-  const FwdParams& p = sp.f;
-  const int lane = threadIdx.x;
-  const int grp = blockIdx.x;
-  const int sample = grp / sp.groups_per_sample;
-  const int g_in = grp - sample * sp.groups_per_sample;
-  const int Bp = p.Bp, K = p.K, H = p.H, W = p.W;
-  const int r_raw = g_in * 64 + lane;
-  const bool ray_ok = r_raw < Bp;
-  const int r = ray_ok ? r_raw : Bp - 1;
-  const long ray = (long)sample * Bp + r;
-  const int n_pts = min(64, Bp - g_in * 64);   // rays of this group (uniform)
-  const bool chan = HD == 64 || lane < HD;
-  const int ch = lane % HD;
-  const bool scatter = sp.d_proj != nullptr;
-  for (int i = lane; i < (CW * CH + 1) * HD; i += 64) cache[i] = 0.0f;
-  const Cam enc = load_cam(p.w2c_enc + sample * 16, p.K_enc + sample * 9);
-  const float4 r0 = reinterpret_cast<const float4*>(p.rays)[ray * 2];
-  const float4 r1 = reinterpret_cast<const float4*>(p.rays)[ray * 2 + 1];
-  const float* zrow = p.z_samp + ray * K;
-  const float* gsrow = sp.gs_ws + ray * K;
-  float* __restrict__ dG = sp.d_proj + (long)sample * H * W * HD;
-  // rows of the group's first ray; ray i of the group is i * K rows further
-  const float* __restrict__ ws = sp.u_ws + ((long)sample * Bp + (long)g_in * 64) * K * HD;
-  const float w_out_ch = p.mlp[sp.w_out_off + proj_hidden_of_storage(ch)];
-  float dw_out = 0.0f, d_empty = 0.0f, db_out = 0.0f;
-  int wx = 0, wy = 0;   // window origin (uniform)
-
-  auto flush = [&](int nwx, int nwy, bool all) {
-    const int wxm = ((wx % CW) + CW) % CW, wym = ((wy % CH) + CH) % CH;
-    for (int sy = 0; sy < CH; ++sy) {
-      const int ty = wy + sy - wym + (sy < wym ? CH : 0);
-      const bool row_out = all || ty < nwy || ty >= nwy + CH;
-      for (int sx = 0; sx < CW; ++sx) {
-        const int tx = wx + sx - wxm + (sx < wxm ? CW : 0);
-        if (row_out || tx < nwx || tx >= nwx + CW) {
-          if (chan) {
-            float* c = &cache[(sy * CW + sx) * HD + ch];
-            const float v = *c;
-            if (v != 0.0f) {
-              atomic_add_f32(dG + ((long)ty * W + tx) * HD + ch, v);
-              *c = 0.0f;
-            }
-          }
-        }
-      }
-    }
-  };
-
-  auto row_of = [&](int k, int i) -> const float* { return ws + ((long)min(i, n_pts - 1) * K + k) * HD + ch; };
-  float cur[RB], nxt[RB];
-#pragma unroll
-  for (int i = 0; i < RB; ++i) cur[i] = (chan && i < n_pts) ? *row_of(K - 1, i) : 0.0f;
-
-  for (int k = K - 1; k >= 0; --k) {
-    const float z = zrow[k];
-    const float gs = ray_ok ? gsrow[k] : 0.0f;
-    db_out += gs;
-    const Proj pe = project<false>(enc, r0.x + z * r0.w, r0.y + z * r1.x, r0.z + z * r1.y);
-    int x0, y0, x1, y1;
-    Taps tp = make_taps_xy(pe.x, pe.y, H, W, x0, y0, x1, y1);
-    const bool use_empty = (p.learn_empty != 0) & pe.invalid;
-    // g_h = [u != 0] w_out g_s: the sample's g_s rides in the tap weights (and, for points that took the empty feature, in ge)
-    const float ge = use_empty ? gs : 0.0f;
-    const float gt = use_empty ? 0.0f : gs;
-    tp.w00 *= gt, tp.w01 *= gt, tp.w10 *= gt, tp.w11 *= gt;
-    bool fits = false;
-    if (scatter) {
-      const int mnx = wave_min_i(x0), mxx = -wave_min_i(-x1), mny = wave_min_i(y0), mxy = -wave_min_i(-y1);
-      fits = (mxx - mnx < CW) && (mxy - mny < CH);
-      if (fits && (mnx < wx || mxx >= wx + CW || mny < wy || mxy >= wy + CH)) {
-        const int nwx = mnx - (CW - (mxx - mnx + 1)) / 2, nwy = mny - (CH - (mxy - mny + 1)) / 2;
-        flush(nwx, nwy, false);
-        wx = nwx, wy = nwy;
-      }
-    }
-    const int rya = (int)((unsigned)y0 % CH) * CW, ryb = (int)((unsigned)y1 % CH) * CW;
-    const int cxa = (int)((unsigned)x0 % CW), cxb = (int)((unsigned)x1 % CW);
-    const bool ddx = x1 != x0, ddy = y1 != y0;
-    const int s00 = (rya + cxa) * HD;
-    const int s01 = ddx ? (rya + cxb) * HD : CW * CH * HD;
-    const int s10 = ddy ? (ryb + cxa) * HD : CW * CH * HD;
-    const int s11 = (ddx && ddy) ? (ryb + cxb) * HD : CW * CH * HD;
-    // prefetch the next step's rows
-#pragma unroll
-    for (int i = 0; i < RB; ++i) nxt[i] = (chan && k > 0 && i < n_pts) ? *row_of(k - 1, i) : 0.0f;
-    auto bc_i = [&](int v, int pnt) { return __builtin_amdgcn_readlane(v, pnt); };
-    auto bc_f = [&](float v, int pnt) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), pnt)); };
-    // every v_readlane below sits in wave-uniform control flow (see scatter_dg_kernel); idle lanes aim at the scratch row
-    if (fits) {
-#pragma unroll
-      for (int i = 0; i < RB; ++i) {
-        const float uv = cur[i];
-        dw_out += uv;
-        const float gv = uv != 0.0f ? w_out_ch : 0.0f;
-        d_empty = __builtin_fmaf(bc_f(ge, i), gv, d_empty);
-        float* c00 = &cache[(chan ? bc_i(s00, i) : CW * CH * HD) + ch];
-        float* c01 = &cache[(chan ? bc_i(s01, i) : CW * CH * HD) + ch];
-        float* c10 = &cache[(chan ? bc_i(s10, i) : CW * CH * HD) + ch];
-        float* c11 = &cache[(chan ? bc_i(s11, i) : CW * CH * HD) + ch];
-        const float a00 = *c00, a01 = *c01, a10 = *c10, a11 = *c11;
-        *c00 = a00 + bc_f(tp.w00, i) * gv;
-        *c01 = a01 + bc_f(tp.w01, i) * gv;
-        *c10 = a10 + bc_f(tp.w10, i) * gv;
-        *c11 = a11 + bc_f(tp.w11, i) * gv;
-        // the broadcasts of later points must not be hoisted up here (unfenced: ~300 SGPRs spilled to VGPR lanes)
-        if (i % 4 == 3) __builtin_amdgcn_sched_barrier(0);
-      }
-    } else {
-      // no scatter wanted, or (rare) a footprint wider than the window: every tap a row of L2 atomics.  The rows are re-read from
-      // the workspace so that the register block is never indexed dynamically
-#pragma unroll 1
-      for (int i = 0; i < n_pts; ++i) {
-        const float uv = chan ? *row_of(k, i) : 0.0f;
-        dw_out += uv;
-        const float gv = uv != 0.0f ? w_out_ch : 0.0f;
-        d_empty = __builtin_fmaf(bc_f(ge, i), gv, d_empty);
-        if (scatter) {
-          const long ya = (long)bc_i(y0, i) * W, yb = (long)bc_i(y1, i) * W;
-          const int xa = bc_i(x0, i), xb = bc_i(x1, i);
-          const float w00 = bc_f(tp.w00, i), w01 = bc_f(tp.w01, i), w10 = bc_f(tp.w10, i), w11 = bc_f(tp.w11, i);
-          if (gv != 0.0f && chan) {
-            atomic_add_f32(dG + (ya + xa) * HD + ch, w00 * gv);
-            atomic_add_f32(dG + (ya + xb) * HD + ch, w01 * gv);
-            atomic_add_f32(dG + (yb + xa) * HD + ch, w10 * gv);
-            atomic_add_f32(dG + (yb + xb) * HD + ch, w11 * gv);
-          }
-        }
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < RB; ++i) cur[i] = nxt[i];
-  }
-  if (scatter) flush(0, 0, true);
-  if (sp.d_mlp) {
-    if (chan && dw_out != 0.0f) atomic_add_f32(sp.d_mlp + sp.w_out_off + proj_hidden_of_storage(ch), dw_out);
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) db_out += __shfl_xor(db_out, off, 64);
-    if (lane == 0 && db_out != 0.0f) atomic_add_f32(sp.d_mlp + sp.b_out_off, db_out);
-  }
-  if (sp.d_empty_proj && chan && d_empty != 0.0f) atomic_add_f32(sp.d_empty_proj + proj_hidden_of_storage(ch), d_empty);
-}
-
-// pass B, second form: one wave per (patch, 32-channel half of the row).  Lanes 0-31 and 32-63 work on DIFFERENT points of the
-// step (points i and i + 32: four patch rows apart, their footprints almost never share a texel), so one read-modify-write round of
-// the window serves two points; the taps of every point come from a small per-wave LDS table (two broadcast reads per pair) instead
-// of twelve v_readlane per point; and at 20 KB of LDS per wave eight waves fit a CU (two per SIMD) where the 64-channel window
-// allowed four.  Pairs whose points do share a window slot (found by comparing the partner's slots, lane = ray) are taken apart:
-// the upper half skips its round and is served afterwards on its own.  Points that took the empty feature aim at a dedicated row of
-// the window, so d_empty falls out of the same rounds.
-template <int HD>
-__global__ __launch_bounds__(64) void scatter_rows2_kernel(const RowsScatterParams sp) {
-  constexpr int CW = 12, CH = 12, NSLOT = CW * CH, SCRATCH = NSLOT * 128, EMPTY = (NSLOT + 1) * 128;   // slot offsets in bytes
+__global__ __launch_bounds__(64) void scatter_kernel(const ScatterMaskParams sp) {
+  constexpr int CW = 12, CH = 12, NSLOT = CW * CH, SCRATCH = NSLOT, EMPTY = NSLOT + 1;   // slot indices; a slot is 32 floats
   constexpr int NW = HD / 32;
   __shared__ __attribute__((aligned(128))) float cache[(NSLOT + 2) * 32];   // aligned: see round()
-  __shared__ float4 tab_w[65];   // + one entry: the upper point of a pair served on its own
-  __shared__ uint2 tab_s[65];
+  __shared__ float4 tab_w[64];   // per point of the step: the four tap weights times g_s
+  __shared__ uint2 tab_sm[64];   //                        x: the four slot indices (8 bits each), y: the gate mask of this channel half
   const FwdParams& p = sp.f;
   const int lane = threadIdx.x;
   const int h = lane >> 5, c = lane & 31;
-  const unsigned c4 = (unsigned)c * 4u;
+  const unsigned c4 = (unsigned)c * 4u, cbit = 1u << c;
   const int grp = blockIdx.x / NW, wv = blockIdx.x - grp * NW;
   const int chg = wv * 32 + c;   // this lane's channel of the row
   const int sample = grp / sp.groups_per_sample;
@@ -529,10 +442,9 @@ __global__ __launch_bounds__(64) void scatter_rows2_kernel(const RowsScatterPara
   const float4 r1 = reinterpret_cast<const float4*>(p.rays)[ray * 2 + 1];
   const float* zrow = p.z_samp + ray * K;
   const float* gsrow = sp.gs_ws + ray * K;
+  const unsigned* mrow = sp.mask_ws + (ray * NW + wv) * K;
   float* __restrict__ dG = sp.d_proj + (long)sample * H * W * HD + chg;
-  const float* __restrict__ ws = sp.u_ws + ((long)sample * Bp + (long)g_in * 64) * K * HD + chg;
   const float w_out_ch = p.mlp[sp.w_out_off + proj_hidden_of_storage(chg)];
-  float dw_out = 0.0f, db_out = 0.0f;
   int wx = 0, wy = 0;   // window origin (uniform)
 
   // evict every slot whose texel lies outside the window at (nwx, nwy); the two lane halves take alternate slots
@@ -553,27 +465,17 @@ __global__ __launch_bounds__(64) void scatter_rows2_kernel(const RowsScatterPara
     }
   };
 
-  // row of point pnt (0..63) of the group at step k, this lane's channel.  Rows of points past the end of a partial group are
-  // read too (the workspace is padded by 64 rays) and masked: unconditional loads keep the prefetch one straight block
-  auto row_of = [&](int k, int pnt) -> const float* { return ws + ((long)pnt * K + k) * HD; };
-  const int lim = n_pts - 32 * h;   // pair i of this lane half exists iff i < lim
-  float cur[32], nxt[32];
-#pragma unroll
-  for (int i = 0; i < 32; ++i) {
-    const float v = *row_of(K - 1, i + 32 * h);
-    cur[i] = i < lim ? v : 0.0f;
-  }
-
-  // one read-modify-write round: this lane's point takes its four taps from the table
-  auto round = [&](int pnt, float gv) {
+  // one read-modify-write round: this lane's point takes its four taps from the table.  Slots start at multiples of 128 bytes:
+  // the lane's channel is or-ed into the address
+  auto round = [&](int pnt) {
     const float4 ww = tab_w[pnt];
-    const uint2 ss = tab_s[pnt];
-    // slot offsets are multiples of 128 bytes: the lane's channel is or-ed in
+    const uint2 sm = tab_sm[pnt];
+    const float gv = (sm.y & cbit) ? w_out_ch : 0.0f;   // g_h = [gate] w_out g_s, g_s rides in the tap weights
     char* const cb = reinterpret_cast<char*>(cache);
-    float* c00 = reinterpret_cast<float*>(cb + ((ss.x & 0xFFFFu) | c4));
-    float* c01 = reinterpret_cast<float*>(cb + ((ss.x >> 16) | c4));
-    float* c10 = reinterpret_cast<float*>(cb + ((ss.y & 0xFFFFu) | c4));
-    float* c11 = reinterpret_cast<float*>(cb + ((ss.y >> 16) | c4));
+    float* c00 = reinterpret_cast<float*>(cb + (((sm.x & 0xFFu) << 7) | c4));
+    float* c01 = reinterpret_cast<float*>(cb + ((((sm.x >> 8) & 0xFFu) << 7) | c4));
+    float* c10 = reinterpret_cast<float*>(cb + ((((sm.x >> 16) & 0xFFu) << 7) | c4));
+    float* c11 = reinterpret_cast<float*>(cb + (((sm.x >> 24) << 7) | c4));
     const float a00 = *c00, a01 = *c01, a10 = *c10, a11 = *c11;
     *c00 = a00 + ww.x * gv;
     *c01 = a01 + ww.y * gv;
@@ -581,15 +483,20 @@ __global__ __launch_bounds__(64) void scatter_rows2_kernel(const RowsScatterPara
     *c11 = a11 + ww.w * gv;
   };
 
+  float z_n = zrow[K - 1], gs_n = ray_ok ? gsrow[K - 1] : 0.0f;
+  unsigned m_n = ray_ok ? mrow[K - 1] : 0u;
   for (int k = K - 1; k >= 0; --k) {
-    const float z = zrow[k];
-    const float gs = ray_ok ? gsrow[k] : 0.0f;
-    db_out += gs;
+    const float z = z_n, gs = gs_n;
+    const unsigned gate = m_n;
+    {  // the next step's inputs
+      const int kn = max(k - 1, 0);
+      z_n = zrow[kn], gs_n = ray_ok ? gsrow[kn] : 0.0f, m_n = ray_ok ? mrow[kn] : 0u;
+    }
     const Proj pe = project<false>(enc, r0.x + z * r0.w, r0.y + z * r1.x, r0.z + z * r1.y);
     int x0, y0, x1, y1;
     Taps tp = make_taps_xy(pe.x, pe.y, H, W, x0, y0, x1, y1);
     const bool use_empty = (p.learn_empty != 0) & pe.invalid;
-    tp.w00 *= gs, tp.w01 *= gs, tp.w10 *= gs, tp.w11 *= gs;   // g_h = [u != 0] w_out g_s: the sample's g_s rides in the tap weights
+    tp.w00 *= gs, tp.w01 *= gs, tp.w10 *= gs, tp.w11 *= gs;
     bool fits = false;
     if (scatter) {
       const int mnx = wave_min_i(x0), mxx = -wave_min_i(-x1), mny = wave_min_i(y0), mxy = -wave_min_i(-y1);
@@ -600,15 +507,15 @@ __global__ __launch_bounds__(64) void scatter_rows2_kernel(const RowsScatterPara
         wx = nwx, wy = nwy;
       }
     }
-    // window slots of the four taps (float offsets).  A clamped tap (x1 == x0 or y1 == y0 at the far border: weight exactly 0) would
-    // alias its neighbour's slot inside one round; it goes to the scratch row.  An empty-feature point sends g_s to the EMPTY row.
+    // window slots of the four taps.  A clamped tap (x1 == x0 or y1 == y0 at the far border: weight exactly 0) would alias its
+    // neighbour's slot inside one round; it goes to the scratch row.  An empty-feature point sends g_s to the EMPTY row.
     const int rya = (int)((unsigned)y0 % CH) * CW, ryb = (int)((unsigned)y1 % CH) * CW;
     const int cxa = (int)((unsigned)x0 % CW), cxb = (int)((unsigned)x1 % CW);
     const bool ddx = x1 != x0, ddy = y1 != y0;
-    int s00 = (rya + cxa) * 128;
-    int s01 = ddx ? (rya + cxb) * 128 : SCRATCH;
-    int s10 = ddy ? (ryb + cxa) * 128 : SCRATCH;
-    int s11 = (ddx && ddy) ? (ryb + cxb) * 128 : SCRATCH;
+    int s00 = rya + cxa;
+    int s01 = ddx ? rya + cxb : SCRATCH;
+    int s10 = ddy ? ryb + cxa : SCRATCH;
+    int s11 = (ddx && ddy) ? ryb + cxb : SCRATCH;
     if (use_empty) s00 = EMPTY, s01 = s10 = s11 = SCRATCH, tp.w00 = gs, tp.w01 = tp.w10 = tp.w11 = 0.0f;
     if (!fits && !use_empty) s00 = s01 = s10 = s11 = SCRATCH;   // handled with direct atomics below
     // pairs (i, i + 32) whose points share a slot: the upper point waits
@@ -625,40 +532,28 @@ __global__ __launch_bounds__(64) void scatter_rows2_kernel(const RowsScatterPara
       amask = (unsigned)__ballot(al);
     }
     const float4 my_w = make_float4(tp.w00, tp.w01, tp.w10, tp.w11);
-    const uint2 my_s = make_uint2((unsigned)s00 | ((unsigned)s01 << 16), (unsigned)s10 | ((unsigned)s11 << 16));
+    const uint2 my_sm = make_uint2((unsigned)s00 | ((unsigned)s01 << 8) | ((unsigned)s10 << 16) | ((unsigned)s11 << 24), gate);
     const bool wait = h == 1 && ((amask >> c) & 1u);   // lane = ray here: this ray is the upper point of a pair that shares a slot
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    tab_w[lane] = wait ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : my_w;
-    tab_s[lane] = wait ? make_uint2((unsigned)SCRATCH | ((unsigned)SCRATCH << 16), (unsigned)SCRATCH | ((unsigned)SCRATCH << 16)) : my_s;
+    tab_w[lane] = my_w;
+    // a waiting point aims at the scratch row with its gate closed: its round must not touch the slots its partner updates
+    tab_sm[lane] = wait ? make_uint2((unsigned)SCRATCH * 0x01010101u, 0u) : my_sm;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // prefetch the next step's rows
-#pragma unroll
-    for (int i = 0; i < 32; ++i) {
-      const float v = *row_of(max(k - 1, 0), i + 32 * h);
-      nxt[i] = i < lim ? v : 0.0f;
-    }
     // one straight block: the table reads of later pairs may run ahead of the window's read-modify-write rounds
 #pragma unroll
-    for (int i = 0; i < 32; ++i) {
-      const float uv = cur[i];
-      dw_out += uv;
-      round(i + 32 * h, uv != 0.0f ? w_out_ch : 0.0f);
-    }
-    // the upper points of the pairs that shared a slot (rows re-read: the register block is never indexed dynamically)
+    for (int i = 0; i < 32; ++i) round(i + 32 * h);
+    // the upper points of the pairs that shared a slot, one at a time
     while (amask) {
       const int i = __builtin_ctz(amask);
       amask &= amask - 1;
-      if (lane == i + 32) tab_w[64] = my_w, tab_s[64] = my_s;
+      if (lane == i + 32) tab_sm[lane] = my_sm;
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      if (h == 1) {
-        const float uv = (i + 32 < n_pts) ? *row_of(k, i + 32) : 0.0f;
-        round(64, uv != 0.0f ? w_out_ch : 0.0f);
-      }
+      if (h == 1) round(i + 32);
     }
     if (scatter && !fits) {
       // rare (a footprint wider than the window: rays nearly through the encoder's centre): every tap a row of L2 atomics
@@ -666,8 +561,7 @@ __global__ __launch_bounds__(64) void scatter_rows2_kernel(const RowsScatterPara
       auto bc_f = [&](float v, int pnt) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), pnt)); };
 #pragma unroll 1
       for (int i = 0; i < n_pts; ++i) {
-        const float uv = *row_of(k, i);
-        const float gv = uv != 0.0f ? w_out_ch : 0.0f;
+        const float gv = ((unsigned)bc_i((int)gate, i) & cbit) ? w_out_ch : 0.0f;
         const long ya = (long)bc_i(y0, i) * W, yb = (long)bc_i(y1, i) * W;
         const int xa = bc_i(x0, i), xb = bc_i(x1, i);
         const float w00 = bc_f(tp.w00, i), w01 = bc_f(tp.w01, i), w10 = bc_f(tp.w10, i), w11 = bc_f(tp.w11, i);
@@ -680,21 +574,10 @@ __global__ __launch_bounds__(64) void scatter_rows2_kernel(const RowsScatterPara
         }
       }
     }
-#pragma unroll
-    for (int i = 0; i < 32; ++i) cur[i] = nxt[i];
   }
   if (scatter) flush(0, 0, true);
-  if (sp.d_mlp) {
-    dw_out += __shfl_xor(dw_out, 32, 64);
-    if (h == 0 && dw_out != 0.0f) atomic_add_f32(sp.d_mlp + sp.w_out_off + proj_hidden_of_storage(chg), dw_out);
-    if (wv == 0) {
-#pragma unroll
-      for (int off = 32; off >= 1; off >>= 1) db_out += __shfl_xor(db_out, off, 64);
-      if (lane == 0 && db_out != 0.0f) atomic_add_f32(sp.d_mlp + sp.b_out_off, db_out);
-    }
-  }
   if (sp.d_empty_proj && h == 0) {
-    const float v = cache[EMPTY / 4 + c];
+    const float v = cache[EMPTY * 32 + c];
     if (v != 0.0f) atomic_add_f32(sp.d_empty_proj + proj_hidden_of_storage(chg), v);
   }
 }
@@ -704,7 +587,7 @@ __global__ __launch_bounds__(64) void scatter_rows2_kernel(const RowsScatterPara
 // ---------------------------------------------------------------------------------------------------------------
 struct DwpeParams {
   FwdParams f;
-  const float* u_ws;
+  const unsigned* mask_ws;
   const float* gs_ws;
   float* d_mlp;
   long rays;   // n * Bp
@@ -723,6 +606,7 @@ __global__ __launch_bounds__(256) void dwpe_kernel(const DwpeParams dp) {
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int h = lane >> 5, col = lane & 31;
+  const unsigned cbit = 1u << col;
   float* tile = pe_tiles[wave];
   const int Bp = p.Bp, K = p.K;
   float w_out_ch[HT];
@@ -741,6 +625,9 @@ __global__ __launch_bounds__(256) void dwpe_kernel(const DwpeParams dp) {
     const cfp rp = as_const(p.rays) + ray * 8;
     const float z = p.z_samp[ray * K + kk];
     const float gs = k < K ? dp.gs_ws[ray * K + k] : 0.0f;
+    unsigned gate[HT];   // relu gates of this lane's sample (closed for lanes past K)
+#pragma unroll
+    for (int ht = 0; ht < HT; ++ht) gate[ht] = k < K ? dp.mask_ws[(ray * HT + ht) * K + k] : 0u;
     const float px = rp[0] + z * rp[3], py = rp[1] + z * rp[4], pz = rp[2] + z * rp[5];
     const Proj pe = p.code_mode == 1 ? project<true>(enc, px, py, pz) : project<false>(enc, px, py, pz);
     float v3[3];
@@ -761,15 +648,16 @@ __global__ __launch_bounds__(256) void dwpe_kernel(const DwpeParams dp) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // k-step s pairs samples s (lanes 0-31) and s + 32 (lanes 32-63); rows past K do not exist: their tile rows are zero
-    const float* __restrict__ urow = dp.u_ws + ray * (long)K * HD + col;
+    // k-step s pairs samples s (lanes 0-31) and s + 32 (lanes 32-63): A[i = channel][k] = [gate] w_out, B[k][j = kin] = g_s pe
 #pragma unroll 8
     for (int s = 0; s < 32; ++s) {
       const int pnt = s + 32 * h;
-      const int pr = min(pnt, K - 1);
       float a[HT];
 #pragma unroll
-      for (int ht = 0; ht < HT; ++ht) a[ht] = urow[(long)pr * HD + ht * 32] != 0.0f ? w_out_ch[ht] : 0.0f;
+      for (int ht = 0; ht < HT; ++ht) {
+        const unsigned g_lo = (unsigned)__builtin_amdgcn_readlane((int)gate[ht], s), g_hi = (unsigned)__builtin_amdgcn_readlane((int)gate[ht], s + 32);
+        a[ht] = ((h ? g_hi : g_lo) & cbit) ? w_out_ch[ht] : 0.0f;
+      }
       const float b0 = tile[pnt * LDX + col];
       const float b1 = col < PE_ROWS - 32 ? tile[pnt * LDX + 32 + col] : 0.0f;
 #pragma unroll
@@ -812,23 +700,17 @@ static int launch_rows(const BwdParams& bp, int n, int grid, hipStream_t s) {
   else if (p.nv <= 4) rows_kernel<C, HD, 4><<<grid, 256, 0, s>>>(bp);
   else rows_kernel<C, HD, 8><<<grid, 256, 0, s>>>(bp);
   hipError_t e = hipGetLastError();
-  if (e == hipSuccess) {
+  if (e == hipSuccess && (bp.d_proj || bp.d_empty_proj)) {
     const MlpLayout ml{C + kPeDim, HD, 0};
-    RowsScatterParams sp;
-    sp.f = p, sp.u_ws = bp.gh_ws, sp.gs_ws = bp.gs_ws, sp.d_proj = bp.d_proj, sp.d_mlp = bp.d_mlp, sp.d_empty_proj = bp.d_empty_proj;
-    sp.groups_per_sample = (p.Bp + 63) / 64, sp.w_out_off = ml.w_out(), sp.b_out_off = ml.b_out();
-#ifdef BTS_PROBE
-    static const bool one_wave = getenv("BTS_SCATTER_V1") != nullptr;   // A/B (probe build): the one-wave-per-patch form of pass B
-#else
-    constexpr bool one_wave = false;
-#endif
-    if (one_wave) scatter_rows_kernel<HD><<<n * sp.groups_per_sample, 64, 0, s>>>(sp);
-    else scatter_rows2_kernel<HD><<<n * sp.groups_per_sample * (HD / 32), 64, 0, s>>>(sp);
+    ScatterMaskParams sp;
+    sp.f = p, sp.mask_ws = bp.mask_ws, sp.gs_ws = bp.gs_ws, sp.d_proj = bp.d_proj, sp.d_empty_proj = bp.d_empty_proj;
+    sp.groups_per_sample = (p.Bp + 63) / 64, sp.w_out_off = ml.w_out();
+    scatter_kernel<HD><<<n * sp.groups_per_sample * (HD / 32), 64, 0, s>>>(sp);
     e = hipGetLastError();
   }
   if (e == hipSuccess && bp.d_mlp) {
     DwpeParams dp;
-    dp.f = p, dp.u_ws = bp.gh_ws, dp.gs_ws = bp.gs_ws, dp.d_mlp = bp.d_mlp, dp.rays = (long)n * p.Bp;
+    dp.f = p, dp.mask_ws = bp.mask_ws, dp.gs_ws = bp.gs_ws, dp.d_mlp = bp.d_mlp, dp.rays = (long)n * p.Bp;
     const long wgs = (dp.rays + 3) / 4;
     dwpe_kernel<C, HD><<<(int)(wgs < 3L * grid / 2 ? wgs : 3L * grid / 2), 256, 0, s>>>(dp);
     e = hipGetLastError();
@@ -840,7 +722,7 @@ static int launch_rows(const BwdParams& bp, int n, int grid, hipStream_t s) {
   return BTS_OK;
 }
 
-// bp.gh_ws: (n*Bp, K, HD) floats, bp.gs_ws: (n*Bp, K) floats; p.groups / chunk_log2 / lpr set for one ray per wave iteration
+// bp.gs_ws: (n*Bp, K) floats, bp.mask_ws: (n*Bp, HD/32, K) dwords; p.groups / chunk_log2 / lpr set for one ray per wave iteration
 int launch_bwd_rows(const BwdParams& bp, int C, int HD, int n, int grid, hipStream_t s) {
   if (C == 64 && HD == 64) return launch_rows<64, 64>(bp, n, grid, s);
   if (C == 32 && HD == 32) return launch_rows<32, 32>(bp, n, grid, s);
