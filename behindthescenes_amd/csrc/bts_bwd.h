@@ -15,7 +15,8 @@ struct BwdParams {
   float* d_empty_proj;    // (HD)
   float* gh_ws;           // lane = ray path: (groups, K, 64, HD) g_h rows for the dG scatter pass, or null: scatter with direct atomics
   float* gs_ws;           // lane = sample path (bts_bwd_rows.hip): (n*Bp, K) gradient at the pre-softplus density
-  unsigned* mask_ws;      //                    (n*Bp, HD/32, K) relu gates of lin_in's output, one bit per channel
+  unsigned* mask_ws;      //                    (n*Bp, HD/32, K) relu gates of lin_in's output per sample, one bit per channel
+  uint2* pmask_ws;        //                    (n*Bp, HD) the same gates per channel, one bit per sample of the ray
 };
 
 __device__ __forceinline__ void atomic_add_f32(float* p, float v) {

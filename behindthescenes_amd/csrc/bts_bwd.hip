@@ -707,10 +707,10 @@ int launch_bwd_rows(const BwdParams& bp, int C, int HD, int n, int grid, hipStre
 static bool rows_path(const BtsFieldCfg* cfg, const BtsRenderArgs* a) { return cfg->n_blocks == 0 && a->K <= 64; }
 
 // workspace = what the passes hand each other.  lane = ray path: groups of 64 rays x K x 64 x d_hidden floats (g_h rows); lane =
-// sample path: rays x K floats (g_s) + rays x K x d_hidden / 32 dwords (relu gates) -- 12 bytes per sample instead of 256.
+// sample path: rays x K floats (g_s) + the relu gates as bits, once per sample and once per channel -- 20 bytes per sample instead of 256.
 size_t render_bwd_workspace_impl(const BtsFieldCfg* cfg, const BtsRenderArgs* a) {
   const size_t rays = (size_t)cfg->n * (size_t)a->rays_per_sample;
-  const size_t v2 = rays * (size_t)a->K * (1 + (size_t)cfg->d_hidden / 32) * sizeof(float);
+  const size_t v2 = rays * ((size_t)a->K * (1 + (size_t)cfg->d_hidden / 32) + 2 * (size_t)cfg->d_hidden) * sizeof(float);
   const size_t groups = (size_t)cfg->n * ((a->rays_per_sample + 255) / 256) * 4;
   const size_t v1 = groups * (size_t)a->K * 64 * (size_t)cfg->d_hidden * sizeof(float);
 #ifdef BTS_PROBE   // either path may serve the call (BTS_BWD_V1)
@@ -765,13 +765,14 @@ int render_bwd_impl(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const BtsR
     bp.gh_ws = nullptr;
     bp.gs_ws = static_cast<float*>(workspace);
     bp.mask_ws = reinterpret_cast<unsigned*>(bp.gs_ws + (size_t)cfg->n * a->rays_per_sample * a->K);
+    bp.pmask_ws = reinterpret_cast<uint2*>(bp.mask_ws + (size_t)cfg->n * a->rays_per_sample * a->K * (cfg->d_hidden / 32));
     const int rc = launch_bwd_rows(bp, cfg->C, cfg->d_hidden, cfg->n, grid, s);
     if (rc != BTS_E_UNSUPPORTED) return rc;
     set_error("%s: unsupported MLP shape C=%ld d_hidden=%ld n_blocks=%ld", "bts_render_bwd", cfg->C, cfg->d_hidden, cfg->n_blocks);
     return rc;
   }
   bp.gh_ws = (bp.d_proj && !direct) ? static_cast<float*>(workspace) : nullptr;
-  bp.gs_ws = nullptr, bp.mask_ws = nullptr;
+  bp.gs_ws = nullptr, bp.mask_ws = nullptr, bp.pmask_ws = nullptr;
   const int grid = bp.f.tiles_per_sample * cfg->n;
   int rc = BTS_E_UNSUPPORTED;
   if (cfg->C == 64 && cfg->d_hidden == 64 && cfg->n_blocks == 0) rc = launch_bwd<64, 64, 0>(bp, grid, s);

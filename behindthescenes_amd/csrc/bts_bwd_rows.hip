@@ -18,6 +18,7 @@
 #include "bts_render_kernel.h"
 #include "bts_bwd.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace bts {
 
@@ -53,30 +54,56 @@ __device__ __forceinline__ float half_transpose_reduce16(float (&w)[16], int col
   return w[0] + __shfl_xor(w[0], 1, 64);
 }
 
+// Lanes L0 / L1 of (v0, v1) take the wave-uniform pairs (x00, x01) / (x10, x11)  (v_writelane_b32 with constant lane selects).
+// gfx950 does NOT interlock a VALU read of an SGPR that a VALU instruction wrote within the previous two wait states (LLVM's
+// VALUWriteSGPRVALURead hazard); hipcc pads its own instructions but does not look into inline assembly, and the values written here
+// are fresh v_cmp results -- without the s_nop 1.6 % of the gate bits came out stale (tools/bwd_debug.py).
+template <int L0, int L1>
+__device__ __forceinline__ void put_lanes(unsigned& v0, unsigned& v1, unsigned x00, unsigned x01, unsigned x10, unsigned x11) {
+  asm("s_nop 1\n\tv_writelane_b32 %0, %2, %6\n\tv_writelane_b32 %1, %3, %6\n\tv_writelane_b32 %0, %4, %7\n\tv_writelane_b32 %1, %5, %7"
+      : "+v"(v0), "+v"(v1)
+      : "s"(x00), "s"(x01), "s"(x10), "s"(x11), "n"(L0), "n"(L1));
+}
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
 // End of a ray in pass A.  acc[ht][pt][i] is channel ht*32 + 16h + i (storage order of G) of point pt*32 + (lane & 31), gs_t the g_s
-// of those two points.  Stores the gate masks of the lane's OWN sample (mrow: [HD/32][K] dwords of this ray) and adds the lane's
-// share of dw_out = sum relu(h) g_s: dw[ht] belongs to channel ht*32 + 16h + (col >> 1), on both lanes of the pair.
+// of those two points.  Stores the relu gates twice -- per sample (mrow: [HD/32][K] dwords of this ray, bit j of dword ht = channel
+// ht*32 + j; what the scatter pass reads) and per channel (prow: [HD] x 64 bits, bit p = sample p; the A operand of the dW_pe pass) --
+// and adds the lane's share of dw_out = sum relu(h) g_s: dw[ht] belongs to channel ht*32 + 16h + (col >> 1), on both lanes of the
+// pair.  The per-channel form is free: the compare that opens a gate leaves exactly that mask over the wave's samples in SGPRs.
 template <int HD>
-__device__ __forceinline__ void gates_and_dwout(const f32x16 (&acc)[HD / 32][2], const float (&gs_t)[2], unsigned* __restrict__ mrow, int K,
-                                                int lane, float (&dw)[HD / 32]) {
+__device__ __forceinline__ void gates_and_dwout(const f32x16 (&acc)[HD / 32][2], const float (&gs_t)[2], unsigned* __restrict__ mrow,
+                                                uint2* __restrict__ prow, int K, int lane, float (&dw)[HD / 32]) {
   constexpr int HT = HD / 32;
   const int col = lane & 31;
-#pragma unroll
-  for (int ht = 0; ht < HT; ++ht) {
+  unsigned pm0 = 0, pm1 = 0;   // lane = channel: gates of samples 0-31 / 32-63
+  static_for<0, HT>([&](auto htc) {
+    constexpr int ht = decltype(htc)::value;
     float r[16];
     unsigned x = 0, y = 0;   // gate bits of the lane's 16 channels: point tile 0 / 1
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
+    static_for<0, 16>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
       const float a0 = acc[ht][0][i], a1 = acc[ht][1][i];
-      x |= (a0 > 0.0f ? 1u : 0u) << i;
-      y |= (a1 > 0.0f ? 1u : 0u) << i;
+      const bool o0 = a0 > 0.0f, o1 = a1 > 0.0f;
+      x |= (o0 ? 1u : 0u) << i;
+      y |= (o1 ? 1u : 0u) << i;
+      // lanes 0-31 of the ballot: channel ht*32 + i of the tile's 32 samples; lanes 32-63: channel ht*32 + 16 + i
+      const unsigned long long b0 = __ballot(o0), b1 = __ballot(o1);
+      put_lanes<ht * 32 + i, ht * 32 + 16 + i>(pm0, pm1, (unsigned)b0, (unsigned)b1, (unsigned)(b0 >> 32), (unsigned)(b1 >> 32));
       r[i] = __builtin_fmaf(relu1(a1), gs_t[1], relu1(a0) * gs_t[0]);
-    }
+    });
     // x' = {tile 0 channels 0-15 | tile 1 channels 0-15}, y' = {tile 0 channels 16-31 | tile 1 channels 16-31}: lane l = sample l
     swap32u(x, y);
     if (lane < K) mrow[ht * K + lane] = x | (y << 16);
     dw[ht] += half_transpose_reduce16(r, col);
-  }
+  });
+  if (lane < HD) prow[lane] = make_uint2(pm0, pm1);
 }
 
 // Cold path of pass A (see eval_point_exact): some sample's encoding argument leaves the fast sincos range.  The forward evaluated
@@ -86,7 +113,7 @@ template <int C, int HD>
 __device__ __attribute__((noinline)) void rows_exact(const float* lds, const float4* G, const float* w2c, const float* Kc, int H, int W,
                                                      int code_mode, int inv_z, float inv_dmax, float inv_range, float d_min, float range,
                                                      float freq_factor, int learn_empty, float px, float py, float pz, float gs,
-                                                     unsigned* mrow, int K, float* dw_out /* [HD/32], per lane */) {
+                                                     unsigned* mrow, uint2* prow, int K, float* dw_out /* [HD/32], per lane */) {
   using L = Lds<C, HD, 0, true>;
   constexpr int HT = HD / 32;
   const int lane = threadIdx.x & 63, h = lane >> 5;
@@ -142,7 +169,7 @@ __device__ __attribute__((noinline)) void rows_exact(const float* lds, const flo
   float dw[HT];
 #pragma unroll
   for (int ht = 0; ht < HT; ++ht) dw[ht] = 0.0f;
-  gates_and_dwout<HD>(acc, gs_t, mrow, K, lane, dw);
+  gates_and_dwout<HD>(acc, gs_t, mrow, prow, K, lane, dw);
 #pragma unroll
   for (int ht = 0; ht < HT; ++ht) dw_out[ht] = dw[ht];
 }
@@ -289,11 +316,12 @@ __global__ __launch_bounds__(256, 2) void rows_kernel(const BwdParams bp) {
     }
     db_acc += g_s;
     unsigned* __restrict__ mrow = bp.mask_ws + ray * (long)(HT * K);
+    uint2* __restrict__ prow = bp.pmask_ws + ray * (long)HD;
 
     if (__builtin_expect(__any(pe_needs_exact(v3, p.freq_factor)), 0)) {
       float dwx[HT];   // through memory: no accumulator array may cross the call (it would be demoted to scratch on the hot path)
       rows_exact<C, HD>(lds, G, p.w2c_enc + sample * 16, p.K_enc + sample * 9, H, W, p.code_mode, p.inv_z, p.inv_dmax, p.inv_range, p.d_min,
-                        p.range, p.freq_factor, p.learn_empty, px, py, pz, g_s, mrow, K, dwx);
+                        p.range, p.freq_factor, p.learn_empty, px, py, pz, g_s, mrow, prow, K, dwx);
 #pragma unroll
       for (int ht = 0; ht < HT; ++ht) dw_acc[ht] += dwx[ht];
       continue;
@@ -360,7 +388,7 @@ __global__ __launch_bounds__(256, 2) void rows_kernel(const BwdParams bp) {
       bcast_tiles(__float_as_uint(g_s * inv_scale), t0, t1);
       gs_t[0] = __uint_as_float(t0), gs_t[1] = __uint_as_float(t1);
     }
-    gates_and_dwout<HD>(acc, gs_t, mrow, K, lane, dw_acc);
+    gates_and_dwout<HD>(acc, gs_t, mrow, prow, K, lane, dw_acc);
   }
 
   // ---------------- dw_out, db_out: wave registers -> work-group LDS -> one atomic per parameter
@@ -583,94 +611,172 @@ __global__ __launch_bounds__(64) void scatter_kernel(const ScatterMaskParams sp)
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// pass C: dW_pe (and db_in: the constant-1 row of the encoding)
+// pass C: dW_pe (and db_in: the constant-1 row of the encoding) on the bf16 matrix pipe.
+//   dW_pe^T[ch][kin] = w_out[ch] * sum_p gate[p][ch] * (g_s pe)[p][kin]
+// The A operand is a 0/1 matrix: exact in bf16.  The B operand g_s * pe spans the full fp32 exponent range (g_s does), so it is cut
+// into three bf16 pieces by truncation (8 + 8 + 8 significand bits: the pieces add up to the fp32 value EXACTLY); 0/1 times a bf16
+// piece is exact and the MFMA accumulates in fp32 -- the result is the fp32-input MFMA's, at 48 wide MFMAs per ray (32 cycles each,
+// vector instructions issue underneath) instead of 128 v_mfma_f32_32x32x2_f32 (64 cycles each with the VALU blocked: 0.6 ms of the
+// first lane = sample backward).  Per ray: the encoding is recomputed lane = sample with the forward's fast sines, scaled by g_s,
+// cut, and laid out [piece][kin][sample] in a per-wave LDS tile (rows padded to 144 bytes: the 16-byte column reads of the B operand
+// then spread over all banks); the A operand comes from the per-channel gate masks pass A stored, eight samples = one byte at a
+// time through a 256-entry table of bf16 octets.
 // ---------------------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
 struct DwpeParams {
   FwdParams f;
-  const unsigned* mask_ws;
-  const float* gs_ws;
+  const uint2* pmask_ws;   // (n*Bp, HD) per-channel gates over the ray's 64 samples
+  const float* gs_ws;      // (n*Bp, K)
   float* d_mlp;
-  long rays;   // n * Bp
+  long rays;               // n * Bp
 };
 
+struct DwpeLds {
+  static constexpr int PE_ROWS = kPeDim + 1;             // 40
+  static constexpr int ROW = 144;                        // bytes per [piece][kin] row: 64 samples x 2 + 16 of padding
+  static constexpr int PLANE = PE_ROWS * ROW;            // one piece
+  static constexpr int WAVE = 3 * PLANE;                 // 17 280 bytes per wave
+  static constexpr int LUT = 0;                          // 256 x 16 bytes: bit j of the index -> bf16 1.0 / 0.0 in position j
+  static constexpr int TILES = LUT + 256 * 16;
+  static constexpr int TOTAL = TILES + 4 * WAVE;         // 73 216 bytes: two work-groups per CU
+};
+
+// g_s * e cut into three bf16 pieces by truncation, [piece][kin][sample]; lane = sample
+__device__ __forceinline__ void write_planes(char* tile, const float (&e)[DwpeLds::PE_ROWS], float gs, int lane) {
+  using L = DwpeLds;
+#pragma unroll
+  for (int i = 0; i < L::PE_ROWS; ++i) {
+    const float v = e[i] * gs;
+    const unsigned b1 = __float_as_uint(v) & 0xFFFF0000u;
+    const float r1 = v - __uint_as_float(b1);
+    const unsigned b2 = __float_as_uint(r1) & 0xFFFF0000u;
+    const float r2 = r1 - __uint_as_float(b2);
+    unsigned short* dst = reinterpret_cast<unsigned short*>(tile + i * L::ROW) + lane;
+    dst[0] = (unsigned short)(b1 >> 16);
+    dst[L::PLANE / 2] = (unsigned short)(b2 >> 16);
+    dst[L::PLANE] = (unsigned short)(__float_as_uint(r2) >> 16);
+  }
+}
+// cold path: some encoding argument of the ray leaves the fast sines' range (as pe_octave); out of line, with its own copy of e[]
+__device__ __attribute__((noinline)) void write_planes_exact(char* tile, float x, float y, float code, float freq_factor, float gs) {
+  const float v3[3] = {x, y, code};
+  float e[DwpeLds::PE_ROWS];
+  e[0] = x, e[1] = y, e[2] = code, e[3] = 1.0f;
+  float ff = freq_factor;
+#pragma unroll 1
+  for (int oct = 0; oct < kNumFreqs; ++oct) {
+    float sc[6];
+    pe_octave_exact(sc, v3, ff);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) e[4 + 6 * oct + i] = sc[i];
+    ff = ff * 2.0f;
+  }
+  write_planes(tile, e, gs, (int)(threadIdx.x & 63));
+}
+
 template <int C, int HD>
-__global__ __launch_bounds__(256) void dwpe_kernel(const DwpeParams dp) {
+__global__ __launch_bounds__(256, 2) void dwpe_kernel(const DwpeParams dp) {
   constexpr int HT = HD / 32;
-  constexpr int PE_ROWS = kPeDim + 1, LDX = PE_ROWS + 1;
+  using L = DwpeLds;
+  constexpr int PE_ROWS = L::PE_ROWS;
   constexpr int D_IN = C + kPeDim;
   const FwdParams& p = dp.f;
-  __shared__ float d_wpe[PE_ROWS * HD];       // work-group accumulator [kin][channel]
-  __shared__ float pe_tiles[4][64 * LDX];     // per wave [sample][kin]: g_s * encoding
+  extern __shared__ __attribute__((aligned(16))) char smem[];
   const MlpLayout ml{D_IN, HD, 0};
-  for (int i = threadIdx.x; i < PE_ROWS * HD; i += blockDim.x) d_wpe[i] = 0.0f;
-  __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int h = lane >> 5, col = lane & 31;
-  const unsigned cbit = 1u << col;
-  float* tile = pe_tiles[wave];
-  const int Bp = p.Bp, K = p.K;
-  float w_out_ch[HT];
+  {
+    u32x4* lut = reinterpret_cast<u32x4*>(smem + L::LUT);
+    const unsigned b = threadIdx.x;   // 256 threads: one entry each
+    u32x4 e;
 #pragma unroll
-  for (int ht = 0; ht < HT; ++ht) w_out_ch[ht] = p.mlp[ml.w_out() + proj_hidden_of_storage(ht * 32 + col)];
+    for (int d = 0; d < 4; ++d) e[d] = ((b >> (2 * d)) & 1u ? 0x3F80u : 0u) | ((b >> (2 * d + 1)) & 1u ? 0x3F800000u : 0u);
+    lut[b] = e;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: a scalar ray loop
+  const int h = lane >> 5, col = lane & 31;
+  char* const tile = smem + L::TILES + wave * L::WAVE;
+  const int Bp = p.Bp, K = p.K;
   f32x16 dw[HT][2];
 #pragma unroll
   for (int ht = 0; ht < HT; ++ht)
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) dw[ht][kt] = zero_acc();
   const int k = lane, kk = min(k, K - 1);
+  // byte offsets of this lane's B-operand rows (kin = col and, clamped, 32 + col) and of its column of samples
+  const int brow0 = col * L::ROW + 16 * h, brow1 = min(32 + col, PE_ROWS - 1) * L::ROW + 16 * h;
   const long stride = (long)gridDim.x * 4;
   for (long ray = (long)blockIdx.x * 4 + wave; ray < dp.rays; ray += stride) {
     const int sample = (int)(ray / Bp);
     const Cam enc = load_cam(p.w2c_enc + sample * 16, p.K_enc + sample * 9);
     const cfp rp = as_const(p.rays) + ray * 8;
     const float z = p.z_samp[ray * K + kk];
-    const float gs = k < K ? dp.gs_ws[ray * K + k] : 0.0f;
-    unsigned gate[HT];   // relu gates of this lane's sample (closed for lanes past K)
+    const float gs = k < K ? dp.gs_ws[ray * K + k] : 0.0f;   // lanes past K contribute exact zeros
+    uint2 pm[HT];   // gates of channel ht*32 + col over the ray's samples
 #pragma unroll
-    for (int ht = 0; ht < HT; ++ht) gate[ht] = k < K ? dp.mask_ws[(ray * HT + ht) * K + k] : 0u;
+    for (int ht = 0; ht < HT; ++ht) pm[ht] = dp.pmask_ws[ray * HD + ht * 32 + col];
     const float px = rp[0] + z * rp[3], py = rp[1] + z * rp[4], pz = rp[2] + z * rp[5];
     const Proj pe = p.code_mode == 1 ? project<true>(enc, px, py, pz) : project<false>(enc, px, py, pz);
     float v3[3];
     v3[0] = pe.x, v3[1] = pe.y;
     v3[2] = depth_code(p.code_mode == 1 ? pe.dist : pe.z, p.inv_z != 0, p.inv_dmax, p.inv_range, p.d_min, p.range);
-    // per-wave tile: the LDS accesses of one wave are performed in order, the fences below only pin the compiler's order
-    float* my = tile + lane * LDX;
-    my[0] = v3[0] * gs, my[1] = v3[1] * gs, my[2] = v3[2] * gs, my[3] = gs;
-    float ff = p.freq_factor;
-#pragma unroll 1
-    for (int oct = 0; oct < kNumFreqs; ++oct) {
-      float sc[6];
-      pe_octave(sc, v3, ff);
+    // ---- the 40 inputs of lin_in's encoding part in kernel order (kernel_to_ref_input: x, y, code, 1, then per octave 3 sines and
+    // 3 "cosines"), times g_s, cut into bf16 pieces
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (__builtin_expect(__any(pe_needs_exact(v3, p.freq_factor)), 0)) {
+      write_planes_exact(tile, v3[0], v3[1], v3[2], p.freq_factor, gs);
+    } else {
+      float e[PE_ROWS];
+      e[0] = v3[0], e[1] = v3[1], e[2] = v3[2], e[3] = 1.0f;
+      float ff = p.freq_factor;
 #pragma unroll
-      for (int i = 0; i < 6; ++i) my[4 + 6 * oct + i] = sc[i] * gs;
-      ff = ff * 2.0f;
+      for (int r = 0; r < kNumFreqs / 2; ++r) {   // octaves 2r (direct) and 2r + 1 (angle doubling), as the forward's regions
+        SinCos3 raw, dbl;
+        float t[6];
+        pe_direct(raw, v3, ff);
+        pe_entries(t, raw, v3, ff);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) e[4 + 12 * r + i] = t[i];
+        pe_double(dbl, raw);
+        pe_entries(t, dbl, v3, ff * 2.0f);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) e[10 + 12 * r + i] = t[i];
+        ff = ff * 4.0f;
+      }
+      write_planes(tile, e, gs, lane);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // k-step s pairs samples s (lanes 0-31) and s + 32 (lanes 32-63): A[i = channel][k] = [gate] w_out, B[k][j = kin] = g_s pe
-#pragma unroll 8
-    for (int s = 0; s < 32; ++s) {
-      const int pnt = s + 32 * h;
-      float a[HT];
+    // ---- four k-slices of 16 samples: A[i = channel][k] = gate, B[k][j = kin] = piece of g_s pe
+#pragma unroll
+    for (int sl = 0; sl < 4; ++sl) {
+      bf16x8 a[HT];
 #pragma unroll
       for (int ht = 0; ht < HT; ++ht) {
-        const unsigned g_lo = (unsigned)__builtin_amdgcn_readlane((int)gate[ht], s), g_hi = (unsigned)__builtin_amdgcn_readlane((int)gate[ht], s + 32);
-        a[ht] = ((h ? g_hi : g_lo) & cbit) ? w_out_ch[ht] : 0.0f;
+        const unsigned word = sl < 2 ? pm[ht].x : pm[ht].y;
+        const unsigned byte = (word >> (16 * (sl & 1) + 8 * h)) & 0xFFu;   // samples 16 sl + 8 h .. + 7
+        a[ht] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(smem + L::LUT + byte * 16));
       }
-      const float b0 = tile[pnt * LDX + col];
-      const float b1 = col < PE_ROWS - 32 ? tile[pnt * LDX + 32 + col] : 0.0f;
 #pragma unroll
-      for (int ht = 0; ht < HT; ++ht) {
-        dw[ht][0] = mfma(a[ht], b0, dw[ht][0]);
-        dw[ht][1] = mfma(a[ht], b1, dw[ht][1]);
+      for (int t = 0; t < 3; ++t) {
+        const bf16x8 b0 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(tile + t * L::PLANE + brow0 + 32 * sl));
+        const bf16x8 b1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(tile + t * L::PLANE + brow1 + 32 * sl));
+#pragma unroll
+        for (int ht = 0; ht < HT; ++ht) {
+          dw[ht][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ht], b0, dw[ht][0], 0, 0, 0);
+          dw[ht][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ht], b1, dw[ht][1], 0, 0, 0);
+        }
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
-  // D[i = channel in tile][j = kin in tile]: register q of a lane of half h holds row mfma_row(q, h), column col
+  // ---- flush: D[i = channel in tile][j = kin in tile], register q of a lane of half h holds row mfma_row(q, h), column col.
+  // Wave registers -> work-group accumulator (the tiles' memory, dead now) -> one global atomic per parameter, times w_out
+  __syncthreads();
+  float* d_wpe = reinterpret_cast<float*>(smem + L::TILES);   // [kin][channel]
+  for (int i = threadIdx.x; i < PE_ROWS * HD; i += blockDim.x) d_wpe[i] = 0.0f;
+  __syncthreads();
 #pragma unroll
   for (int ht = 0; ht < HT; ++ht)
 #pragma unroll
@@ -684,7 +790,7 @@ __global__ __launch_bounds__(256) void dwpe_kernel(const DwpeParams dp) {
   for (int i = threadIdx.x; i < PE_ROWS * HD; i += blockDim.x) {
     const int kin = i / HD, hid = proj_hidden_of_storage(i % HD);
     const int src = kernel_to_ref_input<C>(kin + C);
-    const float v = d_wpe[i];
+    const float v = d_wpe[i] * p.mlp[ml.w_out() + hid];
     if (v != 0.0f) atomic_add_f32(dp.d_mlp + (src >= 0 ? ml.w_in() + hid * D_IN + src : ml.b_in() + hid), v);
   }
 }
@@ -710,9 +816,11 @@ static int launch_rows(const BwdParams& bp, int n, int grid, hipStream_t s) {
   }
   if (e == hipSuccess && bp.d_mlp) {
     DwpeParams dp;
-    dp.f = p, dp.mask_ws = bp.mask_ws, dp.gs_ws = bp.gs_ws, dp.d_mlp = bp.d_mlp, dp.rays = (long)n * p.Bp;
+    dp.f = p, dp.pmask_ws = bp.pmask_ws, dp.gs_ws = bp.gs_ws, dp.d_mlp = bp.d_mlp, dp.rays = (long)n * p.Bp;
     const long wgs = (dp.rays + 3) / 4;
-    dwpe_kernel<C, HD><<<(int)(wgs < 3L * grid / 2 ? wgs : 3L * grid / 2), 256, 0, s>>>(dp);
+    auto kern = dwpe_kernel<C, HD>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, DwpeLds::TOTAL);
+    kern<<<(int)(wgs < grid ? wgs : grid), 256, DwpeLds::TOTAL, s>>>(dp);   // grid = 2 work-groups per CU
     e = hipGetLastError();
   }
   if (e != hipSuccess) {
@@ -722,7 +830,7 @@ static int launch_rows(const BwdParams& bp, int n, int grid, hipStream_t s) {
   return BTS_OK;
 }
 
-// bp.gs_ws: (n*Bp, K) floats, bp.mask_ws: (n*Bp, HD/32, K) dwords; p.groups / chunk_log2 / lpr set for one ray per wave iteration
+// bp.gs_ws: (n*Bp, K) floats, bp.mask_ws: (n*Bp, HD/32, K) dwords, bp.pmask_ws: (n*Bp, HD) x 64 bits; p.groups / chunk_log2 / lpr set for one ray per wave iteration
 int launch_bwd_rows(const BwdParams& bp, int C, int HD, int n, int grid, hipStream_t s) {
   if (C == 64 && HD == 64) return launch_rows<64, 64>(bp, n, grid, s);
   if (C == 32 && HD == 32) return launch_rows<32, 32>(bp, n, grid, s);

@@ -1,7 +1,8 @@
 #!/bin/bash
 # rocprofv3 passes over the render kernels.  Run on the GPU box via gpurun:
-#   gpurun -- bash tools/profile.sh <tag> [fwd|train]
-# fwd (default): tools/kernel_probe.py = the bench.py kernel (BASELINE configs[1]); train: tools/train_probe.py = configs[2] shapes.
+#   gpurun -- bash tools/profile.sh <tag> [fwd|train|bwd]
+# fwd (default): tools/kernel_probe.py = the bench.py kernel (BASELINE configs[1]); train: tools/train_probe.py = configs[2] shapes;
+# bwd: tools/bwd_probe.py = bts_render_bwd alone on the configs[2] shape.
 # Writes raw output under gpurun_out/prof_<tag>/ and a summary (traffic.json with the derived fractions bench.py reports);
 # copy what you want judged into profiles/<tag>/.  Counters are collected in separate --pmc passes with --kernel-trace only.
 set -u
@@ -12,7 +13,7 @@ OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-if [ "$MODE" = train ]; then CMD="python $REPO/tools/train_probe.py 16 3"; else CMD="python $REPO/tools/kernel_probe.py 5"; fi
+if [ "$MODE" = train ]; then CMD="python $REPO/tools/train_probe.py 16 3"; elif [ "$MODE" = bwd ]; then CMD="python $REPO/tools/bwd_probe.py 3"; else CMD="python $REPO/tools/kernel_probe.py 5"; fi
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $CMD > $OUT/trace.log 2>&1 || tail -5 $OUT/trace.log
 for i in 0 1 2 3 4; do
   case $i in
@@ -37,8 +38,9 @@ for f in sorted(glob.glob("$OUT/trace/**/*kernel_stats.csv", recursive=True)):
         dur[row["Name"]] = (float(row["AverageNs"]), int(row["Calls"]))
         if len(dur) <= 10:
             print(f"{float(row['AverageNs']) / 1e6:9.4f} ms x {row['Calls']:>4s}  {row['Name'][:110]}")
-pats = {"fwd": ["render_kernel_p"], "train": ["render_bwd_kernel", "scatter_dg_kernel", "render_kernel_p", "project_kernel", "project_bwd_feat_kernel",
-                                               "project_bwd_weight_kernel", "photometric_loss_kernel"]}[mode]
+train = ["rows_kernel", "scatter_kernel", "dwpe_kernel", "render_bwd_kernel", "scatter_dg_kernel", "render_kernel_p", "project_kernel",
+         "project_bwd_feat_kernel", "project_bwd_weight_kernel", "photometric_loss_kernel"]
+pats = {"fwd": ["render_kernel_p"], "train": train, "bwd": train[:3]}[mode]
 per = {p: collections.defaultdict(list) for p in pats}
 for f in sorted(glob.glob("$OUT/pmc*/**/*counter_collection.csv", recursive=True)):
     for row in csv.DictReader(open(f)):
@@ -70,5 +72,5 @@ if mode == "fwd" and "render_kernel_p" in summary:
     s["mfma_insts_per_ray"] = s["counters"].get("SQ_INSTS_MFMA", 0) / rays
     json.dump(s, open("$OUT/traffic.json", "w"), indent=1)
 else:
-    json.dump(summary, open("$OUT/traffic_train.json", "w"), indent=1)
+    json.dump(summary, open("$OUT/traffic_" + mode + ".json", "w"), indent=1)
 PY
