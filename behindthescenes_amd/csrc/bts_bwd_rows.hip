@@ -298,6 +298,29 @@ __global__ __launch_bounds__(256, 2) void rows_kernel(const BwdParams bp) {
     if (use_empty) tp.w00 = tp.w01 = tp.w10 = tp.w11 = 0.0f;
     tp.w00 *= scale, tp.w01 *= scale, tp.w10 *= scale, tp.w11 *= scale;
 
+    // ---------------- tap offsets / weights of both point tiles on every lane; the first two gather stages go out now: their latency
+    // runs under the compositing gradient below (a scan across the wave, exp / log / divide) instead of in front of the MFMA phase
+    int o[2][4];
+    float wq[2][4];
+    bool emp[2];
+    {
+      unsigned t0, t1;
+      bcast_tiles((unsigned)tp.o00, t0, t1), o[0][0] = (int)t0, o[1][0] = (int)t1;
+      bcast_tiles((unsigned)tp.o01, t0, t1), o[0][1] = (int)t0, o[1][1] = (int)t1;
+      bcast_tiles((unsigned)tp.o10, t0, t1), o[0][2] = (int)t0, o[1][2] = (int)t1;
+      bcast_tiles((unsigned)tp.o11, t0, t1), o[0][3] = (int)t0, o[1][3] = (int)t1;
+      bcast_tiles(__float_as_uint(tp.w00), t0, t1), wq[0][0] = __uint_as_float(t0), wq[1][0] = __uint_as_float(t1);
+      bcast_tiles(__float_as_uint(tp.w01), t0, t1), wq[0][1] = __uint_as_float(t0), wq[1][1] = __uint_as_float(t1);
+      bcast_tiles(__float_as_uint(tp.w10), t0, t1), wq[0][2] = __uint_as_float(t0), wq[1][2] = __uint_as_float(t1);
+      bcast_tiles(__float_as_uint(tp.w11), t0, t1), wq[0][3] = __uint_as_float(t0), wq[1][3] = __uint_as_float(t1);
+      bcast_tiles(use_empty ? 1u : 0u, t0, t1), emp[0] = t0 != 0, emp[1] = t1 != 0;
+    }
+    GBuf ba, bb;
+#ifndef BTS_ROWS_LATE_GATHER
+    stage_load<HD, 0>(ba, G, o, h);
+    stage_load<HD, 1>(bb, G, o, h);
+#endif
+
     // ---------------- compositing gradient (nerf.py:283-299):  g_alpha_k = g_w_k T_k - (sum_{m>k} g_w_m w_m) / (1 - alpha_k + 1e-10)
     float g_s = 0.0f;
     {
@@ -308,7 +331,11 @@ __global__ __launch_bounds__(256, 2) void rows_kernel(const BwdParams bp) {
       const float ex = expf(-fabsf(delta) * fmaxf(sigma, 0.0f));
       const bool capped = (p.hard_cap != 0) & last;
       const float alpha = capped ? 1.0f : 1.0f - ex;
+#ifdef BTS_ABL_R2   // timing ablation: no scan
+      const float S = g_w * alpha;
+#else
       const float S = wave_suffix_excl(valid ? g_w * (alpha * T) : 0.0f, lane);
+#endif
       float g_alpha = g_w * T - S / (capped ? 1e-10f : ex + 1e-10f);
       if (bp.g_alphas) g_alpha += bp.g_alphas[pk];
       if (!capped && !dead && valid) g_s = g_alpha * fabsf(delta) * ex * (s_raw > 20.0f ? 1.0f : sigmoidf(s_raw));
@@ -328,26 +355,12 @@ __global__ __launch_bounds__(256, 2) void rows_kernel(const BwdParams bp) {
     }
 
     // ---------------- h = bilinear(G) + W_pe . PE + b, exactly as render_kernel_p evaluates it (accumulators carry 2^S)
-    int o[2][4];
-    float wq[2][4];
-    bool emp[2];
-    {
-      unsigned t0, t1;
-      bcast_tiles((unsigned)tp.o00, t0, t1), o[0][0] = (int)t0, o[1][0] = (int)t1;
-      bcast_tiles((unsigned)tp.o01, t0, t1), o[0][1] = (int)t0, o[1][1] = (int)t1;
-      bcast_tiles((unsigned)tp.o10, t0, t1), o[0][2] = (int)t0, o[1][2] = (int)t1;
-      bcast_tiles((unsigned)tp.o11, t0, t1), o[0][3] = (int)t0, o[1][3] = (int)t1;
-      bcast_tiles(__float_as_uint(tp.w00), t0, t1), wq[0][0] = __uint_as_float(t0), wq[1][0] = __uint_as_float(t1);
-      bcast_tiles(__float_as_uint(tp.w01), t0, t1), wq[0][1] = __uint_as_float(t0), wq[1][1] = __uint_as_float(t1);
-      bcast_tiles(__float_as_uint(tp.w10), t0, t1), wq[0][2] = __uint_as_float(t0), wq[1][2] = __uint_as_float(t1);
-      bcast_tiles(__float_as_uint(tp.w11), t0, t1), wq[0][3] = __uint_as_float(t0), wq[1][3] = __uint_as_float(t1);
-      bcast_tiles(use_empty ? 1u : 0u, t0, t1), emp[0] = t0 != 0, emp[1] = t1 != 0;
-    }
     f32x16 acc[HT][2];
     {
-      GBuf ba, bb;
+#ifdef BTS_ROWS_LATE_GATHER   // A/B: gather issued in front of the MFMA phase
       stage_load<HD, 0>(ba, G, o, h);
       stage_load<HD, 1>(bb, G, o, h);
+#endif
       f32x16 bias[HT];
       {
         const float* bl = lh + LH::W_RAW + 3 * HD + 4 * h;
@@ -388,7 +401,11 @@ __global__ __launch_bounds__(256, 2) void rows_kernel(const BwdParams bp) {
       bcast_tiles(__float_as_uint(g_s * inv_scale), t0, t1);
       gs_t[0] = __uint_as_float(t0), gs_t[1] = __uint_as_float(t1);
     }
+#ifdef BTS_ABL_R1   // timing ablation: no gate masks / dw_out (one store keeps the accumulators alive)
+    if (lane < K) mrow[lane] = __float_as_uint(acc[0][0][0] + acc[0][1][5] + acc[HT - 1][0][9] + acc[HT - 1][1][15]);
+#else
     gates_and_dwout<HD>(acc, gs_t, mrow, prow, K, lane, dw_acc);
+#endif
   }
 
   // ---------------- dw_out, db_out: wave registers -> work-group LDS -> one atomic per parameter
@@ -421,9 +438,9 @@ __global__ __launch_bounds__(256, 2) void rows_kernel(const BwdParams bp) {
 // float atomics (~5-10 % of the tap updates).  Lanes 0-31 and 32-63 work on DIFFERENT points of the step (points i and i + 32: four
 // patch rows apart, their footprints almost never share a texel), so one round serves two points; the taps and the gate mask of
 // every point come from a small per-wave LDS table (two broadcast reads per pair); at 20 KB of LDS per wave eight waves fit a CU.
-// Pairs whose points do share a window slot (found by comparing the partner's slots, lane = ray) are taken apart: the upper point's
-// table entry is neutralised for the main rounds and served afterwards on its own.  Points that took the empty feature aim at a
-// dedicated row of the window, so d_empty falls out of the same rounds.  A step whose footprint does not fit the window falls back to
+// Pairs whose points do share a window slot (found by comparing the partner's slots, lane = ray) take their rounds one after the
+// other.  Points that took the empty feature aim at a dedicated row of the window (one per lane half), so d_empty falls out of the
+// same rounds.  A step whose footprint does not fit the window falls back to
 // direct row atomics.
 // ---------------------------------------------------------------------------------------------------------------
 struct ScatterMaskParams {
@@ -436,17 +453,28 @@ struct ScatterMaskParams {
   int w_out_off;             // offset of w_out in the packed parameter vector
 };
 
+// wave-wide minimum on the DPP network (row_shr 1/2/4/8, row_bcast15, row_bcast31: lane 63 ends up with the result) -- four of these
+// per step; as six ds_bpermute round trips each they cost as much as the step's read-modify-write rounds
 __device__ __forceinline__ int wave_min_i(int v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v = min(v, __shfl_xor(v, off, 64));
-  return __builtin_amdgcn_readfirstlane(v);
+  auto step = [&](auto ctrl, auto row_mask) {
+    const int y = __builtin_amdgcn_update_dpp(v, v, decltype(ctrl)::value, decltype(row_mask)::value, 0xF, false);
+    v = min(v, y);
+  };
+  step(std::integral_constant<int, kDppRowShr + 1>{}, std::integral_constant<int, 0xF>{});
+  step(std::integral_constant<int, kDppRowShr + 2>{}, std::integral_constant<int, 0xF>{});
+  step(std::integral_constant<int, kDppRowShr + 4>{}, std::integral_constant<int, 0xF>{});
+  step(std::integral_constant<int, kDppRowShr + 8>{}, std::integral_constant<int, 0xF>{});
+  step(std::integral_constant<int, kDppBcast15>{}, std::integral_constant<int, 0xA>{});
+  step(std::integral_constant<int, kDppBcast31>{}, std::integral_constant<int, 0xC>{});
+  return __builtin_amdgcn_readlane(v, 63);
 }
 
 template <int HD>
 __global__ __launch_bounds__(64) void scatter_kernel(const ScatterMaskParams sp) {
-  constexpr int CW = 12, CH = 12, NSLOT = CW * CH, SCRATCH = NSLOT, EMPTY = NSLOT + 1;   // slot indices; a slot is 32 floats
+  constexpr int CW = 12, CH = 12, NSLOT = CW * CH, SCRATCH = NSLOT, EMPTY = NSLOT + 1;   // slot indices; a slot is 32 floats;
+                                                                                           // EMPTY, EMPTY + 1: one row per lane half
   constexpr int NW = HD / 32;
-  __shared__ __attribute__((aligned(128))) float cache[(NSLOT + 2) * 32];   // aligned: see round()
+  __shared__ __attribute__((aligned(128))) float cache[(NSLOT + 3) * 32];   // aligned: see round()
   __shared__ float4 tab_w[64];   // per point of the step: the four tap weights times g_s
   __shared__ uint2 tab_sm[64];   //                        x: the four slot indices (8 bits each), y: the gate mask of this channel half
   const FwdParams& p = sp.f;
@@ -464,7 +492,7 @@ __global__ __launch_bounds__(64) void scatter_kernel(const ScatterMaskParams sp)
   const long ray = (long)sample * Bp + r;
   const int n_pts = min(64, Bp - g_in * 64);
   const bool scatter = sp.d_proj != nullptr;
-  for (int i = lane; i < (NSLOT + 2) * 32; i += 64) cache[i] = 0.0f;
+  for (int i = lane; i < (NSLOT + 3) * 32; i += 64) cache[i] = 0.0f;
   const Cam enc = load_cam(p.w2c_enc + sample * 16, p.K_enc + sample * 9);
   const float4 r0 = reinterpret_cast<const float4*>(p.rays)[ray * 2];
   const float4 r1 = reinterpret_cast<const float4*>(p.rays)[ray * 2 + 1];
@@ -475,22 +503,54 @@ __global__ __launch_bounds__(64) void scatter_kernel(const ScatterMaskParams sp)
   const float w_out_ch = p.mlp[sp.w_out_off + proj_hidden_of_storage(chg)];
   int wx = 0, wy = 0;   // window origin (uniform)
 
-  // evict every slot whose texel lies outside the window at (nwx, nwy); the two lane halves take alternate slots
-  auto flush = [&](int nwx, int nwy, bool all) {
-    const int wxm = ((wx % CW) + CW) % CW, wym = ((wy % CH) + CH) % CH;
-#pragma unroll 1
-    for (int s0 = 0; s0 < NSLOT; s0 += 2) {
-      const int sl = s0 + h, sy = sl / CW, sx = sl - sy * CW;
-      const int ty = wy + sy - wym + (sy < wym ? CH : 0), tx = wx + sx - wxm + (sx < wxm ? CW : 0);
-      if (all || ty < nwy || ty >= nwy + CH || tx < nwx || tx >= nwx + CW) {
-        float* cc = &cache[sl * 32 + c];
-        const float v = *cc;
-        if (v != 0.0f) {
-          atomic_add_f32(dG + ((long)ty * W + tx) * HD, v);
-          *cc = 0.0f;
-        }
-      }
+  // Evict the slots whose texels lie outside the window at (nwx, nwy): the columns leaving on one side (all rows), then the rows
+  // leaving (remaining columns) -- a move of two or three texels touches 30-50 of the 144 slots.  The two lane halves take
+  // alternate slots.  Texels outside the image never received anything (taps are clamped): skipped.
+  auto flush_slot = [&](int tx, int ty) {
+    float* cc = &cache[((int)((unsigned)ty % CH) * CW + (int)((unsigned)tx % CW)) * 32 + c];
+    const float v = *cc;
+    if (v != 0.0f) {
+      atomic_add_f32(dG + ((long)ty * W + tx) * HD, v);
+      *cc = 0.0f;
     }
+  };
+  auto flush_rect = [&](int tx0, int tx1, int ty0, int ty1) {   // texels [tx0, tx1) x [ty0, ty1), inside the current window
+    tx0 = max(tx0, 0), ty0 = max(ty0, 0), tx1 = min(tx1, W), ty1 = min(ty1, H);
+    if (tx1 <= tx0 || ty1 <= ty0) return;
+    if (tx1 - tx0 >= ty1 - ty0) {   // the lane halves pair up along the longer side
+#pragma unroll 1
+      for (int ty = ty0; ty < ty1; ++ty)
+#pragma unroll 1
+        for (int tx = tx0 + h; tx < tx1 + h; tx += 2)
+          if (tx < tx1) flush_slot(tx, ty);
+    } else {
+#pragma unroll 1
+      for (int tx = tx0; tx < tx1; ++tx)
+#pragma unroll 1
+        for (int ty = ty0 + h; ty < ty1 + h; ty += 2)
+          if (ty < ty1) flush_slot(tx, ty);
+    }
+  };
+  auto flush = [&](int nwx, int nwy, bool all) {
+    if (all) {
+      flush_rect(wx, wx + CW, wy, wy + CH);
+      return;
+    }
+    // columns staying: [sx0, sx1) = old window x new window
+    const int sx0 = max(wx, nwx), sx1 = min(wx + CW, nwx + CW);
+    if (sx1 <= sx0) {   // disjoint in x: everything leaves
+      flush_rect(wx, wx + CW, wy, wy + CH);
+      return;
+    }
+    flush_rect(wx, sx0, wy, wy + CH);            // columns left of the new window
+    flush_rect(sx1, wx + CW, wy, wy + CH);       // ... right of it
+    const int sy0 = max(wy, nwy), sy1 = min(wy + CH, nwy + CH);
+    if (sy1 <= sy0) {
+      flush_rect(sx0, sx1, wy, wy + CH);
+      return;
+    }
+    flush_rect(sx0, sx1, wy, sy0);               // rows above
+    flush_rect(sx0, sx1, sy1, wy + CH);          // rows below
   };
 
   // one read-modify-write round: this lane's point takes its four taps from the table.  Slots start at multiples of 128 bytes:
@@ -529,6 +589,9 @@ __global__ __launch_bounds__(64) void scatter_kernel(const ScatterMaskParams sp)
     if (scatter) {
       const int mnx = wave_min_i(x0), mxx = -wave_min_i(-x1), mny = wave_min_i(y0), mxy = -wave_min_i(-y1);
       fits = (mxx - mnx < CW) && (mxy - mny < CH);
+#ifdef BTS_ABL_S2   // timing ablation: the window never moves (wrong results)
+      if (false)
+#endif
       if (fits && (mnx < wx || mxx >= wx + CW || mny < wy || mxy >= wy + CH)) {
         const int nwx = mnx - (CW - (mxx - mnx + 1)) / 2, nwy = mny - (CH - (mxy - mny + 1)) / 2;
         flush(nwx, nwy, false);
@@ -536,7 +599,7 @@ __global__ __launch_bounds__(64) void scatter_kernel(const ScatterMaskParams sp)
       }
     }
     // window slots of the four taps.  A clamped tap (x1 == x0 or y1 == y0 at the far border: weight exactly 0) would alias its
-    // neighbour's slot inside one round; it goes to the scratch row.  An empty-feature point sends g_s to the EMPTY row.
+    // neighbour's slot inside one round; it goes to the scratch row.  An empty-feature point sends g_s to its half's EMPTY row.
     const int rya = (int)((unsigned)y0 % CH) * CW, ryb = (int)((unsigned)y1 % CH) * CW;
     const int cxa = (int)((unsigned)x0 % CW), cxb = (int)((unsigned)x1 % CW);
     const bool ddx = x1 != x0, ddy = y1 != y0;
@@ -544,7 +607,8 @@ __global__ __launch_bounds__(64) void scatter_kernel(const ScatterMaskParams sp)
     int s01 = ddx ? rya + cxb : SCRATCH;
     int s10 = ddy ? ryb + cxa : SCRATCH;
     int s11 = (ddx && ddy) ? ryb + cxb : SCRATCH;
-    if (use_empty) s00 = EMPTY, s01 = s10 = s11 = SCRATCH, tp.w00 = gs, tp.w01 = tp.w10 = tp.w11 = 0.0f;
+    // (one EMPTY row per lane half: with views that look past the encoder's frustum most pairs would otherwise share that slot)
+    if (use_empty) s00 = EMPTY + h, s01 = s10 = s11 = SCRATCH, tp.w00 = gs, tp.w01 = tp.w10 = tp.w11 = 0.0f;
     if (!fits && !use_empty) s00 = s01 = s10 = s11 = SCRATCH;   // handled with direct atomics below
     // pairs (i, i + 32) whose points share a slot: the upper point waits
     unsigned amask;
@@ -559,29 +623,36 @@ __global__ __launch_bounds__(64) void scatter_kernel(const ScatterMaskParams sp)
         for (int j = 0; j < 4; ++j) al |= (a[i] == b[j]) & (a[i] != (unsigned)SCRATCH);
       amask = (unsigned)__ballot(al);
     }
-    const float4 my_w = make_float4(tp.w00, tp.w01, tp.w10, tp.w11);
-    const uint2 my_sm = make_uint2((unsigned)s00 | ((unsigned)s01 << 8) | ((unsigned)s10 << 16) | ((unsigned)s11 << 24), gate);
-    const bool wait = h == 1 && ((amask >> c) & 1u);   // lane = ray here: this ray is the upper point of a pair that shares a slot
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    tab_w[lane] = my_w;
-    // a waiting point aims at the scratch row with its gate closed: its round must not touch the slots its partner updates
-    tab_sm[lane] = wait ? make_uint2((unsigned)SCRATCH * 0x01010101u, 0u) : my_sm;
+    tab_w[lane] = make_float4(tp.w00, tp.w01, tp.w10, tp.w11);
+    tab_sm[lane] = make_uint2((unsigned)s00 | ((unsigned)s01 << 8) | ((unsigned)s10 << 16) | ((unsigned)s11 << 24), gate);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // one straight block: the table reads of later pairs may run ahead of the window's read-modify-write rounds
+    if (amask == 0) {
+      // one straight block: the table reads of later pairs may run ahead of the window's read-modify-write rounds
+#ifdef BTS_ABL_S1   // timing ablation: no read-modify-write rounds
+      if (wx == 0x12345678)
+#endif
 #pragma unroll
-    for (int i = 0; i < 32; ++i) round(i + 32 * h);
-    // the upper points of the pairs that shared a slot, one at a time
-    while (amask) {
-      const int i = __builtin_ctz(amask);
-      amask &= amask - 1;
-      if (lane == i + 32) tab_sm[lane] = my_sm;
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      if (h == 1) round(i + 32);
+      for (int i = 0; i < 32; ++i) round(i + 32 * h);
+    } else {
+      // some pair shares a slot (patches hanging over the image border pile up on the clamped border texels): its two points take
+      // their rounds one after the other
+#pragma unroll 1
+      for (int i = 0; i < 32; ++i) {
+        if ((amask >> i) & 1u) {
+          if (h == 0) round(i);
+          // (convergent barrier: the two masked rounds must not be merged back into one -- to the compiler, lanes are independent)
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          if (h == 1) round(i + 32);
+        } else {
+          round(i + 32 * h);
+        }
+      }
     }
     if (scatter && !fits) {
       // rare (a footprint wider than the window: rays nearly through the encoder's centre): every tap a row of L2 atomics
@@ -605,7 +676,7 @@ __global__ __launch_bounds__(64) void scatter_kernel(const ScatterMaskParams sp)
   }
   if (scatter) flush(0, 0, true);
   if (sp.d_empty_proj && h == 0) {
-    const float v = cache[EMPTY * 32 + c];
+    const float v = cache[EMPTY * 32 + c] + cache[(EMPTY + 1) * 32 + c];
     if (v != 0.0f) atomic_add_f32(sp.d_empty_proj + proj_hidden_of_storage(chg), v);
   }
 }
@@ -706,15 +777,25 @@ __global__ __launch_bounds__(256, 2) void dwpe_kernel(const DwpeParams dp) {
   // byte offsets of this lane's B-operand rows (kin = col and, clamped, 32 + col) and of its column of samples
   const int brow0 = col * L::ROW + 16 * h, brow1 = min(32 + col, PE_ROWS - 1) * L::ROW + 16 * h;
   const long stride = (long)gridDim.x * 4;
+  // per-ray inputs of this lane, fetched one ray ahead (two waves per SIMD do not cover a global load's latency)
+  float z_n = 0.0f, gs_n = 0.0f;
+  uint2 pm_n[HT];
+  auto fetch = [&](long ray) {
+    z_n = p.z_samp[ray * K + kk];
+    gs_n = k < K ? dp.gs_ws[ray * K + k] : 0.0f;   // lanes past K contribute exact zeros
+#pragma unroll
+    for (int ht = 0; ht < HT; ++ht) pm_n[ht] = dp.pmask_ws[ray * HD + ht * 32 + col];
+  };
+  if ((long)blockIdx.x * 4 + wave < dp.rays) fetch((long)blockIdx.x * 4 + wave);
   for (long ray = (long)blockIdx.x * 4 + wave; ray < dp.rays; ray += stride) {
     const int sample = (int)(ray / Bp);
     const Cam enc = load_cam(p.w2c_enc + sample * 16, p.K_enc + sample * 9);
     const cfp rp = as_const(p.rays) + ray * 8;
-    const float z = p.z_samp[ray * K + kk];
-    const float gs = k < K ? dp.gs_ws[ray * K + k] : 0.0f;   // lanes past K contribute exact zeros
+    const float z = z_n, gs = gs_n;
     uint2 pm[HT];   // gates of channel ht*32 + col over the ray's samples
 #pragma unroll
-    for (int ht = 0; ht < HT; ++ht) pm[ht] = dp.pmask_ws[ray * HD + ht * 32 + col];
+    for (int ht = 0; ht < HT; ++ht) pm[ht] = pm_n[ht];
+    if (ray + stride < dp.rays) fetch(ray + stride);
     const float px = rp[0] + z * rp[3], py = rp[1] + z * rp[4], pz = rp[2] + z * rp[5];
     const Proj pe = p.code_mode == 1 ? project<true>(enc, px, py, pz) : project<false>(enc, px, py, pz);
     float v3[3];
@@ -730,6 +811,11 @@ __global__ __launch_bounds__(256, 2) void dwpe_kernel(const DwpeParams dp) {
       float e[PE_ROWS];
       e[0] = v3[0], e[1] = v3[1], e[2] = v3[2], e[3] = 1.0f;
       float ff = p.freq_factor;
+#ifdef BTS_ABL_D3   // timing ablation: no trigonometry
+#pragma unroll
+      for (int i = 4; i < PE_ROWS; ++i) e[i] = v3[i % 3] * (float)i;
+      if (false)
+#endif
 #pragma unroll
       for (int r = 0; r < kNumFreqs / 2; ++r) {   // octaves 2r (direct) and 2r + 1 (angle doubling), as the forward's regions
         SinCos3 raw, dbl;
@@ -744,12 +830,18 @@ __global__ __launch_bounds__(256, 2) void dwpe_kernel(const DwpeParams dp) {
         for (int i = 0; i < 6; ++i) e[10 + 12 * r + i] = t[i];
         ff = ff * 4.0f;
       }
+#ifdef BTS_ABL_D1   // timing ablation: no plane writes
+      if (gs == 12345.0f)
+#endif
       write_planes(tile, e, gs, lane);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     // ---- four k-slices of 16 samples: A[i = channel][k] = gate, B[k][j = kin] = piece of g_s pe
+#ifdef BTS_ABL_D2   // timing ablation: no MFMA block
+    if (__builtin_amdgcn_readfirstlane(__float_as_int(gs)) == 0x12345678)
+#endif
 #pragma unroll
     for (int sl = 0; sl < 4; ++sl) {
       bf16x8 a[HT];
