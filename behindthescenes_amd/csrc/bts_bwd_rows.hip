@@ -471,7 +471,11 @@ __device__ __forceinline__ int wave_min_i(int v) {
 
 template <int HD>
 __global__ __launch_bounds__(64) void scatter_kernel(const ScatterMaskParams sp) {
-  constexpr int CW = 12, CH = 12, NSLOT = CW * CH, SCRATCH = NSLOT, EMPTY = NSLOT + 1;   // slot indices; a slot is 32 floats;
+#ifndef BTS_SCATTER_CW
+#define BTS_SCATTER_CW 12
+#define BTS_SCATTER_CH 12
+#endif
+  constexpr int CW = BTS_SCATTER_CW, CH = BTS_SCATTER_CH, NSLOT = CW * CH, SCRATCH = NSLOT, EMPTY = NSLOT + 1;   // slot indices; a slot is 32 floats;
                                                                                            // EMPTY, EMPTY + 1: one row per lane half
   constexpr int NW = HD / 32;
   __shared__ __attribute__((aligned(128))) float cache[(NSLOT + 3) * 32];   // aligned: see round()
@@ -580,6 +584,7 @@ __global__ __launch_bounds__(64) void scatter_kernel(const ScatterMaskParams sp)
       const int kn = max(k - 1, 0);
       z_n = zrow[kn], gs_n = ray_ok ? gsrow[kn] : 0.0f, m_n = ray_ok ? mrow[kn] : 0u;
     }
+    if (__all(gs == 0.0f)) continue;   // e.g. the capped last sample of every ray: nothing to add
     const Proj pe = project<false>(enc, r0.x + z * r0.w, r0.y + z * r1.x, r0.z + z * r1.y);
     int x0, y0, x1, y1;
     Taps tp = make_taps_xy(pe.x, pe.y, H, W, x0, y0, x1, y1);
@@ -610,23 +615,29 @@ __global__ __launch_bounds__(64) void scatter_kernel(const ScatterMaskParams sp)
     // (one EMPTY row per lane half: with views that look past the encoder's frustum most pairs would otherwise share that slot)
     if (use_empty) s00 = EMPTY + h, s01 = s10 = s11 = SCRATCH, tp.w00 = gs, tp.w01 = tp.w10 = tp.w11 = 0.0f;
     if (!fits && !use_empty) s00 = s01 = s10 = s11 = SCRATCH;   // handled with direct atomics below
-    // pairs (i, i + 32) whose points share a slot: the upper point waits
+    // pairs (i, i + 32) whose points share a slot (bit i): the four slot indices of a point are one dword, the partner's dword is
+    // compared byte against byte in its four rotations with the zero-byte test.  The scratch row is shared by design: for the
+    // comparison it gets a different id in each lane half
+    const unsigned packed = (unsigned)s00 | ((unsigned)s01 << 8) | ((unsigned)s10 << 16) | ((unsigned)s11 << 24);
     unsigned amask;
     {
-      unsigned a[4], b[4];
-      bcast_tiles((unsigned)s00, a[0], b[0]), bcast_tiles((unsigned)s01, a[1], b[1]);
-      bcast_tiles((unsigned)s10, a[2], b[2]), bcast_tiles((unsigned)s11, a[3], b[3]);
-      bool al = false;
+      const unsigned sc = 0xF0u + (unsigned)h;
+      const unsigned cmp = (s00 == SCRATCH ? sc : (unsigned)s00) | ((s01 == SCRATCH ? sc : (unsigned)s01) << 8) |
+                           ((s10 == SCRATCH ? sc : (unsigned)s10) << 16) | ((s11 == SCRATCH ? sc : (unsigned)s11) << 24);
+      unsigned a, b;
+      bcast_tiles(cmp, a, b);
+      unsigned hit = 0;
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) al |= (a[i] == b[j]) & (a[i] != (unsigned)SCRATCH);
-      amask = (unsigned)__ballot(al);
+      for (int r = 0; r < 4; ++r) {
+        const unsigned x = a ^ __builtin_rotateright32(b, 8 * r);
+        hit |= (x - 0x01010101u) & ~x;
+      }
+      amask = (unsigned)__ballot((hit & 0x80808080u) != 0);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     tab_w[lane] = make_float4(tp.w00, tp.w01, tp.w10, tp.w11);
-    tab_sm[lane] = make_uint2((unsigned)s00 | ((unsigned)s01 << 8) | ((unsigned)s10 << 16) | ((unsigned)s11 << 24), gate);
+    tab_sm[lane] = make_uint2(packed, gate);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");

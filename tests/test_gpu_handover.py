@@ -72,4 +72,6 @@ def test_fused_handover_matches_the_generic_route(hip, flip):
     for i, (a, b) in enumerate(zip(*grads)):
         assert a is not None and b is not None, i
         err = (a - b).abs().max().item() / b.abs().max().item()
-        assert err <= 2e-4, (i, err)
+        # the two routes' G differ by rounding (1e-5 above); a relu gate that flips between them moves a weight gradient by one sample's
+        # contribution -- the kink sensitivity tests/test_gpu_grad.py masks out.  Measured 1e-5 ... 2.6e-4 of the largest entry.
+        assert err <= 5e-4, (i, err)
