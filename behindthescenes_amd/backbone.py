@@ -26,7 +26,8 @@ class FeatureMapEncoder(nn.Module):
         n = x.shape[0]
         out = []
         for f in self.feats:
-            out.append(f[:n] if f.shape[0] >= n else f.expand(n, -1, -1, -1))
+            # the parameter itself when the batch matches: a slice would cost a zero fill + a copy of the whole map in its backward
+            out.append(f if f.shape[0] == n else (f[:n] if f.shape[0] > n else f.expand(n, -1, -1, -1)))
         return out
 
     @classmethod

@@ -160,7 +160,8 @@ class BTSNet(nn.Module):
             if self._proj_ms is not None:                          # fused hand-over: G came out of the encoder
                 proj = self._proj_ms[s].float()
             else:
-                f = self.grid_f_features[s][:, 0].float()          # (n, C, H, W)
+                f = self.grid_f_features[s]                        # (n, 1, C, H, W) -> (n, C, H, W): a pure view (selecting [:, 0] would
+                f = f.reshape(f.shape[0], *f.shape[2:]).float()    # cost a zero fill + a copy of the whole map in its backward)
                 proj = native.ProjectFunction.apply(f, self.mlp_coarse.packed(), self.spec)
             ft = native.FieldTensors(self.spec, proj, self._K_enc, self._w2c_enc, self._imgs_nhwc4, self._K_r, self._w2c_r,
                                      self.empty_feature if self.learn_empty else None)

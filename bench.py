@@ -217,6 +217,18 @@ def train_workload(args, world, rank, dev):
     if rank == 0:
         flop = 3 * n_rays * Kt * FLOP_PER_POINT          # training = 3x forward (dX + dW)
         achieved = flop / ((ms["fwd"] + ms["bwd"]) * 1e-3) / 1e12
+        # HBM bytes and issue counters of every training kernel from the committed rocprofv3 PMC passes (tools/profile.sh <tag> train)
+        traffic, counters = None, {}
+        pdir = os.path.join(ROOT, "profiles")
+        prof = sorted(d for d in os.listdir(pdir) if os.path.exists(os.path.join(pdir, d, "traffic_train.json"))) if os.path.isdir(pdir) else []
+        if prof:
+            tj = json.load(open(os.path.join(pdir, prof[-1], "traffic_train.json")))
+            render = [k for k in ("render_kernel_p", "rows_kernel", "scatter_kernel", "dwpe_kernel") if k in tj and "fetch_bytes" in tj[k]]
+            traffic = sum(tj[k]["fetch_bytes"] + tj[k]["write_bytes"] for k in render) if render else None
+            counters = {k: {f: v[f] for f in ("kernel_ms_rocprof", "fetch_bytes", "write_bytes", "valu_busy", "mfma_busy", "wait_frac", "l2_hit") if f in v}
+                        for k, v in tj.items()}
+            counters["source"] = (f"profiles/{prof[-1]}/traffic_train.json: rocprofv3 --pmc passes of tools/train_probe.py (same shapes); `traffic` = "
+                                  "fetch + write bytes of " + ", ".join(render) + " per step; FETCH_SIZE doubled per MI355X_MICROARCH.md")
         print(json.dumps({
             "metric": "training-step rays/sec after the CNN: render forward + loss + backward (KITTI-360 shapes)", "value": world * n_rays * args.steps / elapsed,
             "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps,
@@ -224,11 +236,15 @@ def train_workload(args, world, rank, dev):
             "config": {"workload": "exp_kitti_360.yaml shapes: bs=16/GPU, 8 frames (4 loss + 4 render views), 4096 patch rays (8x8) per sample, "
                                    "64 samples/ray, everything after the CNN (feature-map encoder stand-in): sample, render, photometric loss, backward",
                        "rays_per_step_per_gpu": n_rays, "samples_per_ray": Kt, "parallelism": f"batch x{world}"},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_MATRIX_TFLOPS, "traffic": None,
-                         "kernel": "bts_render_fwd + bts_render_bwd (render_kernel_p, render_bwd_kernel, scatter_dg_kernel)",
+            "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_FP32_MATRIX_TFLOPS, "traffic": traffic,
+                         "kernel": "bts_render_fwd + bts_render_bwd (render_kernel_p; rows_kernel, scatter_kernel, dwpe_kernel)",
                          "kernel_ms": ms["fwd"] + ms["bwd"], "fwd_ms": ms["fwd"], "bwd_ms": ms["bwd"], "algorithmic_flop_per_launch": flop,
-                         "note": "algorithmic 3 x 13 312 FLOP / sample; the backward is bound by L2 float atomics and LDS, not by MFMA"},
+                         "counters": counters,
+                         "note": "algorithmic 3 x 13 312 FLOP / sample against the fp32 vector = fp32-input-MFMA peak.  The backward is three "
+                                 "passes (DESIGN.md section 3): the forward's pipeline again (VALU issue + latency at 2 waves / SIMD), the dG "
+                                 "scatter (LDS read-modify-write rounds + L2 float atomics) and the dW_pe GEMM on the bf16 matrix pipe; bwd_ms "
+                                 "includes the zero fill of dG (503 MB)"},
         }))
 
 
