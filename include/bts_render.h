@@ -122,8 +122,10 @@ int bts_render_fwd(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const BtsRe
 /* Backward of bts_render_fwd.  `a` must carry sigma_raw and trans written by the forward (weights/alphas are not needed).  When
  * a->rgb_samps is non-NULL it is READ here: the forward's per-sample colours, which spare the backward one projection + four taps
  * per view and sample (training requests rgb_samps anyway); NULL = recompute them.
- * workspace: bts_render_bwd_workspace(cfg, a) bytes of device scratch (rays x K x d_hidden floats, rounded up to groups of 64
- * rays: the gradient rows handed from the per-ray pass to the per-texel scatter pass); contents need no initialisation. */
+ * workspace: bts_render_bwd_workspace(cfg, a) bytes of device scratch -- what the backward's passes hand each other: for the plain
+ * MLP (n_blocks = 0) with K <= 64, 20 bytes per sample at d_hidden = 64 (the gradient at the pre-softplus density + the relu gates
+ * as bits, per sample and per channel); otherwise rays x K x d_hidden floats, rounded up to groups of 64 rays (gradient rows of the
+ * per-ray pass for the per-texel scatter pass).  Contents need no initialisation. */
 size_t bts_render_bwd_workspace(const BtsFieldCfg* cfg, const BtsRenderArgs* a);
 int bts_render_bwd(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const BtsRenderArgs* a, const BtsRenderGrads* g,
                    void* workspace, size_t workspace_bytes, void* stream);
