@@ -9,7 +9,7 @@ import threading
 PKG = os.path.dirname(os.path.abspath(__file__))
 # BTS_RENDER_LIB lets the profiling tools load the instrumented probe build (libbts_probe.so); the product always loads libbts_render.so
 LIB_PATH = os.environ.get("BTS_RENDER_LIB") or os.path.join(PKG, "libbts_render.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 BTS_MAX_VIEWS = 8
 ERRORS = {-1: "BTS_E_INVALID", -2: "BTS_E_UNSUPPORTED", -3: "BTS_E_LAUNCH", -4: "BTS_E_WORKSPACE"}
@@ -33,7 +33,7 @@ class BtsFieldTensors(C.Structure):
 class BtsRenderArgs(C.Structure):
     _fields_ = [(k, C.c_int32) for k in ("rays_per_sample", "K", "hard_alpha_cap", "white_bkgd")] + \
                [(k, C.c_void_p) for k in ("rays", "z_samp", "rgb", "depth", "weights", "alphas", "invalid", "rgb_samps",
-                                          "sigma_raw", "trans")]
+                                          "sigma_raw", "trans", "invalid_wsum", "invalid_any")]
 
 
 class BtsRenderGrads(C.Structure):
@@ -44,7 +44,7 @@ class BtsRenderGrads(C.Structure):
 class BtsLossArgs(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in ("rgb", "depth", "weights", "invalid", "rgb_gt", "parts", "g_rgb", "g_depth")] + \
                [(k, C.c_int32) for k in ("n_patches", "patch_h", "patch_w", "nv", "K", "invalid_policy", "edge_aware_smoothness")] + \
-               [("scale_rgb", C.c_float), ("scale_eas", C.c_float)]
+               [("scale_rgb", C.c_float), ("scale_eas", C.c_float)] + [(k, C.c_void_p) for k in ("invalid_wsum", "invalid_any")]
 
 
 # every symbol include/bts_render.h declares: name -> (restype, argtypes)

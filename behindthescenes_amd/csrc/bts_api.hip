@@ -207,7 +207,8 @@ int bts_patch_rays(const float* poses, const float* projs, const float* images, 
 int bts_photometric_loss(const BtsLossArgs* a, void* stream) {
   BTS_CHECK_LAYOUT(a && a->rgb && a->rgb_gt && a->parts && a->n_patches >= 0 && a->patch_h > 0 && a->patch_w > 0 &&
                        a->patch_h * a->patch_w <= 64 && a->nv > 0 && a->invalid_policy >= 0 && a->invalid_policy <= 2 &&
-                       (a->invalid_policy == 0 || (a->invalid && a->K > 0)) && (a->invalid_policy != 2 || a->weights) &&
+                       (a->invalid_policy != 1 || a->invalid_any || (a->invalid && a->K > 0)) &&
+                       (a->invalid_policy != 2 || a->invalid_wsum || (a->invalid && a->weights && a->K > 0)) &&
                        (!a->edge_aware_smoothness || a->depth),
                    "bts_photometric_loss");
   BTS_RET_LAUNCH(photometric_loss_impl(a, (hipStream_t)stream), "bts_photometric_loss");

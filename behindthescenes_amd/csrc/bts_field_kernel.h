@@ -51,6 +51,8 @@ struct FwdParams {
   float* rgb_samps;
   float* sigma_raw;
   float* trans;        // (n*Bp, K) transmittance in front of each sample (saved for the backward)
+  float* invalid_wsum; // (n*Bp, nv) sum_k w_k invalid_k,v } per-ray reductions for the loss' invalid-ray policies (pipelined
+  float* invalid_any;  // (n*Bp, nv) max_k invalid_k,v     } kernel only)
   // query
   const float* xyz;
   float* q_sigma;

@@ -85,6 +85,7 @@ int render_fwd_impl(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const BtsR
   p.Bp = a->rays_per_sample, p.K = a->K, p.hard_cap = a->hard_alpha_cap, p.white_bkgd = a->white_bkgd;
   p.rgb = a->rgb, p.depth = a->depth, p.weights = a->weights, p.alphas = a->alphas, p.invalid = a->invalid;
   p.rgb_samps = a->rgb_samps, p.sigma_raw = a->sigma_raw, p.trans = a->trans;
+  p.invalid_wsum = a->invalid_wsum, p.invalid_any = a->invalid_any;
   p.tiles_per_sample = (a->rays_per_sample + 255) / 256;
 #ifdef BTS_PROBE   // A/B switches exist only in the probe build (python -m behindthescenes_amd.build --probe); the product has one path
   if (getenv("BTS_LANE_IS_RAY")) {  // round-1a mapping (one lane = one ray)
@@ -106,6 +107,10 @@ int render_fwd_impl(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const BtsR
   if (p.proj && getenv("BTS_RENDER_V1")) return launch_render<true>(p, cfg->C, cfg->d_hidden, cfg->n_blocks, grid, s);  // compact lane = sample kernel
 #endif
   if (p.proj) return launch_render_pipelined(p, cfg->C, cfg->d_hidden, cfg->n_blocks, grid, s);
+  if (p.invalid_wsum || p.invalid_any) {
+    set_error("%s: invalid_wsum / invalid_any need the projected feature map (proj_nhwc)", "bts_render_fwd");
+    return BTS_E_UNSUPPORTED;
+  }
   return launch_render<false>(p, cfg->C, cfg->d_hidden, cfg->n_blocks, grid, s);
 }
 

@@ -6,5 +6,9 @@ namespace bts {
 template int launch_field<false, true>(const FwdParams&, int, int, int, int, hipStream_t);
 template int launch_field<true, true>(const FwdParams&, int, int, int, int, hipStream_t);
 template int launch_render<true>(const FwdParams&, int, int, int, int, hipStream_t);
-int launch_render_pipelined(const FwdParams& p, int C, int HD, int NB, int grid, hipStream_t s) { return launch_render_p(p, C, HD, NB, grid, s); }
+int launch_render_pipelined_epi(const FwdParams& p, int C, int HD, int NB, int grid, hipStream_t s);   // bts_fwd_epi.hip
+int launch_render_pipelined(const FwdParams& p, int C, int HD, int NB, int grid, hipStream_t s) {
+  if (p.invalid_wsum || p.invalid_any) return launch_render_pipelined_epi(p, C, HD, NB, grid, s);
+  return launch_render_p<false>(p, C, HD, NB, grid, s);
+}
 }  // namespace bts

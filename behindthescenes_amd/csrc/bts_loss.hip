@@ -24,6 +24,8 @@ struct LossParams {
   const float* depth;    // (B)
   const float* weights;  // (B, K)      (invalid policy weight_guided)
   const float* invalid;  // (B, K, nv)  (policies strict / weight_guided)
+  const float* invalid_wsum;  // (B, nv) or null: sum_k w_k invalid_k,v  } from the renderer's epilogue; replace weights / invalid
+  const float* invalid_any;   // (B, nv) or null: max_k invalid_k,v      }
   const float* rgb_gt;   // (B, 3)
   float* parts;          // (patches, 4): sum rgb term, sum smoothness term, invalid rays, 0
   float* g_rgb;          // (B, nv, 3) or null
@@ -88,7 +90,11 @@ __global__ __launch_bounds__(256) void photometric_loss_kernel(const LossParams 
   if (p.policy != 0) {
     bool all_v = true;
     for (int v = 0; v < nv; ++v) {
-      if (p.policy == 2) {
+      if (p.policy == 2 && p.invalid_wsum) {          // the renderer's epilogue already summed over the samples
+        all_v = all_v && (p.invalid_wsum[ray * nv + v] > 0.9f);
+      } else if (p.policy == 1 && p.invalid_any) {
+        all_v = all_v && (p.invalid_any[ray * nv + v] > 0.5f);
+      } else if (p.policy == 2) {
         float s = 0.0f;
         for (int k = 0; k < K; ++k) s += p.invalid[(ray * K + k) * nv + v] * p.weights[ray * K + k];
         all_v = all_v && (s > 0.9f);
@@ -240,6 +246,7 @@ __global__ __launch_bounds__(256) void photometric_loss_kernel(const LossParams 
 int photometric_loss_impl(const BtsLossArgs* a, hipStream_t s) {
   LossParams p;
   p.rgb = a->rgb, p.depth = a->depth, p.weights = a->weights, p.invalid = a->invalid, p.rgb_gt = a->rgb_gt;
+  p.invalid_wsum = a->invalid_wsum, p.invalid_any = a->invalid_any;
   p.parts = a->parts, p.g_rgb = a->g_rgb, p.g_depth = a->g_depth;
   p.n_patches = a->n_patches, p.ph = a->patch_h, p.pw = a->patch_w, p.nv = a->nv, p.K = a->K, p.policy = a->invalid_policy;
   p.s_rgb = a->scale_rgb, p.s_eas = a->scale_eas, p.has_eas = a->edge_aware_smoothness;

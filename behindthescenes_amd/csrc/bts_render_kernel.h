@@ -596,7 +596,9 @@ __device__ __attribute__((noinline)) float eval_point_exact(const float* lds, co
   return eval_point<C, HD, NB, true>(q, lds, enc, G, (int)(threadIdx.x & 63), b_out, px, py, pz, pe);
 }
 
-template <int C, int HD, int NB, int NVMAX, bool ONE_RAY, bool F16>
+// EPI: also reduce weights * invalid and max invalid over each ray's samples (BtsRenderArgs.invalid_wsum / invalid_any).  A template
+// parameter, not a run-time test: the evaluation instantiations carry no trace of it (16 more spilled SGPRs otherwise).
+template <int C, int HD, int NB, int NVMAX, bool ONE_RAY, bool F16, bool EPI = false>
 __global__ __launch_bounds__(256, 2) void render_kernel_p(const FwdParams p) {
   using L = Lds<C, HD, NB, true>;
   using LH = LdsH<C, HD, NB>;
@@ -917,6 +919,22 @@ __global__ __launch_bounds__(256, 2) void render_kernel_p(const FwdParams p) {
       if (ONE_RAY && K > 64) T_carry = T_carry * __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, incl), 63));
       const float wgt = valid ? alpha * T : 0.0f;
       BTS_TICK(3)
+      // ---------------- per-ray reductions for the loss' invalid-ray policies (loss.py:100-118), instead of weights + invalid in HBM
+      if constexpr (EPI) {
+#pragma unroll
+        for (int j = 0; j < NVMAX; ++j)
+          if (j < nv) {
+            const float ws = seg_scan_add((valid && inv[j]) ? wgt : 0.0f, lpr, kl);       // the last lane of each ray has the sum
+            const unsigned long long hit = __ballot(valid && inv[j]);
+            if (kl == lpr - 1) {
+              const long idx = ray * nv + j;
+              const unsigned long long seg = lpr == 64 ? ~0ull : (((1ull << lpr) - 1ull) << (lane - (lpr - 1)));
+              const float any = (hit & seg) ? 1.0f : 0.0f;
+              if (p.invalid_wsum) p.invalid_wsum[idx] = (kc > 0 ? p.invalid_wsum[idx] : 0.0f) + ws;   // K > 64: chunk after chunk
+              if (p.invalid_any) p.invalid_any[idx] = kc > 0 ? fmaxf(p.invalid_any[idx], any) : any;
+            }
+          }
+      }
       depth_part = depth_part + wgt * z;
       w_part = w_part + wgt;
 #pragma unroll
@@ -969,10 +987,10 @@ __global__ __launch_bounds__(256, 2) void render_kernel_p(const FwdParams p) {
 }
 
 #ifndef BTS_NO_LAUNCH_GLUE
-template <int C, int HD, int NB, int NVMAX>
+template <int C, int HD, int NB, int NVMAX, bool EPI>
 static int launch_render_p_one(const FwdParams& p, int grid, hipStream_t s) {
-  if (p.lpr == 64) render_kernel_p<C, HD, NB, NVMAX, true, true><<<grid, 256, 0, s>>>(p);
-  else render_kernel_p<C, HD, NB, NVMAX, false, true><<<grid, 256, 0, s>>>(p);
+  if (p.lpr == 64) render_kernel_p<C, HD, NB, NVMAX, true, true, EPI><<<grid, 256, 0, s>>>(p);
+  else render_kernel_p<C, HD, NB, NVMAX, false, true, EPI><<<grid, 256, 0, s>>>(p);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     set_error("%s: kernel launch failed (%ld)", hipGetErrorString(e), (long)e);
@@ -981,12 +999,12 @@ static int launch_render_p_one(const FwdParams& p, int grid, hipStream_t s) {
   return BTS_OK;
 }
 
-template <int C, int HD, int NB>
+template <int C, int HD, int NB, bool EPI>
 static int launch_render_p_nv(const FwdParams& p, int grid, hipStream_t s) {
-  if (p.nv <= 1) return launch_render_p_one<C, HD, NB, 1>(p, grid, s);
-  if (p.nv <= 2) return launch_render_p_one<C, HD, NB, 2>(p, grid, s);
-  if (p.nv <= 4) return launch_render_p_one<C, HD, NB, 4>(p, grid, s);
-  return launch_render_p_one<C, HD, NB, 8>(p, grid, s);
+  if (p.nv <= 1) return launch_render_p_one<C, HD, NB, 1, EPI>(p, grid, s);
+  if (p.nv <= 2) return launch_render_p_one<C, HD, NB, 2, EPI>(p, grid, s);
+  if (p.nv <= 4) return launch_render_p_one<C, HD, NB, 4, EPI>(p, grid, s);
+  return launch_render_p_one<C, HD, NB, 8, EPI>(p, grid, s);
 }
 
 #ifdef BTS_PROBE
@@ -997,13 +1015,14 @@ inline int launch_render_p_f32mfma(const FwdParams& p, int grid, hipStream_t s) 
 }
 #endif
 
+template <bool EPI>
 inline int launch_render_p(const FwdParams& p, int C, int HD, int NB, int grid, hipStream_t s) {
 #ifdef BTS_PROBE
-  if (C == 64 && HD == 64 && NB == 0 && p.nv <= 1 && p.lpr == 64 && getenv("BTS_RENDER_F32MFMA")) return launch_render_p_f32mfma(p, grid, s);
+  if (!EPI && C == 64 && HD == 64 && NB == 0 && p.nv <= 1 && p.lpr == 64 && getenv("BTS_RENDER_F32MFMA")) return launch_render_p_f32mfma(p, grid, s);
 #endif
-  if (C == 64 && HD == 64 && NB == 0) return launch_render_p_nv<64, 64, 0>(p, grid, s);
-  if (C == 32 && HD == 32 && NB == 1) return launch_render_p_nv<32, 32, 1>(p, grid, s);
-  if (C == 32 && HD == 32 && NB == 0) return launch_render_p_nv<32, 32, 0>(p, grid, s);
+  if (C == 64 && HD == 64 && NB == 0) return launch_render_p_nv<64, 64, 0, EPI>(p, grid, s);
+  if (C == 32 && HD == 32 && NB == 1) return launch_render_p_nv<32, 32, 1, EPI>(p, grid, s);
+  if (C == 32 && HD == 32 && NB == 0) return launch_render_p_nv<32, 32, 0, EPI>(p, grid, s);
   set_error("%s: unsupported MLP shape C=%ld d_hidden=%ld n_blocks=%ld", "bts", C, HD, NB);
   return BTS_E_UNSUPPORTED;
 }

@@ -17,10 +17,10 @@ class _PhotometricSums(torch.autograd.Function):
     """(sum of the rgb term, sum of the smoothness term, number of invalid rays) over all patches; differentiable w.r.t. rgb, depth."""
 
     @staticmethod
-    def forward(ctx, rgb, depth, weights, invalid, rgb_gt, ph, pw, policy, eas):
+    def forward(ctx, rgb, depth, weights, invalid, rgb_gt, ph, pw, policy, eas, invalid_wsum=None, invalid_any=None):
         need = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
         parts, g_rgb, g_depth = native.photometric_loss(rgb, depth if eas else None, weights, invalid, rgb_gt, ph, pw, policy, eas, 1.0, 1.0,
-                                                        need_grad=need)
+                                                        need_grad=need, invalid_wsum=invalid_wsum, invalid_any=invalid_any)
         ctx.save_for_backward(g_rgb, g_depth)
         ctx.had_depth = depth is not None
         return parts.sum(0)[:3]
@@ -30,7 +30,7 @@ class _PhotometricSums(torch.autograd.Function):
         g_rgb, g_depth = ctx.saved_tensors
         d_rgb = g_rgb * g[0] if (g_rgb is not None and ctx.needs_input_grad[0]) else None
         d_depth = g_depth * g[1] if (g_depth is not None and ctx.needs_input_grad[1]) else None
-        return d_rgb, d_depth, None, None, None, None, None, None, None
+        return d_rgb, d_depth, None, None, None, None, None, None, None, None, None
 
 
 def _flat(t, tail):
@@ -83,6 +83,12 @@ class ReconstructionLoss:
         if c != 3:
             raise NotImplementedError("the fused HIP loss takes 3 colour channels")
         B = n * pc * h * w
+        if "weights" not in level0:     # lean training outputs: the renderer's epilogue reduced weights / invalid per ray and view
+            sums = _PhotometricSums.apply(_flat(rgb, (nv * 3,)), _flat(level["depth"], ()) if eas else None, None, None,
+                                          _flat(rgb_gt, (3,)).detach(), h, w, self.invalid_policy, eas,
+                                          _flat(level0["invalid_wsum"], (nv,)).detach() if self.invalid_policy == "weight_guided" else None,
+                                          _flat(level0["invalid_any"], (nv,)).detach() if self.invalid_policy == "strict" else None)
+            return sums[0] / B, sums[1] / B, sums[2] / B
         K = level0["weights"].shape[-1]
         sums = _PhotometricSums.apply(_flat(rgb, (nv * 3,)), _flat(level["depth"], ()) if eas else None,
                                       _flat(level0["weights"], (K,)).detach() if self.invalid_policy == "weight_guided" else None,
@@ -101,6 +107,14 @@ class ReconstructionLoss:
 
         def keep():   # 1 - invalid ray mask (n, pc, h, w) for the optional regularisers
             nonlocal keep_cache
+            if keep_cache is None and "weights" not in coarse_0:    # lean training outputs
+                if self.invalid_policy == "strict":
+                    bad = torch.all(coarse_0["invalid_any"] > .5, dim=-1)
+                elif self.invalid_policy == "weight_guided":
+                    bad = torch.all(coarse_0["invalid_wsum"] > .9, dim=-1)
+                else:
+                    bad = torch.zeros(coarse_0["depth"].shape, dtype=torch.bool, device=dev)
+                keep_cache = 1 - bad.to(torch.float32)
             if keep_cache is None:
                 inv, wts = coarse_0["invalid"], coarse_0["weights"]
                 if self.invalid_policy == "strict":
@@ -120,8 +134,8 @@ class ReconstructionLoss:
                 m["inv"] = inv_ratio.detach()
             m["coarse"] = m["coarse"] + rgb_loss.detach() * self.lambda_coarse
             if len(fine) > 0:
-                if _same_view(fine["rgb"], coarse["rgb"]) and _same_view(fine_0["weights"], coarse_0["weights"]) \
-                        and _same_view(fine_0["invalid"], coarse_0["invalid"]):
+                mask_keys = ("weights", "invalid") if "weights" in coarse_0 else ("invalid_wsum", "invalid_any")
+                if _same_view(fine["rgb"], coarse["rgb"]) and all(_same_view(fine_0[k], coarse_0[k]) for k in mask_keys):
                     # trainer.py:247-248 aliases fine = dict(coarse): reconstruct() then views the SAME storage once per dict, so the
                     # tensors are different Python objects over identical memory -- one launch serves both terms
                     fine_loss = rgb_loss

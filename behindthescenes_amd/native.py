@@ -137,7 +137,7 @@ INVALID_POLICIES = {None: 0, "none": 0, "strict": 1, "weight_guided": 2}
 
 
 def photometric_loss(rgb, depth, weights, invalid, rgb_gt, patch_h: int, patch_w: int, invalid_policy, eas: bool,
-                     scale_rgb: float, scale_eas: float, need_grad: bool = True):
+                     scale_rgb: float, scale_eas: float, need_grad: bool = True, invalid_wsum=None, invalid_any=None):
     """Patch-ordered renderer outputs -> per-patch partial sums and the loss gradients (bts_photometric_loss).
     rgb (B, nv*3), depth (B) | None, weights (B, K) | None, invalid (B, K, nv) | None, rgb_gt (B, 3)
     -> parts (B / (ph*pw), 4), g_rgb (B, nv*3) | None, g_depth (B) | None."""
@@ -149,11 +149,16 @@ def photometric_loss(rgb, depth, weights, invalid, rgb_gt, patch_h: int, patch_w
     policy = INVALID_POLICIES[invalid_policy]
     _req(rgb, "rgb", (B, nv * 3)), _req(rgb_gt, "rgb_gt", (B, 3))
     K = 0
-    if policy:
+    # the renderer's per-ray reductions (render_fwd(want_invalid_sums=True)) stand in for the per-sample tensors
+    sums = (policy == 2 and invalid_wsum is not None) or (policy == 1 and invalid_any is not None)
+    if sums:
+        _req(invalid_wsum if policy == 2 else invalid_any, "invalid_wsum / invalid_any", (B, nv))
+        weights = invalid = None
+    elif policy:
         K = invalid.shape[1]
         _req(invalid, "invalid", (B, K, nv))
-    if policy == 2:
-        _req(weights, "weights", (B, K))
+        if policy == 2:
+            _req(weights, "weights", (B, K))
     if eas:
         _req(depth, "depth", (B,))
     dev = rgb.device
@@ -166,7 +171,8 @@ def photometric_loss(rgb, depth, weights, invalid, rgb_gt, patch_h: int, patch_w
                          parts=parts.data_ptr(), g_rgb=None if g_rgb is None else g_rgb.data_ptr(),
                          g_depth=None if g_depth is None else g_depth.data_ptr(), n_patches=B // area, patch_h=patch_h, patch_w=patch_w,
                          nv=nv, K=K, invalid_policy=policy, edge_aware_smoothness=int(bool(eas)), scale_rgb=scale_rgb,
-                         scale_eas=scale_eas)
+                         scale_eas=scale_eas, invalid_wsum=invalid_wsum.data_ptr() if (sums and policy == 2) else None,
+                         invalid_any=invalid_any.data_ptr() if (sums and policy == 1) else None)
     _lib.check(_lib.load().bts_photometric_loss(C.byref(a), _stream(rgb)), "bts_photometric_loss")
     return parts, g_rgb, g_depth
 
@@ -295,7 +301,7 @@ def check_supported(spec: FieldSpec, nv: int = 1):
 # --------------------------------------------------------------------------------------------------------------
 # render forward / backward
 # --------------------------------------------------------------------------------------------------------------
-_OUT_KEYS = ("rgb", "depth", "weights", "alphas", "invalid", "rgb_samps", "sigma_raw", "trans")
+_OUT_KEYS = ("rgb", "depth", "weights", "alphas", "invalid", "rgb_samps", "sigma_raw", "trans", "invalid_wsum", "invalid_any")
 
 
 def _render_args(ft: FieldTensors, rays, z_samp, hard_alpha_cap, white_bkgd, outs):
@@ -306,9 +312,11 @@ def _render_args(ft: FieldTensors, rays, z_samp, hard_alpha_cap, white_bkgd, out
 
 def render_fwd(ft: FieldTensors, mlp_params: torch.Tensor, rays: torch.Tensor, z_samp: torch.Tensor, *, hard_alpha_cap: bool,
                white_bkgd: bool = False, want_weights=False, want_alphas=False, want_invalid=True, want_rgb_samps=False,
-               want_saved=False):
+               want_saved=False, want_invalid_sums=False):
     """rays (n*Bp, 8), z_samp (n*Bp, K) -> dict of fresh tensors (bts_render_fwd).  want_saved adds the two per-sample
-    activations the backward needs (sigma_raw, trans)."""
+    activations the backward needs (sigma_raw, trans); want_invalid_sums the per-ray reductions the loss' invalid-ray policies need
+    (invalid_wsum = sum_k weights * invalid, invalid_any = max_k invalid, (n*Bp, nv) each) -- with them a training step can leave
+    weights / invalid / rgb_samps unrequested."""
     B, K = z_samp.shape
     _req(rays, "rays", (B, 8)), _req(z_samp, "z_samp"), _req(mlp_params.detach(), "mlp_params", (ft.spec.mlp_param_count(),))
     if B % ft.n != 0:
@@ -321,7 +329,8 @@ def render_fwd(ft: FieldTensors, mlp_params: torch.Tensor, rays: torch.Tensor, z
     outs = dict(rgb=new(B, nv * 3), depth=new(B), weights=new(B, K) if want_weights else None,
                 alphas=new(B, K) if want_alphas else None, invalid=new(B, K, nv) if want_invalid else None,
                 rgb_samps=new(B, K, nv * 3) if want_rgb_samps else None, sigma_raw=new(B, K) if want_saved else None,
-                trans=new(B, K) if want_saved else None)
+                trans=new(B, K) if want_saved else None, invalid_wsum=new(B, nv) if want_invalid_sums else None,
+                invalid_any=new(B, nv) if want_invalid_sums else None)
     cfg, tens = ft.cfg(), ft.tensors(mlp_params)
     args = _render_args(ft, rays, z_samp, hard_alpha_cap, white_bkgd, outs)
     _lib.check(_lib.load().bts_render_fwd(C.byref(cfg), C.byref(tens), C.byref(args), _stream(rays)), "bts_render_fwd")
@@ -416,26 +425,27 @@ class RenderFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, proj_nhwc, mlp_params, empty_feature, ft: FieldTensors, rays, z_samp, hard_alpha_cap, white_bkgd,
-                want_weights, want_alphas, want_rgb_samps, grad_mode=True):
+                want_weights, want_alphas, want_rgb_samps, grad_mode=True, want_invalid=True, want_invalid_sums=False):
         # needs_input_grad reflects requires_grad even under torch.no_grad(), and inside forward() grad mode is always off: the
         # caller passes the mode it was invoked in, so that evaluation does not allocate / write the 8 B per sample of saved state
         needs_grad = any(ctx.needs_input_grad[:3]) and grad_mode
         out = render_fwd(ft, mlp_params, rays, z_samp, hard_alpha_cap=hard_alpha_cap, white_bkgd=white_bkgd,
-                         want_weights=want_weights, want_alphas=want_alphas, want_invalid=True, want_rgb_samps=want_rgb_samps,
-                         want_saved=needs_grad)
+                         want_weights=want_weights, want_alphas=want_alphas, want_invalid=want_invalid, want_rgb_samps=want_rgb_samps,
+                         want_saved=needs_grad, want_invalid_sums=want_invalid_sums)
         ctx.ft, ctx.hard_alpha_cap, ctx.white_bkgd = ft, hard_alpha_cap, white_bkgd
         if needs_grad:
             # rgb_samps is non-differentiable output the caller asked for: kept for the backward too (it then skips the colour taps)
             ctx.save_for_backward(mlp_params, rays, z_samp, out["sigma_raw"], out["trans"], *([out["rgb_samps"]] if want_rgb_samps else []))
         empty = rays.new_empty(0)
         res = (out["rgb"], out["depth"], out["weights"] if want_weights else empty, out["alphas"] if want_alphas else empty,
-               out["invalid"], out["rgb_samps"] if want_rgb_samps else empty)
-        ctx.mark_non_differentiable(res[4], res[5])
+               out["invalid"] if want_invalid else empty, out["rgb_samps"] if want_rgb_samps else empty,
+               out["invalid_wsum"] if want_invalid_sums else empty, out["invalid_any"] if want_invalid_sums else empty)
+        ctx.mark_non_differentiable(*res[4:])
         ctx.has = (want_weights, want_alphas)
         return res
 
     @staticmethod
-    def backward(ctx, g_rgb, g_depth, g_weights, g_alphas, _g_inv, _g_rs):
+    def backward(ctx, g_rgb, g_depth, g_weights, g_alphas, _g_inv, _g_rs, _g_iw, _g_ia):
         mlp_params, rays, z_samp, sigma_raw, trans, *rest = ctx.saved_tensors
         rgb_samps = rest[0] if rest else None
 
@@ -457,4 +467,4 @@ class RenderFunction(torch.autograd.Function):
                 d_empty = w_f.t() @ d_eproj
             if need_mlp:
                 d_mlp[:spec.d_hidden * spec.d_in].view(spec.d_hidden, spec.d_in)[:, :spec.C] += torch.outer(d_eproj, ft.empty_feature.detach())
-        return (d_proj, d_mlp, d_empty) + (None,) * 9
+        return (d_proj, d_mlp, d_empty) + (None,) * 11

@@ -40,10 +40,17 @@ class RaySampler:
             part = render_dict[key]
             n = part["rgb"].shape[0]
             v = part["rgb"].shape[-1] // channels
-            K = part["weights"].shape[-1]
             part["rgb"] = part["rgb"].view(n, *lead, v, channels)
-            part["weights"] = part["weights"].view(n, *lead, K)
             part["depth"] = part["depth"].view(n, *lead)
+            if "weights" not in part:
+                # lean training outputs (NeRFRenderer.lean_training_outputs): the per-sample tensors never left the kernel, the
+                # loss' invalid-ray mask comes as per-ray, per-view reductions
+                for k in ("invalid_wsum", "invalid_any"):
+                    part[k] = part[k].view(n, *lead, v)
+                render_dict[key] = part
+                continue
+            K = part["weights"].shape[-1]
+            part["weights"] = part["weights"].view(n, *lead, K)
             part["invalid"] = part["invalid"].view(n, *lead, K, v)
             if "alphas" in part:
                 part["alphas"] = part["alphas"].view(n, *lead, K)

@@ -31,7 +31,7 @@ class _RenderWrapper(torch.nn.Module):
 
 class NeRFRenderer(torch.nn.Module):
     def __init__(self, n_coarse=128, n_fine=0, n_fine_depth=0, noise_std=0.0, depth_std=0.01, eval_batch_size=100000,
-                 white_bkgd=False, lindisp=False, sched=None, hard_alpha_cap=False):
+                 white_bkgd=False, lindisp=False, sched=None, hard_alpha_cap=False, lean_training_outputs=False):
         super().__init__()
         self.n_coarse, self.n_fine, self.n_fine_depth = n_coarse, n_fine, n_fine_depth
         self.noise_std, self.depth_std = noise_std, depth_std
@@ -42,6 +42,9 @@ class NeRFRenderer(torch.nn.Module):
         self.register_buffer("iter_idx", torch.tensor(0, dtype=torch.long), persistent=True)
         self.register_buffer("last_sched", torch.tensor(0, dtype=torch.long), persistent=True)
         self.hard_alpha_cap = hard_alpha_cap
+        # SURVEY 8f.1 (not a reference key): in training mode return only what a training step consumes -- rgb, depth and the
+        # per-ray reductions behindthescenes_amd.ReconstructionLoss builds its invalid-ray mask from -- see forward()
+        self.lean_training_outputs = bool(lean_training_outputs)
         if noise_std > 0.0:
             raise NotImplementedError("sigma noise (noise_std > 0) is disabled in every shipped config and is not implemented")
 
@@ -98,9 +101,11 @@ class NeRFRenderer(torch.nn.Module):
         return z
 
     # ---- the hot path (nerf.py:210-313) -------------------------------------------------------------------------------
-    def composite(self, model, rays, z_samp, coarse=True, sb=0, want_weights=True, want_alphas=True, want_rgb_samps=True):
+    def composite(self, model, rays, z_samp, coarse=True, sb=0, want_weights=True, want_alphas=True, want_rgb_samps=True,
+                  want_invalid=True, want_invalid_sums=False):
         """rays (B, 8), z_samp (B, K) -> (weights, rgb, depth, alphas, invalid, z_samp, rgb_samps) like the reference.
-        Entries that were not requested come back as ``None`` (the reference always materialises all of them)."""
+        Entries that were not requested come back as ``None`` (the reference always materialises all of them).  With
+        ``want_invalid_sums`` two more entries follow: (invalid_wsum, invalid_any), (B, nv) each."""
         if not isinstance(model, BTSNet):
             raise native.BtsNativeError("composite() needs a behindthescenes_amd.BTSNet (the fused HIP kernel IS the field query)")
         if not coarse and model.mlp_fine is not None:
@@ -115,11 +120,12 @@ class NeRFRenderer(torch.nn.Module):
         z_samp = z_samp.float().contiguous()
         mlp_params = model.mlp_coarse.packed()
         empty = model.empty_feature if model.learn_empty else None
-        rgb, depth, weights, alphas, invalid, rgb_samps = native.RenderFunction.apply(
+        rgb, depth, weights, alphas, invalid, rgb_samps, inv_wsum, inv_any = native.RenderFunction.apply(
             ft.proj_nhwc, mlp_params, empty, ft, rays, z_samp, bool(self.hard_alpha_cap), bool(self.white_bkgd),
-            bool(want_weights), bool(want_alphas), bool(want_rgb_samps), torch.is_grad_enabled())
-        return (weights if want_weights else None, rgb, depth, alphas if want_alphas else None, invalid, z_samp,
-                rgb_samps if want_rgb_samps else None)
+            bool(want_weights), bool(want_alphas), bool(want_rgb_samps), torch.is_grad_enabled(), bool(want_invalid), bool(want_invalid_sums))
+        ret = (weights if want_weights else None, rgb, depth, alphas if want_alphas else None, invalid if want_invalid else None, z_samp,
+               rgb_samps if want_rgb_samps else None)
+        return ret + (inv_wsum, inv_any) if want_invalid_sums else ret
 
     def forward(self, model, rays, want_weights=False, want_alphas=False, want_z_samps=False, want_rgb_samps=False,
                 sample_from_dist=None):
@@ -137,6 +143,18 @@ class NeRFRenderer(torch.nn.Module):
             ns = prop_weights.shape[-1]
             z_coarse = self.sample_coarse_from_dist(rays, prop_weights.reshape(-1, ns), prop_z.reshape(-1, ns))
             z_coarse, _ = torch.sort(z_coarse, dim=-1)
+        if self.lean_training_outputs and self.training and not self.using_fine and torch.is_grad_enabled():
+            # in a training step nothing downstream of the renderer reads the per-sample tensors except the loss'
+            # invalid-ray mask, and that only through sum_k weights * invalid / any_k invalid per view -- the render kernel's
+            # epilogue emits exactly those (8 B per ray and view), and weights / alphas / invalid are neither written nor returned
+            # even when the (reference) trainer asks for them.  Opt-in (`lean_training_outputs`), training mode only.
+            # (rgb_samps is still written, as the backward's saved state only: the stores are free in the latency-bound forward and
+            # spare the backward one projection + four taps per view and sample; it is not returned)
+            comp = self.composite(model, rays, z_coarse, coarse=True, sb=sb, want_weights=False, want_alphas=False, want_rgb_samps=True,
+                                  want_invalid=False, want_invalid_sums=True)
+            nv = comp[7].shape[-1]
+            return dict(coarse=dict(rgb=comp[1].reshape(sb, -1, comp[1].shape[-1]), depth=comp[2].reshape(sb, -1),
+                                    invalid_wsum=comp[7].reshape(sb, -1, nv), invalid_any=comp[8].reshape(sb, -1, nv)))
         need_w = want_weights or self.using_fine
         comp = self.composite(model, rays, z_coarse, coarse=True, sb=sb, want_weights=need_w, want_alphas=want_alphas,
                               want_rgb_samps=want_rgb_samps)
@@ -186,7 +204,7 @@ class NeRFRenderer(torch.nn.Module):
                    noise_std=conf.get("noise_std", 0.0), depth_std=conf.get("depth_std", 0.01),
                    white_bkgd=conf.get("white_bkgd", white_bkgd), lindisp=conf.get("lindisp", True),
                    eval_batch_size=conf.get("eval_batch_size", eval_batch_size), sched=conf.get("sched", None),
-                   hard_alpha_cap=conf.get("hard_alpha_cap", False))
+                   hard_alpha_cap=conf.get("hard_alpha_cap", False), lean_training_outputs=conf.get("lean_training_outputs", False))
 
     def bind_parallel(self, net, gpus=None, simple_output=False):
         """Same contract as nerf.py:440-457.  Multi-GPU is one process per GPU (DDP over RCCL); the reference's dead

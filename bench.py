@@ -44,6 +44,9 @@ def parse():
                     help="eval (default): BASELINE configs[1], the headline line.  train: configs[2] (exp_kitti_360.yaml shapes), the "
                          "renderer's share of a training step, forward + backward")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--full-outputs", action="store_true",
+                    help="train workload: also materialise weights / alphas / invalid / rgb_samps per sample as the reference trainer's dict "
+                         "has them (default: lean_training_outputs -- the loss reads per-ray reductions from the render kernel's epilogue)")
     ap.add_argument("--no-gpu-eager-baseline", action="store_true",
                     help="skip ref_gpu_baseline: the oracle's torch ops eagerly on the GPU (the reference's own code path on this device, the "
                          "denominator of north_star's >= 10x target); on by default at N = 1")
@@ -142,7 +145,8 @@ def train_workload(args, world, rank, dev):
     net.encoder = bts.FeatureMapEncoder((H, W), C, num_views=n)
     S.set_feature_map(net, scene["feat"])
     net = net.to(dev).train()
-    renderer = bts.NeRFRenderer.from_conf(dict(n_coarse=Kt, lindisp=True, hard_alpha_cap=True)).to(dev).train()
+    renderer = bts.NeRFRenderer.from_conf(dict(n_coarse=Kt, lindisp=True, hard_alpha_cap=True,
+                                               lean_training_outputs=not args.full_outputs)).to(dev).train()
     sampler = bts.PatchRaySampler(ray_batch_size=4096, z_near=3.0, z_far=80.0, patch_size=8)
     images, projs, poses = scene["images"].to(dev), scene["projs"].to(dev), scene["poses"].to(dev)
     ids_loss, ids_render = [0, 1, 2, 3], [4, 5, 6, 7]
@@ -234,7 +238,10 @@ def train_workload(args, world, rank, dev):
             "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
             "config": {"workload": "exp_kitti_360.yaml shapes: bs=16/GPU, 8 frames (4 loss + 4 render views), 4096 patch rays (8x8) per sample, "
-                                   "64 samples/ray, everything after the CNN (feature-map encoder stand-in): sample, render, photometric loss, backward",
+                                   "64 samples/ray, everything after the CNN (feature-map encoder stand-in): sample, render, photometric loss, backward; "
+                                   + ("every per-sample output of the reference trainer's dict materialised (--full-outputs)" if args.full_outputs else
+                                      "lean_training_outputs: the trainer's render call as is, but weights / alphas / invalid / rgb_samps stay in the "
+                                      "kernel -- the loss' invalid-ray mask reads per-ray reductions from the render epilogue (SURVEY 8f.1)"),
                        "rays_per_step_per_gpu": n_rays, "samples_per_ray": Kt, "parallelism": f"batch x{world}"},
             "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_MATRIX_TFLOPS, "traffic": traffic,

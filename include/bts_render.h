@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define BTS_ABI_VERSION 1
+#define BTS_ABI_VERSION 2
 
 enum {
   BTS_OK = 0,
@@ -92,6 +92,10 @@ typedef struct BtsRenderArgs {
   float* rgb_samps;        /* (n*Bp, K, nv*3)  or NULL */
   float* sigma_raw;        /* (n*Bp, K)        or NULL   pre-softplus MLP output  } the two per-sample activations the  */
   float* trans;            /* (n*Bp, K)        or NULL   transmittance before sample } backward needs (8 B per sample)     */
+  /* ABI 2: what the photometric loss' invalid-ray policies (loss.py:100-118) need of `weights` and `invalid`, reduced over the samples
+   * in the kernel's epilogue -- a training step then stores 8 B per ray and view instead of (1 + nv) * 4 * K B per ray */
+  float* invalid_wsum;     /* (n*Bp, nv)       or NULL   sum_k weights_k * invalid_k,v   (policy weight_guided: > 0.9) */
+  float* invalid_any;      /* (n*Bp, nv)       or NULL   max_k invalid_k,v               (policy strict) */
 } BtsRenderArgs;
 
 /* Gradients flowing into / out of the renderer (what torch.autograd would compute through nerf.py:283-299,
@@ -168,8 +172,8 @@ int bts_gen_rays(const float* poses_c2w, const float* projs, int32_t V, int32_t 
 typedef struct {
   const float* rgb;      /* (B, nv, 3) rendered colours per view */
   const float* depth;    /* (B) expected ray termination depth (may be NULL without edge_aware_smoothness) */
-  const float* weights;  /* (B, K)      needed by invalid_policy 2 */
-  const float* invalid;  /* (B, K, nv)  needed by invalid_policy 1, 2 */
+  const float* weights;  /* (B, K)      needed by invalid_policy 2   } unless invalid_wsum / invalid_any */
+  const float* invalid;  /* (B, K, nv)  needed by invalid_policy 1, 2 } below are given                  */
   const float* rgb_gt;   /* (B, 3) */
   float* parts;          /* (n_patches, 4) */
   float* g_rgb;          /* (B, nv, 3) or NULL */
@@ -178,6 +182,9 @@ typedef struct {
   int32_t invalid_policy;          /* 0 none, 1 strict, 2 weight_guided */
   int32_t edge_aware_smoothness;   /* 0 / 1 */
   float scale_rgb, scale_eas;
+  /* ABI 2: the renderer's per-ray reductions (BtsRenderArgs.invalid_wsum / invalid_any); when given they replace weights / invalid */
+  const float* invalid_wsum;   /* (B, nv) or NULL   policy 2 */
+  const float* invalid_any;    /* (B, nv) or NULL   policy 1 */
 } BtsLossArgs;
 int bts_photometric_loss(const BtsLossArgs* args, void* stream);
 

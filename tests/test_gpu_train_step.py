@@ -65,3 +65,52 @@ def test_train_step_loss_and_gradients_vs_reference_golden(fused_loss):
         ref = t[k].view_as(g.cpu())
         err = (g.cpu() - ref).abs().max().item() / (ref.abs().max().item() + 1e-20)
         assert err <= 1e-4, (k, err)
+
+
+@pytest.mark.parametrize("policy", ["weight_guided", "strict"])
+def test_lean_training_outputs_match_the_full_step(policy):
+    """with ``lean_training_outputs`` the render kernel's epilogue hands the loss sum_k w * invalid / max_k invalid per
+    ray and view and the per-sample tensors (weights, alphas, invalid, rgb_samps) never reach HBM.  Same jitter, same patches: loss,
+    invalid ratio and every gradient must equal the full-output step (weight_guided is also the reference golden's policy)."""
+    import behindthescenes_amd as bts
+    from behindthescenes_amd import _lib
+    from tests._hip_helpers import load_mlp, make_conf
+    _lib.load()
+    z = np.load(f"{GOLDEN}/train_step.npz")
+    meta = ast.literal_eval(str(z["meta"]))
+    t = {k: torch.from_numpy(z[k]) for k in z.files if k != "meta"}
+    n, pc, ps, K, H, W = meta["n"], meta["patches"], meta["patch"], meta["K"], meta["H"], meta["W"]
+    cfg = O.FieldConfig(d_min=meta["d_min"], d_max=meta["d_max"])
+    results = []
+    for lean in (False, True):
+        net = bts.BTSNet(make_conf(cfg, meta["C"], meta["Hd"], 0, H, W))
+        load_mlp(net, O.MlpParams(t["w_in"], t["b_in"], [], t["w_out"], t["b_out"]))
+        with torch.no_grad():
+            net.encoder.feats[0].data = t["feat"].clone()
+        net = net.cuda().train()
+        images = t["images"].cuda()
+        net.encode(images, t["projs"].cuda(), t["poses"].cuda(), ids_encoder=[0], ids_render=meta["ids_render"], images_alt=images * .5 + .5)
+        renderer = bts.NeRFRenderer.from_conf(dict(n_coarse=K, lindisp=True, hard_alpha_cap=True, lean_training_outputs=lean)).cuda().train()
+        wrapped = renderer.bind_parallel(net).train()
+        sampler = bts.PatchRaySampler(ray_batch_size=pc * ps * ps, z_near=cfg.d_min, z_far=cfg.d_max, patch_size=ps)
+        torch.manual_seed(11)                                  # the jitter of sample_coarse
+        rd = wrapped(t["rays"].cuda(), want_weights=True, want_alphas=True, want_rgb_samps=True)    # trainer.py:245
+        assert ("weights" in rd["coarse"]) != lean and ("invalid_wsum" in rd["coarse"]) == lean
+        rd["fine"] = dict(rd["coarse"])
+        rd["rgb_gt"] = t["rgb_gt"].cuda()
+        rd = sampler.reconstruct(rd)
+        crit = bts.ReconstructionLoss({"criterion": "l1+ssim", "invalid_policy": policy, "lambda_edge_aware_smoothness": 0.001})
+        loss, parts = crit(dict(coarse=[rd["coarse"]], fine=[rd["fine"]], rgb_gt=rd["rgb_gt"]))
+        loss.backward()
+        results.append((loss.item(), parts["loss_invalid_ratio"], rd["coarse"]["depth"].detach().clone(),
+                        [p.grad.clone() for p in (net.mlp_coarse.lin_in.weight, net.mlp_coarse.lin_out.weight, net.encoder.feats[0])]))
+    (l0, r0, d0, g0), (l1, r1, d1, g1) = results
+    assert torch.equal(d0, d1)                                 # same kernel arithmetic, with and without the epilogue
+    assert abs(l0 - l1) <= 1e-6 and abs(r0 - r1) <= 1e-7, (l0, l1, r0, r1)
+    for a, b in zip(g0, g1):
+        assert (a - b).abs().max().item() <= 2e-5 * b.abs().max().item()    # float atomics: run-to-run summation order
+    # eval mode ignores the flag: every requested per-sample tensor is there
+    wrapped.eval()
+    with torch.no_grad():
+        rd = wrapped(t["rays"].cuda(), want_weights=True, want_alphas=True)
+    assert "weights" in rd["coarse"] and "invalid" in rd["coarse"]
