@@ -196,6 +196,21 @@ __global__ __launch_bounds__(256, 2) void rows_kernel(const BwdParams bp) {
   const int lane = threadIdx.x & 63;
   const int h0 = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#ifdef BTS_GATHER_LDS
+  extern __shared__ __attribute__((aligned(128))) char gather_lds[];   // per wave: ring of 3 x 4 KB + 768 B tap table (render_kernel_p)
+  GatherLds gl;
+  {
+    char* base = gather_lds + wave * kGatherLdsPerWave;
+    gl.ring = base;
+    gl.ring_m0 = (unsigned)(unsigned long)base;
+    gl.tab = reinterpret_cast<unsigned*>(base + 3 * 4096);
+    gl.m = lane >> 3;
+    gl.piece16 = 16u * (unsigned)(((lane & 7) + (lane >> 4)) & 7);
+    const int col = lane & 31;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) gl.rd[q] = (unsigned)(col * 128 + ((4 * h0 + q - ((col & 7) >> 1)) & 7) * 16);
+  }
+#endif
   const int nwg = gridDim.x;  // multiple of 8
   const int wg = xcd_remap(blockIdx.x, nwg);
   const int wg_per_xcd = nwg >> 3;
@@ -315,10 +330,24 @@ __global__ __launch_bounds__(256, 2) void rows_kernel(const BwdParams bp) {
       bcast_tiles(__float_as_uint(tp.w11), t0, t1), wq[0][3] = __uint_as_float(t0), wq[1][3] = __uint_as_float(t1);
       bcast_tiles(use_empty ? 1u : 0u, t0, t1), emp[0] = t0 != 0, emp[1] = t1 != 0;
     }
+#ifdef BTS_GATHER_LDS
+    unsigned off_next[4];
+    GRows rows;
+    {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      gl.tab[lane * 3 + 0] = (unsigned)tp.o00 * (HD * 4u), gl.tab[lane * 3 + 1] = (unsigned)tp.o01 * (HD * 4u), gl.tab[lane * 3 + 2] = (unsigned)tp.o10 * (HD * 4u);   // o11 = o10 + (o01 - o00)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      gl_prologue<HD>(gl, rows, G, off_next);
+    }
+#else
     GBuf ba, bb;
 #ifndef BTS_ROWS_LATE_GATHER
     stage_load<HD, 0>(ba, G, o, h);
     stage_load<HD, 1>(bb, G, o, h);
+#endif
 #endif
 
     // ---------------- compositing gradient (nerf.py:283-299):  g_alpha_k = g_w_k T_k - (sum_{m>k} g_w_m w_m) / (1 - alpha_k + 1e-10)
@@ -357,7 +386,7 @@ __global__ __launch_bounds__(256, 2) void rows_kernel(const BwdParams bp) {
     // ---------------- h = bilinear(G) + W_pe . PE + b, exactly as render_kernel_p evaluates it (accumulators carry 2^S)
     f32x16 acc[HT][2];
     {
-#ifdef BTS_ROWS_LATE_GATHER   // A/B: gather issued in front of the MFMA phase
+#if defined(BTS_ROWS_LATE_GATHER) && !defined(BTS_GATHER_LDS)   // A/B: gather issued in front of the MFMA phase
       stage_load<HD, 0>(ba, G, o, h);
       stage_load<HD, 1>(bb, G, o, h);
 #endif
@@ -377,11 +406,19 @@ __global__ __launch_bounds__(256, 2) void rows_kernel(const BwdParams bp) {
       __builtin_amdgcn_sched_barrier(0);
       int lane4 = lane * 4;
       asm volatile("" : "+v"(lane4));
+#ifdef BTS_GATHER_LDS
+      region_seq_l<HD, 0>(acc, gl, rows, G, wq, off_next, lh + LH::W_F16 + lane4, LH::TERM_STRIDE, raw, v3, p.freq_factor, bias);
+      if constexpr (NS > kNumFreqs) {
+        gl_consume<HD, 12>(acc, gl, rows, G, wq, off_next), gl_consume<HD, 13>(acc, gl, rows, G, wq, off_next);
+        gl_consume<HD, 14>(acc, gl, rows, G, wq, off_next), gl_consume<HD, 15>(acc, gl, rows, G, wq, off_next);
+      }
+#else
       region_seq<HD, 0>(acc, ba, bb, G, o, wq, h, lh + LH::W_F16 + lane4, LH::TERM_STRIDE, raw, v3, p.freq_factor, bias);
       if constexpr (NS > kNumFreqs) {
         stage_blend<HD, 6>(acc, ba, wq);
         stage_blend<HD, 7>(acc, bb, wq);
       }
+#endif
     }
     if (p.learn_empty && __any(use_empty)) {
 #pragma unroll
@@ -904,10 +941,19 @@ __global__ __launch_bounds__(256, 2) void dwpe_kernel(const DwpeParams dp) {
 template <int C, int HD>
 static int launch_rows(const BwdParams& bp, int n, int grid, hipStream_t s) {
   const FwdParams& p = bp.f;
-  if (p.nv <= 1) rows_kernel<C, HD, 1><<<grid, 256, 0, s>>>(bp);
-  else if (p.nv <= 2) rows_kernel<C, HD, 2><<<grid, 256, 0, s>>>(bp);
-  else if (p.nv <= 4) rows_kernel<C, HD, 4><<<grid, 256, 0, s>>>(bp);
-  else rows_kernel<C, HD, 8><<<grid, 256, 0, s>>>(bp);
+#ifdef BTS_GATHER_LDS
+  constexpr int dyn = 4 * kGatherLdsPerWave;
+#else
+  constexpr int dyn = 0;
+#endif
+  auto go = [&](auto kern) {
+    if (dyn) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, dyn);
+    kern<<<grid, 256, dyn, s>>>(bp);
+  };
+  if (p.nv <= 1) go(rows_kernel<C, HD, 1>);
+  else if (p.nv <= 2) go(rows_kernel<C, HD, 2>);
+  else if (p.nv <= 4) go(rows_kernel<C, HD, 4>);
+  else go(rows_kernel<C, HD, 8>);
   hipError_t e = hipGetLastError();
   if (e == hipSuccess && (bp.d_proj || bp.d_empty_proj)) {
     const MlpLayout ml{C + kPeDim, HD, 0};

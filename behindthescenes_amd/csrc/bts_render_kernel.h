@@ -14,6 +14,15 @@
 #pragma once
 #include "bts_field_kernel.h"
 
+// The gather of G goes through LDS (global_load_lds_dwordx4, see GatherLds below) unless the build says -DBTS_GATHER_REGS (the
+// round-1 form: two register buffers per lane; kept for A/B as variants/libbts_gatherregs.so)
+#if !defined(BTS_GATHER_REGS) && !defined(BTS_GATHER_LDS)
+#define BTS_GATHER_LDS
+#endif
+#if defined(BTS_GATHER_LDS) && defined(BTS_ENC_RAY)
+#error "the experimental encoder-camera ray draft is written against the register gather: add -DBTS_GATHER_REGS"
+#endif
+
 namespace bts {
 
 #ifdef BTS_PROBE
@@ -403,6 +412,140 @@ __device__ __forceinline__ void region_seq(f32x16 (&acc)[HD / 32][2], GBuf& ba, 
   }
 }
 
+#ifdef BTS_GATHER_LDS
+constexpr int kGatherLdsPerWave = 3 * 4096 + 768;
+// ---------------------------------------------------------------------------------------------------------------
+// The gather of G through LDS.
+//
+// PMC and the per-view split of the eval frame say the forward is bound by the texture addresser for every ray that does NOT pass
+// through the encoder camera (profiles/README.md, r02f): there each sample of a ray hits its own texels, lane (h, col) reads its 64
+// bytes as four 16-byte loads, and every one of the 64 gather instructions of a ray presents 64 different cache lines to the L1
+// tag pipeline (one per clock): 4 096 clocks per ray and CU, exactly the measured 6.4 ns per ray against 4.2 ns for encoder-camera
+// rays (whose samples share their texels: one line per instruction).
+// Here EIGHT ADJACENT LANES fetch one whole 128-byte row half (global_load_lds_dwordx4: 16 bytes per lane straight into LDS, no
+// VGPRs): 8 lines per instruction instead of 64.  The hardware puts lane L's 16 bytes at M0 + 16 L, so the row of point 8j + m
+// (instruction j of a block, m = L >> 3) lands at block + j * 1024 + m * 128; the pieces are fetched rotated by m >> 1 so that the
+// consumer -- lane (h, col) reading the four pieces 4h .. 4h + 3 of row col as ds_read_b128 -- spreads over all banks.
+// A block = one tap of one (point tile, hidden tile) = 32 rows = 4 KB; a ring of three blocks per wave; block T + 3 is issued into
+// the slot of block T once T has been blended.  The tap offsets of the 64 samples go through a 768-byte per-wave table (lane = sample
+// writes, lane (m, piece) reads the row of sample 32 pt + 8 j + m).  52 KB of dynamic LDS per work-group on top of the weights: two
+// work-groups per CU still fit for every shape (the RE10K model's 29 KB of weights included).
+struct GatherLds {
+  const char* ring;     // this wave's ring (3 blocks of 4 KB), generic pointer
+  unsigned ring_m0;     // ... as an LDS byte address (M0 of the DMA loads)
+  unsigned* tab;        // this wave's tap table: [64 samples][3] byte offsets into G of the taps nw, ne, sw
+  unsigned rd[4];       // byte offset inside a block of this lane's piece q as the CONSUMER (h, col)
+  unsigned piece16;     // 16 * the piece this lane FETCHES: ((L & 7) + (L >> 4)) & 7, i.e. rotated by (m >> 1), m = L >> 3
+  int m;                // L >> 3
+};
+template <int HD, int T>
+struct GBlock {   // block T of a ray, in the order the stages are blended (GStage)
+  static constexpr int HT = HD / 32;
+  static constexpr int S = T / 2, pt = S / (2 * HT), ht = (S / 2) % HT, tap = 2 * (S % 2) + T % 2, slot = T % 3;
+  static constexpr int NBLK = 8 * HT;
+};
+// the four per-lane byte offsets (instructions j = 0..3) of block T
+template <int HD, int T>
+__device__ __forceinline__ void gl_offsets(const GatherLds& c, unsigned (&off)[4]) {
+  using B = GBlock<HD, T>;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const unsigned* row = c.tab + (32 * B::pt + 8 * j + c.m) * 3;   // [o00, o01, o10]; o11 = o10 + (o01 - o00) (clamped taps included)
+    off[j] = (B::tap < 3 ? row[B::tap] : row[2] + row[1] - row[0]) + c.piece16;
+  }
+}
+template <int HD, int T>
+__device__ __forceinline__ void gl_issue(const GatherLds& c, const float4* G, const unsigned (&off)[4], float dep) {
+  using B = GBlock<HD, T>;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    // the instruction offset (ht * 128: the hidden tile's half of the row) is added to the global AND to the LDS address: take it
+    // back out of M0.  `dep` is a value computed FROM the rows of the block whose slot is overwritten: its ds_reads have returned
+    // before this can issue (the memory clobber alone orders the issue, not the completion, of those reads)
+    const unsigned m0v = c.ring_m0 + B::slot * 4096 + j * 1024 - B::ht * 128;
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2 offset:%3"
+                 :: "v"(off[j]), "s"(m0v), "s"(G), "n"(B::ht * 128), "v"(dep) : "memory", "m0");
+  }
+}
+struct GRows {
+  float4 v[2][4];   // the lane's four 16-byte pieces of two blocks (even / odd T)
+};
+// wait until block T has landed, read this lane's pieces.  ISSUED = blocks issued after T at this point of the schedule
+template <int HD, int T, int ISSUED>
+__device__ __forceinline__ void gl_fetch(const GatherLds& c, GRows& r) {
+  using B = GBlock<HD, T>;
+  asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * ISSUED) : "memory");
+#pragma unroll
+  for (int q = 0; q < 4; ++q) r.v[T & 1][q] = *reinterpret_cast<const float4*>(c.ring + B::slot * 4096 + c.rd[q]);
+}
+// one step: the rows of block T + 1 are requested from LDS, block T (read one step ago) is blended (acc += w_tap * row, the order of
+// gblend), block T + 3 goes out into T's slot, the offsets of block T + 4 are fetched from the table
+template <int HD, int T>
+__device__ __forceinline__ void gl_consume(f32x16 (&acc)[HD / 32][2], const GatherLds& c, GRows& r, const float4* G, const float (&w)[2][4],
+                                           unsigned (&off_next)[4]) {
+  using B = GBlock<HD, T>;
+  if constexpr (T + 1 < B::NBLK) gl_fetch<HD, T + 1, (T + 2 < B::NBLK ? 1 : 0)>(c, r);   // issued so far: blocks 0 .. T + 2
+  const f32x2 wv = {w[B::pt][B::tap], w[B::pt][B::tap]};
+  f32x16& a = acc[B::ht][B::pt];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+#pragma unroll
+    for (int e = 0; e < 4; e += 2) {
+      const float* x = reinterpret_cast<const float*>(&r.v[T & 1][q]) + e;
+      const f32x2 xv = {x[0], x[1]};
+      const f32x2 res = __builtin_elementwise_fma(xv, wv, (f32x2){a[4 * q + e], a[4 * q + e + 1]});
+      a[4 * q + e] = res[0], a[4 * q + e + 1] = res[1];
+    }
+  }
+  if constexpr (T + 3 < B::NBLK) {
+    gl_issue<HD, T + 3>(c, G, off_next, a[15]);
+    if constexpr (T + 4 < B::NBLK) gl_offsets<HD, T + 4>(c, off_next);
+  }
+}
+// start of a ray: table written and fenced by the caller; blocks 0, 1, 2 go out, block 0 is requested from LDS, the offsets of block 3
+// wait in off_next
+template <int HD>
+__device__ __forceinline__ void gl_prologue(const GatherLds& c, GRows& r, const float4* G, unsigned (&off_next)[4]) {
+  unsigned o0[4], o1[4], o2[4];
+  gl_offsets<HD, 0>(c, o0), gl_offsets<HD, 1>(c, o1), gl_offsets<HD, 2>(c, o2);
+  gl_issue<HD, 0>(c, G, o0, 0.0f), gl_issue<HD, 1>(c, G, o1, 0.0f), gl_issue<HD, 2>(c, G, o2, 0.0f);
+  gl_offsets<HD, 3>(c, off_next);
+}
+// region_seq with the gather through LDS: region R blends the blocks of stages 2R and 2R + 1 behind its MFMAs
+template <int HD, int R>
+__device__ __forceinline__ void region_seq_l(f32x16 (&acc)[HD / 32][2], const GatherLds& gl, GRows& rows, const float4* __restrict__ G,
+                                             const float (&wq)[2][4], unsigned (&off_next)[4], const float* wf, int term_stride, SinCos3& raw,
+                                             const float (&v3)[3], float ff, const f32x16* bias) {
+  constexpr int HT = HD / 32;
+  constexpr int NS = 4 * HT;
+  if constexpr (R < 3) {
+    constexpr int NE = R == 0 ? 14 : (R == 1 ? 13 : 12);
+    float e[NE];
+    float t[6];
+    pe_entries(t, raw, v3, ff);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) e[i] = t[i];
+    SinCos3 r1;
+    pe_double(r1, raw);
+    pe_entries(t, r1, v3, ff * 2.0f);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) e[6 + i] = t[i];
+    if constexpr (R == 0) e[12] = v3[0], e[13] = v3[1];
+    if constexpr (R == 1) e[12] = v3[2];
+    if constexpr (R + 1 < 3) pe_direct(raw, v3, ff * 4.0f);
+    f16_region<HD, NE, R == 0>(acc, wf + R * HT * 256, term_stride, e, bias);
+    if constexpr (2 * R < NS) {
+      if constexpr (R == 0) gl_fetch<HD, 0, 2>(gl, rows);   // blocks 1, 2 were issued after block 0
+      gl_consume<HD, 4 * R + 0>(acc, gl, rows, G, wq, off_next);
+      gl_consume<HD, 4 * R + 1>(acc, gl, rows, G, wq, off_next);
+      gl_consume<HD, 4 * R + 2>(acc, gl, rows, G, wq, off_next);
+      gl_consume<HD, 4 * R + 3>(acc, gl, rows, G, wq, off_next);
+    }
+    region_seq_l<HD, R + 1>(acc, gl, rows, G, wq, off_next, wf, term_stride, raw, v3, ff * 4.0f, bias);
+  }
+}
+#endif  // BTS_GATHER_LDS
+
 #ifdef BTS_ENC_RAY
 // ---------------------------------------------------------------------------------------------------------------
 // EXPERIMENTAL (not in the shipped library; build with -DBTS_ENC_RAY): encoder-camera rays, exact to first order.
@@ -619,6 +762,21 @@ __global__ __launch_bounds__(256, 2) void render_kernel_p(const FwdParams p) {
   const int lane = threadIdx.x & 63;
   const int h0 = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#ifdef BTS_GATHER_LDS
+  extern __shared__ __attribute__((aligned(128))) char gather_lds[];   // per wave: ring of 3 x 4 KB + 768 B tap table
+  GatherLds gl;
+  {
+    char* base = gather_lds + wave * kGatherLdsPerWave;
+    gl.ring = base;
+    gl.ring_m0 = (unsigned)(unsigned long)base;     // low 32 bits of a generic LDS address = the LDS byte address
+    gl.tab = reinterpret_cast<unsigned*>(base + 3 * 4096);
+    gl.m = lane >> 3;
+    gl.piece16 = 16u * (unsigned)(((lane & 7) + (lane >> 4)) & 7);
+    const int col = lane & 31;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) gl.rd[q] = (unsigned)(col * 128 + ((4 * h0 + q - ((col & 7) >> 1)) & 7) * 16);
+  }
+#endif
   const int nwg = gridDim.x;  // multiple of 8
   const int wg = xcd_remap(blockIdx.x, nwg);
   const int wg_per_xcd = nwg >> 3;
@@ -777,12 +935,28 @@ __global__ __launch_bounds__(256, 2) void render_kernel_p(const FwdParams p) {
       }
       if (!done) {
 #endif
+#ifdef BTS_GATHER_LDS
+      static_assert(F16, "the LDS gather is wired into the f16 path only");
+      unsigned off_next[4];
+      GRows rows;
+      {
+        // tap table of the wave's 64 samples (byte offsets into G), lane = sample
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        gl.tab[lane * 3 + 0] = (unsigned)tp.o00 * (HD * 4u), gl.tab[lane * 3 + 1] = (unsigned)tp.o01 * (HD * 4u), gl.tab[lane * 3 + 2] = (unsigned)tp.o10 * (HD * 4u);   // o11 = o10 + (o01 - o00)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        gl_prologue<HD>(gl, rows, G, off_next);
+      }
+#else
       GBuf ba, bb;
       const bool nogather = BTS_ABL(1);
       if (!nogather) {
         stage_load<HD, 0>(ba, G, o, h);
         stage_load<HD, 1>(bb, G, o, h);
       }
+#endif
       if constexpr (F16) {
         // bias row (times 2^S, fp32): the C operand of the first MFMA of every accumulator tile.  The raw inputs x, y, code ride in
         // the spare k rows of the f16 slices (|x|, |y| <= 2083 here -- beyond that the wave took the exact path above), so the
@@ -803,8 +977,17 @@ __global__ __launch_bounds__(256, 2) void render_kernel_p(const FwdParams p) {
         __builtin_amdgcn_sched_barrier(0);
         int lane4 = lane * 4;
         asm volatile("" : "+v"(lane4));  // keep the A-operand reads inside the loop (see lane_off above)
+#ifdef BTS_GATHER_LDS
+        region_seq_l<HD, 0>(acc, gl, rows, G, wq, off_next, lh + LH::W_F16 + lane4, LH::TERM_STRIDE, raw, v3, p.freq_factor, bias);
+        if constexpr (NS > kNumFreqs) {   // HD = 64: the blocks of stages 6 and 7
+          gl_consume<HD, 12>(acc, gl, rows, G, wq, off_next), gl_consume<HD, 13>(acc, gl, rows, G, wq, off_next);
+          gl_consume<HD, 14>(acc, gl, rows, G, wq, off_next), gl_consume<HD, 15>(acc, gl, rows, G, wq, off_next);
+        }
+#else
         region_seq<HD, 0>(acc, ba, bb, G, o, wq, h, lh + LH::W_F16 + lane4, LH::TERM_STRIDE, raw, v3, p.freq_factor, bias, nosin, nomfma);
+#endif
       } else {
+#ifndef BTS_GATHER_LDS
         const float* wl = lds + L::W_IN + lane_off;
         kstep_first<HD>(acc, wl, 0, v3[0], v3[1]);
         kstep<HD>(acc, wl + 2 * HD, 0, v3[2], 1.0f, nomfma);
@@ -813,13 +996,16 @@ __global__ __launch_bounds__(256, 2) void render_kernel_p(const FwdParams p) {
         pe_direct(raw, v3, p.freq_factor);
         __builtin_amdgcn_sched_barrier(0);
         octave_seq<HD, 0>(acc, ba, bb, G, o, wq, h, wl + 4 * HD, raw, v3, p.freq_factor, nomfma, nosin, nogather);
+#endif
       }
+#ifndef BTS_GATHER_LDS
       if constexpr (NS > kNumFreqs) {  // HD = 64: stages 6 and 7 are still in the buffers
         if (!nogather) {
           stage_blend<HD, 6>(acc, ba, wq);
           stage_blend<HD, 7>(acc, bb, wq);
         }
       }
+#endif
 #ifdef BTS_ENC_RAY
       }
 #endif
@@ -989,8 +1175,18 @@ __global__ __launch_bounds__(256, 2) void render_kernel_p(const FwdParams p) {
 #ifndef BTS_NO_LAUNCH_GLUE
 template <int C, int HD, int NB, int NVMAX, bool EPI>
 static int launch_render_p_one(const FwdParams& p, int grid, hipStream_t s) {
+#ifdef BTS_GATHER_LDS
+  constexpr int dyn = 4 * kGatherLdsPerWave;
+  auto go = [&](auto kern) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, dyn);
+    kern<<<grid, 256, dyn, s>>>(p);
+  };
+  if (p.lpr == 64) go(render_kernel_p<C, HD, NB, NVMAX, true, true, EPI>);
+  else go(render_kernel_p<C, HD, NB, NVMAX, false, true, EPI>);
+#else
   if (p.lpr == 64) render_kernel_p<C, HD, NB, NVMAX, true, true, EPI><<<grid, 256, 0, s>>>(p);
   else render_kernel_p<C, HD, NB, NVMAX, false, true, EPI><<<grid, 256, 0, s>>>(p);
+#endif
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     set_error("%s: kernel launch failed (%ld)", hipGetErrorString(e), (long)e);
@@ -1007,8 +1203,8 @@ static int launch_render_p_nv(const FwdParams& p, int grid, hipStream_t s) {
   return launch_render_p_one<C, HD, NB, 8, EPI>(p, grid, s);
 }
 
-#ifdef BTS_PROBE
-// A/B only (probe build, BTS_RENDER_F32MFMA=1): the same pipeline with lin_in on the fp32-input MFMA, benchmark shape only
+#if defined(BTS_PROBE) && !defined(BTS_GATHER_LDS)
+// A/B only (probe build with -DBTS_GATHER_REGS, BTS_RENDER_F32MFMA=1): the same pipeline with lin_in on the fp32-input MFMA, benchmark shape only
 inline int launch_render_p_f32mfma(const FwdParams& p, int grid, hipStream_t s) {
   render_kernel_p<64, 64, 0, 1, true, false><<<grid, 256, 0, s>>>(p);
   return hipGetLastError() == hipSuccess ? BTS_OK : BTS_E_LAUNCH;
@@ -1017,7 +1213,7 @@ inline int launch_render_p_f32mfma(const FwdParams& p, int grid, hipStream_t s) 
 
 template <bool EPI>
 inline int launch_render_p(const FwdParams& p, int C, int HD, int NB, int grid, hipStream_t s) {
-#ifdef BTS_PROBE
+#if defined(BTS_PROBE) && !defined(BTS_GATHER_LDS)
   if (!EPI && C == 64 && HD == 64 && NB == 0 && p.nv <= 1 && p.lpr == 64 && getenv("BTS_RENDER_F32MFMA")) return launch_render_p_f32mfma(p, grid, s);
 #endif
   if (C == 64 && HD == 64 && NB == 0) return launch_render_p_nv<64, 64, 0, EPI>(p, grid, s);
