@@ -102,9 +102,10 @@ def test_parity_holds_on_a_second_schedule(tag):
     assert re.search(r"\b\d+ passed", r.stdout), r.stdout[-500:]
 
 
-@pytest.mark.parametrize("tag", ["o2", "regionbarrier"])
+@pytest.mark.parametrize("tag", ["o2", "regionbarrier", "gatherregs"])
 def test_second_schedule_matches_the_shipped_build_bit_for_bit(hip, tag, tmp_path):
-    """Same expression tree, -ffp-contract=off: a different instruction schedule must not change a single bit."""
+    """Same expression tree, -ffp-contract=off: a different instruction schedule must not change a single bit.  gatherregs: the
+    round-1 gather (two register buffers per lane) against the shipped gather through LDS -- same blend order, same bits."""
     name = "cfg2_nv1_learn_empty"
     code = f"""
 import sys, torch
