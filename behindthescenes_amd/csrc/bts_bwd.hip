@@ -760,6 +760,10 @@ int render_bwd_impl(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const BtsR
 #endif
   if (rows_path(cfg, a) && !direct && !v1) {
     bp.f.lpr = 64, bp.f.groups = (long)cfg->n * a->rays_per_sample;
+    if (bp.f.groups > 0x7FF00000L) {
+      set_error("%s: too many rays in one call (%ld)", "bts_render_bwd", bp.f.groups);
+      return BTS_E_UNSUPPORTED;
+    }
     const int grid = render_grid(bp.f);
     bp.f.chunk_log2 = render_chunk_log2(grid);
     bp.gh_ws = nullptr;

@@ -219,11 +219,12 @@ __global__ __launch_bounds__(256, 2) void rows_kernel(const BwdParams bp) {
   const int waves_per_xcd = wg_per_xcd * 4;
   // chunk-interleaved ray distribution over the XCDs, as render_kernel_p (one group = one ray here)
   const int CHL = p.chunk_log2;
-  const long n_chunks = (p.groups + (1L << CHL) - 1) >> CHL;
-  auto group_of = [&](long idx) -> long {
-    const long c = ((idx >> CHL) << 3) + xcd;
-    const long gg = (c << CHL) + (idx & ((1L << CHL) - 1));
-    return (c < n_chunks && gg < p.groups) ? gg : -1L;
+  const int n_groups = (int)p.groups;   // 32-bit ray indices (render_bwd_impl checks), 64 bits only for element offsets
+  const int n_chunks = (n_groups + (1 << CHL) - 1) >> CHL;
+  auto group_of = [&](int idx) -> int {
+    const int c = ((idx >> CHL) << 3) + xcd;
+    const int gg = (c << CHL) + (idx & ((1 << CHL) - 1));
+    return (c < n_chunks && gg < n_groups) ? gg : -1;
   };
   const int Bp = p.Bp, K = p.K, H = p.H, W = p.W, nv = p.nv;
   const int k = lane;
@@ -234,14 +235,14 @@ __global__ __launch_bounds__(256, 2) void rows_kernel(const BwdParams bp) {
   float dw_acc[HT], db_acc = 0.0f;   // this lane's share of dw_out (see gates_and_dwout) and of db_out
 #pragma unroll
   for (int ht = 0; ht < HT; ++ht) dw_acc[ht] = 0.0f;
-  long sample_end = Bp;
+  int sample_end = Bp;
   int sample = 0;
-  long idx = lw;
-  long g = group_of(idx);
+  int idx = lw;
+  int g = group_of(idx);
   float z_pre = 0.0f, zn_pre = 0.0f, s_pre = 0.0f, t_pre = 0.0f;
   if (g >= 0) {
-    const long pk = g * K + kk;
-    z_pre = p.z_samp[pk], zn_pre = p.z_samp[g * K + min(kk + 1, K - 1)];
+    const long pk = (long)g * K + kk;
+    z_pre = p.z_samp[pk], zn_pre = p.z_samp[(long)g * K + min(kk + 1, K - 1)];
     s_pre = p.sigma_raw[pk], t_pre = p.trans[pk];
   }
 
@@ -254,10 +255,10 @@ __global__ __launch_bounds__(256, 2) void rows_kernel(const BwdParams bp) {
     const float ox = rp[0], oy = rp[1], oz = rp[2], dx = rp[3], dy = rp[4], dz = rp[5];
     const float z = z_pre, z_nx = zn_pre, s_raw = s_pre, T = t_pre;
     {  // the next ray's per-sample state lands while this ray is evaluated
-      const long gn = group_of(idx + waves_per_xcd);
+      const int gn = group_of(idx + waves_per_xcd);
       if (gn >= 0) {
-        const long pk = gn * K + kk;
-        z_pre = p.z_samp[pk], zn_pre = p.z_samp[gn * K + min(kk + 1, K - 1)];
+        const long pk = (long)gn * K + kk;
+        z_pre = p.z_samp[pk], zn_pre = p.z_samp[(long)gn * K + min(kk + 1, K - 1)];
         s_pre = p.sigma_raw[pk], t_pre = p.trans[pk];
       }
     }

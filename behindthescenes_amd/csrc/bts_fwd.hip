@@ -101,6 +101,10 @@ int render_fwd_impl(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const BtsR
   if (const char* e = getenv("BTS_DBG_PTR")) p.dbg = (unsigned long long*)strtoull(e, nullptr, 0);
 #endif
   render_geometry(p, cfg->n);
+  if (p.groups > 0x7FF00000L) {   // the kernels index ray groups with 32 bits
+    set_error("%s: too many rays in one call (%ld groups)", "bts_render_fwd", p.groups);
+    return BTS_E_UNSUPPORTED;
+  }
   const int grid = render_grid(p);
   p.chunk_log2 = render_chunk_log2(grid);
 #ifdef BTS_PROBE

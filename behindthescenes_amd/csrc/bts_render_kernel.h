@@ -791,11 +791,14 @@ __global__ __launch_bounds__(256, 2) void render_kernel_p(const FwdParams p) {
   // eval_depth in one launch, XCDs 0-3 got the encoder camera's own rays (0.56 ms for all of them alone) and XCDs 4-7 the partner's
   // (0.86 ms alone) -- the launch took 1.69 ms, the slower half's 2 x 0.86, instead of 1.42.
   const int CHL = p.chunk_log2;
-  const long n_chunks = (p.groups + (1L << CHL) - 1) >> CHL;
-  auto group_of = [&](long idx) -> long {   // idx-th group of this XCD's chunk list, or -1 past the end
-    const long c = ((idx >> CHL) << 3) + xcd;
-    const long gg = (c << CHL) + (idx & ((1L << CHL) - 1));
-    return (c < n_chunks && gg < p.groups) ? gg : -1L;
+  // (group indices fit 32 bits -- render_fwd_impl refuses more than 2^31 - 2^20 groups: 64-bit scalar arithmetic here was ~120 SALU
+  // instructions per iteration)
+  const int n_groups = (int)p.groups;
+  const int n_chunks = (n_groups + (1 << CHL) - 1) >> CHL;
+  auto group_of = [&](int idx) -> int {   // idx-th group of this XCD's chunk list, or -1 past the end
+    const int c = ((idx >> CHL) << 3) + xcd;
+    const int gg = (c << CHL) + (idx & ((1 << CHL) - 1));
+    return (c < n_chunks && gg < n_groups) ? gg : -1;
   };
   const int Bp = p.Bp, K = p.K, H = p.H, W = p.W, nv = p.nv;
   const float b_out = as_const(p.mlp)[MlpLayout{C + kPeDim, HD, NB}.b_out()];
@@ -807,21 +810,21 @@ __global__ __launch_bounds__(256, 2) void render_kernel_p(const FwdParams p) {
   unsigned long long t_last = __builtin_readcyclecounter();
   const unsigned long long t_begin = t_last;
 #endif
-  const long groups_per_sample = Bp / R;   // Bp % R == 0 (render_geometry)
-  long sample_end = groups_per_sample;
+  const int groups_per_sample = Bp / R;   // Bp % R == 0 (render_geometry)
+  int sample_end = groups_per_sample;
   int sample = 0;
-  long idx = lw;
-  long g = group_of(idx);
+  int idx = lw;
+  int g = group_of(idx);
   // z of the first ray group
   float z_pre = 0.0f, zn_pre = 0.0f;
   if (g >= 0) {
-    const float* zr = p.z_samp + (g * R + lane / lpr) * K;
+    const float* zr = p.z_samp + ((long)g * R + lane / lpr) * K;
     const int kk = min(kl, K - 1);
     z_pre = zr[kk], zn_pre = zr[min(kk + 1, K - 1)];
   }
 
   for (; g >= 0; idx += waves_per_xcd, g = group_of(idx)) {
-    const long ray = g * R + lane / lpr;
+    const long ray = (long)g * R + lane / lpr;
     // all rays of a group belong to one batch element; g only grows along a wave's chunk list, so the element is tracked by a
     // running boundary (the 64-bit division this replaces was ~140 dependent scalar instructions at the top of every iteration)
     while (g >= sample_end) ++sample, sample_end += groups_per_sample;
@@ -829,7 +832,7 @@ __global__ __launch_bounds__(256, 2) void render_kernel_p(const FwdParams p) {
     const float4* __restrict__ G = reinterpret_cast<const float4*>(p.proj) + (long)sample * H * W * (HD / 4);
     float ox, oy, oz, dx, dy, dz;
     if constexpr (ONE_RAY) {  // wave-uniform ray: scalar loads
-      const cfp rp = as_const(p.rays) + g * 8;
+      const cfp rp = as_const(p.rays) + (long)g * 8;
       ox = rp[0], oy = rp[1], oz = rp[2], dx = rp[3], dy = rp[4], dz = rp[5];
     } else {
       const float4 r0 = reinterpret_cast<const float4*>(p.rays)[ray * 2];
@@ -839,9 +842,9 @@ __global__ __launch_bounds__(256, 2) void render_kernel_p(const FwdParams p) {
     const float* zrow = p.z_samp + ray * K;
     float z_cur = z_pre, zn_cur = zn_pre;
     {  // prefetch the next group's samples; they land while this group is evaluated
-      const long gn = group_of(idx + waves_per_xcd);
+      const int gn = group_of(idx + waves_per_xcd);
       if (gn >= 0) {
-        const float* zr = p.z_samp + (gn * R + lane / lpr) * K;
+        const float* zr = p.z_samp + ((long)gn * R + lane / lpr) * K;
         const int kk = min(kl, K - 1);
         z_pre = zr[kk], zn_pre = zr[min(kk + 1, K - 1)];
       }

@@ -54,3 +54,25 @@ def test_reconstruct_views_match_the_reference(kind):
         assert torch.equal(t, want[k]), k
         assert torch.equal(rd["fine"][k], want[k]), k
     assert rd["rgb_gt"].shape == want["rgb_gt"].shape and torch.equal(rd["rgb_gt"], want["rgb_gt"])
+
+
+def test_lean_training_outputs_reconstruct_and_config():
+    """NeRFRenderer.lean_training_outputs: a config key, off by default; the samplers' reconstruct views the per-ray
+    reductions of the lean dict (no per-sample tensors) in the patch layout."""
+    import behindthescenes_amd as bts
+    assert bts.NeRFRenderer.from_conf(dict(n_coarse=8)).lean_training_outputs is False
+    assert bts.NeRFRenderer.from_conf(dict(n_coarse=8, lean_training_outputs=True)).lean_training_outputs is True
+    n, pc, ps, nv = 2, 3, 8, 4
+    B = pc * ps * ps
+    sampler = bts.PatchRaySampler(ray_batch_size=B, z_near=3.0, z_far=80.0, patch_size=ps)
+    sampler._patch_count = pc
+    lean = dict(rgb=torch.randn(n, B, nv * 3), depth=torch.randn(n, B), invalid_wsum=torch.rand(n, B, nv), invalid_any=torch.rand(n, B, nv).round())
+    rd = dict(coarse=dict(lean), fine=dict(lean), rgb_gt=torch.rand(n, B, 3))
+    out = sampler.reconstruct(rd)
+    for key in ("coarse", "fine"):
+        c = out[key]
+        assert c["rgb"].shape == (n, pc, ps, ps, nv, 3) and c["depth"].shape == (n, pc, ps, ps)
+        assert c["invalid_wsum"].shape == (n, pc, ps, ps, nv) and c["invalid_any"].shape == (n, pc, ps, ps, nv)
+        assert torch.equal(c["invalid_wsum"].reshape(n, B, nv), lean["invalid_wsum"])
+        assert "weights" not in c and "invalid" not in c
+    assert out["rgb_gt"].shape == (n, pc, ps, ps, 3)
