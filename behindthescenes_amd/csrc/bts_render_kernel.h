@@ -478,13 +478,15 @@ __device__ __forceinline__ void gl_fetch(const GatherLds& c, GRows& r) {
 #pragma unroll
   for (int q = 0; q < 4; ++q) r.v[T & 1][q] = *reinterpret_cast<const float4*>(c.ring + B::slot * 4096 + c.rd[q]);
 }
-// one step: the rows of block T + 1 are requested from LDS, block T (read one step ago) is blended (acc += w_tap * row, the order of
-// gblend), block T + 3 goes out into T's slot, the offsets of block T + 4 are fetched from the table
+// one step: the rows of block T + 1 are requested from LDS, block T (requested one step ago) is blended (acc += w_tap * row, the order
+// of gblend), block T + 3 goes out into T's slot, the offsets of block T + 4 are fetched from the table
 template <int HD, int T>
 __device__ __forceinline__ void gl_consume(f32x16 (&acc)[HD / 32][2], const GatherLds& c, GRows& r, const float4* G, const float (&w)[2][4],
                                            unsigned (&off_next)[4]) {
   using B = GBlock<HD, T>;
+#if !defined(BTS_GL_FETCH_LATE) && !defined(BTS_GL_FETCH_MID)
   if constexpr (T + 1 < B::NBLK) gl_fetch<HD, T + 1, (T + 2 < B::NBLK ? 1 : 0)>(c, r);   // issued so far: blocks 0 .. T + 2
+#endif
   const f32x2 wv = {w[B::pt][B::tap], w[B::pt][B::tap]};
   f32x16& a = acc[B::ht][B::pt];
 #pragma unroll
@@ -497,10 +499,29 @@ __device__ __forceinline__ void gl_consume(f32x16 (&acc)[HD / 32][2], const Gath
       a[4 * q + e] = res[0], a[4 * q + e + 1] = res[1];
     }
   }
+#ifdef BTS_GL_FETCH_MID   // A/B: between the blend and the issue of block T + 3 (no gain)
+  if constexpr (T + 1 < B::NBLK) gl_fetch<HD, T + 1, (T + 2 < B::NBLK ? 1 : 0)>(c, r);
+#endif
+#ifdef BTS_GL_OFFSETS_EARLY   // A/B: the table reads of block T + 4 go out before block T + 3 is issued (second register set)
+  if constexpr (T + 3 < B::NBLK) {
+    unsigned cur[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) cur[j] = off_next[j];
+    if constexpr (T + 4 < B::NBLK) gl_offsets<HD, T + 4>(c, off_next);
+    gl_issue<HD, T + 3>(c, G, cur, a[15]);
+  }
+#else
   if constexpr (T + 3 < B::NBLK) {
     gl_issue<HD, T + 3>(c, G, off_next, a[15]);
     if constexpr (T + 4 < B::NBLK) gl_offsets<HD, T + 4>(c, off_next);
   }
+#endif
+#ifdef BTS_GL_FETCH_LATE
+  // NOT SHIPPED: requesting block T + 1 only now (issued so far: blocks 0 .. T + 3) is 4 % faster on the eval frame, but the RE10K
+  // instantiation (d_hidden 32, one ResnetBlockFC, nv 2) then differs between runs in 23 of 24 576 rays
+  // (tests/test_gpu_determinism.py::test_forward_is_bit_deterministic[re10k_nv2]); cause open
+  if constexpr (T + 1 < B::NBLK) gl_fetch<HD, T + 1, (T + 3 < B::NBLK ? 2 : (T + 2 < B::NBLK ? 1 : 0))>(c, r);
+#endif
 }
 // start of a ray: table written and fenced by the caller; blocks 0, 1, 2 go out, block 0 is requested from LDS, the offsets of block 3
 // wait in off_next

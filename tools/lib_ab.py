@@ -36,7 +36,7 @@ def child(rounds, learn_empty):
 def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     le = "--learn-empty" in sys.argv
-    passes = 3
+    passes = int(os.environ.get("LIB_AB_PASSES", "3"))
     res = {a: [] for a in args}
     for _ in range(passes):
         for a in args:
