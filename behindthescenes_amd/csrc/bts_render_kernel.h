@@ -474,7 +474,11 @@ struct GRows {
 template <int HD, int T, int ISSUED>
 __device__ __forceinline__ void gl_fetch(const GatherLds& c, GRows& r) {
   using B = GBlock<HD, T>;
+#if defined(BTS_GL_WAIT_ALL)   // diagnostic: every DMA load and LDS operation drained before the rows are read (5 % slower)
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#else
   asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * ISSUED) : "memory");
+#endif
 #pragma unroll
   for (int q = 0; q < 4; ++q) r.v[T & 1][q] = *reinterpret_cast<const float4*>(c.ring + B::slot * 4096 + c.rd[q]);
 }
@@ -518,8 +522,10 @@ __device__ __forceinline__ void gl_consume(f32x16 (&acc)[HD / 32][2], const Gath
 #endif
 #ifdef BTS_GL_FETCH_LATE
   // NOT SHIPPED: requesting block T + 1 only now (issued so far: blocks 0 .. T + 3) is 4 % faster on the eval frame, but the RE10K
-  // instantiation (d_hidden 32, one ResnetBlockFC, nv 2) then differs between runs in 23 of 24 576 rays
-  // (tests/test_gpu_determinism.py::test_forward_is_bit_deterministic[re10k_nv2]); cause open
+  // instantiations (d_hidden 32, one ResnetBlockFC) then differ between runs in 1 - 23 of 24 576 rays
+  // (tests/test_gpu_determinism.py::test_forward_is_bit_deterministic[re10k_*]) -- even with every counter drained before the
+  // reads (-DBTS_GL_WAIT_ALL), while requesting the rows BEFORE block T + 3 is issued (the shipped order, or -DBTS_GL_FETCH_MID) is
+  // clean over hundreds of runs.  What ds_read_b128 right behind a group of LDS-DMA loads gets wrong is open.
   if constexpr (T + 1 < B::NBLK) gl_fetch<HD, T + 1, (T + 3 < B::NBLK ? 2 : (T + 2 < B::NBLK ? 1 : 0))>(c, r);
 #endif
 }
