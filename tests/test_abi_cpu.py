@@ -51,6 +51,7 @@ int main(void) {
   printf("%zu %zu %zu %zu\n", sizeof(BtsFieldCfg), sizeof(BtsFieldTensors), sizeof(BtsRenderArgs), sizeof(BtsRenderGrads));
   printf("%zu %zu %zu %zu\n", offsetof(BtsFieldCfg, freq_factor), offsetof(BtsFieldTensors, mlp_params), offsetof(BtsRenderArgs, rays),
          offsetof(BtsRenderArgs, trans));
+  printf("%zu %zu %zu\n", offsetof(BtsRenderArgs, invalid_wsum), offsetof(BtsRenderArgs, invalid_any), offsetof(BtsLossArgs, invalid_wsum));
   return 0;
 }'''
     with tempfile.TemporaryDirectory() as d:
@@ -62,7 +63,10 @@ int main(void) {
             _lib.BtsRenderArgs.trans.offset]
     assert [int(x) for x in out[:2]] == [C.sizeof(_lib.BtsLossArgs), _lib.BtsLossArgs.scale_rgb.offset]
     out = out[2:]
-    assert [int(x) for x in out[:4]] == sizes and [int(x) for x in out[4:]] == offs
+    assert [int(x) for x in out[:4]] == sizes and [int(x) for x in out[4:8]] == offs
+    # ABI 2: the loss epilogue's per-ray reductions, appended to both structs
+    assert [int(x) for x in out[8:]] == [_lib.BtsRenderArgs.invalid_wsum.offset, _lib.BtsRenderArgs.invalid_any.offset,
+                                         _lib.BtsLossArgs.invalid_wsum.offset]
 
 
 def test_host_only_entry_points(lib):
@@ -74,6 +78,21 @@ def test_host_only_entry_points(lib):
     assert lib.bts_supported(C.byref(odd)) == 0
     many = native._spec_cfg(native.FieldSpec(C=64, d_hidden=64, n_blocks=0), nv=9)
     assert lib.bts_supported(C.byref(many)) == 0
+
+
+def test_backward_workspace_is_what_the_passes_hand_each_other(lib):
+    """bts_render_bwd_workspace: 20 B per sample for the plain MLP with K <= 64 (g_s + the relu gates as bits, per sample and per
+    channel); g_h rows of 4 * d_hidden B per sample, rays rounded up to groups of 256 per batch element, for the ResnetBlockFC model
+    and for K > 64 (the lane = ray pass)."""
+    def ws(spec, n, rays_per_sample, K, nv=2):
+        cfg = native._spec_cfg(spec, n=n, H=8, W=8, nv=nv)
+        args = _lib.BtsRenderArgs(rays_per_sample=rays_per_sample, K=K, hard_alpha_cap=1, white_bkgd=0)
+        return lib.bts_render_bwd_workspace(C.byref(cfg), C.byref(args))
+    kitti, re10k = native.FieldSpec(C=64, d_hidden=64, n_blocks=0), native.FieldSpec(C=32, d_hidden=32, n_blocks=1)
+    assert ws(kitti, 16, 4096, 64) == 16 * 4096 * (64 * (1 + 2) + 2 * 64) * 4 == 16 * 4096 * 64 * 20        # 84 MB, not 1.07 GB
+    assert ws(kitti, 2, 320, 16) == 2 * 320 * (16 * 3 + 128) * 4
+    assert ws(kitti, 1, 300, 128) == 2 * 4 * 128 * 64 * 64 * 4                                              # K > 64: rows, 512 rays
+    assert ws(re10k, 24, 1024, 48) == 24 * 1024 * 48 * 32 * 4                                                # one ResnetBlockFC: rows
 
 
 def test_errors_are_codes_with_messages_never_exceptions(lib):
