@@ -9,6 +9,7 @@ the CNN and lin_in exactly as they do in the reference."""
 import torch
 import torch.nn.functional as F
 from torch import nn
+from torch.autograd import profiler
 
 from . import native
 from .backbone import make_backbone
@@ -67,7 +68,8 @@ class BTSNet(nn.Module):
         # an encoder that can compose the feature half of lin_in into its last convolution hands the
         # renderer its projected, channels-last map G directly (monodepth2.Monodepth2.forward_projected); `fused_handover: false`
         # keeps the generic route (encoder -> F (NCHW) -> bts_project_features)
-        self.fused_handover = bool(conf.get("fused_handover", True)) and hasattr(self.encoder, "forward_projected")
+        # (whether the CURRENT encoder can do that is looked up at every encode(): callers replace net.encoder after construction)
+        self.fused_handover = bool(conf.get("fused_handover", True))
         self.spec = native.FieldSpec(C=self.encoder.latent_size, d_hidden=self.mlp_coarse.d_hidden,
                                      n_blocks=self.mlp_coarse.n_blocks, num_freqs=self.code_xyz.num_freqs,
                                      freq_factor=self.code_xyz.freq_factor, d_min=float(self.d_min), d_max=float(self.d_max),
@@ -107,7 +109,7 @@ class BTSNet(nn.Module):
             images_encoder = torch.flip(images_encoder, dims=(-1,))
         enc_in = images_encoder.reshape(n * nv_enc, c, h, w)
         self._proj_ms = None
-        if self.fused_handover:
+        if self.fused_handover and hasattr(self.encoder, "forward_projected"):
             # G_s = F_s . w_in[:, :C]^T straight out of the decoder's last convolutions, channels-last (no F in HBM, no projection pass)
             order = native.proj_storage_order(self.spec.d_hidden).to(images.device)
             g_ms = self.encoder.forward_projected(enc_in, self.mlp_coarse.lin_in.weight[:, :c_l][order])
@@ -116,6 +118,10 @@ class BTSNet(nn.Module):
             h_, w_ = g_ms[0].shape[1:3]
             self._proj_ms = [(g if g.shape[1:3] == (h_, w_) else F.interpolate(g.permute(0, 3, 1, 2), (h_, w_)).permute(0, 2, 3, 1)).contiguous()
                              for g in g_ms]
+            # G was composed from lin_in.weight AS IT WAS NOW and under the grad mode of NOW: native_field() refuses to pair it with
+            # other weights (an optimizer step / load_state_dict between encode() and the render) or to render under autograd from a
+            # map that was encoded under no_grad (lin_in and the CNN would silently get no gradient through G)
+            self._proj_version = (self.mlp_coarse.lin_in.weight._version, torch.is_grad_enabled())
             image_latents_ms = None    # the feature map itself is never materialised on this route
         else:
             image_latents_ms = self.encoder(enc_in)
@@ -158,6 +164,13 @@ class BTSNet(nn.Module):
         hit = self._native.get(s)
         if hit is None or hit[1] != version:
             if self._proj_ms is not None:                          # fused hand-over: G came out of the encoder
+                w_version, grad_mode = self._proj_version
+                if w_version != version[0]:
+                    raise native.BtsNativeError("lin_in.weight changed since encode(): the fused hand-over composed the projected feature map "
+                                                "from the old weights -- call encode() again (or build the net with fused_handover=False)")
+                if version[1] and not grad_mode and any(p.requires_grad for p in self.encoder.parameters()):
+                    raise native.BtsNativeError("encode() ran under torch.no_grad() but the render runs under autograd: the projected feature "
+                                                "map carries no graph, lin_in / the encoder would get no gradient -- encode() under grad mode")
                 proj = self._proj_ms[s].float()
             else:
                 f = self.grid_f_features[s]                        # (n, 1, C, H, W) -> (n, C, H, W): a pure view (selecting [:, 0] would
@@ -173,7 +186,7 @@ class BTSNet(nn.Module):
         Forward-only (the reference's callers of this entry point -- occupancy profiles, LiDAR / 3D-bbox evaluators -- run it
         under no_grad); training goes through the renderer's composite, which is differentiable."""
         ft = self.native_field()
-        with torch.no_grad():
+        with torch.no_grad(), profiler.record_function("model_inference"):   # models_bts.py:275
             rgb, invalid, sigma = native.field_query(ft, self.mlp_coarse.packed().detach(), xyz.detach().float().contiguous(),
                                                      only_density=only_density)
         nv = self.grid_c_imgs.shape[1]

@@ -9,6 +9,7 @@ top.  Same constructor keys, same call signature, same ``(loss, loss_dict)`` res
 import math
 
 import torch
+from torch.autograd import profiler
 
 from . import native
 
@@ -97,9 +98,17 @@ class ReconstructionLoss:
         return sums[0] / B, sums[1] / B, sums[2] / B
 
     def __call__(self, data):
+        with profiler.record_function("loss_computation"):       # loss.py:84
+            return self._call(data)
+
+    def _call(self, data):
         n_scales = len(data["coarse"])
         coarse_0, fine_0 = data["coarse"][0], data["fine"][0]
         dev = coarse_0["rgb"].device
+        if "alphas" not in coarse_0 and (self.lambda_alpha_reg > 0 or self.lambda_surfaceness_reg > 0 or self.lambda_entropy > 0):
+            raise KeyError("the alpha / surfaceness / entropy regularisers read the per-sample `alphas`, which this render dict does not "
+                           "carry: call the renderer with want_alphas=True and without lean_training_outputs (NeRFRenderer drops the "
+                           "per-sample tensors in that mode)")
         zero = torch.zeros((), device=dev)
         loss = zero
         m = dict(coarse=zero, fine=zero, depth_reg=zero, alpha_reg=zero, surf=zero, eas=zero, dsmooth=zero, inv=zero)

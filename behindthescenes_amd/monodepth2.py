@@ -10,6 +10,8 @@ G is itself a 3x3 convolution of the decoder's last activation with the COMPOSED
 ``forward_projected`` runs the network in ``torch.channels_last`` and lets that last convolution write G directly -- no F in HBM, no
 projection pass, no projection backward (autograd differentiates the composition, a 64 x 64 x 576 GEMM, for lin_in and the conv).
 """
+import warnings
+
 import torch
 import torch.nn.functional as F
 from torch import nn
@@ -105,9 +107,13 @@ class ResnetEncoder(nn.Module):
             raise NotImplementedError("multi-image input is not used by BehindTheScenes")
         block, layers = _RESNETS[num_layers]
         self.encoder = ResNet(block, layers)
+        # the classifier head is never evaluated (it exists so that torchvision / reference checkpoints load strictly): frozen, or
+        # DistributedDataParallel would wait for its gradient in the second iteration ("Expected to have finished reduction ...")
+        self.encoder.fc.requires_grad_(False)
         self.num_ch_enc = [64, 64, 128, 256, 512] if num_layers <= 34 else [64, 256, 512, 1024, 2048]
         # `pretrained`: the reference downloads ImageNet weights here (monodepth2.py:258 passes True unconditionally); there is no
-        # network in this environment -- load them, or a BTS checkpoint, through load_state_dict (same keys).
+        # network in this environment -- Monodepth2(pretrained_path=...) loads a torchvision ResNet state dict, cp_location a BTS
+        # checkpoint (same keys); without either the constructor warns that the run starts from a random initialisation.
 
     def forward(self, input_image):
         e = self.encoder
@@ -186,9 +192,18 @@ class Decoder(nn.Module):
 
 
 class Monodepth2(nn.Module):
-    def __init__(self, resnet_layers=18, cp_location=None, freeze=False, num_ch_dec=None, d_out=128, scales=range(4), pretrained=True):
+    def __init__(self, resnet_layers=18, cp_location=None, freeze=False, num_ch_dec=None, d_out=128, scales=range(4), pretrained=True,
+                 pretrained_path=None):
         super().__init__()
         self.encoder = ResnetEncoder(resnet_layers, pretrained, 1)
+        if pretrained_path is not None:
+            # torchvision's resnet state dict (what the reference downloads, monodepth2.py:258 -> models.resnetXX(pretrained=True))
+            sd = torch.load(pretrained_path, map_location="cpu")
+            self.encoder.encoder.load_state_dict(sd.get("state_dict", sd) if isinstance(sd, dict) else sd)
+        elif pretrained and cp_location is None:
+            warnings.warn("Monodepth2(pretrained=True): the reference starts from ImageNet ResNet weights (monodepth2.py:258); none were given "
+                          "(`pretrained_path` / `cp_location`), so this encoder starts from a random initialisation and a from-scratch run "
+                          "will not reproduce the reference's quality", stacklevel=2)
         self.num_ch_enc = self.encoder.num_ch_enc
         self.d_out, self.scales = d_out, list(scales)
         self.decoder = Decoder(num_ch_enc=self.num_ch_enc, d_out=d_out, num_ch_dec=num_ch_dec, scales=self.scales)
@@ -226,4 +241,5 @@ class Monodepth2(nn.Module):
     @classmethod
     def from_conf(cls, conf, **kw):
         return cls(cp_location=conf.get("cp_location", None), freeze=conf.get("freeze", False), num_ch_dec=conf.get("num_ch_dec", None),
-                   d_out=conf.get("d_out", 128), resnet_layers=conf.get("resnet_layers", 18), pretrained=conf.get("pretrained", True))
+                   d_out=conf.get("d_out", 128), resnet_layers=conf.get("resnet_layers", 18), pretrained=conf.get("pretrained", True),
+                   pretrained_path=conf.get("pretrained_path", None))

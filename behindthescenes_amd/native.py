@@ -367,17 +367,27 @@ def render_bwd(ft: FieldTensors, mlp_params, rays, z_samp, sigma_raw, trans, *, 
 
 
 _WS = {}
+WORKSPACE_CACHE_LIMIT = 256 << 20   # bytes: larger scratch is allocated per call and goes back to torch's caching allocator
 
 
 def _workspace(dev, n_bytes):
-    """Scratch of the backward (g_h rows between its two passes, ~1 GiB at bs 16 x 4096 rays x 64 samples): one buffer per device
-    and stream, grown on demand and reused -- its contents need no initialisation and every use is ordered on the stream."""
+    """Scratch of the backward (what its passes hand each other: 20 B per sample on the bit path, 4 + 4 d_hidden B per sample on the row
+    path).  Buffers up to WORKSPACE_CACHE_LIMIT are kept per device and stream, grown on demand and reused -- the contents need no
+    initialisation and every use is ordered on the stream; anything larger is a plain torch allocation of this call, so that an
+    occasional huge backward does not pin its scratch for the life of the process (release_workspace() drops the kept ones too)."""
+    if n_bytes > WORKSPACE_CACHE_LIMIT:
+        return torch.empty(n_bytes // 4 + 1, device=dev, dtype=torch.float32)
     key = (dev, torch.cuda.current_stream(dev).cuda_stream)
     buf = _WS.get(key)
     if buf is None or buf.numel() * 4 < n_bytes + 4:
         buf = torch.empty(n_bytes // 4 + 1, device=dev, dtype=torch.float32)
         _WS[key] = buf
     return buf
+
+
+def release_workspace():
+    """Drops the cached backward scratch (e.g. when a process switches from training to evaluation)."""
+    _WS.clear()
 
 
 def field_query(ft: FieldTensors, mlp_params: torch.Tensor, xyz: torch.Tensor, only_density: bool = False):

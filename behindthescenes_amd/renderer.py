@@ -3,6 +3,7 @@
 kernels per chunk) -- is ONE fused HIP kernel here (plus its backward); there is no chunking and no torch fallback: a model
 that is not a ``behindthescenes_amd.BTSNet`` is rejected."""
 import torch
+from torch.autograd import profiler
 
 from . import native
 from .field import BTSNet
@@ -106,6 +107,10 @@ class NeRFRenderer(torch.nn.Module):
         """rays (B, 8), z_samp (B, K) -> (weights, rgb, depth, alphas, invalid, z_samp, rgb_samps) like the reference.
         Entries that were not requested come back as ``None`` (the reference always materialises all of them).  With
         ``want_invalid_sums`` two more entries follow: (invalid_wsum, invalid_any), (B, nv) each."""
+        with profiler.record_function("renderer_composite"):     # the reference's trace range (nerf.py:222); one fused kernel here
+            return self._composite(model, rays, z_samp, coarse, sb, want_weights, want_alphas, want_rgb_samps, want_invalid, want_invalid_sums)
+
+    def _composite(self, model, rays, z_samp, coarse, sb, want_weights, want_alphas, want_rgb_samps, want_invalid, want_invalid_sums):
         if not isinstance(model, BTSNet):
             raise native.BtsNativeError("composite() needs a behindthescenes_amd.BTSNet (the fused HIP kernel IS the field query)")
         if not coarse and model.mlp_fine is not None:
@@ -130,6 +135,10 @@ class NeRFRenderer(torch.nn.Module):
     def forward(self, model, rays, want_weights=False, want_alphas=False, want_z_samps=False, want_rgb_samps=False,
                 sample_from_dist=None):
         """rays (SB, B', 8) -> {"coarse": {...}[, "fine": {...}]} (nerf.py:315-401)."""
+        with profiler.record_function("renderer_forward"):       # nerf.py:328
+            return self._forward(model, rays, want_weights, want_alphas, want_z_samps, want_rgb_samps, sample_from_dist)
+
+    def _forward(self, model, rays, want_weights, want_alphas, want_z_samps, want_rgb_samps, sample_from_dist):
         if self.sched is not None and self.last_sched.item() > 0:
             self.n_coarse = self.sched[1][self.last_sched.item() - 1]
             self.n_fine = self.sched[2][self.last_sched.item() - 1]

@@ -197,3 +197,24 @@ def test_loss_module_keeps_the_reference_interface_and_is_loud_outside_its_envel
     with pytest.raises(bts.BtsNativeError):   # CPU tensors: no fallback
         crit(dict(coarse=[dict(rgb=torch.zeros(1, 1, 8, 8, 1, 3), depth=torch.ones(1, 1, 8, 8), weights=torch.zeros(1, 1, 8, 8, 4),
                                invalid=torch.zeros(1, 1, 8, 8, 4, 1))], fine=[{}], rgb_gt=torch.zeros(1, 1, 8, 8, 3)))
+
+
+def test_lean_render_dict_with_alpha_regularisers_is_rejected_with_a_clear_message():
+    """lean_training_outputs drops alphas / weights from the render dict; the alpha-based regularisers then used to fail
+    with a bare KeyError('alphas')."""
+    crit = bts.ReconstructionLoss({"criterion": "l1+ssim", "invalid_policy": "weight_guided", "lambda_alpha_reg": 0.1})
+    lean = dict(rgb=torch.zeros(1, 1, 8, 8, 1, 3), depth=torch.ones(1, 1, 8, 8), invalid_wsum=torch.zeros(1, 1, 8, 8, 1),
+                invalid_any=torch.zeros(1, 1, 8, 8, 1))
+    with pytest.raises(KeyError, match="want_alphas"):
+        crit(dict(coarse=[lean], fine=[{}], rgb_gt=torch.zeros(1, 1, 8, 8, 3)))
+
+
+def test_drop_in_emits_the_reference_profiler_ranges():
+    """a reference user's torch.profiler trace shows renderer_forward / renderer_composite / model_inference /
+    loss_computation (nerf.py:222, 328, models_bts.py:275, loss.py:84); the drop-in wraps the same entry points in the same ranges."""
+    import inspect
+    from behindthescenes_amd import field, loss, renderer
+    for mod, names in ((renderer, ("renderer_forward", "renderer_composite")), (field, ("model_inference",)), (loss, ("loss_computation",))):
+        src = inspect.getsource(mod)
+        for nme in names:
+            assert f'record_function("{nme}")' in src, nme

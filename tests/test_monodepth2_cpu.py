@@ -38,7 +38,7 @@ def test_btsnet_builds_from_the_shipped_kitti360_config_with_reference_state_dic
 
 def test_forward_shapes_and_fused_handover_equals_projection_of_the_feature_map():
     torch.manual_seed(0)
-    enc = Monodepth2(resnet_layers=18, num_ch_dec=[32, 32, 64, 128, 256], d_out=64).eval()
+    enc = Monodepth2(resnet_layers=18, num_ch_dec=[32, 32, 64, 128, 256], d_out=64, pretrained=False).eval()
     for m in enc.modules():   # make the batch-norm statistics non-trivial
         if isinstance(m, torch.nn.BatchNorm2d):
             m.running_mean.normal_(0, 0.1), m.running_var.uniform_(0.5, 1.5)
@@ -58,6 +58,30 @@ def test_forward_shapes_and_fused_handover_equals_projection_of_the_feature_map(
     enc.forward_projected(x, w2)[0].square().mean().backward()
     head = enc.decoder.decoder[enc.decoder.decoder_keys[("dispconv", 0)]].conv
     assert w2.grad is not None and head.weight.grad is not None and float(w2.grad.abs().sum()) > 0 and float(head.weight.grad.abs().sum()) > 0
+
+
+def test_unused_classifier_head_is_frozen_and_missing_pretrained_weights_are_announced(tmp_path):
+    """(a) ResNet.fc exists only for strict checkpoint loading and is never evaluated -- a trainable unused parameter makes
+    DistributedDataParallel's reducer fail in the second iteration; (b) the reference starts from ImageNet weights
+    (monodepth2.py:258): starting from a random initialisation instead must not be silent; `pretrained_path` loads them."""
+    with pytest.warns(UserWarning, match="random initialisation"):
+        enc = Monodepth2(resnet_layers=18, num_ch_dec=[32, 32, 64, 128, 256], d_out=64)
+    assert not any(p.requires_grad for p in enc.encoder.encoder.fc.parameters())
+    assert "encoder.encoder.fc.weight" in enc.state_dict()
+    # every trainable parameter receives a gradient from the four-scale forward (what DDP's reducer relies on)
+    x = torch.rand(1, 3, 64, 96) * 2 - 1
+    sum(f.square().mean() for f in enc(x)).backward()
+    missing = [k for k, p in enc.named_parameters() if p.requires_grad and p.grad is None]
+    assert missing == [], missing
+    # a torchvision-style state dict through pretrained_path: no warning, weights taken over
+    import warnings
+    path = tmp_path / "resnet18.pth"
+    sd = {k: torch.full_like(v, 0.5) if v.dtype.is_floating_point else v for k, v in enc.encoder.encoder.state_dict().items()}
+    torch.save(sd, path)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        enc2 = Monodepth2(resnet_layers=18, num_ch_dec=[32, 32, 64, 128, 256], d_out=64, pretrained_path=str(path))
+    assert float(enc2.encoder.encoder.conv1.weight.min()) == 0.5
 
 
 @pytest.mark.needs_reference
