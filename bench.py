@@ -40,9 +40,16 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", choices=("eval", "train"), default="eval",
-                    help="eval (default): BASELINE configs[1], the headline line.  train: configs[2] (exp_kitti_360.yaml shapes), the "
-                         "renderer's share of a training step, forward + backward")
+    ap.add_argument("--workload", choices=("eval", "train", "kitti_raw", "re10k"), default="eval",
+                    help="eval (default): BASELINE configs[1], the headline line.  train: configs[2] (exp_kitti_360.yaml shapes), kitti_raw: "
+                         "configs[3] (exp_kitti_raw.yaml, bs 8 / GPU), re10k: configs[4] (exp_re10k.yaml, 256x384, four scales per step): the "
+                         "renderer's share of a training step, forward + loss + backward")
+    ap.add_argument("--samples", type=int, default=0, help="re10k: samples per ray (default 48 = the yaml; BASELINE.json quotes 128)")
+    ap.add_argument("--encoder", choices=("feature_map", "monodepth2"), default="feature_map",
+                    help="training workloads: feature_map (default) = learnable stand-in for the CNN output (the renderer's share of the step); "
+                         "monodepth2 = the shipped Monodepth2 (ResNet of the yaml, random weights): whole step incl. the CNN, fused hand-over "
+                         "(SURVEY 8f.4) unless --no-fused-handover")
+    ap.add_argument("--no-fused-handover", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--full-outputs", action="store_true",
                     help="train workload: also materialise weights / alphas / invalid / rgb_samps per sample as the reference trainer's dict "
@@ -129,27 +136,99 @@ def cpu_child(args):
     print(cpu_baseline(scene, net, args.cpu_rows, threads=args.cpu_child)["value"])
 
 
+TRAIN_WORKLOADS = {
+    # BASELINE configs[2]: configs/exp_kitti_360.yaml (bs 16, kitti360-mono: 4 loss + 4 render frames, 4096 patch rays, 64 samples)
+    "train": dict(yaml="exp_kitti_360.yaml", n=16, V=8, H=192, W=640, C=64, HD=64, NB=0, K=64, ids_loss=[0, 1, 2, 3], ids_render=[4, 5, 6, 7],
+                  rays=4096, z=(3.0, 80.0), intr="K_KITTI360", baseline=0.6, hard_cap=True, code_mode="z", scales=1, resnet=50,
+                  num_ch_dec=[32, 32, 64, 128, 256]),
+    # BASELINE configs[3]: configs/exp_kitti_raw.yaml at 8 samples per GPU (yaml: 16 over the node; BASELINE: bs 8 / GPU), stereo pair x 2
+    # time steps = 2 loss + 2 render frames, 2048 patch rays, 64 samples
+    "kitti_raw": dict(yaml="exp_kitti_raw.yaml", n=8, V=4, H=192, W=640, C=64, HD=64, NB=0, K=64, ids_loss=[0, 1], ids_render=[2, 3],
+                      rays=2048, z=(3.0, 80.0), intr="K_KITTIRAW", baseline=0.54, hard_cap=True, code_mode="z", scales=1, resnet=50,
+                      num_ch_dec=[32, 32, 64, 128, 256]),
+    # BASELINE configs[4]: configs/exp_re10k.yaml (bs 24, 3 frames: 1 loss + 2 render, 256x384, C = 32, one ResnetBlockFC of width 32,
+    # distance code, z in [1, 100], no alpha cap, 1024 patch rays, K = 48; prediction_mode unset -> "multiscale": FOUR renders per step,
+    # trainer.py:220-242)
+    "re10k": dict(yaml="exp_re10k.yaml", n=24, V=3, H=256, W=384, C=32, HD=32, NB=1, K=48, ids_loss=[0], ids_render=[1, 2], rays=1024,
+                  z=(1.0, 100.0), intr="K_RE10K", baseline=0.2, hard_cap=False, code_mode="distance", scales=4, resnet=18,
+                  num_ch_dec=[32, 32, 64, 128, 256]),
+}
+
+
+def train_cpu_baseline(cfg, net, scene, rank):
+    """cpu_baseline of a training workload: the oracle (the reference's torch ops on the CPU) forward + backward of the render for ONE
+    batch sample (bounded: cfg.rays rays x K samples, scale 0), best of 2 after a warm-up, min(16, nproc) threads (the eval sweep's
+    best count).  A port, not the target: it says what the CPU path costs per ray, nothing about kernel quality."""
+    from oracle import bts_oracle as O
+    threads = min(16, os.cpu_count() or 8)
+    prev = torch.get_num_threads()
+    torch.set_num_threads(threads)
+    try:
+        ocfg = O.FieldConfig(d_min=cfg["z"][0], d_max=cfg["z"][1], code_mode=cfg["code_mode"])
+        m = net.mlp_coarse
+        one = {k: v[:1] for k, v in scene.items()}
+        g = torch.Generator().manual_seed(1)
+        rays = O.image_rays(one["poses"][:, cfg["ids_loss"]], one["projs"][:, cfg["ids_loss"]], cfg["H"], cfg["W"], *cfg["z"])
+        rays = rays[:, torch.randperm(rays.shape[1], generator=g)[:cfg["rays"]]].contiguous()
+        u = torch.rand(cfg["rays"], cfg["K"], generator=g)
+        c_rgb = torch.randn(cfg["rays"], 3 * len(cfg["ids_render"]), generator=g)
+        best = float("inf")
+        for i in range(3):
+            t0 = time.perf_counter()
+            params = [p.detach().cpu().clone().requires_grad_(True) for p in
+                      [m.lin_in.weight, m.lin_in.bias] + sum([[b.fc_0.weight, b.fc_0.bias, b.fc_1.weight, b.fc_1.bias] for b in m.blocks], []) +
+                      [m.lin_out.weight, m.lin_out.bias]]
+            blocks = [tuple(params[2 + 4 * j: 6 + 4 * j]) for j in range(len(m.blocks))]
+            mlp = O.MlpParams(params[0], params[1], blocks, params[-2], params[-1])
+            feat = one["feat"].clone().requires_grad_(True)
+            st = O.make_state(dict(one, feat=feat), cfg["ids_render"], ocfg)
+            z = O.sample_coarse(rays.reshape(-1, 8), cfg["K"], True, u)
+            w, rgb, depth, *_ = O.composite(rays.reshape(-1, 8), z, 1, st, mlp, ocfg, hard_alpha_cap=cfg["hard_cap"])
+            ((rgb * c_rgb).sum() + 0.05 * depth.sum()).backward()
+            if i > 0:
+                best = min(best, time.perf_counter() - t0)
+        return dict(value=cfg["rays"] / best, unit="rays/s", cores=threads, kind="port", host_cpus=os.cpu_count(),
+                    sample=f"1 batch sample: {cfg['rays']} rays x {cfg['K']} samples, nv = {len(cfg['ids_render'])}, oracle render forward + "
+                           "autograd backward (MLP + feature map), no loss term, one scale, best of 2",
+                    note="oracle = CPU restatement with the reference's own torch ops")
+    finally:
+        torch.set_num_threads(prev)
+
+
 def train_workload(args, world, rank, dev):
-    """BASELINE configs[2] (configs/exp_kitti_360.yaml): bs 16 per GPU, 8 frames per sample (4 loss + 4 render views), 4096 patch rays
-    (64 patches of 8x8) per sample, 64 samples per ray.  One step = the renderer's share of `trainer.py:208-259` + backward: encode
-    hand-over (no CNN), PatchRaySampler.sample, G = project(F), render with saved activations and every output the trainer asks for
-    (weights, alphas, rgb_samps), reconstruct, the photometric loss (l1+ssim, weight-guided invalid mask, edge-aware smoothness: one
-    HIP pass incl. its gradient), backward through bts_render_bwd and bts_project_features_bwd (MLP and feature-map gradients); under
-    N > 1 the task is wrapped in DistributedDataParallel (parallel.wrap_ddp) and the gradient all-reduce is DDP's own RCCL bucket."""
+    """The training configs of BASELINE.json (TRAIN_WORKLOADS).  One step = the renderer's share of `trainer.py:208-259` + backward:
+    encode hand-over (no CNN unless --encoder monodepth2), PatchRaySampler.sample, G = project(F), render with saved activations and
+    every output the trainer asks for (weights, alphas, rgb_samps) once per scale (multiscale: net.set_scale(s), trainer.py:220-242),
+    reconstruct, the photometric loss (l1+ssim, weight-guided invalid mask, edge-aware smoothness: one HIP pass per scale incl. its
+    gradient), backward through bts_render_bwd and bts_project_features_bwd (MLP and feature-map gradients); the task is wrapped through
+    parallel.wrap_ddp (DistributedDataParallel + RCCL all-reduce of the gradients when N > 1)."""
     import behindthescenes_amd as bts
     from behindthescenes_amd import native, parallel, synthetic as S
-    n, Vt, Kt, NV = 16, 8, 64, 4
-    scene = S.synthetic_scene(n, Vt, H, W, C, seed=2000 + rank, intrinsics=S.K_KITTI360, baseline=0.6, smooth=True)
-    net = bts.BTSNet(S.field_conf(C, HD, 0, H, W))
+    cfg = dict(TRAIN_WORKLOADS[args.workload])
+    if args.samples:
+        cfg["K"] = args.samples
+    n, Vt, Kt, Hh, Ww, Cc, Hd, Nb = cfg["n"], cfg["V"], cfg["K"], cfg["H"], cfg["W"], cfg["C"], cfg["HD"], cfg["NB"]
+    n_scales = cfg["scales"]
+    scene = S.synthetic_scene(n, Vt, Hh, Ww, Cc, seed=2000 + rank, intrinsics=getattr(S, cfg["intr"]), baseline=cfg["baseline"], smooth=True)
+    conf = S.field_conf(Cc, Hd, Nb, Hh, Ww, z_near=cfg["z"][0], z_far=cfg["z"][1], code_mode=cfg["code_mode"])
+    if args.encoder == "monodepth2":
+        conf["encoder"] = dict(type="monodepth2", freeze=False, pretrained=False, resnet_layers=cfg["resnet"], num_ch_dec=cfg["num_ch_dec"], d_out=Cc)
+        conf["fused_handover"] = not args.no_fused_handover
+        torch.manual_seed(99)
+        net = bts.BTSNet(conf)
+        if n_scales == 1:
+            net.encoder.scales = [0]          # prediction_mode default renders scale 0 only; the other output convolutions still run
+    else:
+        net = bts.BTSNet(conf)
+        net.encoder = bts.FeatureMapEncoder((Hh, Ww), Cc, num_views=n, n_scales=n_scales, pyramid=n_scales > 1)
+        S.set_feature_map(net, scene["feat"])
     S.init_mlp_(net.mlp_coarse, seed=7)
-    net.encoder = bts.FeatureMapEncoder((H, W), C, num_views=n)
-    S.set_feature_map(net, scene["feat"])
     net = net.to(dev).train()
-    renderer = bts.NeRFRenderer.from_conf(dict(n_coarse=Kt, lindisp=True, hard_alpha_cap=True,
+    renderer = bts.NeRFRenderer.from_conf(dict(n_coarse=Kt, lindisp=True, hard_alpha_cap=cfg["hard_cap"],
                                                lean_training_outputs=not args.full_outputs)).to(dev).train()
-    sampler = bts.PatchRaySampler(ray_batch_size=4096, z_near=3.0, z_far=80.0, patch_size=8)
+    sampler = bts.PatchRaySampler(ray_batch_size=cfg["rays"], z_near=cfg["z"][0], z_far=cfg["z"][1], patch_size=8)
     images, projs, poses = scene["images"].to(dev), scene["projs"].to(dev), scene["poses"].to(dev)
-    ids_loss, ids_render = [0, 1, 2, 3], [4, 5, 6, 7]
+    ids_loss, ids_render = cfg["ids_loss"], cfg["ids_render"]
     kern = {"fwd": [], "bwd": []}
     orig_fwd, orig_bwd = native.render_fwd, native.render_bwd
 
@@ -165,6 +244,7 @@ def train_workload(args, world, rank, dev):
 
     wrapped = renderer.bind_parallel(net).train()
     crit = bts.ReconstructionLoss({"criterion": "l1+ssim", "invalid_policy": "weight_guided", "lambda_edge_aware_smoothness": 0.001})
+    lo, hi = ids_loss[0], ids_loss[-1] + 1
 
     class Task(torch.nn.Module):
         """trainer.py:208-259 after the CNN, as ONE module so that DistributedDataParallel wraps it exactly as idist.auto_model wraps
@@ -178,18 +258,25 @@ def train_workload(args, world, rank, dev):
         def forward(self, images, projs, poses):
             images_ip = images * .5 + .5
             net.encode(images, projs, poses, ids_encoder=[0], ids_render=ids_render, images_alt=images_ip)
-            all_rays, all_rgb_gt = sampler.sample(images_ip[:, :4], poses[:, :4], projs[:, :4])       # ids_loss = first four frames
-            rd = self.wrapped(all_rays, want_weights=True, want_alphas=True, want_rgb_samps=True)
-            rd["fine"] = dict(rd["coarse"])
-            rd["rgb_gt"], rd["rays"] = all_rgb_gt, all_rays
-            rd = sampler.reconstruct(rd)
-            return crit(dict(coarse=[rd["coarse"]], fine=[rd["fine"]], rgb_gt=rd["rgb_gt"]))[0]
+            all_rays, all_rgb_gt = sampler.sample(images_ip[:, lo:hi], poses[:, lo:hi], projs[:, lo:hi])       # ids_loss are consecutive frames
+            data = dict(coarse=[], fine=[])
+            for scale in (net.encoder.scales if n_scales > 1 else [0]):     # trainer.py:220-242 ("multiscale") / :243-259
+                net.set_scale(scale)
+                rd = self.wrapped(all_rays, want_weights=True, want_alphas=True, want_rgb_samps=True)
+                rd["fine"] = dict(rd["coarse"])
+                rd["rgb_gt"], rd["rays"] = all_rgb_gt, all_rays
+                rd = sampler.reconstruct(rd)
+                data["coarse"].append(rd["coarse"]), data["fine"].append(rd["fine"])
+                data["rgb_gt"] = rd["rgb_gt"]
+            net.set_scale(0)
+            return crit(data)[0]
 
     task = Task()
-    # the stand-in feature maps are per-sample DATA (what the CNN would output), not shared weights: their gradient stays on the rank
-    # (in a real run it flows on into the local CNN backward); the all-reduce carries the MLP here and MLP + CNN in a real run
-    torch.nn.parallel.DistributedDataParallel._set_params_and_buffers_to_ignore_for_model(
-        task, [k for k, _ in task.named_parameters() if ".encoder.feats." in k])
+    if args.encoder == "feature_map":
+        # the stand-in feature maps are per-sample DATA (what the CNN would output), not shared weights: their gradient stays on the rank
+        # (in a real run it flows on into the local CNN backward); the all-reduce carries the MLP here and MLP + CNN in a real run
+        torch.nn.parallel.DistributedDataParallel._set_params_and_buffers_to_ignore_for_model(
+            task, [k for k, _ in task.named_parameters() if ".encoder.feats." in k])
     model = parallel.wrap_ddp(task, dev)
 
     def step():   # base_trainer.py:287-297
@@ -200,59 +287,70 @@ def train_workload(args, world, rank, dev):
         step()
     native.render_fwd, native.render_bwd = timed(orig_fwd, "fwd"), timed(orig_bwd, "bwd")
     torch.cuda.synchronize()
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.barrier()
         torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.barrier()
         torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     native.render_fwd, native.render_bwd = orig_fwd, orig_bwd
-    if world > 1:
+    if torch.distributed.is_initialized():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = t.item()
-    n_rays = n * 4096
-    ms = {k: sum(a.elapsed_time(b) for a, b in v) / max(len(v), 1) for k, v in kern.items()}
+    n_rays = n * cfg["rays"]
+    # per STEP: the four scales of re10k are four launches each
+    ms = {k: sum(a.elapsed_time(b) for a, b in v) / max(args.steps, 1) for k, v in kern.items()}
     if rank == 0:
-        flop = 3 * n_rays * Kt * FLOP_PER_POINT          # training = 3x forward (dX + dW)
+        flop_pt = 2 * ((Cc + 39) * Hd + Nb * 2 * Hd * Hd + Hd)     # 13 312 (KITTI MLP) / 8 704 (RE10K MLP) per field query
+        flop = 3 * n_rays * Kt * flop_pt * n_scales                # training = 3x forward (dX + dW); every scale renders all rays
         achieved = flop / ((ms["fwd"] + ms["bwd"]) * 1e-3) / 1e12
-        # HBM bytes and issue counters of every training kernel from the committed rocprofv3 PMC passes (tools/profile.sh <tag> train)
+        # HBM bytes and issue counters of every training kernel from the committed rocprofv3 PMC passes (tools/profile.sh <tag> <workload>)
         traffic, counters = None, {}
         pdir = os.path.join(ROOT, "profiles")
-        prof = sorted(d for d in os.listdir(pdir) if os.path.exists(os.path.join(pdir, d, "traffic_train.json"))) if os.path.isdir(pdir) else []
+        tname = "traffic_train.json" if args.workload == "train" else f"traffic_{args.workload}.json"
+        prof = sorted(d for d in os.listdir(pdir) if os.path.exists(os.path.join(pdir, d, tname))) if os.path.isdir(pdir) else []
         if prof:
-            tj = json.load(open(os.path.join(pdir, prof[-1], "traffic_train.json")))
-            render = [k for k in ("render_kernel_p", "rows_kernel", "scatter_kernel", "dwpe_kernel") if k in tj and "fetch_bytes" in tj[k]]
+            tj = json.load(open(os.path.join(pdir, prof[-1], tname)))
+            render = [k for k in ("render_kernel_p", "rows_kernel", "scatter_kernel", "dwpe_kernel", "rowsb_kernel", "dwpe_rows_kernel") if k in tj and "fetch_bytes" in tj[k]]
             traffic = sum(tj[k]["fetch_bytes"] + tj[k]["write_bytes"] for k in render) if render else None
             counters = {k: {f: v[f] for f in ("kernel_ms_rocprof", "fetch_bytes", "write_bytes", "valu_busy", "mfma_busy", "wait_frac", "l2_hit") if f in v}
                         for k, v in tj.items()}
-            counters["source"] = (f"profiles/{prof[-1]}/traffic_train.json: rocprofv3 --pmc passes of tools/train_probe.py (same shapes); `traffic` = "
-                                  "fetch + write bytes of " + ", ".join(render) + " per step; FETCH_SIZE doubled per MI355X_MICROARCH.md")
-        print(json.dumps({
-            "metric": "training-step rays/sec after the CNN: render forward + loss + backward (KITTI-360 shapes)", "value": world * n_rays * args.steps / elapsed,
+            counters["source"] = (f"profiles/{prof[-1]}/{tname}: rocprofv3 --pmc passes of tools/train_probe.py (same shapes); `traffic` = "
+                                  "fetch + write bytes of " + ", ".join(render) + " per launch; FETCH_SIZE doubled per MI355X_MICROARCH.md")
+        what = (f"{cfg['yaml']} shapes: bs={n}/GPU, {Vt} frames ({len(ids_loss)} loss + {len(ids_render)} render views), {Hh}x{Ww}, {cfg['rays']} patch "
+                f"rays (8x8) per sample, {Kt} samples/ray, C={Cc}, d_hidden={Hd}, {Nb} ResnetBlockFC, code {cfg['code_mode']}, "
+                + (f"{n_scales} renders per step (multiscale, trainer.py:220-242), " if n_scales > 1 else "")
+                + ("everything after the CNN (feature-map encoder stand-in): " if args.encoder == "feature_map" else
+                   f"whole step incl. the shipped Monodepth2 (ResNet-{cfg['resnet']}, random weights), "
+                   + ("fused hand-over (the decoder's last convolution writes G, SURVEY 8f.4): " if not args.no_fused_handover else "generic hand-over (F -> bts_project_features): "))
+                + "sample, render, photometric loss, backward; "
+                + ("every per-sample output of the reference trainer's dict materialised (--full-outputs)" if args.full_outputs else
+                   "lean_training_outputs: the loss' invalid-ray mask reads per-ray reductions from the render epilogue (SURVEY 8f.1)"))
+        out = {
+            "metric": f"training-step rays/sec ({cfg['yaml']} shapes): render forward + loss + backward" + (" + CNN" if args.encoder != "feature_map" else ""),
+            "value": world * n_rays * args.steps / elapsed,
             "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
-            "config": {"workload": "exp_kitti_360.yaml shapes: bs=16/GPU, 8 frames (4 loss + 4 render views), 4096 patch rays (8x8) per sample, "
-                                   "64 samples/ray, everything after the CNN (feature-map encoder stand-in): sample, render, photometric loss, backward; "
-                                   + ("every per-sample output of the reference trainer's dict materialised (--full-outputs)" if args.full_outputs else
-                                      "lean_training_outputs: the trainer's render call as is, but weights / alphas / invalid / rgb_samps stay in the "
-                                      "kernel -- the loss' invalid-ray mask reads per-ray reductions from the render epilogue (SURVEY 8f.1)"),
-                       "rays_per_step_per_gpu": n_rays, "samples_per_ray": Kt, "parallelism": f"batch x{world}"},
+            "config": {"workload": what, "rays_per_step_per_gpu": n_rays, "samples_per_ray": Kt, "renders_per_step": n_scales,
+                       "parallelism": f"batch x{world}", "peak_hbm_bytes": torch.cuda.max_memory_allocated()},
             "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_MATRIX_TFLOPS, "traffic": traffic,
-                         "kernel": "bts_render_fwd + bts_render_bwd (render_kernel_p; rows_kernel, scatter_kernel, dwpe_kernel)",
-                         "kernel_ms": ms["fwd"] + ms["bwd"], "fwd_ms": ms["fwd"], "bwd_ms": ms["bwd"], "algorithmic_flop_per_launch": flop,
+                         "kernel": "bts_render_fwd + bts_render_bwd, all launches of a step",
+                         "kernel_ms": ms["fwd"] + ms["bwd"], "fwd_ms": ms["fwd"], "bwd_ms": ms["bwd"], "algorithmic_flop_per_step": flop,
                          "counters": counters,
-                         "note": "algorithmic 3 x 13 312 FLOP / sample against the fp32 vector = fp32-input-MFMA peak.  The backward is three "
-                                 "passes (DESIGN.md section 3): the forward's pipeline again (VALU issue + latency at 2 waves / SIMD), the dG "
-                                 "scatter (LDS read-modify-write rounds + L2 float atomics) and the dW_pe GEMM on the bf16 matrix pipe; bwd_ms "
-                                 "includes the zero fill of dG (503 MB)"},
-        }))
+                         "note": f"algorithmic 3 x {flop_pt} FLOP / sample (SURVEY 8d) against the fp32 vector = fp32-input-MFMA peak; bwd_ms includes "
+                                 "the zero fill of dG.  Backward passes: DESIGN.md section 3"},
+        }
+        if world == 1 and not args.no_cpu_baseline and args.encoder == "feature_map":
+            out["cpu_baseline"] = train_cpu_baseline(cfg, net, scene, rank)
+        print(json.dumps(out))
 
 
 def main():
@@ -262,23 +360,24 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ and "MASTER_PORT" in os.environ     # torch.distributed.run contract
+    if launched:   # also at world 1: init("nccl", device_id), barrier and the MAX all-reduce then run over RCCL exactly as at N > 1
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(0)
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    dev = torch.device("cuda", local_rank if launched else 0)
 
     import behindthescenes_amd as bts
     from behindthescenes_amd import _lib
     from behindthescenes_amd import synthetic as S
 
     _lib.load()
-    if args.workload == "train":
+    if args.workload != "eval":
         train_workload(args, world, rank, dev)
-        if world > 1:
+        if launched:
             torch.distributed.destroy_process_group()
         return
     Z_NEAR, Z_FAR = 3.0, 80.0                   # eval_depth.yaml
@@ -324,7 +423,7 @@ def main():
         step()
     native.render_fwd = timed_render_fwd
     torch.cuda.synchronize()
-    if world > 1:
+    if launched:
         torch.distributed.barrier()
         torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -333,12 +432,12 @@ def main():
         step()
         ev[i][1].record()
     torch.cuda.synchronize()
-    if world > 1:
+    if launched:
         torch.distributed.barrier()
         torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     native.render_fwd = orig_render_fwd
-    if world > 1:
+    if launched:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = t.item()
@@ -387,7 +486,7 @@ def main():
                 ref["ours_over_ref"] = value / ref["value"]
                 out["ref_gpu_baseline"] = ref
         print(json.dumps(out))
-    if world > 1:
+    if launched:
         torch.distributed.destroy_process_group()
 
 

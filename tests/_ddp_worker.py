@@ -48,11 +48,13 @@ def build(scene):
 
 def main(out_dir):
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
-    torch.cuda.set_device(0)
     backend = os.environ.get("BTS_TEST_BACKEND", "gloo")
-    if world > 1:
-        dist.init_process_group(backend, rank=rank, world_size=world)
-    dev = torch.device("cuda", 0)
+    # gloo: every rank shares cuda:0 (RCCL refuses two ranks on one device); nccl (= RCCL): one rank per device, as a real run
+    local = int(os.environ.get("LOCAL_RANK", "0")) if backend == "nccl" else 0
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1 or backend == "nccl":
+        dist.init_process_group(backend, rank=rank, world_size=world, **(dict(device_id=dev) if backend == "nccl" else {}))
     scene = S.synthetic_scene(N_TOTAL, V, H, W, C, seed=3, intrinsics=S.K_KITTI360, smooth=True)
     g = torch.Generator().manual_seed(11)
     task = build(scene)
@@ -67,6 +69,10 @@ def main(out_dir):
     model = parallel.wrap_ddp(task, dev)
     if world > 1:
         assert isinstance(model, torch.nn.parallel.DistributedDataParallel)
+    elif dist.is_initialized():    # one RCCL rank: exercise the collectives the multi-GPU paths use (barrier, all-reduce, all-gather)
+        t = torch.ones(4, device=dev)
+        dist.all_reduce(t), dist.barrier()
+        assert parallel.all_gather_cat(t, 0, 4, 1) is t and float(t.sum()) == 4.0
     loss = model(images[s:e], projs[s:e], poses[s:e], rays[s:e], z[s:e].reshape(-1, K), c_rgb[s:e].reshape(-1, 6))
     loss.backward()
     m = task.net.mlp_coarse
@@ -85,7 +91,7 @@ def main(out_dir):
         task.renderer.sample_coarse = orig
     same = {k: bool(torch.equal(full[k], shard[k])) for k in full}
     torch.save(dict(grads={k: v.cpu() for k, v in grads.items()}, loss=float(loss), same=same, backend=backend), os.path.join(out_dir, f"rank{rank}_of{world}.pt"))
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -70,6 +70,36 @@ def test_sharded_render_ddp_and_metric_reduction(world, n_rays):
             assert results[rank] == (True, True, True), (rank, results[rank])
 
 
+def _encoder_worker(rank, world, port, results):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    parallel.init_distributed("gloo")
+    from behindthescenes_amd.monodepth2 import Monodepth2
+    torch.manual_seed(0)
+    enc = Monodepth2(resnet_layers=18, num_ch_dec=[16, 16, 32, 64, 128], d_out=16, pretrained=False)
+    ddp = parallel.wrap_ddp(enc)
+    g = torch.Generator().manual_seed(rank)
+    ok = True
+    try:
+        for _ in range(2):     # the reducer checks at the START of the second iteration that every gradient of the first arrived
+            enc.zero_grad(set_to_none=True)
+            x = torch.rand(1, 3, 64, 96, generator=g) * 2 - 1
+            sum(f.square().mean() for f in ddp(x)).backward()
+    except RuntimeError as e:
+        ok = str(e)[:300]
+    results[rank] = ok
+    dist.destroy_process_group()
+
+
+def test_two_ddp_steps_with_the_shipped_monodepth2_encoder():
+    """ResNet.fc is kept for strict checkpoint loading but never evaluated; as a trainable parameter it made
+    DistributedDataParallel raise 'Expected to have finished reduction in the prior iteration' in the second step."""
+    port = _free_port()
+    with mp.Manager() as m:
+        results = m.dict()
+        mp.spawn(_encoder_worker, args=(2, port, results), nprocs=2, join=True)
+        assert dict(results) == {0: True, 1: True}, dict(results)
+
+
 def test_shard_range_covers_everything():
     for n in (0, 1, 7, 64, 122880):
         for w in (1, 2, 3, 8):

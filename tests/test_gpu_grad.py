@@ -63,7 +63,12 @@ def test_gradients_vs_reference_golden(hip, name, keep_colours):
         assert _rel_to_max(g, c.t[nme].view_as(g.cpu())) <= GRAD_RTOL, (nme, _rel_to_max(g, c.t[nme].view_as(g.cpu())))
 
 
-def _oracle_grads(scene, mlp, cfg, ids_render, rays, z, n, hard_cap, loss_fn, empty=None, dtype=torch.float32):
+def _oracle_grads(scene, mlp, cfg, ids_render, rays, z, n, hard_cap, loss_fn, empty=None, dtype=torch.float32, device="cpu",
+                  loss_fns=None):
+    """torch.autograd through the oracle.  dtype=float64: the same formulas in double, the arbiter between two fp32 evaluations;
+    device="cuda": the oracle's torch ops run eagerly on the GPU (used for the fp64 arbiter at the real training shapes, where a
+    CPU fp64 pass would take minutes -- as "truth" its device does not matter).  `loss_fns` (a list) returns one gradient tuple per
+    loss from ONE forward graph."""
     if dtype == torch.float64:   # fp64 evaluation of the same formulas: the arbiter
         torch.set_default_dtype(torch.float64)
         try:
@@ -71,23 +76,26 @@ def _oracle_grads(scene, mlp, cfg, ids_render, rays, z, n, hard_cap, loss_fn, em
             mlp64 = O.MlpParams(mlp.w_in.double(), mlp.b_in.double(), [tuple(t.double() for t in b) for b in mlp.blocks],
                                 mlp.w_out.double(), mlp.b_out.double())
             return _oracle_grads(scene64, mlp64, cfg, ids_render, rays.double(), z.double(), n, hard_cap, loss_fn,
-                                 None if empty is None else empty.double(), dtype=None)
+                                 None if empty is None else empty.double(), dtype=None, device=device, loss_fns=loss_fns)
         finally:
             torch.set_default_dtype(torch.float32)
-    params = [t.clone().requires_grad_(True) for t in mlp.tensors()]
-    feat = scene["feat"].clone().requires_grad_(True)
+    params = [t.clone().to(device).requires_grad_(True) for t in mlp.tensors()]
+    feat = scene["feat"].clone().to(device).requires_grad_(True)
     nb = len(mlp.blocks)
     blocks = [tuple(params[2 + 4 * i: 6 + 4 * i]) for i in range(nb)]
     m = O.MlpParams(params[0], params[1], blocks, params[-2], params[-1])
     st = O.make_state(scene, ids_render, cfg)
-    e = None if empty is None else empty.clone().requires_grad_(True)
-    st = O.FieldState(feat, st.K_enc, st.w2c_enc, st.imgs, st.K_r, st.w2c_r, e)
-    w, rgb, depth, a, *_ = O.composite(rays.reshape(-1, 8), z, n, st, m, cfg, hard_alpha_cap=hard_cap)
+    e = None if empty is None else empty.clone().to(device).requires_grad_(True)
+    st = O.FieldState(feat, *[t.to(device) for t in (st.K_enc, st.w2c_enc, st.imgs, st.K_r, st.w2c_r)], e)
+    w, rgb, depth, a, *_ = O.composite(rays.reshape(-1, 8).to(device), z.to(device), n, st, m, cfg, hard_alpha_cap=hard_cap)
     wanted = params + [feat] + ([e] if e is not None else [])
-    return torch.autograd.grad(loss_fn(w, rgb, depth, a), wanted)
+    if loss_fns is None:
+        return tuple(g.cpu() for g in torch.autograd.grad(loss_fn(w, rgb, depth, a), wanted))
+    return [tuple(g.cpu() for g in torch.autograd.grad(f(w, rgb, depth, a), wanted, retain_graph=i + 1 < len(loss_fns)))
+            for i, f in enumerate(loss_fns)]
 
 
-def _gate_safe_rays(scene, mlp, cfg, ids_render, rays, z, empty, margin):
+def _gate_safe_rays(scene, mlp, cfg, ids_render, rays, z, empty, margin, stats=None):
     """Rays none of whose samples has a hidden pre-activation within its fp32 uncertainty of the relu kink (fp64 evaluation).  On
     every other ray two correct fp32 evaluations may gate a unit differently, and ONE flipped gate moves a few gradient entries by
     ~1e-4..1e-3 of the largest entry -- an effect of the test point, not of either implementation.  Measured on the KITTI-360
@@ -117,13 +125,21 @@ def _gate_safe_rays(scene, mlp, cfg, ids_render, rays, z, empty, margin):
         m = margin * (1.0 + x[..., C:C + 3].abs().amax(-1, keepdim=True)) + dh          # (n, B'*K, Hd)
         h = F.linear(x, mlp.w_in.double(), mlp.b_in.double())
         near = torch.zeros(h.shape[:-1], dtype=torch.bool)
+        n_units = n_near = 0
         for (w0, b0, w1, b1) in mlp.blocks:
             t = F.linear(torch.relu(h), w0.double(), b0.double())
             mt = F.linear(m * m, w0.double() ** 2).sqrt() + margin      # independent errors add in quadrature
             near |= (h.abs() < m).any(-1) | (t.abs() < mt).any(-1)
+            n_units += h.numel() + t.numel()
+            n_near += int((h.abs() < m).sum()) + int((t.abs() < mt).sum())
             h = h + F.linear(torch.relu(t), w1.double(), b1.double())
             m = (m * m + F.linear(mt * mt, w1.double() ** 2)).sqrt()
         near |= (h.abs() < m).any(-1)
+        n_units += h.numel()
+        n_near += int((h.abs() < m).sum())
+        if stats is not None:   # how many relu inputs (unit x sample) sit inside their uncertainty band
+            stats["units"] = stats.get("units", 0) + n_units
+            stats["near"] = stats.get("near", 0) + n_near
     finally:
         torch.set_default_dtype(torch.float32)
     safe = ~near.view(n, Bp, -1).any(-1)
@@ -185,12 +201,9 @@ def test_gradients_vs_oracle_autograd(hip, learn_empty):
         assert l2_hip <= max(2.0 * l2_ref, 0.1 * GRAD_RTOL), (nme, l2_hip, l2_ref)
 
 
-def _patch_rays_with_kink_mask(scene, mlp, cfg, ids_loss, ids_render, n_patches, K, g, margin):
+def _patch_rays(scene, cfg, ids_loss, n_patches, K, g):
     """`n_patches` random 8x8 patches per sample in PatchRaySampler order (the backward's dG scatter relies on a 64-ray group being
-    one patch) + a per-ray mask that is 0 where some sample of the ray has a hidden unit within `margin` of the relu kink in an fp64
-    evaluation (see _gate_safe_rays).  The tests multiply each ray's upstream gradient by the mask, so such rays contribute to
-    NEITHER path's gradient while the kernels still run on the full, real ray layout.
-    -> rays (n, n_patches*64, 8), z (n*n_patches*64, K), mask (n*n_patches*64,)"""
+    one patch) -> rays (n, n_patches*64, 8), z (n*n_patches*64, K)"""
     n, v, _, H, W = scene["images"].shape
     nl = len(ids_loss)
     all_rays = O.image_rays(scene["poses"][:, ids_loss], scene["projs"][:, ids_loss], H, W, cfg.d_min, cfg.d_max).view(n, nl, H, W, 8)
@@ -200,72 +213,171 @@ def _patch_rays_with_kink_mask(scene, mlp, cfg, ids_loss, ids_render, n_patches,
     rays = torch.stack([torch.cat([all_rays[i, pv[i, j], py[i, j]:py[i, j] + 8, px[i, j]:px[i, j] + 8].reshape(64, 8) for j in range(n_patches)])
                         for i in range(n)]).contiguous()                               # (n, n_patches*64, 8)
     z = O.sample_coarse(rays.reshape(-1, 8), K, True, torch.rand(n * n_patches * 64, K, generator=g))
+    return rays, z.contiguous()
+
+
+def _patch_rays_with_kink_mask(scene, mlp, cfg, ids_loss, ids_render, n_patches, K, g, margin, stats=None):
+    """_patch_rays + a per-ray mask that is 0 where some sample of the ray has a hidden unit within `margin` of the relu kink in an fp64
+    evaluation (see _gate_safe_rays).  The masked tests multiply each ray's upstream gradient by the mask, so such rays contribute to
+    NEITHER path's gradient while the kernels still run on the full, real ray layout.
+    -> rays (n, n_patches*64, 8), z (n*n_patches*64, K), mask (n*n_patches*64,)"""
+    n = scene["images"].shape[0]
+    rays, z = _patch_rays(scene, cfg, ids_loss, n_patches, K, g)
     masks = []
     for i in range(n):   # one sample at a time: fp64 activations
         sc = {k: t[i:i + 1] for k, t in scene.items()}
-        safe, _ = _gate_safe_rays(sc, mlp, cfg, ids_render, rays[i:i + 1], z.view(n, -1, K)[i], None, margin)
+        safe, _ = _gate_safe_rays(sc, mlp, cfg, ids_render, rays[i:i + 1], z.view(n, -1, K)[i], None, margin, stats)
         masks.append(safe.view(-1))
     mask = torch.cat(masks).float()
     print(f"rays whose upstream gradient is zeroed (hidden unit within {margin:g} of the relu kink): {int((1 - mask).sum())} of {mask.numel()}")
-    return rays, z.contiguous(), mask
+    return rays, z, mask
 
 
-def test_gradients_at_the_kitti360_training_shape(hip):
-    """BASELINE configs[2] at its real shape: bs 16, 8 frames (4 loss + 4 render views), 64 patches of 8x8 = 4096 rays per sample,
-    64 samples per ray, nv = 4 -- 4.19 M field queries through bts_render_bwd (two-pass dG scatter, one work-group per 256 rays) and
-    bts_project_features_bwd, against torch.autograd through the CPU oracle.  Bound: 1e-4 of the largest entry."""
+# ---------------------------------------------------------------------------------------------------------------
+# Gradient parity at the REAL training shapes, two instruments on the same inputs (built once per shape):
+#   * masked, strict: rays with a hidden unit inside its fp32 uncertainty of the relu kink get a zero upstream gradient in BOTH
+#     paths; every entry of every gradient tensor must then agree with oracle autograd to 1e-4 of the tensor's largest entry;
+#   * unmasked, fp64-arbitrated (VERDICT r2, item 1): EVERY ray keeps its upstream gradient; an fp64 evaluation of the same formulas
+#     is the truth, and the HIP path may not be further from it than the fp32 oracle (= what the reference computes) is -- in the
+#     max norm, in L2, and in the number of feature-map texels that are off by more than 1e-4 of the largest entry.  A wrong
+#     scatter slot, a stale gate bit or a bad pair-collision round on ANY ray shows up here.
+# ---------------------------------------------------------------------------------------------------------------
+REAL_SHAPES = {
+    # BASELINE configs[2]: bs 16, 8 frames (4 loss + 4 render views), 64 patches of 8x8 = 4096 rays per sample, K = 64, nv = 4
+    "kitti360": dict(n=16, v=8, H=192, W=640, C=64, Hd=64, nb=0, K=64, ids_loss=[0, 1, 2, 3], ids_render=[4, 5, 6, 7], patches=64,
+                     cfg=dict(), hard_cap=True, intr="K_KITTI360", baseline=0.6, seed=303, min_kept=0.4, b_in=True),
+    # exp_re10k.yaml field (C = 32, one ResnetBlockFC of width 32, distance code, no alpha cap): K = 48 (the yaml) and 128 (BASELINE.json),
+    # 256x384 frames, 1024 patch rays per sample, nv = 2
+    "re10k_k48": dict(n=3, v=3, H=256, W=384, C=32, Hd=32, nb=1, K=48, ids_loss=[0], ids_render=[1, 2], patches=16,
+                      cfg=dict(d_min=1.0, d_max=100.0, code_mode="distance"), hard_cap=False, intr="K_RE10K", baseline=0.2, seed=548,
+                      min_kept=0.25, b_in=False),
+    "re10k_k128": dict(n=3, v=3, H=256, W=384, C=32, Hd=32, nb=1, K=128, ids_loss=[0], ids_render=[1, 2], patches=16,
+                       cfg=dict(d_min=1.0, d_max=100.0, code_mode="distance"), hard_cap=False, intr="K_RE10K", baseline=0.2, seed=628,
+                       min_kept=0.25, b_in=False),
+}
+_REAL = {}
+
+
+def _real_case(name):
+    """Inputs, kink mask, oracle gradients (fp32 on the CPU, masked and unmasked upstream gradient from one graph) of a real shape."""
+    if name in _REAL:
+        return _REAL[name]
+    s = REAL_SHAPES[name]
+    cfg = O.FieldConfig(**s["cfg"])
+    g = torch.Generator().manual_seed(s["seed"])
+    scene = O.synthetic_scene(s["n"], s["v"], s["H"], s["W"], s["C"], seed=s["seed"], intrinsics=getattr(O, s["intr"]), baseline=s["baseline"],
+                              smooth=True)
+    mlp = O.init_mlp(s["C"] + 39, s["Hd"], s["nb"], gen=g)
+    if s["b_in"]:
+        mlp.b_in = torch.randn(s["Hd"], generator=g) * 0.1
+    stats = {}
+    rays, z, mask = _patch_rays_with_kink_mask(scene, mlp, cfg, s["ids_loss"], s["ids_render"], s["patches"], s["K"], g, margin=2e-5, stats=stats)
+    B = s["n"] * s["patches"] * 64
+    nv = len(s["ids_render"])
+    c_rgb = torch.randn(B, nv * 3, generator=g)
+
+    def make_loss(m):
+        cm = c_rgb * m.unsqueeze(-1)
+
+        def loss_fn(w, rgb, depth, a):
+            return (rgb * cm.to(rgb.device, rgb.dtype)).sum() + 0.05 * (depth * m.to(depth.device, depth.dtype)).sum()
+        return loss_fn
+
+    masked, full = make_loss(mask), make_loss(torch.ones_like(mask))
+    ref_masked, ref_full = _oracle_grads(scene, mlp, cfg, s["ids_render"], rays, z, s["n"], s["hard_cap"], None, loss_fns=[masked, full])
+    names = ["w_in", "b_in"] + (["fc_0.w", "fc_0.b", "fc_1.w", "fc_1.b"] if s["nb"] else []) + ["w_out", "b_out", "feat"]
+    _REAL[name] = dict(s=s, cfg=cfg, scene=scene, mlp=mlp, rays=rays, z=z, mask=mask, masked=masked, full=full, ref_masked=ref_masked,
+                       ref_full=ref_full, names=names, stats=stats)
+    return _REAL[name]
+
+
+def _hip_real(hip, c, loss_fn):
     from tests._hip_helpers import build_net
-    cfg = O.FieldConfig()
-    g = torch.Generator().manual_seed(303)
-    n, v, H, W, K = 16, 8, 192, 640, 64
-    ids_loss, ids_render = [0, 1, 2, 3], [4, 5, 6, 7]
-    scene = O.synthetic_scene(n, v, H, W, 64, seed=303, intrinsics=O.K_KITTI360, baseline=0.6, smooth=True)
-    mlp = O.init_mlp(103, 64, 0, gen=g)
-    mlp.b_in = torch.randn(64, generator=g) * 0.1
-    rays, z, mask = _patch_rays_with_kink_mask(scene, mlp, cfg, ids_loss, ids_render, 64, K, g, margin=2e-5)
-    assert rays.shape == (n, 4096, 8) and mask.mean() > 0.4
-    c_rgb = torch.randn(n * 4096, 12, generator=g) * mask.unsqueeze(-1)
+    s = c["s"]
+    net = build_net(c["cfg"], c["mlp"], c["scene"], s["ids_render"], train=True)
+    renderer = hip.NeRFRenderer(n_coarse=s["K"], lindisp=True, hard_alpha_cap=s["hard_cap"]).cuda()
+    return _hip_grads(hip, net, renderer, c["rays"].reshape(-1, 8).cuda(), c["z"].cuda(), s["n"], loss_fn)
 
-    def loss_fn(w, rgb, depth, a):
-        return (rgb * c_rgb.to(rgb.device, rgb.dtype)).sum() + 0.05 * (depth * mask.to(depth.device, depth.dtype)).sum()
 
-    ref = _oracle_grads(scene, mlp, cfg, ids_render, rays, z, n, True, loss_fn)
-    net = build_net(cfg, mlp, scene, ids_render, train=True)
-    renderer = hip.NeRFRenderer(n_coarse=K, lindisp=True, hard_alpha_cap=True).cuda()
-    ours = _hip_grads(hip, net, renderer, rays.reshape(-1, 8).cuda(), z.cuda(), n, loss_fn)
-    for a, b, nme in zip(ours, ref, ["w_in", "b_in", "w_out", "b_out", "feat"]):
-        err = _rel_to_max(a, b.view_as(a.cpu()))
-        print(f"{nme}: max err / max entry {err:.2e}")
+@pytest.mark.parametrize("name", list(REAL_SHAPES))
+def test_gradients_at_the_real_training_shapes_masked(hip, name):
+    """bts_render_bwd (every pass) + bts_project_features_bwd at the real shapes against torch.autograd through the CPU oracle, rays
+    with a relu-kink sample set aside (see above).  Bound: 1e-4 of the largest entry of each tensor.  The fraction of rays set aside
+    is checked against what the geometry predicts and recorded (gpurun_out/grad_real_<name>.json)."""
+    c = _real_case(name)
+    s, mask = c["s"], c["mask"]
+    kept = float(mask.mean())
+    assert mask.numel() == s["n"] * s["patches"] * 64 and kept > s["min_kept"], kept
+    # Cross-check of the masked fraction against the unit-level event it is built from: with p = P(a relu input sits inside its fp32
+    # uncertainty band) measured over all (unit, sample) pairs and U relu inputs per ray, independent events would zero
+    # 1 - (1 - p)^U of the rays; the events cluster along a ray (neighbouring samples see almost the same activations), so the
+    # mask may only zero FEWER rays than that -- anything above it means rays are being set aside for another reason.
+    p_unit = c["stats"]["near"] / c["stats"]["units"]
+    units_per_ray = c["stats"]["units"] / mask.numel()
+    bound = 1.0 - (1.0 - p_unit) ** units_per_ray
+    print(f"{name}: P(relu input inside its band) {p_unit:.2e}, {units_per_ray:.0f} relu inputs per ray -> at most {bound:.3f} of the rays "
+          f"zeroed if independent; zeroed: {1 - kept:.3f}")
+    assert 1.0 - kept <= bound + 0.01, (1.0 - kept, bound)
+    ours = _hip_real(hip, c, c["masked"])
+    errs = {}
+    for a, b, nme in zip(ours, c["ref_masked"], c["names"]):
+        errs[nme] = _rel_to_max(a, b.view_as(a.cpu()))
+        print(f"{name} {nme}: max err / max entry {errs[nme]:.2e}")
+    _record(name, dict(masked=dict(rays=int(mask.numel()), kept_fraction=kept, zeroed_fraction_bound_if_independent=bound,
+                                   p_relu_input_inside_band=p_unit, relu_inputs_per_ray=units_per_ray, max_err_over_max_entry=errs)))
+    for nme, err in errs.items():
         assert err <= GRAD_RTOL, (nme, err)
 
 
-@pytest.mark.parametrize("K", [48, 128])
-def test_gradients_re10k_shape(hip, K):
-    """exp_re10k.yaml field (C = 32, one ResnetBlockFC of width 32, distance code, no alpha cap) at its ray-march lengths: K = 48 (the
-    yaml) and 128 (BASELINE.json), 256x384 frames, 1024 patch rays per sample, nv = 2; all ten parameter gradients + the feature map."""
-    from tests._hip_helpers import build_net
-    cfg = O.FieldConfig(d_min=1.0, d_max=100.0, code_mode="distance")
-    g = torch.Generator().manual_seed(500 + K)
-    n, v, H, W = 3, 3, 256, 384
-    scene = O.synthetic_scene(n, v, H, W, 32, seed=500 + K, intrinsics=O.K_RE10K, baseline=0.2, smooth=True)
-    mlp = O.init_mlp(71, 32, 1, gen=g)
-    rays, z, mask = _patch_rays_with_kink_mask(scene, mlp, cfg, [0], [1, 2], 16, K, g, margin=2e-5)
-    assert mask.mean() > 0.25
-    c_rgb = torch.randn(n * 1024, 6, generator=g) * mask.unsqueeze(-1)
+def _record(name, d):
+    """Numbers of the real-shape gradient tests for profiles/ (the test log itself is captured by pytest -q)."""
+    import json
+    import os
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(root, exist_ok=True)
+    path = os.path.join(root, f"grad_real_{name}.json")
+    old = json.load(open(path)) if os.path.exists(path) else {}
+    old.update(d)
+    json.dump(old, open(path, "w"), indent=1)
 
-    def loss_fn(w, rgb, depth, a):
-        return (rgb * c_rgb.to(rgb.device, rgb.dtype)).sum() + 0.05 * (depth * mask.to(depth.device, depth.dtype)).sum()
 
-    ref = _oracle_grads(scene, mlp, cfg, [1, 2], rays, z, n, False, loss_fn)
-    net = build_net(cfg, mlp, scene, [1, 2], train=True)
-    renderer = hip.NeRFRenderer(n_coarse=K, lindisp=True, hard_alpha_cap=False).cuda()
-    ours = _hip_grads(hip, net, renderer, rays.reshape(-1, 8).cuda(), z.cuda(), n, loss_fn)
-    names = ["w_in", "b_in", "fc_0.w", "fc_0.b", "fc_1.w", "fc_1.b", "w_out", "b_out", "feat"]
-    assert len(ours) == len(ref) == len(names)
-    for a, b, nme in zip(ours, ref, names):
-        err = _rel_to_max(a, b.view_as(a.cpu()))
-        print(f"K={K} {nme}: max err / max entry {err:.2e}")
-        assert err <= GRAD_RTOL, (nme, err)
+ARB_FACTOR = 1.5      # HIP may be at most this much further from the fp64 truth than the fp32 oracle is (max norm and L2) ...
+ARB_EPS_MAX = 2e-5    # ... plus this fraction of the tensor's largest entry (max norm)
+ARB_EPS_L2 = 1e-5     # ... / of the tensor's norm (L2): where both are at rounding level the ratio means nothing
+ARB_COUNT = 1.25      # feature-map texels off by > 1e-4 of the largest entry: at most this many times the oracle's own count (+ 10)
+
+
+@pytest.mark.parametrize("name", list(REAL_SHAPES))
+def test_gradients_fp64_arbiter_at_the_real_training_shapes(hip, name):
+    """NO relu-kink mask: every ray keeps its upstream gradient.  Truth = the oracle's formulas in fp64 (torch ops on the GPU);
+    fp32 oracle on the CPU = what the reference computes.  Two correct fp32 evaluations gate a few units differently where a
+    pre-activation sits within rounding of zero, so neither matches the truth to 1e-4 everywhere -- but the HIP path must not be
+    FURTHER from it than the fp32 oracle is."""
+    c = _real_case(name)
+    s = c["s"]
+    truth = _oracle_grads(c["scene"], c["mlp"], c["cfg"], s["ids_render"], c["rays"], c["z"], s["n"], s["hard_cap"], c["full"],
+                          dtype=torch.float64, device="cuda")
+    ours = _hip_real(hip, c, c["full"])
+    rec, fails = {}, []
+    for a, b, t, nme in zip(ours, c["ref_full"], truth, c["names"]):
+        a = a.detach().cpu().double()
+        t, b = t.view_as(a), b.view_as(a).double()
+        tmax, tnorm = t.abs().max().item(), t.norm().item()
+        e_hip, e_ref = (a - t).abs(), (b - t).abs()
+        r = dict(max_hip=e_hip.max().item() / tmax, max_ref=e_ref.max().item() / tmax, l2_hip=e_hip.norm().item() / tnorm,
+                 l2_ref=e_ref.norm().item() / tnorm, n_off_hip=int((e_hip > 1e-4 * tmax).sum()), n_off_ref=int((e_ref > 1e-4 * tmax).sum()),
+                 numel=a.numel())
+        rec[nme] = r
+        print(f"{name} {nme}: max/max-entry HIP {r['max_hip']:.2e} oracle {r['max_ref']:.2e}; L2 HIP {r['l2_hip']:.2e} oracle {r['l2_ref']:.2e}; "
+              f"entries off by > 1e-4 max: HIP {r['n_off_hip']} oracle {r['n_off_ref']} of {r['numel']}")
+        if r["max_hip"] > ARB_FACTOR * r["max_ref"] + ARB_EPS_MAX:
+            fails.append((nme, "max", r["max_hip"], r["max_ref"]))
+        if r["l2_hip"] > ARB_FACTOR * r["l2_ref"] + ARB_EPS_L2:
+            fails.append((nme, "l2", r["l2_hip"], r["l2_ref"]))
+        if r["n_off_hip"] > ARB_COUNT * r["n_off_ref"] + 10:
+            fails.append((nme, "count", r["n_off_hip"], r["n_off_ref"]))
+    _record(name, dict(fp64_arbiter=rec))
+    assert not fails, fails
 
 
 def test_multiscale_render_and_backward_vs_oracle(hip):

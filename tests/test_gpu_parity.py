@@ -161,14 +161,22 @@ def test_layout_kernels_roundtrip(hip):
 
 
 def _oracle_vs_hip(hip, *, n, v, H, W, C, Hd, nb, K, ids_render, cfg, hard_cap, intr, n_rays, seed, norm_dir=True, smooth=False,
-                   want_fp64=False):
+                   want_fp64=False, views=None, patches=None, baseline=0.54):
+    """views: render only the rays of these frames (default: all v); patches = (ids_loss, n_patches): PatchRaySampler-ordered 8x8
+    patch rays from the ids_loss frames instead of whole images (the training shapes)."""
     from tests._cases import robust_ray_mask
     from tests._hip_helpers import build_net
     g = torch.Generator().manual_seed(seed)
-    scene = O.synthetic_scene(n, v, H, W, C, seed=seed, intrinsics=intr, smooth=smooth)
+    scene = O.synthetic_scene(n, v, H, W, C, seed=seed, intrinsics=intr, smooth=smooth, baseline=baseline)
     mlp = O.init_mlp(C + 39, Hd, nb, gen=g)
     empty = torch.randn(C, generator=g) if cfg.learn_empty else None
-    rays = O.image_rays(scene["poses"], scene["projs"], H, W, cfg.d_min, cfg.d_max, norm_dir)
+    if patches is not None:
+        from tests.test_gpu_grad import _patch_rays
+        rays, _ = _patch_rays(scene, cfg, patches[0], patches[1], K, g)
+    else:
+        rays = O.image_rays(scene["poses"], scene["projs"], H, W, cfg.d_min, cfg.d_max, norm_dir)
+        if views is not None:
+            rays = rays.view(n, v, H * W, 8)[:, list(views)].reshape(n, -1, 8).contiguous()
     if n_rays is not None:
         idx = torch.randperm(rays.shape[1], generator=g)[:n_rays].sort().values
         rays = rays[:, idx].contiguous()
@@ -312,6 +320,34 @@ def test_ragged_and_training_shapes_vs_oracle(hip):
         r = _oracle_vs_hip(hip, n=2, v=3, H=64, W=96, C=32, Hd=32, nb=1, K=K, ids_render=[1, 2], cfg=re, hard_cap=False,
                            intr=O.K_RE10K, n_rays=777, seed=6 + K, smooth=True)
         _check(r, depth_floor=1e-3)
+
+
+@pytest.mark.parametrize("K", [48, 128])
+def test_re10k_full_frame_vs_oracle(hip, K):
+    """BASELINE configs[4] field at full frame size: exp_re10k.yaml (C = 32, one ResnetBlockFC of width 32, distance code, z in [1, 100],
+    no alpha cap), 256x384 frames, bs 2, every ray of the first frame (196 608 rays), nv = 2, K = 48 (the yaml) and 128 (BASELINE.json)."""
+    re = O.FieldConfig(d_min=1.0, d_max=100.0, code_mode="distance")
+    r = _oracle_vs_hip(hip, n=2, v=3, H=256, W=384, C=32, Hd=32, nb=1, K=K, ids_render=[1, 2], cfg=re, hard_cap=False, intr=O.K_RE10K,
+                       n_rays=None, seed=60 + K, smooth=True, views=[0], baseline=0.2)
+    assert r["depth"][0].numel() == 2 * 256 * 384
+    _check(r, depth_floor=1e-3)
+
+
+def test_kitti_raw_training_shape_vs_oracle(hip):
+    """BASELINE configs[3] at its per-GPU shape: exp_kitti_raw.yaml, bs 8, 4 frames per sample (stereo pair x 2 time steps: 2 loss +
+    2 render views), 32 patches of 8x8 = 2 048 rays per sample, K = 64, nv = 2, KITTI-Raw intrinsics, learn_empty: false (the yaml sets it)."""
+    r = _oracle_vs_hip(hip, n=8, v=4, H=192, W=640, C=64, Hd=64, nb=0, K=64, ids_render=[2, 3], cfg=O.FieldConfig(),
+                       hard_cap=True, intr=O.K_KITTIRAW, n_rays=None, seed=73, smooth=True, patches=([0, 1], 32))
+    assert r["depth"][0].numel() == 8 * 2048
+    _check(r)
+
+
+def test_kitti360_training_batch_forward_vs_oracle(hip):
+    """BASELINE configs[2] forward at its real batch: bs 16, 8 frames (4 loss + 4 render views), 64 patches = 4 096 rays per sample, nv = 4."""
+    r = _oracle_vs_hip(hip, n=16, v=8, H=192, W=640, C=64, Hd=64, nb=0, K=64, ids_render=[4, 5, 6, 7], cfg=O.FieldConfig(),
+                       hard_cap=True, intr=O.K_KITTI360, n_rays=None, seed=74, smooth=True, patches=([0, 1, 2, 3], 64), baseline=0.6)
+    assert r["depth"][0].numel() == 16 * 4096
+    _check(r)
 
 
 def test_single_ray_and_tiny_k(hip):
