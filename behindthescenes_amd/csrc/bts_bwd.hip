@@ -1,4 +1,8 @@
-// Backward of the fused renderer (projected-feature path) for gfx950.
+// Host side of bts_render_bwd (path choice, workspace) + the ROUND-1 lane = ray backward, kept for A/B in the probe build only
+// (-DBTS_PROBE, env BTS_BWD_V1): the product serves every shape with the lane = sample passes of bts_bwd_rows.hip (plain MLP,
+// K <= 64: gate bits) and bts_bwd_blocks.hip (ResnetBlockFC layers / long rays: rows).
+//
+// Round-1 kernel: backward of the fused renderer (projected-feature path) for gfx950.
 //
 // One lane = one ray, walked BACK TO FRONT so that the suffix sum the compositing gradient needs
 //     g_alpha_k = g_w_k * T_k - (sum_{m>k} g_w_m w_m) / (1 - alpha_k + 1e-10)
@@ -19,6 +23,7 @@
 
 namespace bts {
 
+#ifdef BTS_PROBE
 template <int HD, int NB>
 struct BwdLds {
   static constexpr int PE_ROWS = kPeDim + 1;            // 40
@@ -697,37 +702,41 @@ static int launch_bwd(const BwdParams& bp, int grid, hipStream_t s) {
   return BTS_OK;
 }
 
+#endif  // BTS_PROBE
+
 FwdParams make_params(const BtsFieldCfg* cfg, const BtsFieldTensors* t);
 int render_grid(const FwdParams& p);
 int render_chunk_log2(int grid);
 int launch_bwd_rows(const BwdParams& bp, int C, int HD, int n, int grid, hipStream_t s);
+int launch_bwd_blocks(const BwdParams& bp, float* u0_ws, int C, int HD, int NB, int n, int grid, hipStream_t s);
 
-// plain MLP and at most one wave of samples per ray: the lane = sample passes of bts_bwd_rows.hip; ResnetBlockFC layers (RE10K) and
-// K > 64 keep the lane = ray pass of this file
-static bool rows_path(const BtsFieldCfg* cfg, const BtsRenderArgs* a) { return cfg->n_blocks == 0 && a->K <= 64; }
+// plain MLP and at most one wave of samples per ray: the gate-bit passes of bts_bwd_rows.hip; ResnetBlockFC layers (RE10K) and K > 64:
+// the row passes of bts_bwd_blocks.hip
+static bool bits_path(const BtsFieldCfg* cfg, const BtsRenderArgs* a) { return cfg->n_blocks == 0 && a->K <= 64; }
 
-// workspace = what the passes hand each other.  lane = ray path: groups of 64 rays x K x 64 x d_hidden floats (g_h rows); lane =
-// sample path: rays x K floats (g_s) + the relu gates as bits, once per sample and once per channel -- 20 bytes per sample instead of 256.
+// workspace = what the passes hand each other per sample.  Gate-bit path: g_s (one float) + the relu gates as bits, once per sample
+// and once per channel -- 20 bytes at d_hidden 64.  Row path: the gradient row at lin_in's output (4 d_hidden bytes) + g_s.
+// (Round 1: 256-byte g_h rows per sample AND lane = ray; probe build only.)
 size_t render_bwd_workspace_impl(const BtsFieldCfg* cfg, const BtsRenderArgs* a) {
   const size_t rays = (size_t)cfg->n * (size_t)a->rays_per_sample;
-  const size_t v2 = rays * ((size_t)a->K * (1 + (size_t)cfg->d_hidden / 32) + 2 * (size_t)cfg->d_hidden) * sizeof(float);
+  const size_t bits = rays * ((size_t)a->K * (1 + (size_t)cfg->d_hidden / 32) + 2 * (size_t)cfg->d_hidden) * sizeof(float);
+  const size_t rows = rays * (size_t)a->K * ((size_t)cfg->d_hidden + 1) * sizeof(float);
+#ifdef BTS_PROBE   // any path may serve the call (BTS_BWD_V1)
   const size_t groups = (size_t)cfg->n * ((a->rays_per_sample + 255) / 256) * 4;
   const size_t v1 = groups * (size_t)a->K * 64 * (size_t)cfg->d_hidden * sizeof(float);
-#ifdef BTS_PROBE   // either path may serve the call (BTS_BWD_V1)
-  return v1 > v2 ? v1 : v2;
+  return v1 > rows ? (v1 > bits ? v1 : bits) : (rows > bits ? rows : bits);
 #else
-  return rows_path(cfg, a) ? v2 : v1;
+  return bits_path(cfg, a) ? bits : rows;
 #endif
 }
 
+#ifdef BTS_PROBE
 template <int HD>
 static int launch_scatter(const BwdParams& bp, int n, hipStream_t s) {
   ScatterParams sp;
   sp.f = bp.f, sp.gh_ws = bp.gh_ws, sp.d_proj = bp.d_proj, sp.groups_per_sample = bp.f.tiles_per_sample * 4;
   sp.mode = 0;
-#ifdef BTS_PROBE
   if (const char* e = getenv("BTS_SCATTER_MODE")) sp.mode = atoi(e);
-#endif
   scatter_dg_kernel<HD><<<n * sp.groups_per_sample, 64, 0, s>>>(sp);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
@@ -736,6 +745,7 @@ static int launch_scatter(const BwdParams& bp, int n, hipStream_t s) {
   }
   return BTS_OK;
 }
+#endif
 
 int render_bwd_impl(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const BtsRenderArgs* a, const BtsRenderGrads* g, void* workspace,
                     size_t, hipStream_t s) {
@@ -748,44 +758,46 @@ int render_bwd_impl(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const BtsR
   bp.f.tiles_per_sample = (a->rays_per_sample + 255) / 256;
   bp.g_rgb = g->g_rgb, bp.g_depth = g->g_depth, bp.g_weights = g->g_weights, bp.g_alphas = g->g_alphas;
   bp.d_proj = g->d_proj_nhwc, bp.d_mlp = g->d_mlp_params, bp.d_empty_proj = g->d_empty_proj;
+  bp.gh_ws = nullptr, bp.gs_ws = nullptr, bp.mask_ws = nullptr, bp.pmask_ws = nullptr;
 #ifdef BTS_PROBE
-  static const bool direct = getenv("BTS_BWD_DIRECT_ATOMICS") != nullptr;   // A/B (probe build): single pass, every tap update an L2 atomic
-#else
-  constexpr bool direct = false;
-#endif
-#ifdef BTS_PROBE
-  static const bool v1 = getenv("BTS_BWD_V1") != nullptr;   // A/B (probe build): the lane = ray pass for every shape
-#else
-  constexpr bool v1 = false;
-#endif
-  if (rows_path(cfg, a) && !direct && !v1) {
-    bp.f.lpr = 64, bp.f.groups = (long)cfg->n * a->rays_per_sample;
-    if (bp.f.groups > 0x7FF00000L) {
-      set_error("%s: too many rays in one call (%ld)", "bts_render_bwd", bp.f.groups);
-      return BTS_E_UNSUPPORTED;
-    }
-    const int grid = render_grid(bp.f);
-    bp.f.chunk_log2 = render_chunk_log2(grid);
-    bp.gh_ws = nullptr;
-    bp.gs_ws = static_cast<float*>(workspace);
-    bp.mask_ws = reinterpret_cast<unsigned*>(bp.gs_ws + (size_t)cfg->n * a->rays_per_sample * a->K);
-    bp.pmask_ws = reinterpret_cast<uint2*>(bp.mask_ws + (size_t)cfg->n * a->rays_per_sample * a->K * (cfg->d_hidden / 32));
-    const int rc = launch_bwd_rows(bp, cfg->C, cfg->d_hidden, cfg->n, grid, s);
-    if (rc != BTS_E_UNSUPPORTED) return rc;
-    set_error("%s: unsupported MLP shape C=%ld d_hidden=%ld n_blocks=%ld", "bts_render_bwd", cfg->C, cfg->d_hidden, cfg->n_blocks);
+  static const bool direct = getenv("BTS_BWD_DIRECT_ATOMICS") != nullptr;   // A/B (probe build): round-1 kernel, every tap update an L2 atomic
+  static const bool v1 = getenv("BTS_BWD_V1") != nullptr || direct;         // A/B (probe build): the round-1 lane = ray pass for every shape
+  static const bool rows_always = getenv("BTS_BWD_ROWS") != nullptr;        // A/B (probe build): the row passes for every shape
+  if (v1) {
+    bp.gh_ws = (bp.d_proj && !direct) ? static_cast<float*>(workspace) : nullptr;
+    const int grid = bp.f.tiles_per_sample * cfg->n;
+    int rc = BTS_E_UNSUPPORTED;
+    if (cfg->C == 64 && cfg->d_hidden == 64 && cfg->n_blocks == 0) rc = launch_bwd<64, 64, 0>(bp, grid, s);
+    else if (cfg->C == 32 && cfg->d_hidden == 32 && cfg->n_blocks == 0) rc = launch_bwd<32, 32, 0>(bp, grid, s);
+    else if (cfg->C == 32 && cfg->d_hidden == 32 && cfg->n_blocks == 1) rc = launch_bwd<32, 32, 1>(bp, grid, s);
+    if (rc == BTS_OK && bp.gh_ws) rc = cfg->d_hidden == 64 ? launch_scatter<64>(bp, cfg->n, s) : launch_scatter<32>(bp, cfg->n, s);
     return rc;
   }
-  bp.gh_ws = (bp.d_proj && !direct) ? static_cast<float*>(workspace) : nullptr;
-  bp.gs_ws = nullptr, bp.mask_ws = nullptr, bp.pmask_ws = nullptr;
-  const int grid = bp.f.tiles_per_sample * cfg->n;
-  int rc = BTS_E_UNSUPPORTED;
-  if (cfg->C == 64 && cfg->d_hidden == 64 && cfg->n_blocks == 0) rc = launch_bwd<64, 64, 0>(bp, grid, s);
-  else if (cfg->C == 32 && cfg->d_hidden == 32 && cfg->n_blocks == 0) rc = launch_bwd<32, 32, 0>(bp, grid, s);
-  else if (cfg->C == 32 && cfg->d_hidden == 32 && cfg->n_blocks == 1) rc = launch_bwd<32, 32, 1>(bp, grid, s);
-  if (rc == BTS_OK && bp.gh_ws) rc = cfg->d_hidden == 64 ? launch_scatter<64>(bp, cfg->n, s) : launch_scatter<32>(bp, cfg->n, s);
+#else
+  constexpr bool rows_always = false;
+#endif
+  bp.f.lpr = 64, bp.f.groups = (long)cfg->n * a->rays_per_sample;
+  if (bp.f.groups > 0x7FF00000L) {
+    set_error("%s: too many rays in one call (%ld)", "bts_render_bwd", bp.f.groups);
+    return BTS_E_UNSUPPORTED;
+  }
+  const int grid = render_grid(bp.f);
+  bp.f.chunk_log2 = render_chunk_log2(grid);
+  const size_t samples = (size_t)cfg->n * a->rays_per_sample * a->K;
+  int rc;
+  if (bits_path(cfg, a) && !rows_always) {
+    bp.gs_ws = static_cast<float*>(workspace);
+    bp.mask_ws = reinterpret_cast<unsigned*>(bp.gs_ws + samples);
+    bp.pmask_ws = reinterpret_cast<uint2*>(bp.mask_ws + samples * (cfg->d_hidden / 32));
+    rc = launch_bwd_rows(bp, cfg->C, cfg->d_hidden, cfg->n, grid, s);
+  } else {
+    float* u0_ws = static_cast<float*>(workspace);          // (rays, K, d_hidden): rows first, they are read as 16-byte pieces
+    bp.gs_ws = u0_ws + samples * (size_t)cfg->d_hidden;     // (rays, K)
+    rc = launch_bwd_blocks(bp, u0_ws, cfg->C, cfg->d_hidden, cfg->n_blocks, cfg->n, grid, s);
+  }
   if (rc != BTS_E_UNSUPPORTED) return rc;
   set_error("%s: unsupported MLP shape C=%ld d_hidden=%ld n_blocks=%ld", "bts_render_bwd", cfg->C, cfg->d_hidden, cfg->n_blocks);
-  return BTS_E_UNSUPPORTED;
+  return rc;
 }
 
 }  // namespace bts

@@ -1,0 +1,658 @@
+// Backward of the fused renderer, lane = SAMPLE form, general case: ResnetBlockFC layers (the RE10K model) and / or more than 64
+// samples per ray.  Replaces the round-1 lane = ray kernel (bts_bwd.hip, one wave per SIMD, 0.08 of peak) for every shape the
+// gate-bit passes of bts_bwd_rows.hip do not cover.
+//
+// The factorisation of bts_bwd_rows.hip survives the blocks: with the relu gates m0 (lin_in output h0),
+// mn (fc_0 output n) and m1 (block output h1) the gradient of EVERY layer is g_s (the gradient at the pre-softplus density, one
+// float per sample) times a vector that depends on the gates only:
+//     v1 = m1 . w_out                       g_h1 = g_s v1            (lin_out, resnetfc.py:183)
+//     vn = mn . (W1^T v1)                   g_n  = g_s vn            (fc_1,    resnetfc.py:53-62)
+//     v0 = v1 + m0 . (W0^T vn)              g_h0 = g_s v0            (fc_0 + the residual path)
+//   pass A  rowsb_kernel       one ray per wave iteration (64 samples at a time, chunks of a long ray back to front with the suffix
+//                              sum carried), lane = sample: the FORWARD's pipeline (f16-split lin_in, gather through LDS, f16 block
+//                              layers) recomputes h0, n, h1 bit-identically, the compositing gradient is a suffix scan across the
+//                              lanes, the two transposed mat-vecs run on the matrix pipe in the C layout (the accumulator layout of
+//                              one layer IS the B operand of the next), and u0 = g_s v0 goes to the workspace as one 4 d_hidden
+//                              byte row per sample (storage order of G).  The fc_0 / fc_1 weight gradients need the activations
+//                              themselves: dW1 = sum g_h1 (x) relu(n), dW0 = sum g_n (x) relu(h0) are contracted right here --
+//                              both operands of a point tile transposed through the wave's (idle) gather ring, fp32 MFMA, two
+//                              persistent 32x32 accumulators per wave.  dw_out, db_out, db_0, db_1 ride along.
+//   pass B  scatter_kernel     (bts_bwd_rows.hip, ROWS form) dG += w_tap u0: the sliding LDS texel window, rows instead of gate bits
+//   pass C  dwpe_rows_kernel   (bts_bwd_rows.hip) dW_pe, db_in = sum u0 (x) [pe, 1]: u0 rows straight from the workspace as the A
+//                              operand (lane = channel reads its channel of sample k: no transposition), encoding recomputed.
+// What torch.autograd would do for nerf.py:283-299 + models_bts.py:266-338 + resnetfc.py:53-62, 132-184 of the reference.
+#define BTS_NO_LAUNCH_GLUE
+#include "bts_render_kernel.h"
+#include "bts_bwd.h"
+#include <cstdlib>
+#include <type_traits>
+
+namespace bts {
+
+#ifndef BTS_GATHER_LDS
+#error "bts_bwd_blocks.hip is written against the LDS gather (the wave's gather ring doubles as its transposition tiles)"
+#endif
+
+// fp32 weights of this pass in LDS: the encoding rows of lin_in (k-major: the cold path's A operand), w_out, the projected empty
+// feature, and per block fc_0 / fc_1 ROW-major ([out][in] = nn.Linear.weight: the A operand of the transposed products W^T g)
+template <int HD, int NB>
+struct LdsB {
+  static constexpr int PE_ROWS = kPeDim + 1;
+  static constexpr int W_IN = 0;                       // [40][HD] k-major, kernel input order (kernel_to_ref_input)
+  static constexpr int W_OUT = W_IN + PE_ROWS * HD;    // [HD]
+  static constexpr int EMPTY = W_OUT + HD;             // [HD] projected empty feature (unscaled)
+  static constexpr int BLK = EMPTY + HD;               // per block: w0 [HD][HD], w1 [HD][HD] row-major
+  static constexpr int BLK_STRIDE = 2 * HD * HD;
+  static constexpr int TOTAL = BLK + NB * BLK_STRIDE;
+};
+
+template <int C, int HD, int NB>
+__device__ __forceinline__ void stage_weights_b(float* lb, const float* __restrict__ mlp, const float* __restrict__ empty) {
+  using L = LdsB<HD, NB>;
+  constexpr int D_IN = C + kPeDim;
+  const MlpLayout ml{D_IN, HD, NB};
+  for (int i = threadIdx.x; i < L::PE_ROWS * HD; i += blockDim.x) {
+    const int k = i / HD, hid = i % HD;
+    const int src = kernel_to_ref_input<C>(k + C);   // -1: bias row
+    lb[L::W_IN + i] = src >= 0 ? mlp[ml.w_in() + hid * D_IN + src] : mlp[ml.b_in() + hid];
+  }
+  for (int i = threadIdx.x; i < HD; i += blockDim.x) lb[L::W_OUT + i] = mlp[ml.w_out() + i];
+  for (int hid = threadIdx.x; hid < HD; hid += blockDim.x) {
+    float a = 0.0f;
+    if (empty)
+      for (int c = 0; c < C; ++c) a = __builtin_fmaf(mlp[ml.w_in() + hid * D_IN + c], empty[c], a);
+    lb[L::EMPTY + hid] = a;
+  }
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    float* base = lb + L::BLK + b * L::BLK_STRIDE;
+    for (int i = threadIdx.x; i < HD * HD; i += blockDim.x) {
+      base[i] = mlp[ml.blk_w0(b) + i];
+      base[HD * HD + i] = mlp[ml.blk_w1(b) + i];
+    }
+  }
+}
+
+__device__ __forceinline__ void wave_lds_fence() {   // lanes exchange data through LDS without a barrier: pin the order for the compiler
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// sum over the 32 lanes of each wave half of 16 registers at once (see bts_bwd_rows.hip): afterwards both lanes of the pair
+// (col, col ^ 1) hold the total of register col >> 1
+__device__ __forceinline__ float half_reduce16(float (&w)[16], int col) {
+  int d = 16;
+#pragma unroll
+  for (int n = 16; n > 1; n >>= 1) {
+    const bool up = (col & d) != 0;
+#pragma unroll
+    for (int j = 0; j < n / 2; ++j) {
+      float lo = w[j], hi = w[n / 2 + j];
+      asm("" : "+v"(lo), "+v"(hi));   // opaque values: keep the selects on values, not on a dynamically indexed array
+      const float keep = up ? hi : lo;
+      const float give = up ? lo : hi;
+      w[j] = keep + __shfl_xor(give, d, 64);
+    }
+    d >>= 1;
+  }
+  return w[0] + __shfl_xor(w[0], 1, 64);
+}
+
+// Cold path (see eval_point_exact in bts_render_kernel.h): some sample's encoding argument leaves the fast sincos range.  lin_in's
+// output h0 of the wave's 64 samples with libm sines and fp32-input MFMAs, as the forward evaluated it, written as
+// tile[point of tile PT][hidden] (leading dimension HD + 1) -- one point tile per call: the tile lives in the wave's gather ring.
+// Out of line: inlined, its 36 libm sines cost the hot path > 200 spilled VGPRs.
+template <int C, int HD, int NB>
+__device__ __attribute__((noinline)) void lin_in_exact(const float* lb, const float4* G, const float* w2c, const float* Kc, int H, int W,
+                                                       int code_mode, int inv_z, float inv_dmax, float inv_range, float d_min, float range,
+                                                       float freq_factor, int learn_empty, float px, float py, float pz, float* tile, int pt_sel) {
+  using L = LdsB<HD, NB>;
+  constexpr int HT = HD / 32;
+  const int lane = threadIdx.x & 63, h = lane >> 5, col = lane & 31;
+  const Cam enc = load_cam(w2c, Kc);
+  const Proj pe = code_mode == 1 ? project<true>(enc, px, py, pz) : project<false>(enc, px, py, pz);
+  const Taps tp = make_taps(pe.x, pe.y, H, W);
+  float v3[3];
+  v3[0] = pe.x, v3[1] = pe.y;
+  v3[2] = depth_code(code_mode == 1 ? pe.dist : pe.z, inv_z != 0, inv_dmax, inv_range, d_min, range);
+  const bool use_empty = (learn_empty != 0) & pe.invalid;
+  f32x16 acc[HT][2];
+#pragma unroll
+  for (int ht = 0; ht < HT; ++ht)
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt) acc[ht][pt] = zero_acc();
+  int o[2][4];
+  float wq[2][4];
+  bool emp[2];
+  unsigned t0, t1;
+  bcast_tiles((unsigned)tp.o00, t0, t1), o[0][0] = (int)t0, o[1][0] = (int)t1;
+  bcast_tiles((unsigned)tp.o01, t0, t1), o[0][1] = (int)t0, o[1][1] = (int)t1;
+  bcast_tiles((unsigned)tp.o10, t0, t1), o[0][2] = (int)t0, o[1][2] = (int)t1;
+  bcast_tiles((unsigned)tp.o11, t0, t1), o[0][3] = (int)t0, o[1][3] = (int)t1;
+  bcast_tiles(__float_as_uint(tp.w00), t0, t1), wq[0][0] = __uint_as_float(t0), wq[1][0] = __uint_as_float(t1);
+  bcast_tiles(__float_as_uint(tp.w01), t0, t1), wq[0][1] = __uint_as_float(t0), wq[1][1] = __uint_as_float(t1);
+  bcast_tiles(__float_as_uint(tp.w10), t0, t1), wq[0][2] = __uint_as_float(t0), wq[1][2] = __uint_as_float(t1);
+  bcast_tiles(__float_as_uint(tp.w11), t0, t1), wq[0][3] = __uint_as_float(t0), wq[1][3] = __uint_as_float(t1);
+  bcast_tiles(use_empty ? 1u : 0u, t0, t1), emp[0] = t0 != 0, emp[1] = t1 != 0;
+  {
+    GBuf ga, gb;
+    gload<HD>(ga, G, o[0], 0, 4 * h);
+    gather_seq<HD, 0>(acc, ga, gb, G, o, wq, h);
+  }
+  if (learn_empty && __any(use_empty)) apply_empty<HD>(acc, emp, lb + L::EMPTY, h);
+  const float* wl = lb + L::W_IN + h * HD + col;
+  kstep<HD>(acc, wl, 0, v3[0], v3[1]);
+  kstep<HD>(acc, wl + 2 * HD, 0, v3[2], 1.0f);
+  wl += 4 * HD;
+  float ff = freq_factor;
+#pragma unroll 1
+  for (int oct = 0; oct < kNumFreqs; ++oct) {
+    float sc[6];
+    pe_octave(sc, v3, ff);
+    kstep<HD>(acc, wl, 0, sc[0], sc[1]);
+    kstep<HD>(acc, wl + 2 * HD, 0, sc[2], sc[3]);
+    kstep<HD>(acc, wl + 4 * HD, 0, sc[4], sc[5]);
+    wl += 6 * HD;
+    ff = ff * 2.0f;
+  }
+#pragma unroll
+  for (int ht = 0; ht < HT; ++ht)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const float v = pt_sel ? acc[ht][1][q] : acc[ht][0][q];
+      tile[col * (HD + 1) + ht * 32 + mfma_row(q, h)] = v;
+    }
+}
+
+struct RowsbOut {
+  float* u0_ws;   // (n*Bp, K, HD) g_h0 = gradient at lin_in's output, channels in the storage order of G
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// pass A
+// ---------------------------------------------------------------------------------------------------------------
+template <int C, int HD, int NB, int NVMAX>
+__global__ __launch_bounds__(256, 2) void rowsb_kernel(const BwdParams bp, const RowsbOut ro) {
+  static_assert(NB == 0 || HD == 32, "ResnetBlockFC layers are laid out for d_hidden = 32 (the RE10K model)");
+  const FwdParams& p = bp.f;
+  using L = LdsB<HD, NB>;
+  using LH = LdsH<C, HD, NB>;
+  constexpr int HT = HD / 32;
+  constexpr int NS = 4 * HT;
+  constexpr int LB_PAD = (L::TOTAL + 3) & ~3;
+  __shared__ __attribute__((aligned(16))) float lds[LB_PAD + LH::TOTAL + 4];
+  float* const lh = lds + LB_PAD;   // 16-byte aligned: the f16 A operands are read as ds_read_b128
+  stage_weights_b<C, HD, NB>(lds, p.mlp, p.empty_feature);
+  __syncthreads();
+  stage_weights_h<C, HD, NB>(lh, lds + L::EMPTY, p.mlp);
+  __syncthreads();
+  const float scale = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, lh[LH::SCALE])));
+  const float inv_scale = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, lh[LH::SCALE + 1])));
+
+  const int lane = threadIdx.x & 63;
+  const int h0 = lane >> 5;
+  const int col = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  extern __shared__ __attribute__((aligned(128))) char gather_lds[];   // per wave: ring of 3 x 4 KB + 768 B tap table (render_kernel_p)
+  GatherLds gl;
+  {
+    char* base = gather_lds + wave * kGatherLdsPerWave;
+    gl.ring = base;
+    gl.ring_m0 = (unsigned)(unsigned long)base;
+    gl.tab = reinterpret_cast<unsigned*>(base + 3 * 4096);
+    gl.m = lane >> 3;
+    gl.piece16 = 16u * (unsigned)(((lane & 7) + (lane >> 4)) & 7);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) gl.rd[q] = (unsigned)(col * 128 + ((4 * h0 + q - ((col & 7) >> 1)) & 7) * 16);
+  }
+  // the ring is idle between the last gather block of a ray and the first of the next: its memory serves as the transposition
+  // tiles of the weight-gradient contraction ([32 points][33] x 2) and as the cold path's h0 tile ([32 points][HD + 1])
+  float* const tile_a = reinterpret_cast<float*>(gather_lds + wave * kGatherLdsPerWave);
+  float* const tile_b = tile_a + 32 * 33;
+  static_assert(2 * 32 * 33 * 4 <= 3 * 4096 && 32 * (HD + 1) * 4 <= 3 * 4096, "tiles must fit the wave's gather ring");
+
+  const int nwg = gridDim.x;  // multiple of 8
+  const int wg = xcd_remap(blockIdx.x, nwg);
+  const int wg_per_xcd = nwg >> 3;
+  const int xcd = wg / wg_per_xcd;
+  const int lw = (wg - xcd * wg_per_xcd) * 4 + wave;
+  const int waves_per_xcd = wg_per_xcd * 4;
+  // chunk-interleaved ray distribution over the XCDs, as render_kernel_p (one group = one ray here)
+  const int CHL = p.chunk_log2;
+  const int n_groups = (int)p.groups;
+  const int n_chunks = (n_groups + (1 << CHL) - 1) >> CHL;
+  auto group_of = [&](int idx) -> int {
+    const int c = ((idx >> CHL) << 3) + xcd;
+    const int gg = (c << CHL) + (idx & ((1 << CHL) - 1));
+    return (c < n_chunks && gg < n_groups) ? gg : -1;
+  };
+  const int Bp = p.Bp, K = p.K, H = p.H, W = p.W, nv = p.nv;
+  const int kc_last = ((K - 1) >> 6) << 6;   // first sample of the last 64-sample chunk of a ray: chunks are walked back to front
+
+  // persistent per-wave gradient state
+  float dw_acc[HT], db_acc = 0.0f;   // this lane's share of dw_out (see dw_out below) and of db_out
+#pragma unroll
+  for (int ht = 0; ht < HT; ++ht) dw_acc[ht] = 0.0f;
+  f32x16 dwb[NB > 0 ? NB : 1][2];    // per block: dW0 [out][in], dW1 [out][in] as 32x32 accumulator tiles
+  float dbb[NB > 0 ? NB : 1][2];     // per block: this lane's share of db0 / db1 (channel col, samples of its lane half)
+#pragma unroll
+  for (int b = 0; b < (NB > 0 ? NB : 1); ++b)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) dwb[b][j] = zero_acc(), dbb[b][j] = 0.0f;
+
+  int sample_end = Bp;
+  int sample = 0;
+  int idx = lw;
+  int g = group_of(idx);
+  float z_pre = 0.0f, zn_pre = 0.0f, s_pre = 0.0f, t_pre = 0.0f;
+  auto fetch_state = [&](int gg, int kc) {   // the per-sample state of chunk kc of ray gg
+    const int k = kc + lane;
+    const int kk = k < K ? k : K - 1;
+    const long pk = (long)gg * K + kk;
+    z_pre = p.z_samp[pk], zn_pre = p.z_samp[(long)gg * K + min(kk + 1, K - 1)];
+    s_pre = p.sigma_raw[pk], t_pre = p.trans[pk];
+  };
+  if (g >= 0) fetch_state(g, kc_last);
+
+  for (; g >= 0; idx += waves_per_xcd, g = group_of(idx)) {
+    const long ray = g;
+    while (g >= sample_end) ++sample, sample_end += Bp;
+    const Cam enc = load_cam(p.w2c_enc + sample * 16, p.K_enc + sample * 9);
+    const float4* __restrict__ G = reinterpret_cast<const float4*>(p.proj) + (long)sample * H * W * (HD / 4);
+    const cfp rp = as_const(p.rays) + ray * 8;
+    const float ox = rp[0], oy = rp[1], oz = rp[2], dx = rp[3], dy = rp[4], dz = rp[5];
+    // upstream gradients of the ray
+    float g_rgb[NVMAX * 3];
+    float g_bkgd = 0.0f;
+    {
+      const cfp gr = as_const(bp.g_rgb) + ray * (long)(nv * 3);
+#pragma unroll
+      for (int i = 0; i < NVMAX * 3; ++i) {
+        g_rgb[i] = (bp.g_rgb && i < nv * 3) ? gr[i] : 0.0f;
+        g_bkgd -= g_rgb[i];
+      }
+    }
+    const float g_depth = bp.g_depth ? as_const(bp.g_depth)[ray] : 0.0f;
+    float S_carry = 0.0f;   // sum over the samples of the chunks behind this one of g_w w
+
+    for (int kc = kc_last; kc >= 0; kc -= 64) {
+      const int k = kc + lane;
+      const bool valid = k < K;
+      const int kk = valid ? k : K - 1;
+      const bool last = k == K - 1;
+      const long pk = ray * K + kk;
+      const float z = z_pre, z_nx = zn_pre, s_raw = s_pre, T = t_pre;
+      {  // the state of the chunk evaluated next lands while this one is evaluated
+        if (kc > 0) {
+          fetch_state(g, kc - 64);
+        } else {
+          const int gn = group_of(idx + waves_per_xcd);
+          if (gn >= 0) fetch_state(gn, kc_last);
+        }
+      }
+      int h = h0;
+      asm volatile("" : "+v"(h));   // keep the weight reads inside the persistent loop (see render_kernel_p)
+      const float px = ox + z * dx, py = oy + z * dy, pz = oz + z * dz;
+
+      // ---------------- upstream gradient of this sample's weight: g_w = g_depth z + sum_j g_rgb_j . c_kj (+ g_weights_k)
+      float g_w = g_depth * z;
+      {
+        if (p.white_bkgd) g_w += g_bkgd;   // nerf.py:301-304: rgb = sum_k w_k c_k + 1 - sum_k w_k
+        if (bp.g_weights) g_w += bp.g_weights[pk];
+        if (p.rgb_samps) {
+          const float* cs = p.rgb_samps + pk * (long)(nv * 3);
+#pragma unroll
+          for (int j = 0; j < NVMAX; ++j)
+            if (j < nv) g_w += g_rgb[3 * j] * cs[3 * j] + g_rgb[3 * j + 1] * cs[3 * j + 1] + g_rgb[3 * j + 2] * cs[3 * j + 2];
+        } else {
+#pragma unroll
+          for (int j = 0; j < NVMAX; ++j) {
+            if (j < nv) {
+              const Cam cj = load_cam(p.w2c_r + ((long)sample * nv + j) * 16, p.K_r + ((long)sample * nv + j) * 9);
+              const Proj pc = project<false>(cj, px, py, pz);
+              const Taps tc = make_taps(pc.x, pc.y, H, W);
+              const float4* img = reinterpret_cast<const float4*>(p.imgs) + ((long)sample * nv + j) * H * W;
+              const float4 a = img[tc.o00], b = img[tc.o01], cc = img[tc.o10], d = img[tc.o11];
+              const float c0 = ((a.x * tc.w00 + b.x * tc.w01) + cc.x * tc.w10) + d.x * tc.w11;
+              const float c1 = ((a.y * tc.w00 + b.y * tc.w01) + cc.y * tc.w10) + d.y * tc.w11;
+              const float c2 = ((a.z * tc.w00 + b.z * tc.w01) + cc.z * tc.w10) + d.z * tc.w11;
+              g_w += g_rgb[3 * j] * c0 + g_rgb[3 * j + 1] * c1 + g_rgb[3 * j + 2] * c2;
+            }
+          }
+        }
+      }
+
+      // ---------------- encoder view
+      const Proj pe = p.code_mode == 1 ? project<true>(enc, px, py, pz) : project<false>(enc, px, py, pz);
+      Taps tp = make_taps(pe.x, pe.y, H, W);
+      float v3[3];
+      v3[0] = pe.x, v3[1] = pe.y;
+      v3[2] = depth_code(p.code_mode == 1 ? pe.dist : pe.z, p.inv_z != 0, p.inv_dmax, p.inv_range, p.d_min, p.range);
+      const bool use_empty = (p.learn_empty != 0) & pe.invalid;
+      if (use_empty) tp.w00 = tp.w01 = tp.w10 = tp.w11 = 0.0f;
+      tp.w00 *= scale, tp.w01 *= scale, tp.w10 *= scale, tp.w11 *= scale;
+
+      float wq[2][4];
+      bool emp[2];
+      {
+        unsigned t0, t1;
+        bcast_tiles(__float_as_uint(tp.w00), t0, t1), wq[0][0] = __uint_as_float(t0), wq[1][0] = __uint_as_float(t1);
+        bcast_tiles(__float_as_uint(tp.w01), t0, t1), wq[0][1] = __uint_as_float(t0), wq[1][1] = __uint_as_float(t1);
+        bcast_tiles(__float_as_uint(tp.w10), t0, t1), wq[0][2] = __uint_as_float(t0), wq[1][2] = __uint_as_float(t1);
+        bcast_tiles(__float_as_uint(tp.w11), t0, t1), wq[0][3] = __uint_as_float(t0), wq[1][3] = __uint_as_float(t1);
+        bcast_tiles(use_empty ? 1u : 0u, t0, t1), emp[0] = t0 != 0, emp[1] = t1 != 0;
+      }
+      const bool cold = __any(pe_needs_exact(v3, p.freq_factor));
+      unsigned off_next[4];
+      GRows rows;
+      if (__builtin_expect(!cold, 1)) {
+        // the previous iteration's tile reads have returned (s_waitcnt at its end): the ring may be overwritten
+        wave_lds_fence();
+        gl.tab[lane * 3 + 0] = (unsigned)tp.o00 * (HD * 4u), gl.tab[lane * 3 + 1] = (unsigned)tp.o01 * (HD * 4u), gl.tab[lane * 3 + 2] = (unsigned)tp.o10 * (HD * 4u);   // o11 = o10 + (o01 - o00)
+        wave_lds_fence();
+        gl_prologue<HD>(gl, rows, G, off_next);
+      }
+
+      // ---------------- compositing gradient (nerf.py:283-299):  g_alpha_k = g_w_k T_k - (sum_{m>k} g_w_m w_m) / (1 - alpha_k + 1e-10)
+      float g_s = 0.0f;
+      {
+        float sigma = softplus(s_raw);
+        const bool dead = (p.empty_empty != 0) & pe.invalid;   // sigma forced to 0: no gradient
+        if (dead) sigma = 0.0f;
+        const float delta = last ? 1e10f : (z_nx - z);
+        const float ex = expf(-fabsf(delta) * fmaxf(sigma, 0.0f));
+        const bool capped = (p.hard_cap != 0) & last;
+        const float alpha = capped ? 1.0f : 1.0f - ex;
+        const float gww = valid ? g_w * (alpha * T) : 0.0f;
+        // exclusive suffix sum over the wave + the chunks behind; the wave's total moves on to the chunk in front
+        float incl = gww;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+          const float y = __shfl_down(incl, off, 64);
+          incl += (lane + off < 64) ? y : 0.0f;
+        }
+        const float below = __shfl_down(incl, 1, 64);
+        const float S = (lane == 63 ? 0.0f : below) + S_carry;
+        S_carry += __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, incl)));
+        float g_alpha = g_w * T - S / (capped ? 1e-10f : ex + 1e-10f);
+        if (bp.g_alphas) g_alpha += bp.g_alphas[pk];
+        if (!capped && !dead && valid) g_s = g_alpha * fabsf(delta) * ex * (s_raw > 20.0f ? 1.0f : sigmoidf(s_raw));
+        if (valid) bp.gs_ws[pk] = g_s;
+      }
+      db_acc += g_s;
+
+      // ---------------- h0 = bilinear(G) + W_pe . PE + b, exactly as render_kernel_p evaluates it (accumulators carry 2^S)
+      f32x16 acc[HT][2];
+      if (__builtin_expect(cold, 0)) {
+        // no gather is in flight (the prologue above was skipped).  One point tile per call: the tile lives in the wave's gather ring
+        wave_lds_fence();
+        lin_in_exact<C, HD, NB>(lds, G, p.w2c_enc + sample * 16, p.K_enc + sample * 9, H, W, p.code_mode, p.inv_z, p.inv_dmax, p.inv_range,
+                                p.d_min, p.range, p.freq_factor, p.learn_empty, px, py, pz, tile_a, 0);
+        wave_lds_fence();
+#pragma unroll
+        for (int ht = 0; ht < HT; ++ht)
+#pragma unroll
+          for (int q = 0; q < 16; ++q) acc[ht][0][q] = tile_a[col * (HD + 1) + ht * 32 + mfma_row(q, h)] * scale;
+        wave_lds_fence();
+        lin_in_exact<C, HD, NB>(lds, G, p.w2c_enc + sample * 16, p.K_enc + sample * 9, H, W, p.code_mode, p.inv_z, p.inv_dmax, p.inv_range,
+                                p.d_min, p.range, p.freq_factor, p.learn_empty, px, py, pz, tile_a, 1);
+        wave_lds_fence();
+#pragma unroll
+        for (int ht = 0; ht < HT; ++ht)
+#pragma unroll
+          for (int q = 0; q < 16; ++q) acc[ht][1][q] = tile_a[col * (HD + 1) + ht * 32 + mfma_row(q, h)] * scale;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      } else {
+        f32x16 bias[HT];
+        {
+          const float* bl = lh + LH::W_RAW + 3 * HD + 4 * h;
+#pragma unroll
+          for (int ht = 0; ht < HT; ++ht)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const float4 v = *reinterpret_cast<const float4*>(bl + ht * 32 + 8 * j);
+              bias[ht][4 * j + 0] = v.x, bias[ht][4 * j + 1] = v.y, bias[ht][4 * j + 2] = v.z, bias[ht][4 * j + 3] = v.w;
+            }
+        }
+        SinCos3 raw;
+        pe_direct(raw, v3, p.freq_factor);
+        __builtin_amdgcn_sched_barrier(0);
+        int lane4 = lane * 4;
+        asm volatile("" : "+v"(lane4));
+        region_seq_l<HD, 0>(acc, gl, rows, G, wq, off_next, lh + LH::W_F16 + lane4, LH::TERM_STRIDE, raw, v3, p.freq_factor, bias);
+        if constexpr (NS > kNumFreqs) {
+          gl_consume<HD, 12>(acc, gl, rows, G, wq, off_next), gl_consume<HD, 13>(acc, gl, rows, G, wq, off_next);
+          gl_consume<HD, 14>(acc, gl, rows, G, wq, off_next), gl_consume<HD, 15>(acc, gl, rows, G, wq, off_next);
+        }
+        if (p.learn_empty && __any(use_empty)) {
+#pragma unroll
+          for (int ht = 0; ht < HT; ++ht)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+              const float ev = lh[LH::EMPTY + ht * 32 + mfma_row(q, 0) + 4 * h];
+#pragma unroll
+              for (int pt = 0; pt < 2; ++pt) acc[ht][pt][q] += emp[pt] ? ev : 0.0f;
+            }
+        }
+      }
+
+      // ---------------- ResnetBlockFC layers, forward (as render_kernel_p): keep the block's input h0 and its inner activation n
+      f32x16 hin[NB > 0 ? NB : 1][2], net[NB > 0 ? NB : 1][2];
+      int lane4b = lane * 4;
+      asm volatile("" : "+v"(lane4b));
+      if constexpr (NB > 0) {
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        hin[b][0] = acc[0][0], hin[b][1] = acc[0][1];
+        f32x16 nt[1][2];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const float bias = lh[LH::BIAS + b * 2 * HD + mfma_row(q, 0) + 4 * h];
+          nt[0][0][q] = bias, nt[0][1][q] = bias;
+        }
+        hidden_layer_h(nt, acc, lh + LH::W_BLK + (2 * b) * LH::BLK_LAYER_STRIDE + lane4b, LH::BLK_TERM_STRIDE, inv_scale);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const float bias = lh[LH::BIAS + b * 2 * HD + HD + mfma_row(q, 0) + 4 * h];
+          acc[0][0][q] += bias, acc[0][1][q] += bias;
+        }
+        hidden_layer_h(acc, nt, lh + LH::W_BLK + (2 * b + 1) * LH::BLK_LAYER_STRIDE + lane4b, LH::BLK_TERM_STRIDE, inv_scale);
+        net[b][0] = nt[0][0], net[b][1] = nt[0][1];
+      }
+      }
+
+      // ---------------- g_s of both point tiles; dw_out += relu(h1) g_s (2^S removed through g_s); v = m1 . w_out
+      float gs_t[2];
+      {
+        unsigned t0, t1;
+        bcast_tiles(__float_as_uint(g_s), t0, t1);
+        gs_t[0] = __uint_as_float(t0), gs_t[1] = __uint_as_float(t1);
+      }
+      f32x16 v[HT][2];   // the gate-dependent vector of the current layer, true scale (g_h = g_s v)
+#pragma unroll
+      for (int ht = 0; ht < HT; ++ht) {
+        float r[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const float w2 = lds[L::W_OUT + ht * 32 + mfma_row(q, 0) + 4 * h];
+          const float a0 = acc[ht][0][q], a1 = acc[ht][1][q];
+          r[q] = __builtin_fmaf(relu1(a1), gs_t[1] * inv_scale, relu1(a0) * (gs_t[0] * inv_scale));
+          v[ht][0][q] = a0 > 0.0f ? w2 : 0.0f;
+          v[ht][1][q] = a1 > 0.0f ? w2 : 0.0f;
+        }
+        // dw_acc[ht] belongs to channel ht*32 + mfma_row(col >> 1, h), on both lanes of the pair
+        dw_acc[ht] += half_reduce16(r, col);
+      }
+
+      // ---------------- back through the blocks (resnetfc.py:53-62): h1 = h0 + fc_1(relu(n)), n = fc_0(relu(h0))
+      if constexpr (NB > 0) {
+      int lane_o = lane;
+      asm volatile("" : "+v"(lane_o));   // opaque per iteration: the 32 weight reads of a transposed product stay inside the persistent loop
+#pragma unroll
+      for (int b = NB - 1; b >= 0; --b) {
+        const float* rw = lds + L::BLK + b * L::BLK_STRIDE;
+        // t = W1^T v  (fp32-input MFMA: the C layout of v is the B operand)
+        f32x16 vn[1][2];
+        vn[0][0] = zero_acc(), vn[0][1] = zero_acc();
+        {
+          f32x16 vin[1][2];
+          vin[0][0] = v[0][0], vin[0][1] = v[0][1];
+          hidden_layer<HD, false>(vn, vin, rw + HD * HD, lane_o);
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+#pragma unroll
+          for (int pt = 0; pt < 2; ++pt) vn[0][pt][q] = net[b][pt][q] > 0.0f ? vn[0][pt][q] : 0.0f;
+        if (bp.d_mlp) {
+          // dW1[out][in] += sum_p (g_s v)[p][out] relu(n)[p][in];  db1[out] += sum_p (g_s v)[p][out]
+#pragma unroll
+          for (int pt = 0; pt < 2; ++pt) {
+            wave_lds_fence();
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+              tile_a[col * 33 + mfma_row(q, h)] = v[0][pt][q] * gs_t[pt];
+              tile_b[col * 33 + mfma_row(q, h)] = relu1(net[b][pt][q]) * inv_scale;
+            }
+            wave_lds_fence();
+#pragma unroll 4
+            for (int s = 0; s < 16; ++s) {
+              const int pnt = 2 * s + h;
+              const float a = tile_a[pnt * 33 + col];
+              dbb[b][1] += a;
+              dwb[b][1] = mfma(a, tile_b[pnt * 33 + col], dwb[b][1]);
+            }
+          }
+        }
+        // t2 = W0^T vn;  v <- v + m0 . t2
+        f32x16 t2[1][2];
+        t2[0][0] = zero_acc(), t2[0][1] = zero_acc();
+        hidden_layer<HD, false>(t2, vn, rw, lane_o);
+        if (bp.d_mlp) {
+          // dW0[out][in] += sum_p (g_s vn)[p][out] relu(h0)[p][in];  db0[out] += sum_p (g_s vn)[p][out]
+#pragma unroll
+          for (int pt = 0; pt < 2; ++pt) {
+            wave_lds_fence();
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+              tile_a[col * 33 + mfma_row(q, h)] = vn[0][pt][q] * gs_t[pt];
+              tile_b[col * 33 + mfma_row(q, h)] = relu1(hin[b][pt][q]) * inv_scale;
+            }
+            wave_lds_fence();
+#pragma unroll 4
+            for (int s = 0; s < 16; ++s) {
+              const int pnt = 2 * s + h;
+              const float a = tile_a[pnt * 33 + col];
+              dbb[b][0] += a;
+              dwb[b][0] = mfma(a, tile_b[pnt * 33 + col], dwb[b][0]);
+            }
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+#pragma unroll
+          for (int pt = 0; pt < 2; ++pt) v[0][pt][q] += hin[b][pt][q] > 0.0f ? t2[0][pt][q] : 0.0f;
+      }
+      }
+
+      // ---------------- u0 = g_s v: the gradient at lin_in's output, one row per sample in the storage order of G (this lane's 16
+      // accumulator rows of a hidden tile are 64 contiguous bytes of the row)
+      if (ro.u0_ws) {
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt) {
+          const int ks = kc + pt * 32 + col;
+          if (ks < K) {
+            float4* dst = reinterpret_cast<float4*>(ro.u0_ws + (ray * K + ks) * (long)HD);
+#pragma unroll
+            for (int ht = 0; ht < HT; ++ht)
+#pragma unroll
+              for (int j = 0; j < 4; ++j)
+                dst[ht * 8 + 4 * h + j] = make_float4(v[ht][pt][4 * j] * gs_t[pt], v[ht][pt][4 * j + 1] * gs_t[pt], v[ht][pt][4 * j + 2] * gs_t[pt],
+                                                      v[ht][pt][4 * j + 3] * gs_t[pt]);
+          }
+        }
+      }
+      // the tile reads of this iteration must have returned before the next iteration's gather lands in the ring
+      if constexpr (NB > 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+  }
+
+  // ---------------- flush: wave registers -> work-group LDS (the gather rings, idle now) -> one global atomic per parameter
+  __syncthreads();
+  if (bp.d_mlp) {
+    float* red = reinterpret_cast<float*>(gather_lds);   // [HD + 1] dw_out, db_out; per block: dW0 [HD][HD], db0 [HD], dW1 [HD][HD], db1 [HD]
+    constexpr int RED_BLK = HD + 1, RED_BLK_STRIDE = 2 * HD * HD + 2 * HD;
+    constexpr int RED_TOTAL = RED_BLK + NB * RED_BLK_STRIDE;
+    static_assert(RED_TOTAL * 4 <= 4 * kGatherLdsPerWave, "reduction buffer must fit the work-group's gather rings");
+    for (int i = threadIdx.x; i < RED_TOTAL; i += blockDim.x) red[i] = 0.0f;
+    __syncthreads();
+    if ((lane & 1) == 0) {
+#pragma unroll
+      for (int ht = 0; ht < HT; ++ht) atomicAdd(&red[ht * 32 + mfma_row(col >> 1, h0)], dw_acc[ht]);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) db_acc += __shfl_xor(db_acc, off, 64);
+    if (lane == 0) atomicAdd(&red[HD], db_acc);
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      float* d = red + RED_BLK + b * RED_BLK_STRIDE;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        float* dw = d + j * (HD * HD + HD);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) atomicAdd(&dw[mfma_row(q, h0) * HD + col], dwb[b][j][q]);   // D[i = out][j = in]
+        atomicAdd(&dw[HD * HD + col], dbb[b][j]);   // both lane halves hold a share of channel col
+      }
+    }
+    __syncthreads();
+    const MlpLayout ml{C + kPeDim, HD, NB};
+    for (int i = threadIdx.x; i <= HD; i += blockDim.x) {
+      const float vv = red[i];
+      if (vv != 0.0f) atomic_add_f32(bp.d_mlp + (i < HD ? ml.w_out() + i : ml.b_out()), vv);
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const float* d = red + RED_BLK + b * RED_BLK_STRIDE;
+      for (int i = threadIdx.x; i < RED_BLK_STRIDE; i += blockDim.x) {
+        const float vv = d[i];
+        if (vv != 0.0f) atomic_add_f32(bp.d_mlp + ml.blk(b) + i, vv);   // packed order: w0, b0, w1, b1 = the LDS order
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// launch
+// ---------------------------------------------------------------------------------------------------------------
+int launch_scatter_rows(const FwdParams& p, const float* gs_ws, const float* u0_ws, float* d_proj, float* d_empty_proj, int HD, int n, hipStream_t s);
+int launch_dwpe_rows(const FwdParams& p, const float* u0_ws, float* d_mlp, int C, int HD, int NB, int n, int grid, hipStream_t s);
+
+template <int C, int HD, int NB>
+static int launch_rowsb(const BwdParams& bp, const RowsbOut& ro, int grid, hipStream_t s) {
+  constexpr int dyn = 4 * kGatherLdsPerWave;
+  auto go = [&](auto kern) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, dyn);
+    kern<<<grid, 256, dyn, s>>>(bp, ro);
+  };
+  if (bp.f.nv <= 1) go(rowsb_kernel<C, HD, NB, 1>);
+  else if (bp.f.nv <= 2) go(rowsb_kernel<C, HD, NB, 2>);
+  else if (bp.f.nv <= 4) go(rowsb_kernel<C, HD, NB, 4>);
+  else go(rowsb_kernel<C, HD, NB, 8>);
+  return hipGetLastError() == hipSuccess ? BTS_OK : BTS_E_LAUNCH;
+}
+
+// bp.gs_ws: (n*Bp, K) floats; u0_ws: (n*Bp, K, HD) floats; p.groups / chunk_log2 / lpr set for one ray per wave iteration
+int launch_bwd_blocks(const BwdParams& bp, float* u0_ws, int C, int HD, int NB, int n, int grid, hipStream_t s) {
+  RowsbOut ro;
+  ro.u0_ws = (bp.d_proj || bp.d_empty_proj || bp.d_mlp) ? u0_ws : nullptr;
+  int rc = BTS_E_UNSUPPORTED;
+  if (C == 64 && HD == 64 && NB == 0) rc = launch_rowsb<64, 64, 0>(bp, ro, grid, s);
+  else if (C == 32 && HD == 32 && NB == 1) rc = launch_rowsb<32, 32, 1>(bp, ro, grid, s);
+  else if (C == 32 && HD == 32 && NB == 0) rc = launch_rowsb<32, 32, 0>(bp, ro, grid, s);
+  if (rc == BTS_OK && (bp.d_proj || bp.d_empty_proj)) rc = launch_scatter_rows(bp.f, bp.gs_ws, u0_ws, bp.d_proj, bp.d_empty_proj, HD, n, s);
+  if (rc == BTS_OK && bp.d_mlp) rc = launch_dwpe_rows(bp.f, u0_ws, bp.d_mlp, C, HD, NB, n, grid, s);
+  if (rc == BTS_E_LAUNCH) set_error("%s: backward kernel launch failed (%ld)", hipGetErrorString(hipGetLastError()), 0);
+  return rc;
+}
+
+}  // namespace bts

@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256, 2) void rows_kernel(const BwdParams bp) {
   float* const lh = lds + ((L::TOTAL + 3) & ~3);
   stage_weights<C, HD, 0, true>(lds, p.mlp, p.empty_feature);
   __syncthreads();
-  stage_weights_h<C, HD, 0>(lh, lds, p.mlp);
+  stage_weights_h<C, HD, 0>(lh, lds + L::EMPTY, p.mlp);
   __syncthreads();
   const float scale = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, lh[LH::SCALE])));
   const float inv_scale = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, lh[LH::SCALE + 1])));
@@ -484,6 +484,7 @@ __global__ __launch_bounds__(256, 2) void rows_kernel(const BwdParams bp) {
 struct ScatterMaskParams {
   FwdParams f;
   const unsigned* mask_ws;   // (n*Bp, HD/32, K) relu gates of lin_in's output, bit j of dword ht = channel ht*32 + j (storage order of G)
+  const float* u0_ws;        // ROWS form (bts_bwd_blocks.hip): (n*Bp, K, HD) gradient rows at lin_in's output instead of gates x w_out x g_s
   const float* gs_ws;        // (n*Bp, K)
   float* d_proj;             // or null: only d_empty
   float* d_empty_proj;       // or null
@@ -507,7 +508,10 @@ __device__ __forceinline__ int wave_min_i(int v) {
   return __builtin_amdgcn_readlane(v, 63);
 }
 
-template <int HD>
+// ROWS = false: g_h[p][ch] = [gate] w_out[ch] g_s[p] from the gate bits (plain MLP, K <= 64).  ROWS = true: g_h rows from the workspace
+// (ResnetBlockFC layers / long rays, bts_bwd_blocks.hip): lane (h, c) keeps channel c of the 32 points of its lane half in registers,
+// fetched one step ahead.
+template <int HD, bool ROWS = false>
 __global__ __launch_bounds__(64) void scatter_kernel(const ScatterMaskParams sp) {
 #ifndef BTS_SCATTER_CW
 #define BTS_SCATTER_CW 12
@@ -540,9 +544,13 @@ __global__ __launch_bounds__(64) void scatter_kernel(const ScatterMaskParams sp)
   const float4 r1 = reinterpret_cast<const float4*>(p.rays)[ray * 2 + 1];
   const float* zrow = p.z_samp + ray * K;
   const float* gsrow = sp.gs_ws + ray * K;
-  const unsigned* mrow = sp.mask_ws + (ray * NW + wv) * K;
+  const unsigned* mrow = ROWS ? nullptr : sp.mask_ws + (ray * NW + wv) * K;
   float* __restrict__ dG = sp.d_proj + (long)sample * H * W * HD + chg;
-  const float w_out_ch = p.mlp[sp.w_out_off + proj_hidden_of_storage(chg)];
+  const float w_out_ch = ROWS ? 0.0f : p.mlp[sp.w_out_off + proj_hidden_of_storage(chg)];
+  // ROWS: channel chg of point i of this lane's half at step k is urow[(i K + k) HD]
+  const float* urow = ROWS ? sp.u0_ws + ((long)sample * Bp + g_in * 64 + 32 * h) * K * HD + chg : nullptr;
+  const int half_pts = min(32, max(0, n_pts - 32 * h));   // points of this lane half that exist
+  const long pstride = (long)K * HD;
   int wx = 0, wy = 0;   // window origin (uniform)
 
   // Evict the slots whose texels lie outside the window at (nwx, nwy): the columns leaving on one side (all rows), then the rows
@@ -597,10 +605,10 @@ __global__ __launch_bounds__(64) void scatter_kernel(const ScatterMaskParams sp)
 
   // one read-modify-write round: this lane's point takes its four taps from the table.  Slots start at multiples of 128 bytes:
   // the lane's channel is or-ed into the address
-  auto round = [&](int pnt) {
+  auto round = [&](int pnt, float row_v) {
     const float4 ww = tab_w[pnt];
     const uint2 sm = tab_sm[pnt];
-    const float gv = (sm.y & cbit) ? w_out_ch : 0.0f;   // g_h = [gate] w_out g_s, g_s rides in the tap weights
+    const float gv = ROWS ? row_v : ((sm.y & cbit) ? w_out_ch : 0.0f);   // g_h = [gate] w_out g_s, g_s rides in the tap weights
     char* const cb = reinterpret_cast<char*>(cache);
     float* c00 = reinterpret_cast<float*>(cb + (((sm.x & 0xFFu) << 7) | c4));
     float* c01 = reinterpret_cast<float*>(cb + ((((sm.x >> 8) & 0xFFu) << 7) | c4));
@@ -614,20 +622,33 @@ __global__ __launch_bounds__(64) void scatter_kernel(const ScatterMaskParams sp)
   };
 
   float z_n = zrow[K - 1], gs_n = ray_ok ? gsrow[K - 1] : 0.0f;
-  unsigned m_n = ray_ok ? mrow[K - 1] : 0u;
+  unsigned m_n = (!ROWS && ray_ok) ? mrow[K - 1] : 0u;
+  constexpr int NROW = ROWS ? 32 : 1;
+  float cur[NROW], nxt[NROW];
+  if constexpr (ROWS) {
+#pragma unroll
+    for (int i = 0; i < 32; ++i) nxt[i] = i < half_pts ? urow[i * pstride + (long)(K - 1) * HD] : 0.0f;
+  }
   for (int k = K - 1; k >= 0; --k) {
     const float z = z_n, gs = gs_n;
     const unsigned gate = m_n;
     {  // the next step's inputs
       const int kn = max(k - 1, 0);
-      z_n = zrow[kn], gs_n = ray_ok ? gsrow[kn] : 0.0f, m_n = ray_ok ? mrow[kn] : 0u;
+      z_n = zrow[kn], gs_n = ray_ok ? gsrow[kn] : 0.0f;
+      if constexpr (!ROWS) m_n = ray_ok ? mrow[kn] : 0u;
+      if constexpr (ROWS) {
+#pragma unroll
+        for (int i = 0; i < 32; ++i) cur[i] = nxt[i];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) nxt[i] = (i < half_pts && k > 0) ? urow[i * pstride + (long)kn * HD] : 0.0f;
+      }
     }
     if (__all(gs == 0.0f)) continue;   // e.g. the capped last sample of every ray: nothing to add
     const Proj pe = project<false>(enc, r0.x + z * r0.w, r0.y + z * r1.x, r0.z + z * r1.y);
     int x0, y0, x1, y1;
     Taps tp = make_taps_xy(pe.x, pe.y, H, W, x0, y0, x1, y1);
     const bool use_empty = (p.learn_empty != 0) & pe.invalid;
-    tp.w00 *= gs, tp.w01 *= gs, tp.w10 *= gs, tp.w11 *= gs;
+    if constexpr (!ROWS) tp.w00 *= gs, tp.w01 *= gs, tp.w10 *= gs, tp.w11 *= gs;   // ROWS: g_s is part of the rows
     bool fits = false;
     if (scatter) {
       const int mnx = wave_min_i(x0), mxx = -wave_min_i(-x1), mny = wave_min_i(y0), mxy = -wave_min_i(-y1);
@@ -651,7 +672,7 @@ __global__ __launch_bounds__(64) void scatter_kernel(const ScatterMaskParams sp)
     int s10 = ddy ? ryb + cxa : SCRATCH;
     int s11 = (ddx && ddy) ? ryb + cxb : SCRATCH;
     // (one EMPTY row per lane half: with views that look past the encoder's frustum most pairs would otherwise share that slot)
-    if (use_empty) s00 = EMPTY + h, s01 = s10 = s11 = SCRATCH, tp.w00 = gs, tp.w01 = tp.w10 = tp.w11 = 0.0f;
+    if (use_empty) s00 = EMPTY + h, s01 = s10 = s11 = SCRATCH, tp.w00 = ROWS ? 1.0f : gs, tp.w01 = tp.w10 = tp.w11 = 0.0f;
     if (!fits && !use_empty) s00 = s01 = s10 = s11 = SCRATCH;   // handled with direct atomics below
     // pairs (i, i + 32) whose points share a slot (bit i): the four slot indices of a point are one dword, the partner's dword is
     // compared byte against byte in its four rotations with the zero-byte test.  The scratch row is shared by design: for the
@@ -685,21 +706,23 @@ __global__ __launch_bounds__(64) void scatter_kernel(const ScatterMaskParams sp)
       if (wx == 0x12345678)
 #endif
 #pragma unroll
-      for (int i = 0; i < 32; ++i) round(i + 32 * h);
+      for (int i = 0; i < 32; ++i) round(i + 32 * h, cur[ROWS ? i : 0]);
     } else {
       // some pair shares a slot (patches hanging over the image border pile up on the clamped border texels): its two points take
       // their rounds one after the other
 #pragma unroll 1
       for (int i = 0; i < 32; ++i) {
+        // (the register block is never indexed dynamically -- that would demote it to scratch memory: this path re-reads the row)
+        const float rv = (ROWS && i < half_pts) ? urow[i * pstride + (long)k * HD] : 0.0f;
         if ((amask >> i) & 1u) {
-          if (h == 0) round(i);
+          if (h == 0) round(i, rv);
           // (convergent barrier: the two masked rounds must not be merged back into one -- to the compiler, lanes are independent)
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           __builtin_amdgcn_wave_barrier();
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-          if (h == 1) round(i + 32);
+          if (h == 1) round(i + 32, rv);
         } else {
-          round(i + 32 * h);
+          round(i + 32 * h, rv);
         }
       }
     }
@@ -709,7 +732,8 @@ __global__ __launch_bounds__(64) void scatter_kernel(const ScatterMaskParams sp)
       auto bc_f = [&](float v, int pnt) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), pnt)); };
 #pragma unroll 1
       for (int i = 0; i < n_pts; ++i) {
-        const float gv = ((unsigned)bc_i((int)gate, i) & cbit) ? w_out_ch : 0.0f;
+        const float gv = ROWS ? sp.u0_ws[(((long)sample * Bp + g_in * 64 + i) * K + k) * HD + chg]
+                              : (((unsigned)bc_i((int)gate, i) & cbit) ? w_out_ch : 0.0f);
         const long ya = (long)bc_i(y0, i) * W, yb = (long)bc_i(y1, i) * W;
         const int xa = bc_i(x0, i), xb = bc_i(x1, i);
         const float w00 = bc_f(tp.w00, i), w01 = bc_f(tp.w01, i), w10 = bc_f(tp.w10, i), w11 = bc_f(tp.w11, i);
@@ -937,6 +961,148 @@ __global__ __launch_bounds__(256, 2) void dwpe_kernel(const DwpeParams dp) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// pass C, ROWS form (ResnetBlockFC layers / long rays, bts_bwd_blocks.hip):  dW_pe^T[ch][kin] = sum_p u0[p][ch] pe[p][kin], the
+// constant-1 row of the encoding gives db_in.  u0 = the gradient at lin_in's output is a general fp32 row here (no 0/1 factor to
+// exploit), so the contraction runs as fp32-input MFMAs (exact products, fp32 accumulation): the A operand A[i = channel][k = sample]
+// is read STRAIGHT from the workspace -- lane (h, col) loads channel col of sample 2s + h, two 128-byte rows per instruction, no
+// transposition -- and the B operand B[k = sample][j = kin] comes from a per-wave LDS tile the encoding is written to lane = sample.
+// One unit = 64 samples of one ray.
+// ---------------------------------------------------------------------------------------------------------------
+struct DwpeRowsParams {
+  FwdParams f;
+  const float* u0_ws;   // (n*Bp, K, HD), channels in the storage order of G
+  float* d_mlp;
+  long rays;            // n * Bp
+};
+
+constexpr int kPeLd = kPeDim + 2;   // 41: leading dimension of the [sample][kin] tile (odd: conflict-free rows and columns)
+
+// cold path: some encoding argument of the unit leaves the fast sines' range (as pe_octave); out of line, with its own copy of e[]
+__device__ __attribute__((noinline)) void write_pe_tile_exact(float* tile, float x, float y, float code, float freq_factor) {
+  const float v3[3] = {x, y, code};
+  float* row = tile + (threadIdx.x & 63) * kPeLd;
+  row[0] = x, row[1] = y, row[2] = code, row[3] = 1.0f;
+  float ff = freq_factor;
+#pragma unroll 1
+  for (int oct = 0; oct < kNumFreqs; ++oct) {
+    float sc[6];
+    pe_octave_exact(sc, v3, ff);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) row[4 + 6 * oct + i] = sc[i];
+    ff = ff * 2.0f;
+  }
+}
+
+template <int C, int HD>
+__global__ __launch_bounds__(256, 2) void dwpe_rows_kernel(const DwpeRowsParams dp) {
+  constexpr int HT = HD / 32;
+  constexpr int PE_ROWS = kPeDim + 1;   // 40
+  constexpr int D_IN = C + kPeDim;
+  const FwdParams& p = dp.f;
+  __shared__ float tiles[4 * 64 * kPeLd];   // per wave [64 samples][41]; reused as the work-group accumulator at the end
+  static_assert(4 * 64 * kPeLd >= PE_ROWS * HD, "the flush buffer lives in the tiles");
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int h = lane >> 5, col = lane & 31;
+  float* const tile = tiles + wave * 64 * kPeLd;
+  const int Bp = p.Bp, K = p.K;
+  const int nch = (K + 63) >> 6;
+  const long units = dp.rays * nch;
+  f32x16 dw[HT][2];
+#pragma unroll
+  for (int ht = 0; ht < HT; ++ht)
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) dw[ht][kt] = zero_acc();
+  const long stride = (long)gridDim.x * 4;
+  for (long unit = (long)blockIdx.x * 4 + wave; unit < units; unit += stride) {
+    const long ray = unit / nch;
+    const int kc = (int)(unit - ray * nch) * 64;
+    const int sample = (int)(ray / Bp);
+    // ---- A operand: channel ht*32 + col of samples kc + 2s + h, all 32 k-steps up front (they land under the trigonometry)
+    float a[HT][32];
+    {
+      const float* ur = dp.u0_ws + (ray * K + kc + h) * (long)HD + col;
+#pragma unroll
+      for (int s2 = 0; s2 < 32; ++s2) {
+        const bool ok = kc + 2 * s2 + h < K;
+#pragma unroll
+        for (int ht = 0; ht < HT; ++ht) a[ht][s2] = ok ? ur[(long)(2 * s2) * HD + ht * 32] : 0.0f;
+      }
+    }
+    // ---- B operand: the 40 inputs of lin_in's encoding part in kernel order (x, y, code, 1, then per octave 3 sines and 3 "cosines")
+    const Cam enc = load_cam(p.w2c_enc + sample * 16, p.K_enc + sample * 9);
+    const cfp rp = as_const(p.rays) + ray * 8;
+    const int kk = min(kc + lane, K - 1);
+    const float z = p.z_samp[ray * K + kk];
+    const float px = rp[0] + z * rp[3], py = rp[1] + z * rp[4], pz = rp[2] + z * rp[5];
+    const Proj pe = p.code_mode == 1 ? project<true>(enc, px, py, pz) : project<false>(enc, px, py, pz);
+    float v3[3];
+    v3[0] = pe.x, v3[1] = pe.y;
+    v3[2] = depth_code(p.code_mode == 1 ? pe.dist : pe.z, p.inv_z != 0, p.inv_dmax, p.inv_range, p.d_min, p.range);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (__builtin_expect(__any(pe_needs_exact(v3, p.freq_factor)), 0)) {
+      write_pe_tile_exact(tile, v3[0], v3[1], v3[2], p.freq_factor);
+    } else {
+      float* row = tile + lane * kPeLd;
+      row[0] = v3[0], row[1] = v3[1], row[2] = v3[2], row[3] = 1.0f;
+      float ff = p.freq_factor;
+#pragma unroll
+      for (int r = 0; r < kNumFreqs / 2; ++r) {   // octaves 2r (direct) and 2r + 1 (angle doubling), as the forward's regions
+        SinCos3 raw, dbl;
+        float t[6];
+        pe_direct(raw, v3, ff);
+        pe_entries(t, raw, v3, ff);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) row[4 + 12 * r + i] = t[i];
+        pe_double(dbl, raw);
+        pe_entries(t, dbl, v3, ff * 2.0f);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) row[10 + 12 * r + i] = t[i];
+        ff = ff * 4.0f;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // ---- 32 k-steps of two samples each
+#pragma unroll
+    for (int s2 = 0; s2 < 32; ++s2) {
+      const float* brow = tile + (2 * s2 + h) * kPeLd;
+      const float b0 = brow[col];
+      const float b1 = col < PE_ROWS - 32 ? brow[32 + col] : 0.0f;
+#pragma unroll
+      for (int ht = 0; ht < HT; ++ht) {
+        dw[ht][0] = mfma(a[ht][s2], b0, dw[ht][0]);
+        dw[ht][1] = mfma(a[ht][s2], b1, dw[ht][1]);
+      }
+    }
+  }
+  // ---- flush: D[i = channel in tile (storage order)][j = kin in tile], register q of a lane of half h holds row mfma_row(q, h),
+  // column col.  Wave registers -> work-group accumulator (the tiles' memory, dead now) -> one global atomic per parameter
+  __syncthreads();
+  float* d_wpe = tiles;   // [kin][channel]
+  for (int i = threadIdx.x; i < PE_ROWS * HD; i += blockDim.x) d_wpe[i] = 0.0f;
+  __syncthreads();
+#pragma unroll
+  for (int ht = 0; ht < HT; ++ht)
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int chn = ht * 32 + mfma_row(q, h), kin = kt * 32 + col;
+        if (kin < PE_ROWS) atomicAdd(&d_wpe[kin * HD + chn], dw[ht][kt][q]);
+      }
+  __syncthreads();
+  for (int i = threadIdx.x; i < PE_ROWS * HD; i += blockDim.x) {
+    const int kin = i / HD, hid = proj_hidden_of_storage(i % HD);
+    const int src = kernel_to_ref_input<C>(kin + C);
+    const float v = d_wpe[i];
+    // w_in / b_in sit at the start of the packed parameters whatever the number of blocks
+    if (v != 0.0f) atomic_add_f32(dp.d_mlp + (src >= 0 ? hid * D_IN + src : HD * D_IN + hid), v);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // launch
 // ---------------------------------------------------------------------------------------------------------------
 template <int C, int HD>
@@ -959,7 +1125,7 @@ static int launch_rows(const BwdParams& bp, int n, int grid, hipStream_t s) {
   if (e == hipSuccess && (bp.d_proj || bp.d_empty_proj)) {
     const MlpLayout ml{C + kPeDim, HD, 0};
     ScatterMaskParams sp;
-    sp.f = p, sp.mask_ws = bp.mask_ws, sp.gs_ws = bp.gs_ws, sp.d_proj = bp.d_proj, sp.d_empty_proj = bp.d_empty_proj;
+    sp.f = p, sp.mask_ws = bp.mask_ws, sp.u0_ws = nullptr, sp.gs_ws = bp.gs_ws, sp.d_proj = bp.d_proj, sp.d_empty_proj = bp.d_empty_proj;
     sp.groups_per_sample = (p.Bp + 63) / 64, sp.w_out_off = ml.w_out();
     scatter_kernel<HD><<<n * sp.groups_per_sample * (HD / 32), 64, 0, s>>>(sp);
     e = hipGetLastError();
@@ -978,6 +1144,30 @@ static int launch_rows(const BwdParams& bp, int n, int grid, hipStream_t s) {
     return BTS_E_LAUNCH;
   }
   return BTS_OK;
+}
+
+// ROWS form of pass B / pass C for bts_bwd_blocks.hip
+int launch_scatter_rows(const FwdParams& p, const float* gs_ws, const float* u0_ws, float* d_proj, float* d_empty_proj, int HD, int n, hipStream_t s) {
+  ScatterMaskParams sp;
+  sp.f = p, sp.mask_ws = nullptr, sp.u0_ws = u0_ws, sp.gs_ws = gs_ws, sp.d_proj = d_proj, sp.d_empty_proj = d_empty_proj;
+  sp.groups_per_sample = (p.Bp + 63) / 64, sp.w_out_off = 0;
+  if (HD == 64) scatter_kernel<64, true><<<n * sp.groups_per_sample * 2, 64, 0, s>>>(sp);
+  else if (HD == 32) scatter_kernel<32, true><<<n * sp.groups_per_sample, 64, 0, s>>>(sp);
+  else return BTS_E_UNSUPPORTED;
+  return hipGetLastError() == hipSuccess ? BTS_OK : BTS_E_LAUNCH;
+}
+
+int launch_dwpe_rows(const FwdParams& p, const float* u0_ws, float* d_mlp, int C, int HD, int NB, int n, int grid, hipStream_t s) {
+  DwpeRowsParams dp;
+  dp.f = p, dp.u0_ws = u0_ws, dp.d_mlp = d_mlp, dp.rays = (long)n * p.Bp;
+  const long units = dp.rays * ((p.K + 63) / 64);
+  const long wgs = (units + 3) / 4;
+  const int g = (int)(wgs < grid ? wgs : grid);   // grid = 2 work-groups per CU
+  if (C == 64 && HD == 64) dwpe_rows_kernel<64, 64><<<g, 256, 0, s>>>(dp);
+  else if (C == 32 && HD == 32) dwpe_rows_kernel<32, 32><<<g, 256, 0, s>>>(dp);
+  else return BTS_E_UNSUPPORTED;
+  (void)NB;
+  return hipGetLastError() == hipSuccess ? BTS_OK : BTS_E_LAUNCH;
 }
 
 // bp.gs_ws: (n*Bp, K) floats, bp.mask_ws: (n*Bp, HD/32, K) dwords, bp.pmask_ws: (n*Bp, HD) x 64 bits; p.groups / chunk_log2 / lpr set for one ray per wave iteration

@@ -185,10 +185,10 @@ struct LdsH {  // in floats, placed behind Lds<C, HD, NB, true>
 #endif
 };
 
+// empty_proj: the projected empty feature [HD] (fp32, unscaled) as stage_weights left it in LDS
 template <int C, int HD, int NB>
-__device__ __forceinline__ void stage_weights_h(float* lh, const float* lds_old, const float* __restrict__ mlp) {
+__device__ __forceinline__ void stage_weights_h(float* lh, const float* empty_proj, const float* __restrict__ mlp) {
   using LH = LdsH<C, HD, NB>;
-  using L = Lds<C, HD, NB, true>;
   constexpr int HT = HD / 32;
   constexpr int D_IN = C + kPeDim;
   const MlpLayout ml{D_IN, HD, NB};
@@ -260,7 +260,7 @@ __device__ __forceinline__ void stage_weights_h(float* lh, const float* lds_old,
     const int b = i / (2 * HD), j = i % (2 * HD);
     lh[LH::BIAS + i] = (j < HD ? mlp[ml.blk_b0(b) + j] : mlp[ml.blk_b1(b) + j - HD]) * scale;
   }
-  for (int i = threadIdx.x; i < HD; i += blockDim.x) lh[LH::EMPTY + i] = lds_old[L::EMPTY + i] * scale;
+  for (int i = threadIdx.x; i < HD; i += blockDim.x) lh[LH::EMPTY + i] = empty_proj[i] * scale;
 }
 
 __device__ __forceinline__ void swap32u(unsigned& a, unsigned& b) {
@@ -779,7 +779,7 @@ __global__ __launch_bounds__(256, 2) void render_kernel_p(const FwdParams p) {
   stage_weights<C, HD, NB, true>(lds, p.mlp, p.empty_feature);
   __syncthreads();
   if constexpr (F16) {
-    stage_weights_h<C, HD, NB>(lh, lds, p.mlp);
+    stage_weights_h<C, HD, NB>(lh, lds + L::EMPTY, p.mlp);
     __syncthreads();
   }
   // 2^S carried by the accumulators of the f16 path (1 on the fp32 path)

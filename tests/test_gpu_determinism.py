@@ -94,7 +94,7 @@ def test_parity_holds_on_a_second_schedule(tag):
     """The reference goldens, the fp64 arbiter, the ragged / training shapes and the gradient goldens against a differently scheduled
     build of the same sources (its own process: the library is chosen at load time through BTS_RENDER_LIB)."""
     env = dict(os.environ, BTS_RENDER_LIB=_variant(tag))
-    sel = "golden or fp64_arbiter or ragged_and_training or single_ray"
+    sel = "(golden or test_fp64_arbiter or ragged_and_training or single_ray) and not real_training"
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-k", sel, "-p", "no:cacheprovider",
                         os.path.join(ROOT, "tests", "test_gpu_parity.py"), os.path.join(ROOT, "tests", "test_gpu_grad.py")],
                        env=env, capture_output=True, text=True, cwd=ROOT)

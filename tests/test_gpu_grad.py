@@ -146,10 +146,13 @@ def _gate_safe_rays(scene, mlp, cfg, ids_render, rays, z, empty, margin, stats=N
     return safe, int((~safe).sum())
 
 
+@pytest.mark.parametrize("C,K", [(64, 64), (64, 80), (32, 70), (64, 130)])
 @pytest.mark.parametrize("learn_empty", [False, True])
-def test_gradients_vs_oracle_autograd(hip, learn_empty):
-    """Training-like shape in the small (n=3, nv=4, K=64, ragged ray count), a loss that also feeds gradient into `weights` and
-    `alphas` (the alpha / entropy regularisers of loss.py use them), with and without learn_empty.  The strict bound -- every
+def test_gradients_vs_oracle_autograd(hip, learn_empty, C, K):
+    """Training-like shape in the small (n=3, nv=4, ragged ray count), a loss that also feeds gradient into `weights` and
+    `alphas` (the alpha / entropy regularisers of loss.py use them), with and without learn_empty.  K = 64: the gate-bit passes;
+    K = 80 / 70 / 130 (plain MLP of width 64 / 32, one and two ragged extra chunks): the row passes of bts_bwd_blocks.hip with the
+    suffix sum of the compositing gradient carried from chunk to chunk.  The strict bound -- every
     entry within 1e-4 of the largest one -- is asserted against an fp64 evaluation on rays that keep a margin from every relu kink
     (round 1 had ratcheted this test to 20e-4 "because of gate flips"; with those rays identified and set aside, and the two
     round-2 root causes fixed, the strict bound holds)."""
@@ -157,11 +160,11 @@ def test_gradients_vs_oracle_autograd(hip, learn_empty):
     from tests._cases import robust_ray_mask
     cfg = O.FieldConfig(learn_empty=learn_empty)
     g = torch.Generator().manual_seed(77)
-    n, v, H, W, K, NR = 3, 5, 48, 160, 64, 700
-    scene = O.synthetic_scene(n, v, H, W, 64, seed=77, intrinsics=O.K_KITTI360, smooth=True)
-    mlp = O.init_mlp(103, 64, 0, gen=g)
-    mlp.b_in = torch.randn(64, generator=g) * 0.1
-    empty = torch.randn(64, generator=g) if learn_empty else None
+    n, v, H, W, NR = 3, 5, 48, 160, 700
+    scene = O.synthetic_scene(n, v, H, W, C, seed=77, intrinsics=O.K_KITTI360, smooth=True)
+    mlp = O.init_mlp(C + 39, C, 0, gen=g)
+    mlp.b_in = torch.randn(C, generator=g) * 0.1
+    empty = torch.randn(C, generator=g) if learn_empty else None
     rays = O.image_rays(scene["poses"], scene["projs"], H, W, 3.0, 80.0)
     rays = rays[:, torch.randperm(rays.shape[1], generator=g)[:1600].sort().values].contiguous()
     z = O.sample_coarse(rays.reshape(-1, 8), K, True, torch.rand(n * 1600, K, generator=g))
@@ -170,8 +173,10 @@ def test_gradients_vs_oracle_autograd(hip, learn_empty):
     keep = robust_ray_mask(O.make_state(scene, [1, 2, 3, 4], cfg, empty), rays, z).view(n, -1)
     safe, n_gate = _gate_safe_rays(scene, mlp, cfg, [1, 2, 3, 4], rays, z, empty, margin=2e-5)
     print(f"rays excluded for a hidden unit within 2e-5 of the relu kink: {n_gate} of {n * 1600}")
-    assert n_gate <= 0.5 * n * 1600
+    assert n_gate <= 0.6 * n * 1600
     keep = keep & safe
+    NR = min(NR, int(keep.sum(1).min()))      # (long rays meet more kinks: fewer rays survive)
+    assert NR >= 300, NR
     idx = torch.stack([torch.nonzero(keep[i])[:NR, 0] for i in range(n)])
     assert idx.shape == (n, NR)
     rays = torch.gather(rays, 1, idx.unsqueeze(-1).expand(-1, -1, 8)).contiguous()
@@ -344,7 +349,10 @@ def _record(name, d):
 ARB_FACTOR = 1.5      # HIP may be at most this much further from the fp64 truth than the fp32 oracle is (max norm and L2) ...
 ARB_EPS_MAX = 2e-5    # ... plus this fraction of the tensor's largest entry (max norm)
 ARB_EPS_L2 = 1e-5     # ... / of the tensor's norm (L2): where both are at rounding level the ratio means nothing
-ARB_COUNT = 1.25      # feature-map texels off by > 1e-4 of the largest entry: at most this many times the oracle's own count (+ 10)
+ARB_COUNT = 1.25      # feature-map texels off by > 1e-4 of the largest entry: at most this many times the oracle's own count ...
+ARB_COUNT_SIGMA = 3   # ... + 3 sigma of the count's own scatter: the off texels come in clusters -- a flipped gate of lin_in's output moves
+                      # the 4 taps of ONE channel of dG (plain MLP: G's channels are the hidden units), a flipped gate inside the
+                      # ResnetBlockFC all 32 channels at the 4 taps -- so a count N is N / c events of c entries, sd = sqrt(c N)
 
 
 @pytest.mark.parametrize("name", list(REAL_SHAPES))
@@ -374,7 +382,8 @@ def test_gradients_fp64_arbiter_at_the_real_training_shapes(hip, name):
             fails.append((nme, "max", r["max_hip"], r["max_ref"]))
         if r["l2_hip"] > ARB_FACTOR * r["l2_ref"] + ARB_EPS_L2:
             fails.append((nme, "l2", r["l2_hip"], r["l2_ref"]))
-        if r["n_off_hip"] > ARB_COUNT * r["n_off_ref"] + 10:
+        cluster = 4 * (1 + 31 * s["nb"])
+        if r["n_off_hip"] > ARB_COUNT * r["n_off_ref"] + 10 + ARB_COUNT_SIGMA * (cluster * max(r["n_off_ref"], 1)) ** 0.5:
             fails.append((nme, "count", r["n_off_hip"], r["n_off_ref"]))
     _record(name, dict(fp64_arbiter=rec))
     assert not fails, fails

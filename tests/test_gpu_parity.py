@@ -196,17 +196,39 @@ def _oracle_vs_hip(hip, *, n, v, H, W, C, Hd, nb, K, ids_render, cfg, hard_cap, 
     on_border = ~robust_ray_mask(st, rays, z, margin=3e-6)
     out = dict(depth=(depth.cpu(), odepth), rgb=(rgb.cpu(), orgb), w=(w.cpu(), ow), a=(a.cpu(), oa), flips=flips, robust=robust,
                on_border=on_border)
-    if want_fp64:   # the same formulas in double: the arbiter between two fp32 evaluations
-        dd = lambda t: None if t is None else t.double()
+    if want_fp64:   # the same formulas in double (torch ops on the GPU: as the truth its device does not matter): the arbiter between
+        dd = lambda t: None if t is None else t.double().cuda()                                        # two fp32 evaluations
         torch.set_default_dtype(torch.float64)
         try:
             st64 = O.FieldState(dd(st.feat), dd(st.K_enc), dd(st.w2c_enc), dd(st.imgs), dd(st.K_r), dd(st.w2c_r), dd(st.empty_feature))
             mlp64 = O.MlpParams(dd(mlp.w_in), dd(mlp.b_in), [tuple(dd(t) for t in b) for b in mlp.blocks], dd(mlp.w_out), dd(mlp.b_out))
             with torch.no_grad():
-                out["a64"] = O.composite(dd(rays.reshape(-1, 8)), dd(z), n, st64, mlp64, cfg, hard_alpha_cap=hard_cap)[3]
+                o64 = O.composite(dd(rays.reshape(-1, 8)), dd(z), n, st64, mlp64, cfg, hard_alpha_cap=hard_cap)
+            out["a64"] = o64[3].cpu()
+            out["o64"] = dict(w=o64[0].cpu(), rgb=o64[1].cpu(), depth=o64[2].cpu(), a=o64[3].cpu())
         finally:
             torch.set_default_dtype(torch.float32)
     return out
+
+
+def _check_arbitrated(r, keys=("rgb", "w", "a")):
+    """For inputs on which two correct fp32 evaluations cannot agree to 1e-5 everywhere (samples next to a render camera's plane:
+    the perspective divide amplifies the fp32 rounding of the projection; white-noise frames): the fp64 evaluation of the same
+    formulas arbitrates.  The HIP path may not have more entries beyond 1e-5 of the truth than the fp32 reference restatement has
+    (x 1.25 + 10), nor a larger maximum (x 1.5); depth keeps the strict 1e-4 relative bound."""
+    flips, border = r["flips"], r["on_border"]
+    assert not (flips & ~border).any(), "flag differs on a ray that is not within 3e-6 of any frustum border"
+    ok = ~flips
+    d, od = r["depth"]
+    assert ((d - od).abs() / od.abs())[ok].max().item() <= DEPTH_RTOL
+    for key in keys:
+        hip_, ref_, t = r[key][0][ok].double(), r[key][1][ok].double(), r["o64"][key][ok]
+        e_hip, e_ref = (hip_ - t).abs(), (ref_ - t).abs()
+        n_hip, n_ref = int((e_hip > ABS_TOL).sum()), int((e_ref > ABS_TOL).sum())
+        print(f"  {key}: beyond 1e-5 of the fp64 evaluation: HIP {n_hip}, fp32 reference restatement {n_ref} of {t.numel()}; max HIP {e_hip.max().item():.2e} "
+              f"reference {e_ref.max().item():.2e}")
+        assert n_hip <= 1.25 * n_ref + 10, (key, n_hip, n_ref)
+        assert e_hip.max().item() <= 1.5 * e_ref.max().item() + 1e-7, (key, e_hip.max().item(), e_ref.max().item())
 
 
 NOISE_FLOOR = 5e-5   # max |fp32 reference - fp64 evaluation| of weights / colours on the full-size scene (alphas: 1.3e-4)
@@ -325,11 +347,12 @@ def test_ragged_and_training_shapes_vs_oracle(hip):
 @pytest.mark.parametrize("K", [48, 128])
 def test_re10k_full_frame_vs_oracle(hip, K):
     """BASELINE configs[4] field at full frame size: exp_re10k.yaml (C = 32, one ResnetBlockFC of width 32, distance code, z in [1, 100],
-    no alpha cap), 256x384 frames, bs 2, every ray of the first frame (196 608 rays), nv = 2, K = 48 (the yaml) and 128 (BASELINE.json)."""
+    no alpha cap), 256x384 frames, every ray of the first frame of bs 2 (K = 48, the yaml) / bs 1 (K = 128, BASELINE.json), nv = 2."""
     re = O.FieldConfig(d_min=1.0, d_max=100.0, code_mode="distance")
-    r = _oracle_vs_hip(hip, n=2, v=3, H=256, W=384, C=32, Hd=32, nb=1, K=K, ids_render=[1, 2], cfg=re, hard_cap=False, intr=O.K_RE10K,
+    n = 2 if K == 48 else 1      # (the CPU oracle is what takes the time: 12.6 M field queries either way)
+    r = _oracle_vs_hip(hip, n=n, v=3, H=256, W=384, C=32, Hd=32, nb=1, K=K, ids_render=[1, 2], cfg=re, hard_cap=False, intr=O.K_RE10K,
                        n_rays=None, seed=60 + K, smooth=True, views=[0], baseline=0.2)
-    assert r["depth"][0].numel() == 2 * 256 * 384
+    assert r["depth"][0].numel() == n * 256 * 384
     _check(r, depth_floor=1e-3)
 
 
@@ -343,11 +366,15 @@ def test_kitti_raw_training_shape_vs_oracle(hip):
 
 
 def test_kitti360_training_batch_forward_vs_oracle(hip):
-    """BASELINE configs[2] forward at its real batch: bs 16, 8 frames (4 loss + 4 render views), 64 patches = 4 096 rays per sample, nv = 4."""
+    """BASELINE configs[2] forward at its real batch: bs 16, 8 frames (4 loss + 4 render views), 64 patches = 4 096 rays per sample, nv = 4.
+    The render views sit 2 - 3 m in FRONT of the rays' origins (kitti360-mono: later time steps), so the first samples of many rays
+    pass within centimetres of a render camera's plane, where the perspective divide amplifies the projection's fp32 rounding: the
+    fp32 oracle itself is then > 1e-5 off the fp64 evaluation in ~2e-4 of the colours (measured) -- arbitrated, not tolerated."""
     r = _oracle_vs_hip(hip, n=16, v=8, H=192, W=640, C=64, Hd=64, nb=0, K=64, ids_render=[4, 5, 6, 7], cfg=O.FieldConfig(),
-                       hard_cap=True, intr=O.K_KITTI360, n_rays=None, seed=74, smooth=True, patches=([0, 1, 2, 3], 64), baseline=0.6)
+                       hard_cap=True, intr=O.K_KITTI360, n_rays=None, seed=74, smooth=True, patches=([0, 1, 2, 3], 64), baseline=0.6,
+                       want_fp64=True)
     assert r["depth"][0].numel() == 16 * 4096
-    _check(r)
+    _check_arbitrated(r)
 
 
 def test_single_ray_and_tiny_k(hip):
