@@ -9,7 +9,7 @@ import threading
 PKG = os.path.dirname(os.path.abspath(__file__))
 # BTS_RENDER_LIB lets the profiling tools load the instrumented probe build (libbts_probe.so); the product always loads libbts_render.so
 LIB_PATH = os.environ.get("BTS_RENDER_LIB") or os.path.join(PKG, "libbts_render.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 BTS_MAX_VIEWS = 8
 ERRORS = {-1: "BTS_E_INVALID", -2: "BTS_E_UNSUPPORTED", -3: "BTS_E_LAUNCH", -4: "BTS_E_WORKSPACE"}
@@ -62,6 +62,7 @@ SYMBOLS = {
     "bts_project_features": (C.c_int, [C.POINTER(BtsFieldCfg), _P, _P, _I, _P, _P]),
     "bts_project_features_bwd": (C.c_int, [C.POINTER(BtsFieldCfg), _P, _P, _P, _I, _P, _P, _P]),
     "bts_field_query": (C.c_int, [C.POINTER(BtsFieldCfg), C.POINTER(BtsFieldTensors), _P, _I, _I, _P, _P, _P, _P]),
+    "bts_occupancy_profile": (C.c_int, [C.POINTER(BtsFieldCfg), C.POINTER(BtsFieldTensors), _P, _I, _I, C.c_float, _I, _P, _P, _P]),
     "bts_nchw_to_nhwc": (C.c_int, [_P, _P, _I, _I, _I, _I, _P]),
     "bts_nhwc_to_nchw": (C.c_int, [_P, _P, _I, _I, _I, _I, _P]),
     "bts_pack_rgb": (C.c_int, [_P, _P, _I, _I, _I, C.c_float, C.c_float, _P]),

@@ -28,6 +28,8 @@ int project_features_bwd_impl(int C, int HD, const float* feat, const float* dpr
 int render_fwd_impl(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const BtsRenderArgs* a, hipStream_t s);
 int field_query_impl(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const float* xyz, int P, int only_density, float* rgb,
                      float* invalid, float* sigma, hipStream_t s);
+int occupancy_profile_impl(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const float* xyz, int Y, int cols, float threshold,
+                           int only_density, float* profile, float* sigma, hipStream_t s);
 size_t render_bwd_workspace_impl(const BtsFieldCfg* cfg, const BtsRenderArgs* a);
 int render_bwd_impl(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const BtsRenderArgs* a, const BtsRenderGrads* g, void* ws,
                     size_t ws_bytes, hipStream_t s);
@@ -163,6 +165,21 @@ int bts_field_query(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const floa
     return BTS_E_INVALID;
   }
   return field_query_impl(cfg, t, xyz, P, only_density, rgb, invalid, sigma, (hipStream_t)stream);
+}
+
+int bts_occupancy_profile(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const float* xyz, int32_t Y, int32_t columns, float threshold,
+                          int32_t only_density, float* profile, float* sigma, void* stream) {
+  int rc = check_cfg(cfg, t, !only_density);
+  if (rc) return rc;
+  if (!xyz || !profile || Y <= 0 || columns <= 0) {
+    set_error("%s: NULL/empty argument (Y=%ld, columns=%ld)", "bts_occupancy_profile", Y, columns);
+    return BTS_E_INVALID;
+  }
+  if (Y > 64 || !t->proj_nhwc || (long)Y * columns > 0x7FFFFFFFL) {
+    set_error("%s: needs Y <= 64 levels (got %ld), the projected feature map and fewer than 2^31 points", "bts_occupancy_profile", Y);
+    return BTS_E_UNSUPPORTED;
+  }
+  return occupancy_profile_impl(cfg, t, xyz, Y, columns, threshold, only_density, profile, sigma, (hipStream_t)stream);
 }
 
 #define BTS_CHECK_LAYOUT(cond, name)                      \

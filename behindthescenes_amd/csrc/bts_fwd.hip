@@ -118,15 +118,25 @@ int render_fwd_impl(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const BtsR
   return launch_render<false>(p, cfg->C, cfg->d_hidden, cfg->n_blocks, grid, s);
 }
 
+int query_impl(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const float* xyz, int P, int only_density, float* rgb, float* invalid,
+               float* sigma, int cols, int col_len, float threshold, float* profile, hipStream_t s);   // bts_query.hip
+
 int field_query_impl(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const float* xyz, int P, int only_density, float* rgb,
                      float* invalid, float* sigma, hipStream_t s) {
+  // projected feature map (the default hand-over): the pipelined lane = point kernel of bts_query.hip; raw channels-last features
+  // (callers that cannot pre-project): the compact kernel below
+  if (t->proj_nhwc) return query_impl(cfg, t, xyz, P, only_density, only_density ? nullptr : rgb, invalid, sigma, 0, 0, 0.0f, nullptr, s);
   FwdParams p = make_params(cfg, t);
   p.xyz = xyz, p.Bp = P, p.K = 1, p.only_density = only_density;
   if (only_density) p.nv = 0;
   p.rgb = rgb, p.invalid = invalid, p.q_sigma = sigma;
   p.tiles_per_sample = (P + 255) / 256;
-  if (p.proj) return launch_field<true, true>(p, cfg->C, cfg->d_hidden, cfg->n_blocks, p.tiles_per_sample * cfg->n, s);
   return launch_field<true, false>(p, cfg->C, cfg->d_hidden, cfg->n_blocks, p.tiles_per_sample * cfg->n, s);
+}
+
+int occupancy_profile_impl(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const float* xyz, int Y, int cols, float threshold,
+                           int only_density, float* profile, float* sigma, hipStream_t s) {
+  return query_impl(cfg, t, xyz, Y * cols, only_density, nullptr, nullptr, sigma, cols, Y, threshold, profile, s);
 }
 
 }  // namespace bts

@@ -194,3 +194,13 @@ class BTSNet(nn.Module):
             rgb = torch.zeros((xyz.shape[0], xyz.shape[1], nv * 3), device=sigma.device)
             invalid = invalid.unsqueeze(1)   # the reference returns (n, nv_enc=1, P, 1) here (models_bts.py:337)
         return rgb, invalid, sigma
+
+    def occupancy_profile(self, q_pts, levels, threshold=8.0, only_density=False, want_sigma=False):
+        """scripts/inference_setup.py:201-229 (render_profile) as one fused pass: q_pts (n, levels * columns, 3), a dense grid with the
+        vertical level slowest (get_pts' order) -> (n, columns) fraction of levels whose running density sum stays <= threshold, points
+        flagged invalid by any view counting as density 1 (only_density: by the encoder view only).  The reference chunks the 4.19 M
+        points of its grid into 50 000-point field queries and post-processes in torch; here no per-point tensor reaches HBM."""
+        ft = self.native_field()
+        with torch.no_grad(), profiler.record_function("model_inference"):
+            return native.occupancy_profile(ft, self.mlp_coarse.packed().detach(), q_pts.detach().float().contiguous(), int(levels),
+                                            float(threshold), only_density, want_sigma)

@@ -407,6 +407,23 @@ def field_query(ft: FieldTensors, mlp_params: torch.Tensor, xyz: torch.Tensor, o
     return rgb, invalid, sigma
 
 
+def occupancy_profile(ft: FieldTensors, mlp_params: torch.Tensor, xyz: torch.Tensor, levels: int, threshold: float = 8.0,
+                      only_density: bool = False, want_sigma: bool = False):
+    """xyz (n, levels * columns, 3): a dense grid of query points, the vertical level slowest -> profile (n, columns)
+    [, sigma (n, levels * columns)]  (bts_occupancy_profile: render_profile of scripts/inference_setup.py in one pass)."""
+    n, P, _ = xyz.shape
+    _req(xyz, "xyz", (ft.n, P, 3))
+    if levels <= 0 or P % levels:
+        raise BtsNativeError(f"{P} points are not {levels} whole levels")
+    cols = P // levels
+    profile = torch.empty((n, cols), device=xyz.device, dtype=torch.float32)
+    sigma = torch.empty((n, P), device=xyz.device, dtype=torch.float32) if want_sigma else None
+    cfg, tens = ft.cfg(nv=0 if only_density else None), ft.tensors(mlp_params)
+    _lib.check(_lib.load().bts_occupancy_profile(C.byref(cfg), C.byref(tens), _ptr(xyz), levels, cols, float(threshold), int(only_density),
+                                                 _ptr(profile), _ptr(sigma), _stream(xyz)), "bts_occupancy_profile")
+    return (profile, sigma) if want_sigma else profile
+
+
 # --------------------------------------------------------------------------------------------------------------
 # autograd glue
 # --------------------------------------------------------------------------------------------------------------

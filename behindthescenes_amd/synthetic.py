@@ -84,3 +84,12 @@ def build_net(scene, d_hidden=64, n_blocks=0, ids_render=(0,), device="cuda", tr
     net.encode(scene["images"].to(device), scene["projs"].to(device), scene["poses"].to(device), ids_encoder=[0],
                ids_render=list(ids_render))
     return net
+
+
+def profile_points(x_range=(-9, 9), y_range=(.0, .75), z_range=(21, 3), x_res=256, y_res=64, z_res=256):
+    """The query grid of the reference's occupancy profile (scripts/inference_setup.py:84-97 with the defaults of :46-52):
+    (y_res, z_res, x_res, 3), the vertical level slowest -- 4.19 M points."""
+    x = torch.linspace(x_range[0], x_range[1], x_res).view(1, 1, x_res).expand(y_res, z_res, -1)
+    z = torch.linspace(z_range[0], z_range[1], z_res).view(1, z_res, 1).expand(y_res, -1, x_res)
+    y = torch.linspace(y_range[0], y_range[1], y_res).view(y_res, 1, 1).expand(-1, z_res, x_res)
+    return torch.stack((x, y, z), dim=-1)

@@ -40,10 +40,11 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", choices=("eval", "train", "kitti_raw", "re10k"), default="eval",
+    ap.add_argument("--workload", choices=("eval", "train", "kitti_raw", "re10k", "profile"), default="eval",
                     help="eval (default): BASELINE configs[1], the headline line.  train: configs[2] (exp_kitti_360.yaml shapes), kitti_raw: "
                          "configs[3] (exp_kitti_raw.yaml, bs 8 / GPU), re10k: configs[4] (exp_re10k.yaml, 256x384, four scales per step): the "
-                         "renderer's share of a training step, forward + loss + backward")
+                         "renderer's share of a training step, forward + loss + backward; profile: SURVEY 8f.3, the 64 x 256 x 256 occupancy grid of "
+                         "scripts/inference_setup.py (render_profile) as one fused pass, density queries/s")
     ap.add_argument("--samples", type=int, default=0, help="re10k: samples per ray (default 48 = the yaml; BASELINE.json quotes 128)")
     ap.add_argument("--encoder", choices=("feature_map", "monodepth2"), default="feature_map",
                     help="training workloads: feature_map (default) = learnable stand-in for the CNN output (the renderer's share of the step); "
@@ -353,6 +354,113 @@ def train_workload(args, world, rank, dev):
         print(json.dumps(out))
 
 
+def profile_workload(args, world, rank, dev):
+    """the occupancy profile of scripts/inference_setup.py:201-229 -- 64 x 256 x 256 = 4.19 M density queries of the
+    KITTI-360 field per frame, sigma := 1 on invalid points, running sum over the 64 vertical levels, count(<= 8) / 64.  One step =
+    `net.occupancy_profile(grid, 64)` (bts_occupancy_profile: ONE kernel, no per-point tensor in HBM).  Beside it, once: the
+    reference's own flow on the HIP field query (84 chunks of 50 000 points through net.forward + torch post-processing)."""
+    import behindthescenes_amd as bts
+    from behindthescenes_amd import synthetic as S
+    Hh, Ww = 192, 640
+    scene = S.synthetic_scene(1, 2, Hh, Ww, C, seed=3000 + rank, intrinsics=S.K_KITTI360, baseline=0.6, smooth=True)
+    torch.manual_seed(4242)
+    net = bts.BTSNet(S.field_conf(C, HD, 0, Hh, Ww, learn_empty=True))
+    S.init_mlp_(net.mlp_coarse, seed=7)
+    with torch.no_grad():
+        net.mlp_coarse.lin_out.bias.fill_(-2.0)      # densities of 0.1 - 1: the running sums cross the threshold inside the grid
+    S.set_feature_map(net, scene["feat"])
+    net = net.to(dev).eval()
+    grid = S.profile_points()
+    Y, Z, X, _ = grid.shape
+    pts = grid.reshape(1, -1, 3).to(dev).contiguous()
+    with torch.no_grad():
+        net.encode(scene["images"].to(dev), scene["projs"].to(dev), scene["poses"].to(dev), ids_encoder=[0], ids_render=[0, 1])
+
+    def step():
+        return net.occupancy_profile(pts, Y)
+
+    def reference_flow():   # inference_setup.py:205-228 on the HIP field query
+        sig, inv = [], []
+        for f in range(0, pts.shape[1], 50000):
+            _, i_, s_ = net(pts[:, f:f + 50000].contiguous())
+            sig.append(s_), inv.append(i_)
+        sigmas, invalid = torch.cat(sig, 1), torch.cat(inv, 1)
+        sigmas[torch.any(invalid > 0, dim=-1)] = 1
+        a = sigmas.reshape(Y, Z, X)
+        return (torch.cumsum(a, 0) <= 8).float().sum(0) / Y
+
+    for _ in range(args.warmup):
+        step()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    torch.cuda.synchronize()
+    if torch.distributed.is_initialized():
+        torch.distributed.barrier()
+        torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ev[i][0].record()
+        prof = step()
+        ev[i][1].record()
+    torch.cuda.synchronize()
+    if torch.distributed.is_initialized():
+        torch.distributed.barrier()
+        torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if torch.distributed.is_initialized():
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = t.item()
+    kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
+    n_pts = Y * Z * X
+    if rank == 0:
+        ref_ms, agree = None, None
+        if world == 1:
+            with torch.no_grad():
+                reference_flow()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                ref_prof = reference_flow()
+                torch.cuda.synchronize()
+                ref_ms = (time.perf_counter() - t1) * 1e3
+            agree = float((ref_prof.reshape(-1) == prof.reshape(-1)).float().mean())
+        flop = n_pts * FLOP_PER_POINT
+        achieved = flop / (kernel_ms * 1e-3) / 1e12
+        out = {
+            "metric": "density-field queries/sec (64x256x256 occupancy profile, scripts/inference_setup.py)", "value": world * n_pts * args.steps / elapsed,
+            "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
+            "config": {"workload": "occupancy profile of one KITTI-360 frame: 64 x 256 x 256 = 4 194 304 query points (get_pts defaults), nv = 2 "
+                                   "views flag invalid points, learn_empty=True, one fused pass (bts_occupancy_profile)", "points_per_step_per_gpu": n_pts,
+                       "parallelism": f"frames x{world}",
+                       "reference_flow_on_hip_queries_ms": ref_ms, "columns_equal_to_reference_flow": agree},
+            "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MATRIX_TFLOPS,
+                         "traffic": None, "kernel": "bts::query_kernel_p<64,64,0,2> (profile mode)", "kernel_ms": kernel_ms,
+                         "algorithmic_flop_per_launch": flop,
+                         "note": "algorithmic 13 312 FLOP / query (SURVEY 8d) against the fp32 vector = fp32-input-MFMA peak; the kernel executes the "
+                                 "projected-feature form (DESIGN.md section 3), like the render kernel"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import bts_oracle as O
+            threads = min(16, os.cpu_count() or 8)
+            prev = torch.get_num_threads()
+            torch.set_num_threads(threads)
+            small = O.profile_points(x_res=64, z_res=64)
+            m = net.mlp_coarse
+            mlp = O.MlpParams(m.lin_in.weight.detach().cpu(), m.lin_in.bias.detach().cpu(), [], m.lin_out.weight.detach().cpu(), m.lin_out.bias.detach().cpu())
+            st = O.make_state(scene, [0, 1], O.FieldConfig(learn_empty=True), net.empty_feature.detach().cpu())
+            best = float("inf")
+            with torch.no_grad():
+                for i in range(3):
+                    t1 = time.perf_counter()
+                    O.occupancy_profile(small, st, mlp, O.FieldConfig(learn_empty=True))
+                    if i:
+                        best = min(best, time.perf_counter() - t1)
+            torch.set_num_threads(prev)
+            out["cpu_baseline"] = dict(value=small.numel() / 3 / best, unit="points/s", cores=threads, kind="port", host_cpus=os.cpu_count(),
+                                       sample="64 x 64 x 64 = 262 144 points of the same grid, oracle render_profile (50 000-point chunks), best of 2")
+        print(json.dumps(out))
+
+
 def main():
     args = parse()
     if args.cpu_child:
@@ -376,7 +484,7 @@ def main():
 
     _lib.load()
     if args.workload != "eval":
-        train_workload(args, world, rank, dev)
+        (profile_workload if args.workload == "profile" else train_workload)(args, world, rank, dev)
         if launched:
             torch.distributed.destroy_process_group()
         return

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define BTS_ABI_VERSION 2
+#define BTS_ABI_VERSION 3
 
 enum {
   BTS_OK = 0,
@@ -128,8 +128,8 @@ int bts_render_fwd(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const BtsRe
  * per view and sample (training requests rgb_samps anyway); NULL = recompute them.
  * workspace: bts_render_bwd_workspace(cfg, a) bytes of device scratch -- what the backward's passes hand each other: for the plain
  * MLP (n_blocks = 0) with K <= 64, 20 bytes per sample at d_hidden = 64 (the gradient at the pre-softplus density + the relu gates
- * as bits, per sample and per channel); otherwise rays x K x d_hidden floats, rounded up to groups of 64 rays (gradient rows of the
- * per-ray pass for the per-texel scatter pass).  Contents need no initialisation. */
+ * as bits, per sample and per channel); with ResnetBlockFC layers or K > 64, 4 (d_hidden + 1) bytes per sample (the gradient row at
+ * lin_in's output + the gradient at the pre-softplus density).  Contents need no initialisation. */
 size_t bts_render_bwd_workspace(const BtsFieldCfg* cfg, const BtsRenderArgs* a);
 int bts_render_bwd(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const BtsRenderArgs* a, const BtsRenderGrads* g,
                    void* workspace, size_t workspace_bytes, void* stream);
@@ -148,6 +148,15 @@ int bts_project_features_bwd(const BtsFieldCfg* cfg, const float* feat_nchw, con
  * sigma (n, P).  only_density != 0 skips the colour taps: rgb may be NULL and invalid is (n, P, 1). */
 int bts_field_query(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const float* xyz, int32_t P, int32_t only_density,
                     float* rgb, float* invalid, float* sigma, void* stream);
+
+/* The occupancy profile of scripts/inference_setup.py:201-229 (render_profile) in one pass: xyz (n, Y * columns, 3) is a dense grid
+ * of query points with the vertical level y SLOWEST (get_pts' order, :169-187: point (y, c) at index y * columns + c).  Per column
+ * c: sigma := 1 where any view flags the point invalid (:219), running sum over the levels y = 0 .. Y-1 (:224), profile (n, columns)
+ * = (number of levels whose running sum is <= threshold) / Y (:225; threshold 8 in the reference).  only_density != 0: only the
+ * encoder view's frustum test counts as invalid (the LiDAR / 3D-bbox evaluators' query mode, evaluator_lidar.py:300-308).
+ * sigma (n, Y * columns), when given, also receives the raw densities.  Y <= 64 (the reference uses 64); needs proj_nhwc.  ABI 3. */
+int bts_occupancy_profile(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const float* xyz, int32_t Y, int32_t columns, float threshold,
+                          int32_t only_density, float* profile, float* sigma, void* stream);
 
 /* Layout changes at the hand-off from the (PyTorch) encoder: F (N, C, H, W) <-> (N, H, W, C); frames (N, 3, H, W) ->
  * (N, H, W, 4) with `scale`*x + `shift` applied (encode's x*0.5+0.5, models_bts.py:82). */

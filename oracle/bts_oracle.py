@@ -303,6 +303,36 @@ def render(rays: torch.Tensor, z_samp: torch.Tensor, st: FieldState, mlp: MlpPar
 
 
 # ----------------------------------------------------------------------------------------------
+# f3: occupancy profile (scripts/inference_setup.py:84-97 get_pts, :201-229 render_profile)
+# ----------------------------------------------------------------------------------------------
+def profile_points(x_range=(-9, 9), y_range=(.0, .75), z_range=(21, 3), x_res=256, y_res=64, z_res=256):
+    """get_pts (inference_setup.py:84-97) with the OUT_RES defaults (:46-52), no camera-inclination adjustment: (y_res, z_res, x_res, 3),
+    the vertical level y slowest."""
+    x = torch.linspace(x_range[0], x_range[1], x_res).view(1, 1, x_res).expand(y_res, z_res, -1)
+    z = torch.linspace(z_range[0], z_range[1], z_res).view(1, z_res, 1).expand(y_res, -1, x_res)
+    y = torch.linspace(y_range[0], y_range[1], y_res).view(y_res, 1, 1).expand(-1, z_res, x_res)
+    return torch.stack((x, y, z), dim=-1)
+
+
+def occupancy_profile(q_pts: torch.Tensor, st: FieldState, mlp: MlpParams, cfg: FieldConfig, threshold: float = 8.0, batch_size: int = 50000):
+    """render_profile (inference_setup.py:201-229): q_pts (Y, Z, X, 3) -> profile (Z, X), sigma (Y*Z*X,), invalid (Y*Z*X, nv).
+    Field queries in chunks of 50 000 points (:205-217), sigma := 1 where ANY view flags the point (:219), running sum along y
+    (:224), fraction of levels whose running sum is <= 8 (:225)."""
+    Y, Z, X, _ = q_pts.shape
+    pts = q_pts.reshape(1, -1, 3)
+    sig, inv = [], []
+    for f in range(0, pts.shape[1], batch_size):
+        _, i_, s_ = field_forward(pts[:, f:f + batch_size], st, mlp, cfg)
+        sig.append(s_), inv.append(i_)
+    sigmas, invalid = torch.cat(sig, dim=1), torch.cat(inv, dim=1)
+    raw = sigmas.reshape(-1).clone()
+    sigmas[torch.any(invalid > 0, dim=-1)] = 1
+    alphas = sigmas.reshape(Y, Z, X)
+    profile = (torch.cumsum(alphas, dim=0) <= threshold).float().sum(dim=0) / Y
+    return profile, raw, invalid[0]
+
+
+# ----------------------------------------------------------------------------------------------
 # a14: ray distance -> z depth (projection_operations.py:4-16)
 # ----------------------------------------------------------------------------------------------
 def distance_to_z(depths: torch.Tensor, projs: torch.Tensor) -> torch.Tensor:

@@ -38,7 +38,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
         assert hasattr(lib, n), f"{n} declared in include/bts_render.h but not exported"
         assert n in _lib.SYMBOLS, f"{n} has no ctypes signature in _lib.SYMBOLS"
     assert set(_lib.SYMBOLS) == set(names)
-    assert lib.bts_abi_version() == _lib.ABI_VERSION == 2
+    assert lib.bts_abi_version() == _lib.ABI_VERSION == 3
 
 
 def test_ctypes_structs_match_the_c_layout():
