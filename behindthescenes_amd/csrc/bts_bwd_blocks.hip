@@ -33,21 +33,26 @@ namespace bts {
 #error "bts_bwd_blocks.hip is written against the LDS gather (the wave's gather ring doubles as its transposition tiles)"
 #endif
 
-// fp32 weights of this pass in LDS: the encoding rows of lin_in (k-major: the cold path's A operand), w_out, the projected empty
-// feature, and per block fc_0 / fc_1 ROW-major ([out][in] = nn.Linear.weight: the A operand of the transposed products W^T g)
+// Weights of this pass in LDS next to the forward's f16 operands (LdsH): the encoding rows of lin_in in fp32 (k-major: the cold path's
+// A operand), w_out, the projected empty feature, and per block fc_1 / fc_0 TRANSPOSED as split-precision f16 A operands (the layout of
+// LdsH::W_BLK with the roles of input and output swapped) for the products W^T g of the backward.
 template <int HD, int NB>
 struct LdsB {
   static constexpr int PE_ROWS = kPeDim + 1;
   static constexpr int W_IN = 0;                       // [40][HD] k-major, kernel input order (kernel_to_ref_input)
   static constexpr int W_OUT = W_IN + PE_ROWS * HD;    // [HD]
   static constexpr int EMPTY = W_OUT + HD;             // [HD] projected empty feature (unscaled)
-  static constexpr int BLK = EMPTY + HD;               // per block: w0 [HD][HD], w1 [HD][HD] row-major
-  static constexpr int BLK_STRIDE = 2 * HD * HD;
+  static constexpr int VSCALE = EMPTY + HD;            // [0] s_v = a power of two with max |w_out| s_v in [8, 16), [1] 1 / s_v, [2] scratch
+  static constexpr int BLK = VSCALE + 4;               // per block: layer 0 = fc_0^T, layer 1 = fc_1^T, each [term hi/lo][k-slice 2][64 lanes][8 halves] x 2^S
+  static constexpr int BLK_TERM_STRIDE = 2 * 64 * 4;   // floats
+  static constexpr int BLK_LAYER_STRIDE = 2 * BLK_TERM_STRIDE;
+  static constexpr int BLK_STRIDE = 2 * BLK_LAYER_STRIDE;
   static constexpr int TOTAL = BLK + NB * BLK_STRIDE;
 };
 
+// `scale` = 2^S of the forward's f16 operands (LdsH::SCALE): the transposed copies carry the same factor
 template <int C, int HD, int NB>
-__device__ __forceinline__ void stage_weights_b(float* lb, const float* __restrict__ mlp, const float* __restrict__ empty) {
+__device__ __forceinline__ void stage_weights_b(float* lb, const float* __restrict__ mlp, const float* __restrict__ empty, float scale) {
   using L = LdsB<HD, NB>;
   constexpr int D_IN = C + kPeDim;
   const MlpLayout ml{D_IN, HD, NB};
@@ -63,12 +68,52 @@ __device__ __forceinline__ void stage_weights_b(float* lb, const float* __restri
       for (int c = 0; c < C; ++c) a = __builtin_fmaf(mlp[ml.w_in() + hid * D_IN + c], empty[c], a);
     lb[L::EMPTY + hid] = a;
   }
+  if (threadIdx.x == 0) {
+    float m = 0.0f;
+    for (int i = 0; i < HD; ++i) m = fmaxf(m, fabsf(mlp[ml.w_out() + i]));
+    int ex = 0;
+    if (m > 0.0f && m < 3.0e38f) frexpf(m, &ex);      // m = f 2^ex, f in [0.5, 1)
+    const int sv = max(-60, min(60, 4 - ex));
+    lb[L::VSCALE] = ldexpf(1.0f, sv), lb[L::VSCALE + 1] = ldexpf(1.0f, -sv);
+  }
+  if constexpr (NB > 0) {
+    _Float16* wb = reinterpret_cast<_Float16*>(lb + L::BLK);
+    for (int i = threadIdx.x; i < NB * 2 * 2 * 64 * 8; i += blockDim.x) {
+      const int e = i & 7, lane = (i >> 3) & 63, sl = (i >> 9) & 1, layer = i >> 10;   // layer = 2 * block + {0: fc_0^T, 1: fc_1^T}
+      const int kout = mfma_row(8 * sl + e, lane >> 5), in = lane & 31;                  // contraction over the layer's OUTPUT channel
+      float w = mlp[((layer & 1) ? ml.blk_w1(layer >> 1) : ml.blk_w0(layer >> 1)) + kout * HD + in] * scale;
+      asm("" : "+v"(w));
+      const _Float16 hi = (_Float16)w;
+      _Float16* dst = wb + layer * L::BLK_LAYER_STRIDE * 2 + (sl * 64 + lane) * 8 + e;
+      dst[0] = hi;
+      dst[L::BLK_TERM_STRIDE * 2] = (_Float16)(w - (float)hi);
+    }
+  }
+}
+
+// out[pt] += (W^T 2^S) . (in[pt] in_mul) for one transposed ResnetBlockFC linear of width 32 on the f16 pipe (split precision, the
+// backward twin of hidden_layer_h): the lane's own 16 values of a point tile in the C layout are the B operand of two 16-row k-slices.
+__device__ __forceinline__ void hidden_layer_ht(f32x16 (&out)[1][2], const f32x16 (&in)[1][2], const float* wl /* lane-resolved, this layer */,
+                                                int term_stride, float in_mul) {
 #pragma unroll
-  for (int b = 0; b < NB; ++b) {
-    float* base = lb + L::BLK + b * L::BLK_STRIDE;
-    for (int i = threadIdx.x; i < HD * HD; i += blockDim.x) {
-      base[i] = mlp[ml.blk_w0(b) + i];
-      base[HD * HD + i] = mlp[ml.blk_w1(b) + i];
+  for (int sl = 0; sl < 2; ++sl) {
+    const h8 ah = *reinterpret_cast<const h8*>(wl + sl * 256);
+    const h8 al = *reinterpret_cast<const h8*>(wl + term_stride + sl * 256);
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt) {
+      _Float16 hi[8], lo[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        float vc = __builtin_amdgcn_fmed3f(in[0][pt][8 * sl + i] * in_mul, -6.0e4f, 6.0e4f);
+        asm("" : "+v"(vc));   // opaque fp32 value: both conversions below must see the same rounding (see f16_region)
+        hi[i] = (_Float16)vc;
+        lo[i] = (_Float16)(vc - (float)hi[i]);
+      }
+      const h8 bh = __builtin_bit_cast(h8, (u32x4){pack_h2(hi[0], hi[1]), pack_h2(hi[2], hi[3]), pack_h2(hi[4], hi[5]), pack_h2(hi[6], hi[7])});
+      const h8 bl = __builtin_bit_cast(h8, (u32x4){pack_h2(lo[0], lo[1]), pack_h2(lo[2], lo[3]), pack_h2(lo[4], lo[5]), pack_h2(lo[6], lo[7])});
+      out[0][pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, out[0][pt], 0, 0, 0);
+      out[0][pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, out[0][pt], 0, 0, 0);
+      out[0][pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, out[0][pt], 0, 0, 0);
     }
   }
 }
@@ -183,12 +228,21 @@ __global__ __launch_bounds__(256, 2) void rowsb_kernel(const BwdParams bp, const
   constexpr int LB_PAD = (L::TOTAL + 3) & ~3;
   __shared__ __attribute__((aligned(16))) float lds[LB_PAD + LH::TOTAL + 4];
   float* const lh = lds + LB_PAD;   // 16-byte aligned: the f16 A operands are read as ds_read_b128
-  stage_weights_b<C, HD, NB>(lds, p.mlp, p.empty_feature);
+  for (int hid = threadIdx.x; hid < HD; hid += blockDim.x) {   // the projected empty feature first: stage_weights_h scales it
+    float a = 0.0f;
+    if (p.empty_feature)
+      for (int c = 0; c < C; ++c) a = __builtin_fmaf(p.mlp[hid * (C + kPeDim) + c], p.empty_feature[c], a);
+    lds[L::EMPTY + hid] = a;
+  }
   __syncthreads();
   stage_weights_h<C, HD, NB>(lh, lds + L::EMPTY, p.mlp);
   __syncthreads();
   const float scale = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, lh[LH::SCALE])));
   const float inv_scale = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, lh[LH::SCALE + 1])));
+  stage_weights_b<C, HD, NB>(lds, p.mlp, p.empty_feature, scale);
+  __syncthreads();
+  const float s_v = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, lds[L::VSCALE])));
+  const float inv_s_v = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, lds[L::VSCALE + 1])));
 
   const int lane = threadIdx.x & 63;
   const int h0 = lane >> 5;
@@ -469,15 +523,16 @@ __global__ __launch_bounds__(256, 2) void rowsb_kernel(const BwdParams bp, const
         bcast_tiles(__float_as_uint(g_s), t0, t1);
         gs_t[0] = __uint_as_float(t0), gs_t[1] = __uint_as_float(t1);
       }
-      f32x16 v[HT][2];   // the gate-dependent vector of the current layer, true scale (g_h = g_s v)
+      f32x16 v[HT][2];   // the gate-dependent vector of the current layer times s_v (g_h = (g_s / s_v) v)
+      gs_t[0] *= inv_s_v, gs_t[1] *= inv_s_v;    // exact: a power of two
 #pragma unroll
       for (int ht = 0; ht < HT; ++ht) {
         float r[16];
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-          const float w2 = lds[L::W_OUT + ht * 32 + mfma_row(q, 0) + 4 * h];
+          const float w2 = lds[L::W_OUT + ht * 32 + mfma_row(q, 0) + 4 * h] * s_v;
           const float a0 = acc[ht][0][q], a1 = acc[ht][1][q];
-          r[q] = __builtin_fmaf(relu1(a1), gs_t[1] * inv_scale, relu1(a0) * (gs_t[0] * inv_scale));
+          r[q] = __builtin_fmaf(relu1(a1), gs_t[1] * (s_v * inv_scale), relu1(a0) * (gs_t[0] * (s_v * inv_scale)));
           v[ht][0][q] = a0 > 0.0f ? w2 : 0.0f;
           v[ht][1][q] = a1 > 0.0f ? w2 : 0.0f;
         }
@@ -487,23 +542,23 @@ __global__ __launch_bounds__(256, 2) void rowsb_kernel(const BwdParams bp, const
 
       // ---------------- back through the blocks (resnetfc.py:53-62): h1 = h0 + fc_1(relu(n)), n = fc_0(relu(h0))
       if constexpr (NB > 0) {
-      int lane_o = lane;
-      asm volatile("" : "+v"(lane_o));   // opaque per iteration: the 32 weight reads of a transposed product stay inside the persistent loop
+      int lane4t = lane * 4;
+      asm volatile("" : "+v"(lane4t));   // opaque per iteration: the A operands of the transposed products stay inside the persistent loop
 #pragma unroll
       for (int b = NB - 1; b >= 0; --b) {
-        const float* rw = lds + L::BLK + b * L::BLK_STRIDE;
-        // t = W1^T v  (fp32-input MFMA: the C layout of v is the B operand)
+        const float* wt = lds + L::BLK + b * L::BLK_STRIDE + lane4t;
+        // vn = mn . (W1^T v): the C layout of v is the B operand; the result carries 2^S (and s_v)
         f32x16 vn[1][2];
         vn[0][0] = zero_acc(), vn[0][1] = zero_acc();
         {
           f32x16 vin[1][2];
           vin[0][0] = v[0][0], vin[0][1] = v[0][1];
-          hidden_layer<HD, false>(vn, vin, rw + HD * HD, lane_o);
+          hidden_layer_ht(vn, vin, wt + L::BLK_LAYER_STRIDE, L::BLK_TERM_STRIDE, 1.0f);
         }
 #pragma unroll
         for (int q = 0; q < 16; ++q)
 #pragma unroll
-          for (int pt = 0; pt < 2; ++pt) vn[0][pt][q] = net[b][pt][q] > 0.0f ? vn[0][pt][q] : 0.0f;
+          for (int pt = 0; pt < 2; ++pt) vn[0][pt][q] = net[b][pt][q] > 0.0f ? vn[0][pt][q] * inv_scale : 0.0f;
         if (bp.d_mlp) {
           // dW1[out][in] += sum_p (g_s v)[p][out] relu(n)[p][in];  db1[out] += sum_p (g_s v)[p][out]
 #pragma unroll
@@ -527,7 +582,7 @@ __global__ __launch_bounds__(256, 2) void rowsb_kernel(const BwdParams bp, const
         // t2 = W0^T vn;  v <- v + m0 . t2
         f32x16 t2[1][2];
         t2[0][0] = zero_acc(), t2[0][1] = zero_acc();
-        hidden_layer<HD, false>(t2, vn, rw, lane_o);
+        hidden_layer_ht(t2, vn, wt, L::BLK_TERM_STRIDE, 1.0f);
         if (bp.d_mlp) {
           // dW0[out][in] += sum_p (g_s vn)[p][out] relu(h0)[p][in];  db0[out] += sum_p (g_s vn)[p][out]
 #pragma unroll
@@ -551,7 +606,7 @@ __global__ __launch_bounds__(256, 2) void rowsb_kernel(const BwdParams bp, const
 #pragma unroll
         for (int q = 0; q < 16; ++q)
 #pragma unroll
-          for (int pt = 0; pt < 2; ++pt) v[0][pt][q] += hin[b][pt][q] > 0.0f ? t2[0][pt][q] : 0.0f;
+          for (int pt = 0; pt < 2; ++pt) v[0][pt][q] += hin[b][pt][q] > 0.0f ? t2[0][pt][q] * inv_scale : 0.0f;
       }
       }
 

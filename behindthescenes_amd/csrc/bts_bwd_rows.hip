@@ -490,6 +490,8 @@ struct ScatterMaskParams {
   float* d_empty_proj;       // or null
   int groups_per_sample;
   int w_out_off;             // offset of w_out in the packed parameter vector
+  int nseg, kseg;            // the K steps of a ray group are cut into nseg segments of kseg steps, one wave each (own window, own flush):
+                             // a batch of few patches (RE10K: 384, KITTI-Raw: 256) otherwise leaves most of the 1024 SIMDs idle
 };
 
 // wave-wide minimum on the DPP network (row_shr 1/2/4/8, row_bcast15, row_bcast31: lane 63 ends up with the result) -- four of these
@@ -527,7 +529,8 @@ __global__ __launch_bounds__(64) void scatter_kernel(const ScatterMaskParams sp)
   const int lane = threadIdx.x;
   const int h = lane >> 5, c = lane & 31;
   const unsigned c4 = (unsigned)c * 4u, cbit = 1u << c;
-  const int grp = blockIdx.x / NW, wv = blockIdx.x - grp * NW;
+  const int unit = blockIdx.x / sp.nseg, seg = blockIdx.x - unit * sp.nseg;
+  const int grp = unit / NW, wv = unit - grp * NW;
   const int chg = wv * 32 + c;   // this lane's channel of the row
   const int sample = grp / sp.groups_per_sample;
   const int g_in = grp - sample * sp.groups_per_sample;
@@ -621,26 +624,28 @@ __global__ __launch_bounds__(64) void scatter_kernel(const ScatterMaskParams sp)
     *c11 = a11 + ww.w * gv;
   };
 
-  float z_n = zrow[K - 1], gs_n = ray_ok ? gsrow[K - 1] : 0.0f;
-  unsigned m_n = (!ROWS && ray_ok) ? mrow[K - 1] : 0u;
+  const int k_lo = seg * sp.kseg, k_hi = min(K, k_lo + sp.kseg);   // this wave's steps: k_hi - 1 down to k_lo
+  if (k_lo >= k_hi) return;
+  float z_n = zrow[k_hi - 1], gs_n = ray_ok ? gsrow[k_hi - 1] : 0.0f;
+  unsigned m_n = (!ROWS && ray_ok) ? mrow[k_hi - 1] : 0u;
   constexpr int NROW = ROWS ? 32 : 1;
   float cur[NROW], nxt[NROW];
   if constexpr (ROWS) {
 #pragma unroll
-    for (int i = 0; i < 32; ++i) nxt[i] = i < half_pts ? urow[i * pstride + (long)(K - 1) * HD] : 0.0f;
+    for (int i = 0; i < 32; ++i) nxt[i] = i < half_pts ? urow[i * pstride + (long)(k_hi - 1) * HD] : 0.0f;
   }
-  for (int k = K - 1; k >= 0; --k) {
+  for (int k = k_hi - 1; k >= k_lo; --k) {
     const float z = z_n, gs = gs_n;
     const unsigned gate = m_n;
     {  // the next step's inputs
-      const int kn = max(k - 1, 0);
+      const int kn = max(k - 1, k_lo);
       z_n = zrow[kn], gs_n = ray_ok ? gsrow[kn] : 0.0f;
       if constexpr (!ROWS) m_n = ray_ok ? mrow[kn] : 0u;
       if constexpr (ROWS) {
 #pragma unroll
         for (int i = 0; i < 32; ++i) cur[i] = nxt[i];
 #pragma unroll
-        for (int i = 0; i < 32; ++i) nxt[i] = (i < half_pts && k > 0) ? urow[i * pstride + (long)kn * HD] : 0.0f;
+        for (int i = 0; i < 32; ++i) nxt[i] = (i < half_pts && k > k_lo) ? urow[i * pstride + (long)kn * HD] : 0.0f;
       }
     }
     if (__all(gs == 0.0f)) continue;   // e.g. the capped last sample of every ray: nothing to add
@@ -966,7 +971,6 @@ __global__ __launch_bounds__(256, 2) void dwpe_kernel(const DwpeParams dp) {
 // exploit), so the contraction runs as fp32-input MFMAs (exact products, fp32 accumulation): the A operand A[i = channel][k = sample]
 // is read STRAIGHT from the workspace -- lane (h, col) loads channel col of sample 2s + h, two 128-byte rows per instruction, no
 // transposition -- and the B operand B[k = sample][j = kin] comes from a per-wave LDS tile the encoding is written to lane = sample.
-// One unit = 64 samples of one ray.
 // ---------------------------------------------------------------------------------------------------------------
 struct DwpeRowsParams {
   FwdParams f;
@@ -1005,8 +1009,11 @@ __global__ __launch_bounds__(256, 2) void dwpe_rows_kernel(const DwpeRowsParams 
   const int h = lane >> 5, col = lane & 31;
   float* const tile = tiles + wave * 64 * kPeLd;
   const int Bp = p.Bp, K = p.K;
-  const int nch = (K + 63) >> 6;
-  const long units = dp.rays * nch;
+  // One unit = 64 CONSECUTIVE samples of one batch element's (ray, k) list -- the rows of u0 are contiguous in exactly that order, so
+  // a ray of 48 samples wastes no k-steps (units run across ray boundaries; lane = sample looks its own ray up)
+  const int per_sample = Bp * K;                         // samples per batch element (< 2^31: checked by the launcher)
+  const int units_per_sample = (per_sample + 63) >> 6;
+  const long units = (long)p.n * units_per_sample;
   f32x16 dw[HT][2];
 #pragma unroll
   for (int ht = 0; ht < HT; ++ht)
@@ -1014,26 +1021,29 @@ __global__ __launch_bounds__(256, 2) void dwpe_rows_kernel(const DwpeRowsParams 
     for (int kt = 0; kt < 2; ++kt) dw[ht][kt] = zero_acc();
   const long stride = (long)gridDim.x * 4;
   for (long unit = (long)blockIdx.x * 4 + wave; unit < units; unit += stride) {
-    const long ray = unit / nch;
-    const int kc = (int)(unit - ray * nch) * 64;
-    const int sample = (int)(ray / Bp);
-    // ---- A operand: channel ht*32 + col of samples kc + 2s + h, all 32 k-steps up front (they land under the trigonometry)
+    const int sample = (int)(unit / units_per_sample);
+    const int s0 = (int)(unit - (long)sample * units_per_sample) * 64;     // first sample of the unit inside its batch element
+    const int n_valid = min(64, per_sample - s0);                          // wave-uniform
+    // ---- A operand: channel ht*32 + col of samples s0 + 2 s2 + h, all k-steps up front (they land under the trigonometry)
     float a[HT][32];
     {
-      const float* ur = dp.u0_ws + (ray * K + kc + h) * (long)HD + col;
+      const float* ur = dp.u0_ws + ((long)sample * per_sample + s0 + h) * (long)HD + col;
 #pragma unroll
       for (int s2 = 0; s2 < 32; ++s2) {
-        const bool ok = kc + 2 * s2 + h < K;
+        const bool ok = 2 * s2 + h < n_valid;
 #pragma unroll
         for (int ht = 0; ht < HT; ++ht) a[ht][s2] = ok ? ur[(long)(2 * s2) * HD + ht * 32] : 0.0f;
       }
     }
     // ---- B operand: the 40 inputs of lin_in's encoding part in kernel order (x, y, code, 1, then per octave 3 sines and 3 "cosines")
     const Cam enc = load_cam(p.w2c_enc + sample * 16, p.K_enc + sample * 9);
-    const cfp rp = as_const(p.rays) + ray * 8;
-    const int kk = min(kc + lane, K - 1);
-    const float z = p.z_samp[ray * K + kk];
-    const float px = rp[0] + z * rp[3], py = rp[1] + z * rp[4], pz = rp[2] + z * rp[5];
+    const int si = min(s0 + lane, per_sample - 1);
+    const int r_in = si / K;
+    const long ray = (long)sample * Bp + r_in;
+    const float4 r0 = reinterpret_cast<const float4*>(p.rays)[ray * 2];
+    const float4 r1 = reinterpret_cast<const float4*>(p.rays)[ray * 2 + 1];
+    const float z = p.z_samp[(long)sample * per_sample + si];
+    const float px = r0.x + z * r0.w, py = r0.y + z * r1.x, pz = r0.z + z * r1.y;
     const Proj pe = p.code_mode == 1 ? project<true>(enc, px, py, pz) : project<false>(enc, px, py, pz);
     float v3[3];
     v3[0] = pe.x, v3[1] = pe.y;
@@ -1105,6 +1115,8 @@ __global__ __launch_bounds__(256, 2) void dwpe_rows_kernel(const DwpeRowsParams 
 // ---------------------------------------------------------------------------------------------------------------
 // launch
 // ---------------------------------------------------------------------------------------------------------------
+static void scatter_segments(ScatterMaskParams& sp, long units, int K);
+
 template <int C, int HD>
 static int launch_rows(const BwdParams& bp, int n, int grid, hipStream_t s) {
   const FwdParams& p = bp.f;
@@ -1127,7 +1139,9 @@ static int launch_rows(const BwdParams& bp, int n, int grid, hipStream_t s) {
     ScatterMaskParams sp;
     sp.f = p, sp.mask_ws = bp.mask_ws, sp.u0_ws = nullptr, sp.gs_ws = bp.gs_ws, sp.d_proj = bp.d_proj, sp.d_empty_proj = bp.d_empty_proj;
     sp.groups_per_sample = (p.Bp + 63) / 64, sp.w_out_off = ml.w_out();
-    scatter_kernel<HD><<<n * sp.groups_per_sample * (HD / 32), 64, 0, s>>>(sp);
+    const long units = (long)n * sp.groups_per_sample * (HD / 32);
+    scatter_segments(sp, units, p.K);
+    scatter_kernel<HD><<<(int)(units * sp.nseg), 64, 0, s>>>(sp);
     e = hipGetLastError();
   }
   if (e == hipSuccess && bp.d_mlp) {
@@ -1146,13 +1160,25 @@ static int launch_rows(const BwdParams& bp, int n, int grid, hipStream_t s) {
   return BTS_OK;
 }
 
+// segments of the K steps per ray group: enough waves for two per SIMD (2048), at least 8 steps each (window set-up + final flush)
+static void scatter_segments(ScatterMaskParams& sp, long units, int K) {
+  long want = (2048 + units - 1) / units;
+  const long most = K >= 8 ? K / 8 : 1;
+  if (want > most) want = most;
+  if (want < 1) want = 1;
+  sp.kseg = (int)((K + want - 1) / want);
+  sp.nseg = (K + sp.kseg - 1) / sp.kseg;
+}
+
 // ROWS form of pass B / pass C for bts_bwd_blocks.hip
 int launch_scatter_rows(const FwdParams& p, const float* gs_ws, const float* u0_ws, float* d_proj, float* d_empty_proj, int HD, int n, hipStream_t s) {
   ScatterMaskParams sp;
   sp.f = p, sp.mask_ws = nullptr, sp.u0_ws = u0_ws, sp.gs_ws = gs_ws, sp.d_proj = d_proj, sp.d_empty_proj = d_empty_proj;
   sp.groups_per_sample = (p.Bp + 63) / 64, sp.w_out_off = 0;
-  if (HD == 64) scatter_kernel<64, true><<<n * sp.groups_per_sample * 2, 64, 0, s>>>(sp);
-  else if (HD == 32) scatter_kernel<32, true><<<n * sp.groups_per_sample, 64, 0, s>>>(sp);
+  const long units = (long)n * sp.groups_per_sample * (HD / 32);
+  scatter_segments(sp, units, p.K);
+  if (HD == 64) scatter_kernel<64, true><<<(int)(units * sp.nseg), 64, 0, s>>>(sp);
+  else if (HD == 32) scatter_kernel<32, true><<<(int)(units * sp.nseg), 64, 0, s>>>(sp);
   else return BTS_E_UNSUPPORTED;
   return hipGetLastError() == hipSuccess ? BTS_OK : BTS_E_LAUNCH;
 }
@@ -1160,7 +1186,9 @@ int launch_scatter_rows(const FwdParams& p, const float* gs_ws, const float* u0_
 int launch_dwpe_rows(const FwdParams& p, const float* u0_ws, float* d_mlp, int C, int HD, int NB, int n, int grid, hipStream_t s) {
   DwpeRowsParams dp;
   dp.f = p, dp.u0_ws = u0_ws, dp.d_mlp = d_mlp, dp.rays = (long)n * p.Bp;
-  const long units = dp.rays * ((p.K + 63) / 64);
+  if ((long)p.Bp * p.K > 0x7FFFFF00L) return BTS_E_UNSUPPORTED;
+  dp.f.n = n;
+  const long units = (long)n * (((long)p.Bp * p.K + 63) / 64);
   const long wgs = (units + 3) / 4;
   const int g = (int)(wgs < grid ? wgs : grid);   // grid = 2 work-groups per CU
   if (C == 64 && HD == 64) dwpe_rows_kernel<64, 64><<<g, 256, 0, s>>>(dp);
