@@ -22,6 +22,7 @@
 //                              operand (lane = channel reads its channel of sample k: no transposition), encoding recomputed.
 // What torch.autograd would do for nerf.py:283-299 + models_bts.py:266-338 + resnetfc.py:53-62, 132-184 of the reference.
 #define BTS_NO_LAUNCH_GLUE
+#undef BTS_GATHER_REGS   // (the register-gather A/B build, variants/libbts_gatherregs.so, concerns the render kernels: the row passes of the backward exist in the LDS-gather form only)
 #include "bts_render_kernel.h"
 #include "bts_bwd.h"
 #include <cstdlib>
@@ -91,30 +92,27 @@ __device__ __forceinline__ void stage_weights_b(float* lb, const float* __restri
   }
 }
 
-// out[pt] += (W^T 2^S) . (in[pt] in_mul) for one transposed ResnetBlockFC linear of width 32 on the f16 pipe (split precision, the
-// backward twin of hidden_layer_h): the lane's own 16 values of a point tile in the C layout are the B operand of two 16-row k-slices.
-__device__ __forceinline__ void hidden_layer_ht(f32x16 (&out)[1][2], const f32x16 (&in)[1][2], const float* wl /* lane-resolved, this layer */,
-                                                int term_stride, float in_mul) {
+// out += (W^T 2^S) . (in in_mul) for ONE point tile of one transposed ResnetBlockFC linear of width 32 on the f16 pipe (split precision,
+// the backward twin of hidden_layer_h): the lane's own 16 values of the tile in the C layout are the B operand of two 16-row k-slices.
+__device__ __forceinline__ void hidden_layer_ht(f32x16& out, const f32x16& in, const float* wl /* lane-resolved, this layer */, int term_stride,
+                                                float in_mul) {
 #pragma unroll
   for (int sl = 0; sl < 2; ++sl) {
     const h8 ah = *reinterpret_cast<const h8*>(wl + sl * 256);
     const h8 al = *reinterpret_cast<const h8*>(wl + term_stride + sl * 256);
+    _Float16 hi[8], lo[8];
 #pragma unroll
-    for (int pt = 0; pt < 2; ++pt) {
-      _Float16 hi[8], lo[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        float vc = __builtin_amdgcn_fmed3f(in[0][pt][8 * sl + i] * in_mul, -6.0e4f, 6.0e4f);
-        asm("" : "+v"(vc));   // opaque fp32 value: both conversions below must see the same rounding (see f16_region)
-        hi[i] = (_Float16)vc;
-        lo[i] = (_Float16)(vc - (float)hi[i]);
-      }
-      const h8 bh = __builtin_bit_cast(h8, (u32x4){pack_h2(hi[0], hi[1]), pack_h2(hi[2], hi[3]), pack_h2(hi[4], hi[5]), pack_h2(hi[6], hi[7])});
-      const h8 bl = __builtin_bit_cast(h8, (u32x4){pack_h2(lo[0], lo[1]), pack_h2(lo[2], lo[3]), pack_h2(lo[4], lo[5]), pack_h2(lo[6], lo[7])});
-      out[0][pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, out[0][pt], 0, 0, 0);
-      out[0][pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, out[0][pt], 0, 0, 0);
-      out[0][pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, out[0][pt], 0, 0, 0);
+    for (int i = 0; i < 8; ++i) {
+      float vc = __builtin_amdgcn_fmed3f(in[8 * sl + i] * in_mul, -6.0e4f, 6.0e4f);
+      asm("" : "+v"(vc));   // opaque fp32 value: both conversions below must see the same rounding (see f16_region)
+      hi[i] = (_Float16)vc;
+      lo[i] = (_Float16)(vc - (float)hi[i]);
     }
+    const h8 bh = __builtin_bit_cast(h8, (u32x4){pack_h2(hi[0], hi[1]), pack_h2(hi[2], hi[3]), pack_h2(hi[4], hi[5]), pack_h2(hi[6], hi[7])});
+    const h8 bl = __builtin_bit_cast(h8, (u32x4){pack_h2(lo[0], lo[1]), pack_h2(lo[2], lo[3]), pack_h2(lo[4], lo[5]), pack_h2(lo[6], lo[7])});
+    out = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, out, 0, 0, 0);
+    out = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, out, 0, 0, 0);
+    out = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, out, 0, 0, 0);
   }
 }
 
@@ -281,7 +279,7 @@ __global__ __launch_bounds__(256, 2) void rowsb_kernel(const BwdParams bp, const
     const int gg = (c << CHL) + (idx & ((1 << CHL) - 1));
     return (c < n_chunks && gg < n_groups) ? gg : -1;
   };
-  const int Bp = p.Bp, K = p.K, H = p.H, W = p.W, nv = p.nv;
+  const int Bp = p.Bp, K = p.K;
   const int kc_last = ((K - 1) >> 6) << 6;   // first sample of the last 64-sample chunk of a ray: chunks are walked back to front
 
   // persistent per-wave gradient state
@@ -310,24 +308,27 @@ __global__ __launch_bounds__(256, 2) void rowsb_kernel(const BwdParams bp, const
   if (g >= 0) fetch_state(g, kc_last);
 
   for (; g >= 0; idx += waves_per_xcd, g = group_of(idx)) {
+    auto qb = kernarg_view<BwdParams>();   // this iteration's parameters, re-read where they are used (bts_common.h: kernarg_view)
+    asm volatile("" : "+s"(qb));
+    const int H = qb->f.H, W = qb->f.W, nv = qb->f.nv;
     const long ray = g;
     while (g >= sample_end) ++sample, sample_end += Bp;
-    const Cam enc = load_cam(p.w2c_enc + sample * 16, p.K_enc + sample * 9);
-    const float4* __restrict__ G = reinterpret_cast<const float4*>(p.proj) + (long)sample * H * W * (HD / 4);
-    const cfp rp = as_const(p.rays) + ray * 8;
+    const Cam enc = load_cam(qb->f.w2c_enc + sample * 16, qb->f.K_enc + sample * 9);
+    const float4* __restrict__ G = reinterpret_cast<const float4*>(qb->f.proj) + (long)sample * H * W * (HD / 4);
+    const cfp rp = as_const(qb->f.rays) + ray * 8;
     const float ox = rp[0], oy = rp[1], oz = rp[2], dx = rp[3], dy = rp[4], dz = rp[5];
     // upstream gradients of the ray
     float g_rgb[NVMAX * 3];
     float g_bkgd = 0.0f;
     {
-      const cfp gr = as_const(bp.g_rgb) + ray * (long)(nv * 3);
+      const cfp gr = as_const(qb->g_rgb) + ray * (long)(nv * 3);
 #pragma unroll
       for (int i = 0; i < NVMAX * 3; ++i) {
-        g_rgb[i] = (bp.g_rgb && i < nv * 3) ? gr[i] : 0.0f;
+        g_rgb[i] = (qb->g_rgb && i < nv * 3) ? gr[i] : 0.0f;
         g_bkgd -= g_rgb[i];
       }
     }
-    const float g_depth = bp.g_depth ? as_const(bp.g_depth)[ray] : 0.0f;
+    const float g_depth = qb->g_depth ? as_const(qb->g_depth)[ray] : 0.0f;
     float S_carry = 0.0f;   // sum over the samples of the chunks behind this one of g_w w
 
     for (int kc = kc_last; kc >= 0; kc -= 64) {
@@ -352,10 +353,10 @@ __global__ __launch_bounds__(256, 2) void rowsb_kernel(const BwdParams bp, const
       // ---------------- upstream gradient of this sample's weight: g_w = g_depth z + sum_j g_rgb_j . c_kj (+ g_weights_k)
       float g_w = g_depth * z;
       {
-        if (p.white_bkgd) g_w += g_bkgd;   // nerf.py:301-304: rgb = sum_k w_k c_k + 1 - sum_k w_k
-        if (bp.g_weights) g_w += bp.g_weights[pk];
-        if (p.rgb_samps) {
-          const float* cs = p.rgb_samps + pk * (long)(nv * 3);
+        if (qb->f.white_bkgd) g_w += g_bkgd;   // nerf.py:301-304: rgb = sum_k w_k c_k + 1 - sum_k w_k
+        if (qb->g_weights) g_w += qb->g_weights[pk];
+        if (qb->f.rgb_samps) {
+          const float* cs = qb->f.rgb_samps + pk * (long)(nv * 3);
 #pragma unroll
           for (int j = 0; j < NVMAX; ++j)
             if (j < nv) g_w += g_rgb[3 * j] * cs[3 * j] + g_rgb[3 * j + 1] * cs[3 * j + 1] + g_rgb[3 * j + 2] * cs[3 * j + 2];
@@ -363,10 +364,10 @@ __global__ __launch_bounds__(256, 2) void rowsb_kernel(const BwdParams bp, const
 #pragma unroll
           for (int j = 0; j < NVMAX; ++j) {
             if (j < nv) {
-              const Cam cj = load_cam(p.w2c_r + ((long)sample * nv + j) * 16, p.K_r + ((long)sample * nv + j) * 9);
+              const Cam cj = load_cam(qb->f.w2c_r + ((long)sample * nv + j) * 16, qb->f.K_r + ((long)sample * nv + j) * 9);
               const Proj pc = project<false>(cj, px, py, pz);
               const Taps tc = make_taps(pc.x, pc.y, H, W);
-              const float4* img = reinterpret_cast<const float4*>(p.imgs) + ((long)sample * nv + j) * H * W;
+              const float4* img = reinterpret_cast<const float4*>(qb->f.imgs) + ((long)sample * nv + j) * H * W;
               const float4 a = img[tc.o00], b = img[tc.o01], cc = img[tc.o10], d = img[tc.o11];
               const float c0 = ((a.x * tc.w00 + b.x * tc.w01) + cc.x * tc.w10) + d.x * tc.w11;
               const float c1 = ((a.y * tc.w00 + b.y * tc.w01) + cc.y * tc.w10) + d.y * tc.w11;
@@ -378,12 +379,12 @@ __global__ __launch_bounds__(256, 2) void rowsb_kernel(const BwdParams bp, const
       }
 
       // ---------------- encoder view
-      const Proj pe = p.code_mode == 1 ? project<true>(enc, px, py, pz) : project<false>(enc, px, py, pz);
+      const Proj pe = qb->f.code_mode == 1 ? project<true>(enc, px, py, pz) : project<false>(enc, px, py, pz);
       Taps tp = make_taps(pe.x, pe.y, H, W);
       float v3[3];
       v3[0] = pe.x, v3[1] = pe.y;
-      v3[2] = depth_code(p.code_mode == 1 ? pe.dist : pe.z, p.inv_z != 0, p.inv_dmax, p.inv_range, p.d_min, p.range);
-      const bool use_empty = (p.learn_empty != 0) & pe.invalid;
+      v3[2] = depth_code(qb->f.code_mode == 1 ? pe.dist : pe.z, qb->f.inv_z != 0, qb->f.inv_dmax, qb->f.inv_range, qb->f.d_min, qb->f.range);
+      const bool use_empty = (qb->f.learn_empty != 0) & pe.invalid;
       if (use_empty) tp.w00 = tp.w01 = tp.w10 = tp.w11 = 0.0f;
       tp.w00 *= scale, tp.w01 *= scale, tp.w10 *= scale, tp.w11 *= scale;
 
@@ -397,7 +398,7 @@ __global__ __launch_bounds__(256, 2) void rowsb_kernel(const BwdParams bp, const
         bcast_tiles(__float_as_uint(tp.w11), t0, t1), wq[0][3] = __uint_as_float(t0), wq[1][3] = __uint_as_float(t1);
         bcast_tiles(use_empty ? 1u : 0u, t0, t1), emp[0] = t0 != 0, emp[1] = t1 != 0;
       }
-      const bool cold = __any(pe_needs_exact(v3, p.freq_factor));
+      const bool cold = __any(pe_needs_exact(v3, qb->f.freq_factor));
       unsigned off_next[4];
       GRows rows;
       if (__builtin_expect(!cold, 1)) {
@@ -412,11 +413,11 @@ __global__ __launch_bounds__(256, 2) void rowsb_kernel(const BwdParams bp, const
       float g_s = 0.0f;
       {
         float sigma = softplus(s_raw);
-        const bool dead = (p.empty_empty != 0) & pe.invalid;   // sigma forced to 0: no gradient
+        const bool dead = (qb->f.empty_empty != 0) & pe.invalid;   // sigma forced to 0: no gradient
         if (dead) sigma = 0.0f;
         const float delta = last ? 1e10f : (z_nx - z);
         const float ex = expf(-fabsf(delta) * fmaxf(sigma, 0.0f));
-        const bool capped = (p.hard_cap != 0) & last;
+        const bool capped = (qb->f.hard_cap != 0) & last;
         const float alpha = capped ? 1.0f : 1.0f - ex;
         const float gww = valid ? g_w * (alpha * T) : 0.0f;
         // exclusive suffix sum over the wave + the chunks behind; the wave's total moves on to the chunk in front
@@ -430,9 +431,9 @@ __global__ __launch_bounds__(256, 2) void rowsb_kernel(const BwdParams bp, const
         const float S = (lane == 63 ? 0.0f : below) + S_carry;
         S_carry += __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, incl)));
         float g_alpha = g_w * T - S / (capped ? 1e-10f : ex + 1e-10f);
-        if (bp.g_alphas) g_alpha += bp.g_alphas[pk];
+        if (qb->g_alphas) g_alpha += qb->g_alphas[pk];
         if (!capped && !dead && valid) g_s = g_alpha * fabsf(delta) * ex * (s_raw > 20.0f ? 1.0f : sigmoidf(s_raw));
-        if (valid) bp.gs_ws[pk] = g_s;
+        if (valid) qb->gs_ws[pk] = g_s;
       }
       db_acc += g_s;
 
@@ -441,16 +442,16 @@ __global__ __launch_bounds__(256, 2) void rowsb_kernel(const BwdParams bp, const
       if (__builtin_expect(cold, 0)) {
         // no gather is in flight (the prologue above was skipped).  One point tile per call: the tile lives in the wave's gather ring
         wave_lds_fence();
-        lin_in_exact<C, HD, NB>(lds, G, p.w2c_enc + sample * 16, p.K_enc + sample * 9, H, W, p.code_mode, p.inv_z, p.inv_dmax, p.inv_range,
-                                p.d_min, p.range, p.freq_factor, p.learn_empty, px, py, pz, tile_a, 0);
+        lin_in_exact<C, HD, NB>(lds, G, qb->f.w2c_enc + sample * 16, qb->f.K_enc + sample * 9, H, W, qb->f.code_mode, qb->f.inv_z, qb->f.inv_dmax, qb->f.inv_range,
+                                qb->f.d_min, qb->f.range, qb->f.freq_factor, qb->f.learn_empty, px, py, pz, tile_a, 0);
         wave_lds_fence();
 #pragma unroll
         for (int ht = 0; ht < HT; ++ht)
 #pragma unroll
           for (int q = 0; q < 16; ++q) acc[ht][0][q] = tile_a[col * (HD + 1) + ht * 32 + mfma_row(q, h)] * scale;
         wave_lds_fence();
-        lin_in_exact<C, HD, NB>(lds, G, p.w2c_enc + sample * 16, p.K_enc + sample * 9, H, W, p.code_mode, p.inv_z, p.inv_dmax, p.inv_range,
-                                p.d_min, p.range, p.freq_factor, p.learn_empty, px, py, pz, tile_a, 1);
+        lin_in_exact<C, HD, NB>(lds, G, qb->f.w2c_enc + sample * 16, qb->f.K_enc + sample * 9, H, W, qb->f.code_mode, qb->f.inv_z, qb->f.inv_dmax, qb->f.inv_range,
+                                qb->f.d_min, qb->f.range, qb->f.freq_factor, qb->f.learn_empty, px, py, pz, tile_a, 1);
         wave_lds_fence();
 #pragma unroll
         for (int ht = 0; ht < HT; ++ht)
@@ -470,16 +471,16 @@ __global__ __launch_bounds__(256, 2) void rowsb_kernel(const BwdParams bp, const
             }
         }
         SinCos3 raw;
-        pe_direct(raw, v3, p.freq_factor);
+        pe_direct(raw, v3, qb->f.freq_factor);
         __builtin_amdgcn_sched_barrier(0);
         int lane4 = lane * 4;
         asm volatile("" : "+v"(lane4));
-        region_seq_l<HD, 0>(acc, gl, rows, G, wq, off_next, lh + LH::W_F16 + lane4, LH::TERM_STRIDE, raw, v3, p.freq_factor, bias);
+        region_seq_l<HD, 0>(acc, gl, rows, G, wq, off_next, lh + LH::W_F16 + lane4, LH::TERM_STRIDE, raw, v3, qb->f.freq_factor, bias);
         if constexpr (NS > kNumFreqs) {
           gl_consume<HD, 12>(acc, gl, rows, G, wq, off_next), gl_consume<HD, 13>(acc, gl, rows, G, wq, off_next);
           gl_consume<HD, 14>(acc, gl, rows, G, wq, off_next), gl_consume<HD, 15>(acc, gl, rows, G, wq, off_next);
         }
-        if (p.learn_empty && __any(use_empty)) {
+        if (qb->f.learn_empty && __any(use_empty)) {
 #pragma unroll
           for (int ht = 0; ht < HT; ++ht)
 #pragma unroll
@@ -516,105 +517,92 @@ __global__ __launch_bounds__(256, 2) void rowsb_kernel(const BwdParams bp, const
       }
       }
 
-      // ---------------- g_s of both point tiles; dw_out += relu(h1) g_s (2^S removed through g_s); v = m1 . w_out
+      // ---------------- g_s of both point tiles; dw_out += relu(h1) g_s (2^S removed through g_s)
       float gs_t[2];
       {
         unsigned t0, t1;
         bcast_tiles(__float_as_uint(g_s), t0, t1);
         gs_t[0] = __uint_as_float(t0), gs_t[1] = __uint_as_float(t1);
       }
-      f32x16 v[HT][2];   // the gate-dependent vector of the current layer times s_v (g_h = (g_s / s_v) v)
-      gs_t[0] *= inv_s_v, gs_t[1] *= inv_s_v;    // exact: a power of two
 #pragma unroll
       for (int ht = 0; ht < HT; ++ht) {
         float r[16];
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          const float w2 = lds[L::W_OUT + ht * 32 + mfma_row(q, 0) + 4 * h] * s_v;
-          const float a0 = acc[ht][0][q], a1 = acc[ht][1][q];
-          r[q] = __builtin_fmaf(relu1(a1), gs_t[1] * (s_v * inv_scale), relu1(a0) * (gs_t[0] * (s_v * inv_scale)));
-          v[ht][0][q] = a0 > 0.0f ? w2 : 0.0f;
-          v[ht][1][q] = a1 > 0.0f ? w2 : 0.0f;
-        }
+        for (int q = 0; q < 16; ++q)
+          r[q] = __builtin_fmaf(relu1(acc[ht][1][q]), gs_t[1] * inv_scale, relu1(acc[ht][0][q]) * (gs_t[0] * inv_scale));
         // dw_acc[ht] belongs to channel ht*32 + mfma_row(col >> 1, h), on both lanes of the pair
         dw_acc[ht] += half_reduce16(r, col);
       }
+      gs_t[0] *= inv_s_v, gs_t[1] *= inv_s_v;    // exact (a power of two): the vectors below carry s_v
 
-      // ---------------- back through the blocks (resnetfc.py:53-62): h1 = h0 + fc_1(relu(n)), n = fc_0(relu(h0))
-      if constexpr (NB > 0) {
+      // ---------------- one point tile (32 samples) at a time -- the transient vectors of the block backward are 16 registers each
+      // instead of 32: v = m1 . w_out, then back through the blocks (resnetfc.py:53-62: h1 = h0 + fc_1(relu(n)), n = fc_0(relu(h0))),
+      // the fc_0 / fc_1 weight gradients of the tile, and u0 = g_s v0, the gradient row at lin_in's output
       int lane4t = lane * 4;
       asm volatile("" : "+v"(lane4t));   // opaque per iteration: the A operands of the transposed products stay inside the persistent loop
 #pragma unroll
-      for (int b = NB - 1; b >= 0; --b) {
-        const float* wt = lds + L::BLK + b * L::BLK_STRIDE + lane4t;
-        // vn = mn . (W1^T v): the C layout of v is the B operand; the result carries 2^S (and s_v)
-        f32x16 vn[1][2];
-        vn[0][0] = zero_acc(), vn[0][1] = zero_acc();
-        {
-          f32x16 vin[1][2];
-          vin[0][0] = v[0][0], vin[0][1] = v[0][1];
-          hidden_layer_ht(vn, vin, wt + L::BLK_LAYER_STRIDE, L::BLK_TERM_STRIDE, 1.0f);
-        }
+      for (int pt = 0; pt < 2; ++pt) {
+        f32x16 v[HT];   // the gate-dependent vector of the current layer times s_v (g_h = (g_s / s_v) v)
 #pragma unroll
-        for (int q = 0; q < 16; ++q)
+        for (int ht = 0; ht < HT; ++ht)
 #pragma unroll
-          for (int pt = 0; pt < 2; ++pt) vn[0][pt][q] = net[b][pt][q] > 0.0f ? vn[0][pt][q] * inv_scale : 0.0f;
-        if (bp.d_mlp) {
-          // dW1[out][in] += sum_p (g_s v)[p][out] relu(n)[p][in];  db1[out] += sum_p (g_s v)[p][out]
+          for (int q = 0; q < 16; ++q) {
+            const float w2 = lds[L::W_OUT + ht * 32 + mfma_row(q, 0) + 4 * h] * s_v;
+            v[ht][q] = acc[ht][pt][q] > 0.0f ? w2 : 0.0f;
+          }
+        if constexpr (NB > 0) {
 #pragma unroll
-          for (int pt = 0; pt < 2; ++pt) {
-            wave_lds_fence();
+          for (int b = NB - 1; b >= 0; --b) {
+            const float* wt = lds + L::BLK + b * L::BLK_STRIDE + lane4t;
+            // vn = mn . (W1^T v): the C layout of v is the B operand; the product carries 2^S (and s_v)
+            f32x16 vn = zero_acc();
+            hidden_layer_ht(vn, v[0], wt + L::BLK_LAYER_STRIDE, L::BLK_TERM_STRIDE, 1.0f);
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-              tile_a[col * 33 + mfma_row(q, h)] = v[0][pt][q] * gs_t[pt];
-              tile_b[col * 33 + mfma_row(q, h)] = relu1(net[b][pt][q]) * inv_scale;
-            }
-            wave_lds_fence();
+            for (int q = 0; q < 16; ++q) vn[q] = net[b][pt][q] > 0.0f ? vn[q] * inv_scale : 0.0f;
+            if (qb->d_mlp) {
+              // dW1[out][in] += sum_p (g_s v)[p][out] relu(n)[p][in];  db1[out] += sum_p (g_s v)[p][out]
+              wave_lds_fence();
+#pragma unroll
+              for (int q = 0; q < 16; ++q) {
+                tile_a[col * 33 + mfma_row(q, h)] = v[0][q] * gs_t[pt];
+                tile_b[col * 33 + mfma_row(q, h)] = relu1(net[b][pt][q]) * inv_scale;
+              }
+              wave_lds_fence();
 #pragma unroll 4
-            for (int s = 0; s < 16; ++s) {
-              const int pnt = 2 * s + h;
-              const float a = tile_a[pnt * 33 + col];
-              dbb[b][1] += a;
-              dwb[b][1] = mfma(a, tile_b[pnt * 33 + col], dwb[b][1]);
+              for (int s2 = 0; s2 < 16; ++s2) {
+                const int pnt = 2 * s2 + h;
+                const float a = tile_a[pnt * 33 + col];
+                dbb[b][1] += a;
+                dwb[b][1] = mfma(a, tile_b[pnt * 33 + col], dwb[b][1]);
+              }
             }
+            // t2 = W0^T vn;  v <- v + m0 . t2
+            f32x16 t2 = zero_acc();
+            hidden_layer_ht(t2, vn, wt, L::BLK_TERM_STRIDE, 1.0f);
+            if (qb->d_mlp) {
+              // dW0[out][in] += sum_p (g_s vn)[p][out] relu(h0)[p][in];  db0[out] += sum_p (g_s vn)[p][out]
+              wave_lds_fence();
+#pragma unroll
+              for (int q = 0; q < 16; ++q) {
+                tile_a[col * 33 + mfma_row(q, h)] = vn[q] * gs_t[pt];
+                tile_b[col * 33 + mfma_row(q, h)] = relu1(hin[b][pt][q]) * inv_scale;
+              }
+              wave_lds_fence();
+#pragma unroll 4
+              for (int s2 = 0; s2 < 16; ++s2) {
+                const int pnt = 2 * s2 + h;
+                const float a = tile_a[pnt * 33 + col];
+                dbb[b][0] += a;
+                dwb[b][0] = mfma(a, tile_b[pnt * 33 + col], dwb[b][0]);
+              }
+            }
+#pragma unroll
+            for (int q = 0; q < 16; ++q) v[0][q] += hin[b][pt][q] > 0.0f ? t2[q] * inv_scale : 0.0f;
           }
         }
-        // t2 = W0^T vn;  v <- v + m0 . t2
-        f32x16 t2[1][2];
-        t2[0][0] = zero_acc(), t2[0][1] = zero_acc();
-        hidden_layer_ht(t2, vn, wt, L::BLK_TERM_STRIDE, 1.0f);
-        if (bp.d_mlp) {
-          // dW0[out][in] += sum_p (g_s vn)[p][out] relu(h0)[p][in];  db0[out] += sum_p (g_s vn)[p][out]
-#pragma unroll
-          for (int pt = 0; pt < 2; ++pt) {
-            wave_lds_fence();
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-              tile_a[col * 33 + mfma_row(q, h)] = vn[0][pt][q] * gs_t[pt];
-              tile_b[col * 33 + mfma_row(q, h)] = relu1(hin[b][pt][q]) * inv_scale;
-            }
-            wave_lds_fence();
-#pragma unroll 4
-            for (int s = 0; s < 16; ++s) {
-              const int pnt = 2 * s + h;
-              const float a = tile_a[pnt * 33 + col];
-              dbb[b][0] += a;
-              dwb[b][0] = mfma(a, tile_b[pnt * 33 + col], dwb[b][0]);
-            }
-          }
-        }
-#pragma unroll
-        for (int q = 0; q < 16; ++q)
-#pragma unroll
-          for (int pt = 0; pt < 2; ++pt) v[0][pt][q] += hin[b][pt][q] > 0.0f ? t2[0][pt][q] * inv_scale : 0.0f;
-      }
-      }
-
-      // ---------------- u0 = g_s v: the gradient at lin_in's output, one row per sample in the storage order of G (this lane's 16
-      // accumulator rows of a hidden tile are 64 contiguous bytes of the row)
-      if (ro.u0_ws) {
-#pragma unroll
-        for (int pt = 0; pt < 2; ++pt) {
+        // u0 = g_s v: one row per sample in the storage order of G (this lane's 16 accumulator rows of a hidden tile are 64 contiguous
+        // bytes of the row)
+        if (ro.u0_ws) {
           const int ks = kc + pt * 32 + col;
           if (ks < K) {
             float4* dst = reinterpret_cast<float4*>(ro.u0_ws + (ray * K + ks) * (long)HD);
@@ -622,8 +610,8 @@ __global__ __launch_bounds__(256, 2) void rowsb_kernel(const BwdParams bp, const
             for (int ht = 0; ht < HT; ++ht)
 #pragma unroll
               for (int j = 0; j < 4; ++j)
-                dst[ht * 8 + 4 * h + j] = make_float4(v[ht][pt][4 * j] * gs_t[pt], v[ht][pt][4 * j + 1] * gs_t[pt], v[ht][pt][4 * j + 2] * gs_t[pt],
-                                                      v[ht][pt][4 * j + 3] * gs_t[pt]);
+                dst[ht * 8 + 4 * h + j] = make_float4(v[ht][4 * j] * gs_t[pt], v[ht][4 * j + 1] * gs_t[pt], v[ht][4 * j + 2] * gs_t[pt],
+                                                      v[ht][4 * j + 3] * gs_t[pt]);
           }
         }
       }

@@ -226,7 +226,7 @@ __global__ __launch_bounds__(256, 2) void rows_kernel(const BwdParams bp) {
     const int gg = (c << CHL) + (idx & ((1 << CHL) - 1));
     return (c < n_chunks && gg < n_groups) ? gg : -1;
   };
-  const int Bp = p.Bp, K = p.K, H = p.H, W = p.W, nv = p.nv;
+  const int Bp = p.Bp, K = p.K;
   const int k = lane;
   const bool valid = k < K;
   const int kk = valid ? k : K - 1;
@@ -247,19 +247,22 @@ __global__ __launch_bounds__(256, 2) void rows_kernel(const BwdParams bp) {
   }
 
   for (; g >= 0; idx += waves_per_xcd, g = group_of(idx)) {
+    auto qb = kernarg_view<BwdParams>();   // this iteration's parameters, re-read where they are used (bts_common.h: kernarg_view)
+    asm volatile("" : "+s"(qb));
+    const int H = qb->f.H, W = qb->f.W, nv = qb->f.nv;
     const long ray = g;
     while (g >= sample_end) ++sample, sample_end += Bp;
-    const Cam enc = load_cam(p.w2c_enc + sample * 16, p.K_enc + sample * 9);
-    const float4* __restrict__ G = reinterpret_cast<const float4*>(p.proj) + (long)sample * H * W * (HD / 4);
-    const cfp rp = as_const(p.rays) + ray * 8;
+    const Cam enc = load_cam(qb->f.w2c_enc + sample * 16, qb->f.K_enc + sample * 9);
+    const float4* __restrict__ G = reinterpret_cast<const float4*>(qb->f.proj) + (long)sample * H * W * (HD / 4);
+    const cfp rp = as_const(qb->f.rays) + ray * 8;
     const float ox = rp[0], oy = rp[1], oz = rp[2], dx = rp[3], dy = rp[4], dz = rp[5];
     const float z = z_pre, z_nx = zn_pre, s_raw = s_pre, T = t_pre;
     {  // the next ray's per-sample state lands while this ray is evaluated
       const int gn = group_of(idx + waves_per_xcd);
       if (gn >= 0) {
         const long pk = (long)gn * K + kk;
-        z_pre = p.z_samp[pk], zn_pre = p.z_samp[(long)gn * K + min(kk + 1, K - 1)];
-        s_pre = p.sigma_raw[pk], t_pre = p.trans[pk];
+        z_pre = qb->f.z_samp[pk], zn_pre = qb->f.z_samp[(long)gn * K + min(kk + 1, K - 1)];
+        s_pre = qb->f.sigma_raw[pk], t_pre = qb->f.trans[pk];
       }
     }
     int lane_off = h0 * HD + (lane & 31), h = h0;
@@ -270,19 +273,19 @@ __global__ __launch_bounds__(256, 2) void rows_kernel(const BwdParams bp) {
     // ---------------- upstream gradient of this sample's weight: g_w = g_depth z + sum_j g_rgb_j . c_kj (+ g_weights_k)
     float g_w = 0.0f;
     {
-      const cfp gr = as_const(bp.g_rgb) + ray * (long)(nv * 3);
+      const cfp gr = as_const(qb->g_rgb) + ray * (long)(nv * 3);
       float g_rgb[NVMAX * 3];
       float g_bkgd = 0.0f;
 #pragma unroll
       for (int i = 0; i < NVMAX * 3; ++i) {
-        g_rgb[i] = (bp.g_rgb && i < nv * 3) ? gr[i] : 0.0f;
+        g_rgb[i] = (qb->g_rgb && i < nv * 3) ? gr[i] : 0.0f;
         g_bkgd -= g_rgb[i];
       }
-      if (bp.g_depth) g_w = as_const(bp.g_depth)[ray] * z;
-      if (p.white_bkgd) g_w += g_bkgd;   // nerf.py:301-304: rgb = sum_k w_k c_k + 1 - sum_k w_k
-      if (bp.g_weights) g_w += bp.g_weights[pk];
-      if (p.rgb_samps) {
-        const float* cs = p.rgb_samps + pk * (long)(nv * 3);
+      if (qb->g_depth) g_w = as_const(qb->g_depth)[ray] * z;
+      if (qb->f.white_bkgd) g_w += g_bkgd;   // nerf.py:301-304: rgb = sum_k w_k c_k + 1 - sum_k w_k
+      if (qb->g_weights) g_w += qb->g_weights[pk];
+      if (qb->f.rgb_samps) {
+        const float* cs = qb->f.rgb_samps + pk * (long)(nv * 3);
 #pragma unroll
         for (int j = 0; j < NVMAX; ++j)
           if (j < nv) g_w += g_rgb[3 * j] * cs[3 * j] + g_rgb[3 * j + 1] * cs[3 * j + 1] + g_rgb[3 * j + 2] * cs[3 * j + 2];
@@ -290,10 +293,10 @@ __global__ __launch_bounds__(256, 2) void rows_kernel(const BwdParams bp) {
 #pragma unroll
         for (int j = 0; j < NVMAX; ++j) {
           if (j < nv) {
-            const Cam cj = load_cam(p.w2c_r + ((long)sample * nv + j) * 16, p.K_r + ((long)sample * nv + j) * 9);
+            const Cam cj = load_cam(qb->f.w2c_r + ((long)sample * nv + j) * 16, qb->f.K_r + ((long)sample * nv + j) * 9);
             const Proj pc = project<false>(cj, px, py, pz);
             const Taps tc = make_taps(pc.x, pc.y, H, W);
-            const float4* img = reinterpret_cast<const float4*>(p.imgs) + ((long)sample * nv + j) * H * W;
+            const float4* img = reinterpret_cast<const float4*>(qb->f.imgs) + ((long)sample * nv + j) * H * W;
             const float4 a = img[tc.o00], b = img[tc.o01], cc = img[tc.o10], d = img[tc.o11];
             const float c0 = ((a.x * tc.w00 + b.x * tc.w01) + cc.x * tc.w10) + d.x * tc.w11;
             const float c1 = ((a.y * tc.w00 + b.y * tc.w01) + cc.y * tc.w10) + d.y * tc.w11;
@@ -305,12 +308,12 @@ __global__ __launch_bounds__(256, 2) void rows_kernel(const BwdParams bp) {
     }
 
     // ---------------- encoder view
-    const Proj pe = p.code_mode == 1 ? project<true>(enc, px, py, pz) : project<false>(enc, px, py, pz);
+    const Proj pe = qb->f.code_mode == 1 ? project<true>(enc, px, py, pz) : project<false>(enc, px, py, pz);
     Taps tp = make_taps(pe.x, pe.y, H, W);
     float v3[3];
     v3[0] = pe.x, v3[1] = pe.y;
-    v3[2] = depth_code(p.code_mode == 1 ? pe.dist : pe.z, p.inv_z != 0, p.inv_dmax, p.inv_range, p.d_min, p.range);
-    const bool use_empty = (p.learn_empty != 0) & pe.invalid;
+    v3[2] = depth_code(qb->f.code_mode == 1 ? pe.dist : pe.z, qb->f.inv_z != 0, qb->f.inv_dmax, qb->f.inv_range, qb->f.d_min, qb->f.range);
+    const bool use_empty = (qb->f.learn_empty != 0) & pe.invalid;
     if (use_empty) tp.w00 = tp.w01 = tp.w10 = tp.w11 = 0.0f;
     tp.w00 *= scale, tp.w01 *= scale, tp.w10 *= scale, tp.w11 *= scale;
 
@@ -355,11 +358,11 @@ __global__ __launch_bounds__(256, 2) void rows_kernel(const BwdParams bp) {
     float g_s = 0.0f;
     {
       float sigma = softplus(s_raw);
-      const bool dead = (p.empty_empty != 0) & pe.invalid;   // sigma forced to 0: no gradient
+      const bool dead = (qb->f.empty_empty != 0) & pe.invalid;   // sigma forced to 0: no gradient
       if (dead) sigma = 0.0f;
       const float delta = last ? 1e10f : (z_nx - z);
       const float ex = expf(-fabsf(delta) * fmaxf(sigma, 0.0f));
-      const bool capped = (p.hard_cap != 0) & last;
+      const bool capped = (qb->f.hard_cap != 0) & last;
       const float alpha = capped ? 1.0f : 1.0f - ex;
 #ifdef BTS_ABL_R2   // timing ablation: no scan
       const float S = g_w * alpha;
@@ -367,18 +370,18 @@ __global__ __launch_bounds__(256, 2) void rows_kernel(const BwdParams bp) {
       const float S = wave_suffix_excl(valid ? g_w * (alpha * T) : 0.0f, lane);
 #endif
       float g_alpha = g_w * T - S / (capped ? 1e-10f : ex + 1e-10f);
-      if (bp.g_alphas) g_alpha += bp.g_alphas[pk];
+      if (qb->g_alphas) g_alpha += qb->g_alphas[pk];
       if (!capped && !dead && valid) g_s = g_alpha * fabsf(delta) * ex * (s_raw > 20.0f ? 1.0f : sigmoidf(s_raw));
-      if (valid) bp.gs_ws[pk] = g_s;
+      if (valid) qb->gs_ws[pk] = g_s;
     }
     db_acc += g_s;
-    unsigned* __restrict__ mrow = bp.mask_ws + ray * (long)(HT * K);
-    uint2* __restrict__ prow = bp.pmask_ws + ray * (long)HD;
+    unsigned* __restrict__ mrow = qb->mask_ws + ray * (long)(HT * K);
+    uint2* __restrict__ prow = qb->pmask_ws + ray * (long)HD;
 
-    if (__builtin_expect(__any(pe_needs_exact(v3, p.freq_factor)), 0)) {
+    if (__builtin_expect(__any(pe_needs_exact(v3, qb->f.freq_factor)), 0)) {
       float dwx[HT];   // through memory: no accumulator array may cross the call (it would be demoted to scratch on the hot path)
-      rows_exact<C, HD>(lds, G, p.w2c_enc + sample * 16, p.K_enc + sample * 9, H, W, p.code_mode, p.inv_z, p.inv_dmax, p.inv_range, p.d_min,
-                        p.range, p.freq_factor, p.learn_empty, px, py, pz, g_s, mrow, prow, K, dwx);
+      rows_exact<C, HD>(lds, G, qb->f.w2c_enc + sample * 16, qb->f.K_enc + sample * 9, H, W, qb->f.code_mode, qb->f.inv_z, qb->f.inv_dmax, qb->f.inv_range, qb->f.d_min,
+                        qb->f.range, qb->f.freq_factor, qb->f.learn_empty, px, py, pz, g_s, mrow, prow, K, dwx);
 #pragma unroll
       for (int ht = 0; ht < HT; ++ht) dw_acc[ht] += dwx[ht];
       continue;
@@ -403,25 +406,25 @@ __global__ __launch_bounds__(256, 2) void rows_kernel(const BwdParams bp) {
           }
       }
       SinCos3 raw;
-      pe_direct(raw, v3, p.freq_factor);
+      pe_direct(raw, v3, qb->f.freq_factor);
       __builtin_amdgcn_sched_barrier(0);
       int lane4 = lane * 4;
       asm volatile("" : "+v"(lane4));
 #ifdef BTS_GATHER_LDS
-      region_seq_l<HD, 0>(acc, gl, rows, G, wq, off_next, lh + LH::W_F16 + lane4, LH::TERM_STRIDE, raw, v3, p.freq_factor, bias);
+      region_seq_l<HD, 0>(acc, gl, rows, G, wq, off_next, lh + LH::W_F16 + lane4, LH::TERM_STRIDE, raw, v3, qb->f.freq_factor, bias);
       if constexpr (NS > kNumFreqs) {
         gl_consume<HD, 12>(acc, gl, rows, G, wq, off_next), gl_consume<HD, 13>(acc, gl, rows, G, wq, off_next);
         gl_consume<HD, 14>(acc, gl, rows, G, wq, off_next), gl_consume<HD, 15>(acc, gl, rows, G, wq, off_next);
       }
 #else
-      region_seq<HD, 0>(acc, ba, bb, G, o, wq, h, lh + LH::W_F16 + lane4, LH::TERM_STRIDE, raw, v3, p.freq_factor, bias);
+      region_seq<HD, 0>(acc, ba, bb, G, o, wq, h, lh + LH::W_F16 + lane4, LH::TERM_STRIDE, raw, v3, qb->f.freq_factor, bias);
       if constexpr (NS > kNumFreqs) {
         stage_blend<HD, 6>(acc, ba, wq);
         stage_blend<HD, 7>(acc, bb, wq);
       }
 #endif
     }
-    if (p.learn_empty && __any(use_empty)) {
+    if (qb->f.learn_empty && __any(use_empty)) {
 #pragma unroll
       for (int ht = 0; ht < HT; ++ht)
 #pragma unroll

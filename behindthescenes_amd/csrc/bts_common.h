@@ -70,6 +70,17 @@ __device__ __forceinline__ Cam load_cam(const float* w2c_, const float* K_) {
   return c;
 }
 
+// A kernel's by-value parameter struct as it lies in the kernarg segment (offset 0: every kernel here takes ONE struct).  The
+// persistent kernels read their parameters through this view, laundered once per iteration (asm volatile "+s"): hipcc otherwise loads
+// all ~60 parameter dwords before the loop, keeps them in SGPRs for its whole life and -- 106 SGPRs do not hold them next to the
+// cameras, the ray and the loop state -- spills ~120 of them to VGPR lanes: ~300 v_writelane / v_readlane per iteration of the render
+// kernel, VALU instructions in a VALU-issue-bound loop.  Reloading a field where it is used is an s_load from the scalar cache (SMEM
+// issues beside the VALU); the spill traffic drops to ~100 lane operations per iteration.
+template <class T>
+__device__ __forceinline__ const T __attribute__((address_space(4)))* kernarg_view() {
+  return (const T __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
+}
+
 // same through ordinary (vector) loads: the values land in VGPRs
 __device__ __forceinline__ Cam load_cam_v(const float* __restrict__ w2c, const float* __restrict__ K) {
   Cam c;

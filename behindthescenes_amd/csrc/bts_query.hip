@@ -12,6 +12,7 @@
 // cumulative sum along y, count of levels whose running sum stays <= 8, / Y -- is a wave scan + a ballot in the same kernel and no
 // per-point tensor reaches HBM at all.
 #define BTS_NO_LAUNCH_GLUE
+#undef BTS_GATHER_REGS   // (the register-gather A/B build, variants/libbts_gatherregs.so, concerns the render kernels: the query kernel exist in the LDS-gather form only)
 #include "bts_render_kernel.h"
 
 namespace bts {
@@ -72,7 +73,7 @@ __global__ __launch_bounds__(256, 2) void query_kernel_p(const QueryParams qp) {
     const int gg = (c << CHL) + (idx & ((1 << CHL) - 1));
     return (c < n_chunks && gg < n_groups) ? gg : -1;
   };
-  const int P = p.Bp, H = p.H, W = p.W, nv = p.nv;
+  const int P = p.Bp;
   const bool prof = qp.cols > 0;
   const int groups_per_sample = prof ? qp.cols : (P + 63) / 64;
   const float b_out = as_const(p.mlp)[MlpLayout{C + kPeDim, HD, NB}.b_out()];
@@ -102,12 +103,15 @@ __global__ __launch_bounds__(256, 2) void query_kernel_p(const QueryParams qp) {
   }
 
   for (; g >= 0; idx += waves_per_xcd, g = group_of(idx)) {
+    auto qq = kernarg_view<QueryParams>();   // this iteration's parameters, re-read where they are used (bts_common.h: kernarg_view)
+    asm volatile("" : "+s"(qq));
+    const int H = qq->f.H, W = qq->f.W, nv = qq->f.nv;
     while (g >= sample_end) ++sample, sample_end += groups_per_sample;
     const int g_in = g - (sample_end - groups_per_sample);
     bool valid;
     const long pidx = (long)sample * P + point_of(g_in, valid);
-    const Cam enc = load_cam(p.w2c_enc + sample * 16, p.K_enc + sample * 9);
-    const float4* __restrict__ G = reinterpret_cast<const float4*>(p.proj) + (long)sample * H * W * (HD / 4);
+    const Cam enc = load_cam(qq->f.w2c_enc + sample * 16, qq->f.K_enc + sample * 9);
+    const float4* __restrict__ G = reinterpret_cast<const float4*>(qq->f.proj) + (long)sample * H * W * (HD / 4);
     const float px = xp, py = yp, pz = zp;
     {  // the next group's points land while this group is evaluated
       const int gn = group_of(idx + waves_per_xcd);
@@ -115,7 +119,7 @@ __global__ __launch_bounds__(256, 2) void query_kernel_p(const QueryParams qp) {
         const int sn = gn / groups_per_sample;
         bool ok;
         const long pi = point_of(gn - sn * groups_per_sample, ok);
-        const float* q = p.xyz + ((long)sn * P + pi) * 3;
+        const float* q = qq->f.xyz + ((long)sn * P + pi) * 3;
         xp = q[0], yp = q[1], zp = q[2];
       }
     }
@@ -123,12 +127,12 @@ __global__ __launch_bounds__(256, 2) void query_kernel_p(const QueryParams qp) {
     asm volatile("" : "+v"(h));   // keep the weight reads inside the persistent loop (see render_kernel_p)
 
     // ---------------- encoder view: projection, taps, depth code
-    const Proj pe = p.code_mode == 1 ? project<true>(enc, px, py, pz) : project<false>(enc, px, py, pz);
+    const Proj pe = qq->f.code_mode == 1 ? project<true>(enc, px, py, pz) : project<false>(enc, px, py, pz);
     Taps tp = make_taps(pe.x, pe.y, H, W);
     float v3[3];
     v3[0] = pe.x, v3[1] = pe.y;
-    v3[2] = depth_code(p.code_mode == 1 ? pe.dist : pe.z, p.inv_z != 0, p.inv_dmax, p.inv_range, p.d_min, p.range);
-    const bool use_empty = (p.learn_empty != 0) & pe.invalid;
+    v3[2] = depth_code(qq->f.code_mode == 1 ? pe.dist : pe.z, qq->f.inv_z != 0, qq->f.inv_dmax, qq->f.inv_range, qq->f.d_min, qq->f.range);
+    const bool use_empty = (qq->f.learn_empty != 0) & pe.invalid;
     if (use_empty) tp.w00 = tp.w01 = tp.w10 = tp.w11 = 0.0f;
     tp.w00 *= scale, tp.w01 *= scale, tp.w10 *= scale, tp.w11 *= scale;
     float wq[2][4];
@@ -143,9 +147,9 @@ __global__ __launch_bounds__(256, 2) void query_kernel_p(const QueryParams qp) {
     }
 
     float s_raw;
-    if (__builtin_expect(__any(pe_needs_exact(v3, p.freq_factor)), 0)) {
-      s_raw = eval_point_exact<C, HD, NB>(lds, G, p.w2c_enc + sample * 16, p.K_enc + sample * 9, H, W, p.code_mode, p.inv_z, p.inv_dmax,
-                                          p.inv_range, p.d_min, p.range, p.freq_factor, p.learn_empty, b_out, px, py, pz);
+    if (__builtin_expect(__any(pe_needs_exact(v3, qq->f.freq_factor)), 0)) {
+      s_raw = eval_point_exact<C, HD, NB>(lds, G, qq->f.w2c_enc + sample * 16, qq->f.K_enc + sample * 9, H, W, qq->f.code_mode, qq->f.inv_z, qq->f.inv_dmax,
+                                          qq->f.inv_range, qq->f.d_min, qq->f.range, qq->f.freq_factor, qq->f.learn_empty, b_out, px, py, pz);
     } else {
       // ---------------- h = bilinear(G) + W_pe . PE + b (render_kernel_p's pipeline)
       f32x16 acc[HT][2];
@@ -172,16 +176,16 @@ __global__ __launch_bounds__(256, 2) void query_kernel_p(const QueryParams qp) {
           }
       }
       SinCos3 raw;
-      pe_direct(raw, v3, p.freq_factor);
+      pe_direct(raw, v3, qq->f.freq_factor);
       __builtin_amdgcn_sched_barrier(0);
       int lane4 = lane * 4;
       asm volatile("" : "+v"(lane4));
-      region_seq_l<HD, 0>(acc, gl, rows, G, wq, off_next, lh + LH::W_F16 + lane4, LH::TERM_STRIDE, raw, v3, p.freq_factor, bias);
+      region_seq_l<HD, 0>(acc, gl, rows, G, wq, off_next, lh + LH::W_F16 + lane4, LH::TERM_STRIDE, raw, v3, qq->f.freq_factor, bias);
       if constexpr (NS > kNumFreqs) {
         gl_consume<HD, 12>(acc, gl, rows, G, wq, off_next), gl_consume<HD, 13>(acc, gl, rows, G, wq, off_next);
         gl_consume<HD, 14>(acc, gl, rows, G, wq, off_next), gl_consume<HD, 15>(acc, gl, rows, G, wq, off_next);
       }
-      if (p.learn_empty && __any(use_empty)) {
+      if (qq->f.learn_empty && __any(use_empty)) {
 #pragma unroll
         for (int ht = 0; ht < HT; ++ht)
 #pragma unroll
@@ -226,43 +230,43 @@ __global__ __launch_bounds__(256, 2) void query_kernel_p(const QueryParams qp) {
       s_raw = __builtin_fmaf(p0 + p1, inv_scale, b_out);
     }
     float sigma = softplus(s_raw);
-    if (p.empty_empty) sigma = pe.invalid ? 0.0f : sigma;
+    if (qq->f.empty_empty) sigma = pe.invalid ? 0.0f : sigma;
 
     // ---------------- colours / per-view invalid flags (models_bts.py:218-264, 333)
     bool any_inv = pe.invalid;
-    if (!p.only_density) {
+    if (!qq->f.only_density) {
 #pragma unroll
       for (int j = 0; j < NVMAX; ++j) {
         if (j < nv) {
-          const Cam cj = load_cam(p.w2c_r + ((long)sample * nv + j) * 16, p.K_r + ((long)sample * nv + j) * 9);
+          const Cam cj = load_cam(qq->f.w2c_r + ((long)sample * nv + j) * 16, qq->f.K_r + ((long)sample * nv + j) * 9);
           const Proj pc = project<false>(cj, px, py, pz);
           const bool inv = pc.invalid | pe.invalid;
           any_inv |= inv;
-          if (valid && p.invalid) p.invalid[pidx * nv + j] = inv ? 1.0f : 0.0f;
-          if (p.rgb) {
+          if (valid && qq->f.invalid) qq->f.invalid[pidx * nv + j] = inv ? 1.0f : 0.0f;
+          if (qq->f.rgb) {
             const Taps tc = make_taps(pc.x, pc.y, H, W);
-            const float4* img = reinterpret_cast<const float4*>(p.imgs) + ((long)sample * nv + j) * H * W;
+            const float4* img = reinterpret_cast<const float4*>(qq->f.imgs) + ((long)sample * nv + j) * H * W;
             const float4 a = img[tc.o00], b = img[tc.o01], cc = img[tc.o10], d = img[tc.o11];
             if (valid) {
-              p.rgb[(pidx * nv + j) * 3 + 0] = ((a.x * tc.w00 + b.x * tc.w01) + cc.x * tc.w10) + d.x * tc.w11;
-              p.rgb[(pidx * nv + j) * 3 + 1] = ((a.y * tc.w00 + b.y * tc.w01) + cc.y * tc.w10) + d.y * tc.w11;
-              p.rgb[(pidx * nv + j) * 3 + 2] = ((a.z * tc.w00 + b.z * tc.w01) + cc.z * tc.w10) + d.z * tc.w11;
+              qq->f.rgb[(pidx * nv + j) * 3 + 0] = ((a.x * tc.w00 + b.x * tc.w01) + cc.x * tc.w10) + d.x * tc.w11;
+              qq->f.rgb[(pidx * nv + j) * 3 + 1] = ((a.y * tc.w00 + b.y * tc.w01) + cc.y * tc.w10) + d.y * tc.w11;
+              qq->f.rgb[(pidx * nv + j) * 3 + 2] = ((a.z * tc.w00 + b.z * tc.w01) + cc.z * tc.w10) + d.z * tc.w11;
             }
           }
         }
       }
-    } else if (valid && p.invalid) {
-      p.invalid[pidx] = pe.invalid ? 1.0f : 0.0f;
+    } else if (valid && qq->f.invalid) {
+      qq->f.invalid[pidx] = pe.invalid ? 1.0f : 0.0f;
     }
-    if (valid && p.q_sigma) p.q_sigma[pidx] = sigma;
+    if (valid && qq->f.q_sigma) qq->f.q_sigma[pidx] = sigma;
 
     // ---------------- occupancy profile of this column (inference_setup.py:219-228): sigma := 1 where any view flags the point,
     // running sum along y (lane), fraction of levels whose running sum is still <= threshold
     if (prof) {
       const float a = valid ? (any_inv ? 1.0f : sigma) : 0.0f;
       const float run = seg_scan_add(a, 64, lane);
-      const unsigned long long under = __ballot(valid && run <= qp.threshold);
-      if (lane == 0) qp.profile[(long)sample * qp.cols + g_in] = (float)__popcll(under) / (float)qp.col_len;
+      const unsigned long long under = __ballot(valid && run <= qq->threshold);
+      if (lane == 0) qq->profile[(long)sample * qq->cols + g_in] = (float)__popcll(under) / (float)qq->col_len;
     }
   }
 }

@@ -827,7 +827,7 @@ __global__ __launch_bounds__(256, 2) void render_kernel_p(const FwdParams p) {
     const int gg = (c << CHL) + (idx & ((1 << CHL) - 1));
     return (c < n_chunks && gg < n_groups) ? gg : -1;
   };
-  const int Bp = p.Bp, K = p.K, H = p.H, W = p.W, nv = p.nv;
+  const int Bp = p.Bp;
   const float b_out = as_const(p.mlp)[MlpLayout{C + kPeDim, HD, NB}.b_out()];
   const int lane_off0 = h0 * HD + (lane & 31);
   const bool nomfma = BTS_ABL(4), nosin = BTS_ABL(2);
@@ -845,33 +845,39 @@ __global__ __launch_bounds__(256, 2) void render_kernel_p(const FwdParams p) {
   // z of the first ray group
   float z_pre = 0.0f, zn_pre = 0.0f;
   if (g >= 0) {
+    const int K = p.K;
     const float* zr = p.z_samp + ((long)g * R + lane / lpr) * K;
     const int kk = min(kl, K - 1);
     z_pre = zr[kk], zn_pre = zr[min(kk + 1, K - 1)];
   }
 
   for (; g >= 0; idx += waves_per_xcd, g = group_of(idx)) {
+    // the parameters of this iteration: re-read from the kernarg segment where they are used instead of held (and spilled) for the
+    // whole life of the kernel (bts_common.h: kernarg_view)
+    auto q = kernarg_view<FwdParams>();
+    asm volatile("" : "+s"(q));
+    const int K = q->K, H = q->H, W = q->W, nv = q->nv;
     const long ray = (long)g * R + lane / lpr;
     // all rays of a group belong to one batch element; g only grows along a wave's chunk list, so the element is tracked by a
     // running boundary (the 64-bit division this replaces was ~140 dependent scalar instructions at the top of every iteration)
     while (g >= sample_end) ++sample, sample_end += groups_per_sample;
-    const Cam enc = load_cam(p.w2c_enc + sample * 16, p.K_enc + sample * 9);
-    const float4* __restrict__ G = reinterpret_cast<const float4*>(p.proj) + (long)sample * H * W * (HD / 4);
+    const Cam enc = load_cam(q->w2c_enc + sample * 16, q->K_enc + sample * 9);
+    const float4* __restrict__ G = reinterpret_cast<const float4*>(q->proj) + (long)sample * H * W * (HD / 4);
     float ox, oy, oz, dx, dy, dz;
     if constexpr (ONE_RAY) {  // wave-uniform ray: scalar loads
-      const cfp rp = as_const(p.rays) + (long)g * 8;
+      const cfp rp = as_const(q->rays) + (long)g * 8;
       ox = rp[0], oy = rp[1], oz = rp[2], dx = rp[3], dy = rp[4], dz = rp[5];
     } else {
-      const float4 r0 = reinterpret_cast<const float4*>(p.rays)[ray * 2];
-      const float4 r1 = reinterpret_cast<const float4*>(p.rays)[ray * 2 + 1];
+      const float4 r0 = reinterpret_cast<const float4*>(q->rays)[ray * 2];
+      const float4 r1 = reinterpret_cast<const float4*>(q->rays)[ray * 2 + 1];
       ox = r0.x, oy = r0.y, oz = r0.z, dx = r0.w, dy = r1.x, dz = r1.y;
     }
-    const float* zrow = p.z_samp + ray * K;
+    const float* zrow = q->z_samp + ray * K;
     float z_cur = z_pre, zn_cur = zn_pre;
     {  // prefetch the next group's samples; they land while this group is evaluated
       const int gn = group_of(idx + waves_per_xcd);
       if (gn >= 0) {
-        const float* zr = p.z_samp + ((long)gn * R + lane / lpr) * K;
+        const float* zr = q->z_samp + ((long)gn * R + lane / lpr) * K;
         const int kk = min(kl, K - 1);
         z_pre = zr[kk], zn_pre = zr[min(kk + 1, K - 1)];
       }
@@ -898,12 +904,12 @@ __global__ __launch_bounds__(256, 2) void render_kernel_p(const FwdParams p) {
       const float px = ox + z * dx, py = oy + z * dy, pz = oz + z * dz;
 
       // ---------------- encoder view: projection, taps, depth code
-      const Proj pe = p.code_mode == 1 ? project<true>(enc, px, py, pz) : project<false>(enc, px, py, pz);
+      const Proj pe = q->code_mode == 1 ? project<true>(enc, px, py, pz) : project<false>(enc, px, py, pz);
       Taps tp = make_taps(pe.x, pe.y, H, W);
       float v3[3];
       v3[0] = pe.x, v3[1] = pe.y;
-      v3[2] = depth_code(p.code_mode == 1 ? pe.dist : pe.z, p.inv_z != 0, p.inv_dmax, p.inv_range, p.d_min, p.range);
-      const bool use_empty = (p.learn_empty != 0) & pe.invalid;
+      v3[2] = depth_code(q->code_mode == 1 ? pe.dist : pe.z, q->inv_z != 0, q->inv_dmax, q->inv_range, q->d_min, q->range);
+      const bool use_empty = (q->learn_empty != 0) & pe.invalid;
       if (use_empty) tp.w00 = tp.w01 = tp.w10 = tp.w11 = 0.0f;  // the empty feature is added after the blend
       if constexpr (F16) tp.w00 *= scale, tp.w01 *= scale, tp.w10 *= scale, tp.w11 *= scale;  // exact: power of two
 
@@ -938,14 +944,14 @@ __global__ __launch_bounds__(256, 2) void render_kernel_p(const FwdParams p) {
         const bool ok = !pe.invalid & (fabsf(ixk - ixr) <= 0.00048828125f) & (fabsf(iyk - iyr) <= 0.00048828125f) &
                         (fabsf(pe.x - xr) <= 3.814697265625e-6f) & (fabsf(pe.y - yr) <= 3.814697265625e-6f) &
                         (ixr >= 1.5f) & (ixr <= (float)W - 2.5f) & (iyr >= 1.5f) & (iyr <= (float)H - 2.5f);
-        enc_ray = __all(ok) && !(p.ablate & 64);
+        enc_ray = __all(ok) && !(q->ablate & 64);
       }
 #endif
 
       float s_raw;
-      if (__builtin_expect(__any(pe_needs_exact(v3, p.freq_factor)), 0)) {
-        s_raw = eval_point_exact<C, HD, NB>(lds, G, p.w2c_enc + sample * 16, p.K_enc + sample * 9, H, W, p.code_mode, p.inv_z, p.inv_dmax,
-                                            p.inv_range, p.d_min, p.range, p.freq_factor, p.learn_empty, b_out, px, py, pz);
+      if (__builtin_expect(__any(pe_needs_exact(v3, q->freq_factor)), 0)) {
+        s_raw = eval_point_exact<C, HD, NB>(lds, G, q->w2c_enc + sample * 16, q->K_enc + sample * 9, H, W, q->code_mode, q->inv_z, q->inv_dmax,
+                                            q->inv_range, q->d_min, q->range, q->freq_factor, q->learn_empty, b_out, px, py, pz);
       } else {
       BTS_TICK(0)
       // ---------------- h = bilinear(G) + W_pe . PE + b: gather two stages ahead, blend between the octaves
@@ -956,10 +962,10 @@ __global__ __launch_bounds__(256, 2) void render_kernel_p(const FwdParams p) {
         if (enc_ray) {
           int lane4e = lane * 4;
           asm volatile("" : "+v"(lane4e));
-          done = enc_ray_lin_in<C, HD, NB>(acc, lds, lh, G, W, lane, h, wave, ixr, iyr, xr, yr, ixk, iyk, pe.x, pe.y, v3[2], p.freq_factor,
+          done = enc_ray_lin_in<C, HD, NB>(acc, lds, lh, G, W, lane, h, wave, ixr, iyr, xr, yr, ixk, iyk, pe.x, pe.y, v3[2], q->freq_factor,
                                            scale, lane4e);
 #ifdef BTS_PROBE
-          if (done && lane == 0 && p.dbg) atomicAdd(p.dbg + 63, 1ull);   // how many rays took the path (BTS_DBG_PTR buffer, slot 63)
+          if (done && lane == 0 && q->dbg) atomicAdd(q->dbg + 63, 1ull);   // how many rays took the path (BTS_DBG_PTR buffer, slot 63)
 #endif
         }
       }
@@ -1003,18 +1009,18 @@ __global__ __launch_bounds__(256, 2) void render_kernel_p(const FwdParams p) {
             }
         }
         SinCos3 raw;
-        pe_direct(raw, v3, p.freq_factor);
+        pe_direct(raw, v3, q->freq_factor);
         __builtin_amdgcn_sched_barrier(0);
         int lane4 = lane * 4;
         asm volatile("" : "+v"(lane4));  // keep the A-operand reads inside the loop (see lane_off above)
 #ifdef BTS_GATHER_LDS
-        region_seq_l<HD, 0>(acc, gl, rows, G, wq, off_next, lh + LH::W_F16 + lane4, LH::TERM_STRIDE, raw, v3, p.freq_factor, bias);
+        region_seq_l<HD, 0>(acc, gl, rows, G, wq, off_next, lh + LH::W_F16 + lane4, LH::TERM_STRIDE, raw, v3, q->freq_factor, bias);
         if constexpr (NS > kNumFreqs) {   // HD = 64: the blocks of stages 6 and 7
           gl_consume<HD, 12>(acc, gl, rows, G, wq, off_next), gl_consume<HD, 13>(acc, gl, rows, G, wq, off_next);
           gl_consume<HD, 14>(acc, gl, rows, G, wq, off_next), gl_consume<HD, 15>(acc, gl, rows, G, wq, off_next);
         }
 #else
-        region_seq<HD, 0>(acc, ba, bb, G, o, wq, h, lh + LH::W_F16 + lane4, LH::TERM_STRIDE, raw, v3, p.freq_factor, bias, nosin, nomfma);
+        region_seq<HD, 0>(acc, ba, bb, G, o, wq, h, lh + LH::W_F16 + lane4, LH::TERM_STRIDE, raw, v3, q->freq_factor, bias, nosin, nomfma);
 #endif
       } else {
 #ifndef BTS_GATHER_LDS
@@ -1023,9 +1029,9 @@ __global__ __launch_bounds__(256, 2) void render_kernel_p(const FwdParams p) {
         kstep<HD>(acc, wl + 2 * HD, 0, v3[2], 1.0f, nomfma);
         SinCos3 raw;
         __builtin_amdgcn_sched_barrier(0);
-        pe_direct(raw, v3, p.freq_factor);
+        pe_direct(raw, v3, q->freq_factor);
         __builtin_amdgcn_sched_barrier(0);
-        octave_seq<HD, 0>(acc, ba, bb, G, o, wq, h, wl + 4 * HD, raw, v3, p.freq_factor, nomfma, nosin, nogather);
+        octave_seq<HD, 0>(acc, ba, bb, G, o, wq, h, wl + 4 * HD, raw, v3, q->freq_factor, nomfma, nosin, nogather);
 #endif
       }
 #ifndef BTS_GATHER_LDS
@@ -1039,7 +1045,7 @@ __global__ __launch_bounds__(256, 2) void render_kernel_p(const FwdParams p) {
 #ifdef BTS_ENC_RAY
       }
 #endif
-      if (p.learn_empty && __any(use_empty)) {
+      if (q->learn_empty && __any(use_empty)) {
 #pragma unroll
         for (int ht = 0; ht < HT; ++ht)
 #pragma unroll
@@ -1099,7 +1105,7 @@ __global__ __launch_bounds__(256, 2) void render_kernel_p(const FwdParams p) {
       s_raw = F16 ? __builtin_fmaf(p0 + p1, inv_scale, b_out) : (p0 + p1) + b_out;
       }
       float sigma = softplus(s_raw);
-      if (p.empty_empty) sigma = pe.invalid ? 0.0f : sigma;
+      if (q->empty_empty) sigma = pe.invalid ? 0.0f : sigma;
       BTS_TICK(2)
 
       // ---------------- colours (models_bts.py:218-264): projection into each render view + 4-tap fetch of the rgb0-packed frame.
@@ -1111,10 +1117,10 @@ __global__ __launch_bounds__(256, 2) void render_kernel_p(const FwdParams p) {
         col[3 * j] = col[3 * j + 1] = col[3 * j + 2] = 0.0f;
         inv[j] = pe.invalid;
         if (j < nv && !BTS_ABL(8)) {
-          const Cam cj = load_cam(p.w2c_r + ((long)sample * nv + j) * 16, p.K_r + ((long)sample * nv + j) * 9);
+          const Cam cj = load_cam(q->w2c_r + ((long)sample * nv + j) * 16, q->K_r + ((long)sample * nv + j) * 9);
           const Proj pc = project<false>(cj, px, py, pz);
           const Taps tc = make_taps(pc.x, pc.y, H, W);
-          const float4* img = reinterpret_cast<const float4*>(p.imgs) + ((long)sample * nv + j) * H * W;
+          const float4* img = reinterpret_cast<const float4*>(q->imgs) + ((long)sample * nv + j) * H * W;
           const float4 a = img[tc.o00], b = img[tc.o01], cc = img[tc.o10], d = img[tc.o11];
           col[3 * j + 0] = ((a.x * tc.w00 + b.x * tc.w01) + cc.x * tc.w10) + d.x * tc.w11;
           col[3 * j + 1] = ((a.y * tc.w00 + b.y * tc.w01) + cc.y * tc.w10) + d.y * tc.w11;
@@ -1126,7 +1132,7 @@ __global__ __launch_bounds__(256, 2) void render_kernel_p(const FwdParams p) {
       // ---------------- alpha compositing (nerf.py:225-299): segmented DPP scan over the lanes of each ray
       const float delta = (k + 1 < K) ? (z_nx - z) : 1e10f;
       float alpha = 1.0f - expf(-fabsf(delta) * fmaxf(sigma, 0.0f));
-      if (p.hard_cap && k == K - 1) alpha = 1.0f;
+      if (q->hard_cap && k == K - 1) alpha = 1.0f;
       const float t = valid ? (1.0f - alpha) + 1e-10f : 1.0f;
       const float incl = seg_scan_mul(t, lpr, kl);
       float excl = dpp_f<kDppWaveShr1>(1.0f, incl);
@@ -1146,8 +1152,8 @@ __global__ __launch_bounds__(256, 2) void render_kernel_p(const FwdParams p) {
               const long idx = ray * nv + j;
               const unsigned long long seg = lpr == 64 ? ~0ull : (((1ull << lpr) - 1ull) << (lane - (lpr - 1)));
               const float any = (hit & seg) ? 1.0f : 0.0f;
-              if (p.invalid_wsum) p.invalid_wsum[idx] = (kc > 0 ? p.invalid_wsum[idx] : 0.0f) + ws;   // K > 64: chunk after chunk
-              if (p.invalid_any) p.invalid_any[idx] = kc > 0 ? fmaxf(p.invalid_any[idx], any) : any;
+              if (q->invalid_wsum) q->invalid_wsum[idx] = (kc > 0 ? q->invalid_wsum[idx] : 0.0f) + ws;   // K > 64: chunk after chunk
+              if (q->invalid_any) q->invalid_any[idx] = kc > 0 ? fmaxf(q->invalid_any[idx], any) : any;
             }
           }
       }
@@ -1157,22 +1163,22 @@ __global__ __launch_bounds__(256, 2) void render_kernel_p(const FwdParams p) {
       for (int i = 0; i < NVMAX * 3; ++i) rgb_part[i] = rgb_part[i] + wgt * col[i];
       if (valid && !BTS_ABL(16)) {
         const long pk = ray * K + k;
-        if (p.weights) p.weights[pk] = wgt;
-        if (p.alphas) p.alphas[pk] = alpha;
-        if (p.sigma_raw) p.sigma_raw[pk] = s_raw;
-        if (p.trans) p.trans[pk] = T;
-        if (p.invalid) {
+        if (q->weights) q->weights[pk] = wgt;
+        if (q->alphas) q->alphas[pk] = alpha;
+        if (q->sigma_raw) q->sigma_raw[pk] = s_raw;
+        if (q->trans) q->trans[pk] = T;
+        if (q->invalid) {
 #pragma unroll
           for (int j = 0; j < NVMAX; ++j)
-            if (j < nv) p.invalid[pk * nv + j] = inv[j] ? 1.0f : 0.0f;
+            if (j < nv) q->invalid[pk * nv + j] = inv[j] ? 1.0f : 0.0f;
         }
-        if (p.rgb_samps) {
+        if (q->rgb_samps) {
 #pragma unroll
           for (int j = 0; j < NVMAX; ++j)
             if (j < nv) {
-              p.rgb_samps[(pk * nv + j) * 3 + 0] = col[3 * j + 0];
-              p.rgb_samps[(pk * nv + j) * 3 + 1] = col[3 * j + 1];
-              p.rgb_samps[(pk * nv + j) * 3 + 2] = col[3 * j + 2];
+              q->rgb_samps[(pk * nv + j) * 3 + 0] = col[3 * j + 0];
+              q->rgb_samps[(pk * nv + j) * 3 + 1] = col[3 * j + 1];
+              q->rgb_samps[(pk * nv + j) * 3 + 2] = col[3 * j + 2];
             }
         }
       }
@@ -1185,10 +1191,10 @@ __global__ __launch_bounds__(256, 2) void render_kernel_p(const FwdParams p) {
     for (int i = 0; i < NVMAX * 3; ++i)
       if (i < nv * 3) rgb_part[i] = seg_scan_add(rgb_part[i], lpr, kl);
     if (kl == lpr - 1) {
-      p.depth[ray] = depth_part;
+      q->depth[ray] = depth_part;
 #pragma unroll
       for (int i = 0; i < NVMAX * 3; ++i)
-        if (i < nv * 3) p.rgb[ray * nv * 3 + i] = p.white_bkgd ? (rgb_part[i] + 1.0f) - w_part : rgb_part[i];  // nerf.py:301-304
+        if (i < nv * 3) q->rgb[ray * nv * 3 + i] = q->white_bkgd ? (rgb_part[i] + 1.0f) - w_part : rgb_part[i];  // nerf.py:301-304
     }
     BTS_TICK(5)
   }
