@@ -355,7 +355,11 @@ __global__ __launch_bounds__(256, 2) void rowsb_kernel(const BwdParams bp, const
       {
         if (qb->f.white_bkgd) g_w += g_bkgd;   // nerf.py:301-304: rgb = sum_k w_k c_k + 1 - sum_k w_k
         if (qb->g_weights) g_w += qb->g_weights[pk];
+#ifdef BTS_ABL_B1   // timing ablation: no per-sample colour loads
+        if (false) {
+#else
         if (qb->f.rgb_samps) {
+#endif
           const float* cs = qb->f.rgb_samps + pk * (long)(nv * 3);
 #pragma unroll
           for (int j = 0; j < NVMAX; ++j)
@@ -422,11 +426,13 @@ __global__ __launch_bounds__(256, 2) void rowsb_kernel(const BwdParams bp, const
         const float gww = valid ? g_w * (alpha * T) : 0.0f;
         // exclusive suffix sum over the wave + the chunks behind; the wave's total moves on to the chunk in front
         float incl = gww;
+#ifndef BTS_ABL_B6   // timing ablation: no suffix scan
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
           const float y = __shfl_down(incl, off, 64);
           incl += (lane + off < 64) ? y : 0.0f;
         }
+#endif
         const float below = __shfl_down(incl, 1, 64);
         const float S = (lane == 63 ? 0.0f : below) + S_carry;
         S_carry += __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, incl)));
@@ -531,7 +537,11 @@ __global__ __launch_bounds__(256, 2) void rowsb_kernel(const BwdParams bp, const
         for (int q = 0; q < 16; ++q)
           r[q] = __builtin_fmaf(relu1(acc[ht][1][q]), gs_t[1] * inv_scale, relu1(acc[ht][0][q]) * (gs_t[0] * inv_scale));
         // dw_acc[ht] belongs to channel ht*32 + mfma_row(col >> 1, h), on both lanes of the pair
+#ifdef BTS_ABL_B4   // timing ablation: no butterfly
+        dw_acc[ht] += r[0] + r[5] + r[15];
+#else
         dw_acc[ht] += half_reduce16(r, col);
+#endif
       }
       gs_t[0] *= inv_s_v, gs_t[1] *= inv_s_v;    // exact (a power of two): the vectors below carry s_v
 
@@ -556,10 +566,18 @@ __global__ __launch_bounds__(256, 2) void rowsb_kernel(const BwdParams bp, const
             const float* wt = lds + L::BLK + b * L::BLK_STRIDE + lane4t;
             // vn = mn . (W1^T v): the C layout of v is the B operand; the product carries 2^S (and s_v)
             f32x16 vn = zero_acc();
+#ifdef BTS_ABL_B5   // timing ablation: no transposed products
+            vn = v[0];
+#else
             hidden_layer_ht(vn, v[0], wt + L::BLK_LAYER_STRIDE, L::BLK_TERM_STRIDE, 1.0f);
+#endif
 #pragma unroll
             for (int q = 0; q < 16; ++q) vn[q] = net[b][pt][q] > 0.0f ? vn[q] * inv_scale : 0.0f;
+#ifdef BTS_ABL_B3   // timing ablation: no fc_0 / fc_1 weight gradients
+            if (false) {
+#else
             if (qb->d_mlp) {
+#endif
               // dW1[out][in] += sum_p (g_s v)[p][out] relu(n)[p][in];  db1[out] += sum_p (g_s v)[p][out]
               wave_lds_fence();
 #pragma unroll
@@ -578,8 +596,16 @@ __global__ __launch_bounds__(256, 2) void rowsb_kernel(const BwdParams bp, const
             }
             // t2 = W0^T vn;  v <- v + m0 . t2
             f32x16 t2 = zero_acc();
+#ifdef BTS_ABL_B5
+            t2 = vn;
+#else
             hidden_layer_ht(t2, vn, wt, L::BLK_TERM_STRIDE, 1.0f);
+#endif
+#ifdef BTS_ABL_B3
+            if (false) {
+#else
             if (qb->d_mlp) {
+#endif
               // dW0[out][in] += sum_p (g_s vn)[p][out] relu(h0)[p][in];  db0[out] += sum_p (g_s vn)[p][out]
               wave_lds_fence();
 #pragma unroll
@@ -604,7 +630,11 @@ __global__ __launch_bounds__(256, 2) void rowsb_kernel(const BwdParams bp, const
         // bytes of the row)
         if (ro.u0_ws) {
           const int ks = kc + pt * 32 + col;
+#ifdef BTS_ABL_B2   // timing ablation: no row stores
+          if (ks < K && gs_t[pt] == 12345.0f) {
+#else
           if (ks < K) {
+#endif
             float4* dst = reinterpret_cast<float4*>(ro.u0_ws + (ray * K + ks) * (long)HD);
 #pragma unroll
             for (int ht = 0; ht < HT; ++ht)

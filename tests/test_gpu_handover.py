@@ -75,3 +75,73 @@ def test_fused_handover_matches_the_generic_route(hip, flip):
         # the two routes' G differ by rounding (1e-5 above); a relu gate that flips between them moves a weight gradient by one sample's
         # contribution -- the kink sensitivity tests/test_gpu_grad.py masks out.  Measured 1e-5 ... 2.6e-4 of the largest entry.
         assert err <= 5e-4, (i, err)
+
+
+def test_fused_handover_vs_oracle_autograd(hip):
+    """Row f4 anchored to the ORACLE (not to our own generic route): the fused route -- decoder tail writes G, render, backward through
+    bts_render_bwd and through the composed convolution -- against torch.autograd through the CPU oracle on F = decoder(x), F being the
+    shipped Monodepth2's ordinary output (same GPU convolutions, so the CNN is common to both and the render path is what differs).
+    Outputs of scales 0 and 2 and the gradients of lin_in (feature AND encoding half), lin_out, the scale-0 / scale-2 output
+    convolutions and the first ResNet convolution."""
+    import torch.nn.functional as F
+    from oracle import bts_oracle as O
+    from behindthescenes_amd import synthetic as S
+    torch.manual_seed(5)
+    n, v, H, W, K = 2, 3, 64, 96, 16
+    net = hip.BTSNet(_conf(True, False))
+    S.init_mlp_(net.mlp_coarse, seed=3)
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.1), m.running_var.uniform_(0.5, 1.5)
+    net = net.cuda().train()
+    scene = S.synthetic_scene(n, v, H, W, 64, seed=9, intrinsics=S.K_KITTI360, smooth=True)
+    images, projs, poses = scene["images"].cuda(), scene["projs"].cuda(), scene["poses"].cuda()
+    renderer = hip.NeRFRenderer(n_coarse=K, lindisp=True, hard_alpha_cap=True).cuda()
+    sampler = hip.PatchRaySampler(ray_batch_size=256, z_near=3.0, z_far=80.0, patch_size=8)
+    torch.manual_seed(77)
+    rays, _ = sampler.sample(images[:, :1] * .5 + .5, poses[:, :1], projs[:, :1])
+    z = renderer.sample_coarse(rays.reshape(-1, 8), torch.rand(rays.shape[0] * rays.shape[1], K, device="cuda"))
+    c_rgb = torch.randn(rays.shape[0] * rays.shape[1], 6, device="cuda")
+    scales = (0, 2)
+    dec = net.encoder.decoder
+    watched = [dec.decoder[dec.decoder_keys[("dispconv", 0)]].conv.weight, dec.decoder[dec.decoder_keys[("dispconv", 2)]].conv.weight,
+               net.encoder.encoder.encoder.conv1.weight]
+    # ---- HIP, fused route
+    net.zero_grad(set_to_none=True)
+    net.encode(images, projs, poses, ids_encoder=[0], ids_render=[1, 2])
+    assert net.grid_f_features is None          # the feature map itself was never materialised
+    total, ours_out = 0.0, []
+    for s in scales:
+        net.set_scale(s)
+        w, rgb, depth, *_ = renderer.composite(net, rays.reshape(-1, 8), z, sb=n)
+        ours_out.append((rgb.detach().cpu(), depth.detach().cpu()))
+        total = total + (rgb * c_rgb).sum() + 0.05 * depth.sum()
+    total.backward()
+    mc = net.mlp_coarse
+    ours = [mc.lin_in.weight.grad.cpu(), mc.lin_in.bias.grad.cpu(), mc.lin_out.weight.grad.cpu()] + [p.grad.cpu() for p in watched]
+    # ---- oracle on F = the encoder's ordinary output
+    cfg = O.FieldConfig()
+    feats = net.encoder(images[:, 0])                                  # [(n, 64, H >> s, W >> s)], graph on the GPU
+    ups = [feats[s] if s == 0 else F.interpolate(feats[s], (H, W)) for s in scales]      # BTSNet.encode: nearest resize to scale 0's size
+    leaves = [u.detach().cpu().requires_grad_(True) for u in ups]
+    params = [mc.lin_in.weight.detach().cpu().requires_grad_(True), mc.lin_in.bias.detach().cpu().requires_grad_(True),
+              mc.lin_out.weight.detach().cpu().requires_grad_(True), mc.lin_out.bias.detach().cpu().requires_grad_(True)]
+    mlp = O.MlpParams(params[0], params[1], [], params[2], params[3])
+    o_total, o_out = 0.0, []
+    cpu_scene = {k: t.cpu() for k, t in scene.items()}
+    for leaf in leaves:
+        st = O.make_state(dict(cpu_scene, feat=leaf), [1, 2], cfg)
+        ow, orgb, odepth, *_ = O.composite(rays.reshape(-1, 8).cpu(), z.cpu(), n, st, mlp, cfg, hard_alpha_cap=True)
+        o_out.append((orgb.detach(), odepth.detach()))
+        o_total = o_total + (orgb * c_rgb.cpu()).sum() + 0.05 * odepth.sum()
+    g = torch.autograd.grad(o_total, params[:3] + leaves)
+    g_watched = torch.autograd.grad(ups, watched, grad_outputs=[t.cuda() for t in g[3:]])
+    ref = list(g[:3]) + [t.cpu() for t in g_watched]
+    for (rgb, depth), (orgb, odepth) in zip(ours_out, o_out):
+        assert (rgb - orgb).abs().max().item() <= 1e-5 and ((depth - odepth).abs() / odepth.abs()).max().item() <= 1e-4
+    for i, (a, b) in enumerate(zip(ours, ref)):
+        err = (a - b.view_as(a)).abs().max().item() / b.abs().max().item()
+        print(f"gradient {i}: max err / max entry {err:.2e}")
+        # G = F . W^T composed into the convolution vs bilinear(F) -> lin_in: rounding-level differences of h, hence the occasional
+        # flipped relu gate (see test_fused_handover_matches_the_generic_route); measured 1e-6 ... 2e-4
+        assert err <= 5e-4, (i, err)

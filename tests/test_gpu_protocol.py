@@ -70,3 +70,47 @@ def test_white_background_forward_and_backward_vs_reference(hip):
     for g, name in zip(grads, ["g_w_in", "g_b_in", "g_w_out", "g_b_out", "g_feat"]):
         err = _rel_to_max(g, G[f"wb_{name}"].view_as(g.cpu()))
         assert err <= 1e-4, (name, err)
+
+
+def test_two_pass_forward_with_the_shared_mlp_end_to_end(hip):
+    """`using_fine` (n_fine > 0) with mlp_fine: empty -- the fine pass queries the COARSE MLP (models_bts.py:300-304) on
+    the sorted union of the coarse samples, n_fine - n_fine_depth importance samples and n_fine_depth samples around the coarse depth
+    (nerf.py:352-373).  No shipped config turns it on; the drop-in runs it end to end on the fused kernel: both passes against the
+    oracle on the very samples the renderer drew (want_z_samps), the fine samples inside [near, far], sorted, the coarse ones among
+    them, and gradients reaching the MLP from both passes."""
+    from oracle import bts_oracle as O
+    from tests._cases import robust_ray_mask
+    from tests._hip_helpers import build_net
+    cfg = O.FieldConfig()
+    g = torch.Generator().manual_seed(12)
+    n, v, H, W, Kc, Kf, Kfd = 2, 3, 48, 160, 16, 12, 4
+    scene = O.synthetic_scene(n, v, H, W, 64, seed=12, intrinsics=O.K_KITTI360, smooth=True)
+    mlp = O.init_mlp(103, 64, 0, gen=g)
+    rays = O.image_rays(scene["poses"], scene["projs"], H, W, 3.0, 80.0)
+    rays = rays[:, torch.randperm(rays.shape[1], generator=g)[:640].sort().values].contiguous()
+    net = build_net(cfg, mlp, scene, [1, 2], train=True)
+    renderer = hip.NeRFRenderer.from_conf(dict(n_coarse=Kc, n_fine=Kf, n_fine_depth=Kfd, depth_std=1.0, lindisp=True, hard_alpha_cap=True)).cuda().train()
+    assert renderer.using_fine
+    torch.manual_seed(3)
+    out = renderer.bind_parallel(net)(rays.cuda(), want_weights=True, want_alphas=True, want_z_samps=True)
+    assert set(out) == {"coarse", "fine"}
+    zc, zf = out["coarse"]["z_samps"], out["fine"]["z_samps"]
+    assert zc.shape == (n, 640, Kc) and zf.shape == (n, 640, Kc + Kf)
+    assert (zf[..., 1:] >= zf[..., :-1]).all() and zf.min() >= 3.0 - 1e-4 and zf.max() <= 80.0 + 1e-3
+    # every coarse sample is among the fine pass' samples
+    assert (torch.isclose(zc.unsqueeze(-1), zf.unsqueeze(-2), rtol=0, atol=0).any(-1)).all()
+    st = O.make_state(scene, [1, 2], cfg)
+    for part, z in (("coarse", zc), ("fine", zf)):
+        zz = z.reshape(-1, z.shape[-1]).detach().cpu()
+        with torch.no_grad():
+            ow, orgb, odepth, oa, oinv, _, _ = O.composite(rays.reshape(-1, 8), zz, n, st, mlp, cfg, hard_alpha_cap=True)
+        ok = robust_ray_mask(st, rays, zz)
+        d = out[part]
+        torch.testing.assert_close(d["depth"].detach().cpu().reshape(-1)[ok], odepth[ok], rtol=1e-4, atol=0)
+        torch.testing.assert_close(d["rgb"].detach().cpu().reshape(-1, 6)[ok], orgb[ok], rtol=0, atol=1e-5)
+        torch.testing.assert_close(d["weights"].detach().cpu().reshape(-1, z.shape[-1])[ok], ow[ok], rtol=0, atol=1e-5)
+    # both passes are differentiable through the one MLP
+    net.zero_grad(set_to_none=True)
+    (out["coarse"]["rgb"].square().mean() + out["fine"]["rgb"].square().mean() + 0.01 * out["fine"]["depth"].mean()).backward()
+    gw = net.mlp_coarse.lin_in.weight.grad
+    assert gw is not None and torch.isfinite(gw).all() and float(gw.abs().sum()) > 0
