@@ -33,7 +33,7 @@ class BtsFieldTensors(C.Structure):
 class BtsRenderArgs(C.Structure):
     _fields_ = [(k, C.c_int32) for k in ("rays_per_sample", "K", "hard_alpha_cap", "white_bkgd")] + \
                [(k, C.c_void_p) for k in ("rays", "z_samp", "rgb", "depth", "weights", "alphas", "invalid", "rgb_samps",
-                                          "sigma_raw", "trans", "invalid_wsum", "invalid_any")]
+                                          "sigma_raw", "trans", "invalid_wsum", "invalid_any", "sigma_noise")]
 
 
 class BtsRenderGrads(C.Structure):

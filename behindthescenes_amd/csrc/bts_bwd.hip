@@ -753,7 +753,7 @@ int render_bwd_impl(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const BtsR
   bp.f = make_params(cfg, t);
   bp.f.rays = a->rays, bp.f.z_samp = a->z_samp;
   bp.f.Bp = a->rays_per_sample, bp.f.K = a->K, bp.f.hard_cap = a->hard_alpha_cap, bp.f.white_bkgd = a->white_bkgd;
-  bp.f.sigma_raw = a->sigma_raw, bp.f.trans = a->trans;
+  bp.f.sigma_raw = a->sigma_raw, bp.f.trans = a->trans, bp.f.sigma_noise = a->sigma_noise;
   bp.f.rgb_samps = a->rgb_samps;   // optional INPUT here: the forward's per-sample colours (else they are recomputed)
   bp.f.tiles_per_sample = (a->rays_per_sample + 255) / 256;
   bp.g_rgb = g->g_rgb, bp.g_depth = g->g_depth, bp.g_weights = g->g_weights, bp.g_alphas = g->g_alphas;

@@ -419,6 +419,8 @@ __global__ __launch_bounds__(256, 2) void rowsb_kernel(const BwdParams bp, const
         float sigma = softplus(s_raw);
         const bool dead = (qb->f.empty_empty != 0) & pe.invalid;   // sigma forced to 0: no gradient
         if (dead) sigma = 0.0f;
+        if (qb->f.sigma_noise) sigma += qb->f.sigma_noise[pk];   // nerf.py:279-280: relu(sigma + noise) -- no gradient where the sum is <= 0
+        const bool cut = sigma <= 0.0f && qb->f.sigma_noise != nullptr;
         const float delta = last ? 1e10f : (z_nx - z);
         const float ex = expf(-fabsf(delta) * fmaxf(sigma, 0.0f));
         const bool capped = (qb->f.hard_cap != 0) & last;
@@ -438,7 +440,7 @@ __global__ __launch_bounds__(256, 2) void rowsb_kernel(const BwdParams bp, const
         S_carry += __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, incl)));
         float g_alpha = g_w * T - S / (capped ? 1e-10f : ex + 1e-10f);
         if (qb->g_alphas) g_alpha += qb->g_alphas[pk];
-        if (!capped && !dead && valid) g_s = g_alpha * fabsf(delta) * ex * (s_raw > 20.0f ? 1.0f : sigmoidf(s_raw));
+        if (!capped && !dead && !cut && valid) g_s = g_alpha * fabsf(delta) * ex * (s_raw > 20.0f ? 1.0f : sigmoidf(s_raw));
         if (valid) qb->gs_ws[pk] = g_s;
       }
       db_acc += g_s;

@@ -360,6 +360,8 @@ __global__ __launch_bounds__(256, 2) void rows_kernel(const BwdParams bp) {
       float sigma = softplus(s_raw);
       const bool dead = (qb->f.empty_empty != 0) & pe.invalid;   // sigma forced to 0: no gradient
       if (dead) sigma = 0.0f;
+      if (qb->f.sigma_noise) sigma += qb->f.sigma_noise[pk];   // nerf.py:279-280: relu(sigma + noise) -- no gradient where the sum is <= 0
+      const bool cut = sigma <= 0.0f && qb->f.sigma_noise != nullptr;
       const float delta = last ? 1e10f : (z_nx - z);
       const float ex = expf(-fabsf(delta) * fmaxf(sigma, 0.0f));
       const bool capped = (qb->f.hard_cap != 0) & last;
@@ -371,7 +373,7 @@ __global__ __launch_bounds__(256, 2) void rows_kernel(const BwdParams bp) {
 #endif
       float g_alpha = g_w * T - S / (capped ? 1e-10f : ex + 1e-10f);
       if (qb->g_alphas) g_alpha += qb->g_alphas[pk];
-      if (!capped && !dead && valid) g_s = g_alpha * fabsf(delta) * ex * (s_raw > 20.0f ? 1.0f : sigmoidf(s_raw));
+      if (!capped && !dead && !cut && valid) g_s = g_alpha * fabsf(delta) * ex * (s_raw > 20.0f ? 1.0f : sigmoidf(s_raw));
       if (valid) qb->gs_ws[pk] = g_s;
     }
     db_acc += g_s;
@@ -1000,8 +1002,10 @@ __device__ __attribute__((noinline)) void write_pe_tile_exact(float* tile, float
   }
 }
 
+// (three work-groups per CU at d_hidden 32: the pass is latency-bound -- row loads from HBM, then the trigonometry, then a chain of
+// MFMAs -- and 42 KB of LDS per work-group allow it)
 template <int C, int HD>
-__global__ __launch_bounds__(256, 2) void dwpe_rows_kernel(const DwpeRowsParams dp) {
+__global__ __launch_bounds__(256, HD == 32 ? 3 : 2) void dwpe_rows_kernel(const DwpeRowsParams dp) {
   constexpr int HT = HD / 32;
   constexpr int PE_ROWS = kPeDim + 1;   // 40
   constexpr int D_IN = C + kPeDim;
@@ -1193,7 +1197,8 @@ int launch_dwpe_rows(const FwdParams& p, const float* u0_ws, float* d_mlp, int C
   dp.f.n = n;
   const long units = (long)n * (((long)p.Bp * p.K + 63) / 64);
   const long wgs = (units + 3) / 4;
-  const int g = (int)(wgs < grid ? wgs : grid);   // grid = 2 work-groups per CU
+  const long cap = HD == 32 ? (long)grid / 2 * 3 : grid;   // grid = 2 work-groups per CU; this kernel fits 3 at d_hidden 32
+  const int g = (int)(wgs < cap ? wgs : cap);
   if (C == 64 && HD == 64) dwpe_rows_kernel<64, 64><<<g, 256, 0, s>>>(dp);
   else if (C == 32 && HD == 32) dwpe_rows_kernel<32, 32><<<g, 256, 0, s>>>(dp);
   else return BTS_E_UNSUPPORTED;

@@ -53,6 +53,7 @@ struct FwdParams {
   float* trans;        // (n*Bp, K) transmittance in front of each sample (saved for the backward)
   float* invalid_wsum; // (n*Bp, nv) sum_k w_k invalid_k,v } per-ray reductions for the loss' invalid-ray policies (pipelined
   float* invalid_any;  // (n*Bp, nv) max_k invalid_k,v     } kernel only)
+  const float* sigma_noise;  // (n*Bp, K) or null: added to the density before relu / alpha (nerf.py:279-280)
   // query
   const float* xyz;
   float* q_sigma;
@@ -603,6 +604,9 @@ __global__ __launch_bounds__(256, 2) void field_kernel(const FwdParams p) {
     const float s_raw = eval_point<C, HD, NB, PROJ>(p, lds, enc, featp, lane, b_out, px, py, pz, pe);
     float sigma = softplus(s_raw);
     if (p.empty_empty) sigma = pe.invalid ? 0.0f : sigma;
+    if constexpr (!QUERY) {
+      if (p.sigma_noise) sigma += p.sigma_noise[ray * K + k];
+    }
 
     // ---------------- colour taps (models_bts.py:218-264)
     float col[NVMAX * 3];
@@ -737,6 +741,7 @@ __device__ __forceinline__ void render_group(const FwdParams& p, const float* ld
       const float s_raw = eval_point<C, HD, NB, PROJ>(p, lds, enc, featp, lane, b_out, px, py, pz, pe);
       float sigma = softplus(s_raw);
       if (p.empty_empty) sigma = pe.invalid ? 0.0f : sigma;
+      if (p.sigma_noise) sigma += p.sigma_noise[ray * K + kk];
 
       // ---------------- colour taps (models_bts.py:218-264)
       float col[NVMAX * 3];

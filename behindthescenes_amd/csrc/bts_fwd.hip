@@ -18,12 +18,15 @@ bool shape_supported(int C, int HD, int NB) {
   return (C == 64 && HD == 64 && NB == 0) || (C == 32 && HD == 32 && NB == 1) || (C == 32 && HD == 32 && NB == 0);
 }
 
-template int launch_field<false, false>(const FwdParams&, int, int, int, int, hipStream_t);
+// raw channels-last features (feat_nhwc, for callers that cannot pre-project): the compact lane = sample render kernel and the
+// lane = point query kernel; everything else of bts_field_kernel.h is instantiated in the probe build only
 template int launch_field<true, false>(const FwdParams&, int, int, int, int, hipStream_t);
-extern template int launch_field<false, true>(const FwdParams&, int, int, int, int, hipStream_t);
-extern template int launch_field<true, true>(const FwdParams&, int, int, int, int, hipStream_t);
 template int launch_render<false>(const FwdParams&, int, int, int, int, hipStream_t);
+#ifdef BTS_PROBE
+template int launch_field<false, false>(const FwdParams&, int, int, int, int, hipStream_t);
+extern template int launch_field<false, true>(const FwdParams&, int, int, int, int, hipStream_t);
 extern template int launch_render<true>(const FwdParams&, int, int, int, int, hipStream_t);
+#endif
 int launch_render_pipelined(const FwdParams& p, int C, int HD, int NB, int grid, hipStream_t s);
 
 FwdParams make_params(const BtsFieldCfg* cfg, const BtsFieldTensors* t) {
@@ -86,15 +89,13 @@ int render_fwd_impl(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const BtsR
   p.rgb = a->rgb, p.depth = a->depth, p.weights = a->weights, p.alphas = a->alphas, p.invalid = a->invalid;
   p.rgb_samps = a->rgb_samps, p.sigma_raw = a->sigma_raw, p.trans = a->trans;
   p.invalid_wsum = a->invalid_wsum, p.invalid_any = a->invalid_any;
+  p.sigma_noise = a->sigma_noise;
   p.tiles_per_sample = (a->rays_per_sample + 255) / 256;
 #ifdef BTS_PROBE   // A/B switches exist only in the probe build (python -m behindthescenes_amd.build --probe); the product has one path
   if (getenv("BTS_LANE_IS_RAY")) {  // round-1a mapping (one lane = one ray)
     if (p.proj) return launch_field<false, true>(p, cfg->C, cfg->d_hidden, cfg->n_blocks, p.tiles_per_sample * cfg->n, s);
     return launch_field<false, false>(p, cfg->C, cfg->d_hidden, cfg->n_blocks, p.tiles_per_sample * cfg->n, s);
   }
-#endif
-#ifdef BTS_ENC_RAY
-  if (getenv("BTS_RENDER_NO_ENCRAY")) p.ablate |= 64;   // experimental build only: A/B switch for the encoder-camera ray path
 #endif
 #ifdef BTS_PROBE
   if (const char* e = getenv("BTS_ABLATE")) p.ablate |= atoi(e);

@@ -19,9 +19,6 @@
 #if !defined(BTS_GATHER_REGS) && !defined(BTS_GATHER_LDS)
 #define BTS_GATHER_LDS
 #endif
-#if defined(BTS_GATHER_LDS) && defined(BTS_ENC_RAY)
-#error "the experimental encoder-camera ray draft is written against the register gather: add -DBTS_GATHER_REGS"
-#endif
 
 namespace bts {
 
@@ -97,50 +94,6 @@ __device__ __forceinline__ void stage_blend(f32x16 (&acc)[HD / 32][2], const GBu
   gblend<false>(acc[St::ht][St::pt], b, w[St::pt][2 * St::tp2], w[St::pt][2 * St::tp2 + 1]);
 }
 
-// octave OCT of the positional encoding with gather stage OCT blended behind its MFMAs (buffers alternate by parity).
-// EXACT selects libm sines (wave-level slow path for arguments beyond the fast range); the fast variant is branch-free so that the
-// whole gather + encoding + MFMA phase is ONE basic block the scheduler can interleave.
-// Octave OCT of the positional encoding with gather stage OCT blended behind its MFMAs (buffers alternate by parity).
-// One scheduling region per octave: the sines of octave OCT+1 (direct for even octaves, by angle doubling for odd ones), the 12 MFMAs
-// of octave OCT, the blend of gather stage OCT and the loads of stage OCT+2 may interleave freely; nothing moves across the
-// region boundary (that bounds the live ranges: an unconstrained schedule of this block spills > 200 VGPRs).
-template <int HD, int OCT>
-__device__ __forceinline__ void octave_seq(f32x16 (&acc)[HD / 32][2], GBuf& ba, GBuf& bb, const float4* __restrict__ G,
-                                           const int (&o)[2][4], const float (&wq)[2][4], int h, const float* wl, SinCos3& raw,
-                                           const float (&v3)[3], float ff, bool nomfma, bool nosin, bool nogather) {
-  constexpr int NS = 4 * (HD / 32);
-  if constexpr (OCT < kNumFreqs) {
-    float sc[6];
-    if (nosin) {
-#pragma unroll
-      for (int i = 0; i < 6; ++i) sc[i] = v3[i % 3] * ff;
-    } else {
-      pe_entries(sc, raw, v3, ff);
-    }
-    if constexpr (OCT + 1 < kNumFreqs) {
-      if (!nosin) {
-        if constexpr ((OCT + 1) % 2 == 0) {
-          pe_direct(raw, v3, ff * 2.0f);
-        } else {
-          const SinCos3 prev = raw;
-          pe_double(raw, prev);
-        }
-      }
-    }
-    kstep<HD>(acc, wl, 0, sc[0], sc[1], nomfma);
-    kstep<HD>(acc, wl + 2 * HD, 0, sc[2], sc[3], nomfma);
-    kstep<HD>(acc, wl + 4 * HD, 0, sc[4], sc[5], nomfma);
-    if constexpr (OCT < NS) {
-      if (!nogather) {
-        stage_blend<HD, OCT>(acc, ba, wq);
-        if constexpr (OCT + 2 < NS) stage_load<HD, OCT + 2>(ba, G, o, h);
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    octave_seq<HD, OCT + 1>(acc, bb, ba, G, o, wq, h, wl + 6 * HD, raw, v3, ff * 2.0f, nomfma, nosin, nogather);
-  }
-}
-
 // ---------------------------------------------------------------------------------------------------------------
 // Split-precision lin_in on the f16 matrix pipe.
 // Measured on gfx950 (tools/ubench/mfma_valu_overlap*.hip): v_mfma_f32_32x32x2_f32 occupies the SIMD for its full 64 cycles -- no
@@ -172,17 +125,7 @@ struct LdsH {  // in floats, placed behind Lds<C, HD, NB, true>
   static constexpr int W_BLK = SCALE + 4;
   static constexpr int BLK_TERM_STRIDE = 2 * 64 * 4;
   static constexpr int BLK_LAYER_STRIDE = 2 * BLK_TERM_STRIDE;
-#ifdef BTS_ENC_RAY   // experimental: not part of the shipped library
-  static constexpr int W_Z = W_BLK + NB * 2 * BLK_LAYER_STRIDE;   // [term hi/lo][HT][64 lanes][8 halves]: 12 depth-code trig rows + raw code
-  static constexpr int WZ_TERM_STRIDE = HT * 64 * 4;
-  static constexpr int UBUF = W_Z + 2 * WZ_TERM_STRIDE;           // per wave [term][HT][64 lanes][8 halves]: the six per-ray rows
-  static constexpr int UBUF_TERM_STRIDE = HT * 64 * 4;
-  static constexpr int UBUF_WAVE_STRIDE = 2 * UBUF_TERM_STRIDE;
-  static constexpr int BASE = UBUF + 4 * UBUF_WAVE_STRIDE;        // per wave [HD]: ray-constant part of lin_in's output (times 2^S)
-  static constexpr int TOTAL = BASE + 4 * HD;
-#else
   static constexpr int TOTAL = W_BLK + NB * 2 * BLK_LAYER_STRIDE;
-#endif
 };
 
 // empty_proj: the projected empty feature [HD] (fp32, unscaled) as stage_weights left it in LDS
@@ -240,22 +183,6 @@ __device__ __forceinline__ void stage_weights_h(float* lh, const float* empty_pr
       dst[LH::BLK_TERM_STRIDE * 2] = (_Float16)(w - (float)hi);
     }
   }
-#ifdef BTS_ENC_RAY
-  {
-    _Float16* wz = reinterpret_cast<_Float16*>(lh + LH::W_Z);
-    for (int i = threadIdx.x; i < HT * 64 * 8; i += blockDim.x) {
-      const int e = i & 7, lane = (i >> 3) & 63, ht = i >> 9;
-      const int slot = 8 * (lane >> 5) + e, hid = ht * 32 + (lane & 31);
-      float w = 0.0f;   // slot 2*oct + {0: sin, 1: "cos"} of the depth code, slot 12: the raw depth code
-      if (slot < 12) w = mlp[ml.w_in() + hid * D_IN + C + 3 + 6 * (slot >> 1) + 3 * (slot & 1) + 2] * scale;
-      else if (slot == 12) w = mlp[ml.w_in() + hid * D_IN + C + 2] * scale;
-      const _Float16 hi = (_Float16)w;
-      wz[i] = hi;
-      wz[i + LH::WZ_TERM_STRIDE * 2] = (_Float16)(w - (float)hi);
-    }
-    for (int i = threadIdx.x; i < 4 * LH::UBUF_WAVE_STRIDE; i += blockDim.x) lh[LH::UBUF + i] = 0.0f;   // k rows 6..15 stay zero
-  }
-#endif
   for (int i = threadIdx.x; i < NB * 2 * HD; i += blockDim.x) {
     const int b = i / (2 * HD), j = i % (2 * HD);
     lh[LH::BIAS + i] = (j < HD ? mlp[ml.blk_b0(b) + j] : mlp[ml.blk_b1(b) + j - HD]) * scale;
@@ -488,7 +415,7 @@ template <int HD, int T>
 __device__ __forceinline__ void gl_consume(f32x16 (&acc)[HD / 32][2], const GatherLds& c, GRows& r, const float4* G, const float (&w)[2][4],
                                            unsigned (&off_next)[4]) {
   using B = GBlock<HD, T>;
-#if !defined(BTS_GL_FETCH_LATE) && !defined(BTS_GL_FETCH_MID)
+#if !defined(BTS_GL_FETCH_LATE)
   if constexpr (T + 1 < B::NBLK) gl_fetch<HD, T + 1, (T + 2 < B::NBLK ? 1 : 0)>(c, r);   // issued so far: blocks 0 .. T + 2
 #endif
   const f32x2 wv = {w[B::pt][B::tap], w[B::pt][B::tap]};
@@ -503,28 +430,15 @@ __device__ __forceinline__ void gl_consume(f32x16 (&acc)[HD / 32][2], const Gath
       a[4 * q + e] = res[0], a[4 * q + e + 1] = res[1];
     }
   }
-#ifdef BTS_GL_FETCH_MID   // A/B: between the blend and the issue of block T + 3 (no gain)
-  if constexpr (T + 1 < B::NBLK) gl_fetch<HD, T + 1, (T + 2 < B::NBLK ? 1 : 0)>(c, r);
-#endif
-#ifdef BTS_GL_OFFSETS_EARLY   // A/B: the table reads of block T + 4 go out before block T + 3 is issued (second register set)
-  if constexpr (T + 3 < B::NBLK) {
-    unsigned cur[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) cur[j] = off_next[j];
-    if constexpr (T + 4 < B::NBLK) gl_offsets<HD, T + 4>(c, off_next);
-    gl_issue<HD, T + 3>(c, G, cur, a[15]);
-  }
-#else
   if constexpr (T + 3 < B::NBLK) {
     gl_issue<HD, T + 3>(c, G, off_next, a[15]);
     if constexpr (T + 4 < B::NBLK) gl_offsets<HD, T + 4>(c, off_next);
   }
-#endif
 #ifdef BTS_GL_FETCH_LATE
   // NOT SHIPPED: requesting block T + 1 only now (issued so far: blocks 0 .. T + 3) is 4 % faster on the eval frame, but the RE10K
   // instantiations (d_hidden 32, one ResnetBlockFC) then differ between runs in 1 - 23 of 24 576 rays
   // (tests/test_gpu_determinism.py::test_forward_is_bit_deterministic[re10k_*]) -- even with every counter drained before the
-  // reads (-DBTS_GL_WAIT_ALL), while requesting the rows BEFORE block T + 3 is issued (the shipped order, or -DBTS_GL_FETCH_MID) is
+  // reads (-DBTS_GL_WAIT_ALL), while requesting the rows BEFORE block T + 3 is issued (the shipped order) is
   // clean over hundreds of runs.  What ds_read_b128 right behind a group of LDS-DMA loads gets wrong is open.
   if constexpr (T + 1 < B::NBLK) gl_fetch<HD, T + 1, (T + 3 < B::NBLK ? 2 : (T + 2 < B::NBLK ? 1 : 0))>(c, r);
 #endif
@@ -573,183 +487,6 @@ __device__ __forceinline__ void region_seq_l(f32x16 (&acc)[HD / 32][2], const Ga
 }
 #endif  // BTS_GATHER_LDS
 
-#ifdef BTS_ENC_RAY
-// ---------------------------------------------------------------------------------------------------------------
-// EXPERIMENTAL (not in the shipped library; build with -DBTS_ENC_RAY): encoder-camera rays, exact to first order.
-//
-// A ray through the encoder camera's centre projects to one pixel of the encoder view at every depth.  Its samples' image
-// coordinates x_k, y_k (and the pixel coordinates ix_k, iy_k derived from them) agree to a few ulp -- the reference's own rounding
-// noise -- but that noise matters at the 1e-5 bar ("Not taken"), so the per-ray constant is corrected per sample
-// with the first-order terms:
-//   h_k = [ f(ix0, iy0) + W_xy . PE(x_r, y_r) + b ]                                    (per ray, lane = hidden unit)
-//       + dix-_k u_x- + dix+_k u_x+ + diy-_k u_y- + diy+_k u_y+ + da_x,k v_x + da_y,k v_y   (six k rows, A operand per ray)
-//       + W_z . PE(zn_k) + w_code zn_k                                                 (13 k rows, constant A operand)
-// dix = ix_k - ix0 split by sign: rays through pixel centres sit exactly on a texel boundary, where the bilinear interpolant has
-// different one-sided slopes u_x-, u_x+; ix0 is then the boundary itself.  da = fl(x_k ff) - fl(x_r ff): every octave's argument is
-// an exact power-of-two multiple of fl(x ff), so ONE scalar per axis carries the argument jitter of all six octaves
-// (v_x = sum_oct 2^oct (W_sin cos(arg) - W_cos sin(arg)) + W_raw / ff).  Second-order terms are below 3e-7 under the entry
-// condition (|dix| <= 2^-11 px, |dx| <= 2^-18).  Per sample that leaves 6 sincos and 2 k-slices (24 f16 MFMAs) and no gather.
-__device__ __forceinline__ void wave_lds_fence_r() {   // lanes exchange data through LDS without a barrier: pin the order for the compiler
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-__device__ __forceinline__ float bcast_lane(float v, int l) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
-}
-
-// pixel coordinates as make_taps computes them (GridSampler unnormalize + border clip)
-__device__ __forceinline__ void pixel_coords(float x, float y, int H, int W, float& ix, float& iy) {
-  ix = ((x + 1.0f) * (float)W - 1.0f) / 2.0f;
-  iy = ((y + 1.0f) * (float)H - 1.0f) / 2.0f;
-  ix = fminf((float)(W - 1), fmaxf(ix, 0.0f));
-  iy = fminf((float)(H - 1), fmaxf(iy, 0.0f));
-}
-
-// one axis of the reference point: first texel c0 of a 3-texel window, value weights V and one-sided slope weights DL / DR on it
-struct AxisRef {
-  int c0;
-  float p0;          // reference coordinate (the texel boundary itself when the samples straddle one)
-  float V[3], DL[3], DR[3];
-};
-__device__ __forceinline__ AxisRef axis_ref(float pr) {
-  AxisRef a;
-  const float nb = rintf(pr);
-  const bool near = fabsf(pr - nb) <= 0.0009765625f;   // 2^-10 px: the cluster (radius <= 2^-11) may straddle boundary nb
-  if (near) {
-    a.c0 = (int)nb - 1, a.p0 = nb;
-    a.V[0] = 0.0f, a.V[1] = 1.0f, a.V[2] = 0.0f;
-    a.DL[0] = -1.0f, a.DL[1] = 1.0f, a.DL[2] = 0.0f;     // slope in cell [nb-1, nb]
-    a.DR[0] = 0.0f, a.DR[1] = -1.0f, a.DR[2] = 1.0f;     // slope in cell [nb, nb+1]
-  } else {
-    const float fl = floorf(pr), fr = pr - fl;
-    a.c0 = (int)fl, a.p0 = pr;
-    a.V[0] = 1.0f - fr, a.V[1] = fr, a.V[2] = 0.0f;
-    a.DL[0] = -1.0f, a.DL[1] = 1.0f, a.DL[2] = 0.0f;
-    a.DR[0] = -1.0f, a.DR[1] = 1.0f, a.DR[2] = 0.0f;
-  }
-  return a;
-}
-
-// returns false (wave-uniform) when the per-ray rows would leave the f16 range: the caller then takes the ordinary path
-template <int C, int HD, int NB>
-__device__ __forceinline__ bool enc_ray_lin_in(f32x16 (&acc)[HD / 32][2], const float* lds, float* lh, const float4* __restrict__ G, int W,
-                                               int lane, int h, int wave, float ixr, float iyr, float xr, float yr, float ix, float iy,
-                                               float x, float y, float zn, float ff, float scale, int lane4) {
-  using L = Lds<C, HD, NB, true>;
-  using LH = LdsH<C, HD, NB>;
-  constexpr int HT = HD / 32;
-  constexpr float kDelScale = 4096.0f, kArgScale = 1048576.0f;   // 2^12, 2^20: the per-sample corrections as normal f16 numbers
-  const AxisRef ax = axis_ref(ixr), ay = axis_ref(iyr);            // wave-uniform
-  int hs = lane % HD;                              // stored channel of G handled by this lane ...
-  asm volatile("" : "+v"(hs));                     // (opaque per ray: keeps the weight reads below out of the persistent loop's preheader)
-  const int hid = proj_hidden_of_storage(hs);      // ... which is this hidden unit
-  const float* __restrict__ Gf = reinterpret_cast<const float*>(G);
-
-  // ---- per ray, lane = hidden unit: value and one-sided slopes of the bilinear interpolant at the reference point (9 texel rows)
-  float f0 = 0.0f, uxm = 0.0f, uxp = 0.0f, uym = 0.0f, uyp = 0.0f;
-#pragma unroll
-  for (int a = 0; a < 3; ++a) {
-    float rv = 0.0f, rl = 0.0f, rr = 0.0f;
-#pragma unroll
-    for (int b = 0; b < 3; ++b) {
-      const float g = Gf[((long)(ay.c0 + a) * W + (ax.c0 + b)) * HD + hs];
-      rv = __builtin_fmaf(ax.V[b], g, rv);
-      rl = __builtin_fmaf(ax.DL[b], g, rl);
-      rr = __builtin_fmaf(ax.DR[b], g, rr);
-    }
-    f0 = __builtin_fmaf(ay.V[a], rv, f0);
-    uxm = __builtin_fmaf(ay.V[a], rl, uxm);
-    uxp = __builtin_fmaf(ay.V[a], rr, uxp);
-    uym = __builtin_fmaf(ay.DL[a], rv, uym);
-    uyp = __builtin_fmaf(ay.DR[a], rv, uyp);
-  }
-  // ---- x, y encoding at the representative coordinates: lane l < 12 evaluates octave l >> 1 of axis l & 1
-  float es, ec, sn2, cs2;
-  {
-    const int oct = (lane >> 1) % kNumFreqs;
-    const float po = (float)(1 << oct);
-    const float arg = ((lane & 1) ? yr : xr) * (ff * po);
-    float sn, cs;
-    sincos_small(arg, sn, cs);
-    pe_entry1(arg, sn, cs, es, ec);
-    sn2 = sn * po, cs2 = cs * po;                  // d/d(x ff) of sin / cos at this octave
-  }
-  const float* wl = lds + L::W_IN + hid;
-  float p0 = wl[3 * HD];                           // bias row
-  p0 = __builtin_fmaf(wl[0], xr, p0);
-  p0 = __builtin_fmaf(wl[HD], yr, p0);
-  float vx = wl[0] / ff, vy = wl[HD] / ff;         // raw rows: d(w x)/d(x ff)
-#pragma unroll 1   // once per ray: keep it compact (unrolled, its 24 weight reads and 48 broadcasts cost ~100 spilled VGPRs around it)
-  for (int l = 0; l < 12; ++l) {
-    const float w_s = wl[(4 + 6 * (l >> 1) + (l & 1)) * HD], w_c = wl[(4 + 6 * (l >> 1) + 3 + (l & 1)) * HD];
-    p0 = __builtin_fmaf(w_s, bcast_lane(es, l), p0);
-    p0 = __builtin_fmaf(w_c, bcast_lane(ec, l), p0);
-    // d/da [w_s sin(a 2^oct) + w_c sin(a 2^oct + P)] = 2^oct (w_s cos - w_c sin)
-    const float dv = __builtin_fmaf(w_s, bcast_lane(cs2, l), -(w_c * bcast_lane(sn2, l)));
-    vy += (l & 1) ? dv : 0.0f;
-    vx += (l & 1) ? 0.0f : dv;
-  }
-  // ---- the six per-ray k rows (times 2^S and the inverse of the B scale), range check, split, per-wave LDS
-  const float r0 = uxm * (scale / kDelScale), r1 = uxp * (scale / kDelScale), r2 = uym * (scale / kDelScale), r3 = uyp * (scale / kDelScale);
-  const float r4 = vx * (scale / kArgScale), r5 = vy * (scale / kArgScale);
-  const float big = fmaxf(fmaxf(fmaxf(fabsf(r0), fabsf(r1)), fmaxf(fabsf(r2), fabsf(r3))), fmaxf(fabsf(r4), fabsf(r5)));
-  if (!__all(big < 3.0e4f)) return false;
-  float* bl = lh + LH::BASE + wave * HD;
-  bl[hid] = (f0 + p0) * scale;
-  {
-    unsigned* ub = reinterpret_cast<unsigned*>(lh + LH::UBUF + wave * LH::UBUF_WAVE_STRIDE) + ((hid >> 5) * 64 + (hid & 31)) * 4;
-    const float rows[6] = {r0, r1, r2, r3, r4, r5};
-    _Float16 hi[6], lo[6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) hi[i] = (_Float16)rows[i], lo[i] = (_Float16)(rows[i] - (float)hi[i]);
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      ub[j] = pack_h2(hi[2 * j], hi[2 * j + 1]);
-      ub[LH::UBUF_TERM_STRIDE + j] = pack_h2(lo[2 * j], lo[2 * j + 1]);
-    }
-  }
-  wave_lds_fence_r();
-  // ---- per sample: accumulators start from the ray constant (rows ht*32 + 8j + 4h + {0..3} of this lane, both point tiles)
-#pragma unroll
-  for (int ht = 0; ht < HT; ++ht)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float4 v = *reinterpret_cast<const float4*>(bl + ht * 32 + 8 * j + 4 * h);
-      acc[ht][0][4 * j + 0] = v.x, acc[ht][0][4 * j + 1] = v.y, acc[ht][0][4 * j + 2] = v.z, acc[ht][0][4 * j + 3] = v.w;
-      acc[ht][1][4 * j + 0] = v.x, acc[ht][1][4 * j + 1] = v.y, acc[ht][1][4 * j + 2] = v.z, acc[ht][1][4 * j + 3] = v.w;
-    }
-  // depth-code slice: octaves 0, 2, 4 direct, 1, 3, 5 by angle doubling (as region_seq), then the raw code
-  {
-    float e[13];
-    float f = ff;
-#pragma unroll
-    for (int o2 = 0; o2 < kNumFreqs; o2 += 2) {
-      float sn, cs;
-      sincos_small(zn * f, sn, cs);
-      pe_entry1(zn * f, sn, cs, e[2 * o2], e[2 * o2 + 1]);
-      const float tt = sn + sn;
-      pe_entry1(zn * (f * 2.0f), tt * cs, __builtin_fmaf(-tt, sn, 1.0f), e[2 * o2 + 2], e[2 * o2 + 3]);
-      f = f * 4.0f;
-    }
-    e[12] = zn;
-    f16_region<HD, 13>(acc, lh + LH::W_Z + lane4, LH::WZ_TERM_STRIDE, e);
-  }
-  // correction slice: this sample's offsets from the reference point
-  {
-    const float dx = ix - ax.p0, dy = iy - ay.p0;                   // exact (Sterbenz)
-    const float dax = x * ff - xr * ff, day = y * ff - yr * ff;     // fl(x ff) - fl(x_r ff): contraction is off, both products round
-    float e[8];
-    e[0] = fminf(dx, 0.0f) * kDelScale, e[1] = fmaxf(dx, 0.0f) * kDelScale;
-    e[2] = fminf(dy, 0.0f) * kDelScale, e[3] = fmaxf(dy, 0.0f) * kDelScale;
-    e[4] = dax * kArgScale, e[5] = day * kArgScale, e[6] = 0.0f, e[7] = 0.0f;
-    f16_region<HD, 8>(acc, lh + LH::UBUF + wave * LH::UBUF_WAVE_STRIDE + lane4, LH::UBUF_TERM_STRIDE, e);
-  }
-  wave_lds_fence_r();   // the next ray's rows must not overtake these reads
-  return true;
-}
-#endif  // BTS_ENC_RAY
 
 // Cold path: a wave in which some sample's encoding argument leaves the fast sincos range (|arg| > 1e5: points within millimetres
 // of the encoder's camera plane) evaluates that iteration with the compact lane = point routine (libm range reduction inside).
@@ -770,6 +507,7 @@ __device__ __attribute__((noinline)) float eval_point_exact(const float* lds, co
 // parameter, not a run-time test: the evaluation instantiations carry no trace of it (16 more spilled SGPRs otherwise).
 template <int C, int HD, int NB, int NVMAX, bool ONE_RAY, bool F16, bool EPI = false>
 __global__ __launch_bounds__(256, 2) void render_kernel_p(const FwdParams p) {
+  static_assert(F16, "lin_in runs on the f16 matrix pipe in split precision: the fp32-input-MFMA form of rounds 1 - 2 is gone (git history)");
   using L = Lds<C, HD, NB, true>;
   using LH = LdsH<C, HD, NB>;
   constexpr int HT = HD / 32;
@@ -933,20 +671,6 @@ __global__ __launch_bounds__(256, 2) void render_kernel_p(const FwdParams p) {
         bcast_tiles(use_empty ? 1u : 0u, t0, t1), emp[0] = t0 != 0, emp[1] = t1 != 0;
       }
 
-#ifdef BTS_ENC_RAY
-      // encoder-camera ray?  wave-uniform: every sample inside the frustum, away from the border texels, and all of them within
-      // 2^-11 px / 2^-18 of lane 0's coordinates
-      bool enc_ray = false;
-      float ixk = 0.0f, iyk = 0.0f, ixr = 0.0f, iyr = 0.0f, xr = 0.0f, yr = 0.0f;
-      if constexpr (ONE_RAY && F16) {
-        pixel_coords(pe.x, pe.y, H, W, ixk, iyk);
-        ixr = bcast_lane(ixk, 0), iyr = bcast_lane(iyk, 0), xr = bcast_lane(pe.x, 0), yr = bcast_lane(pe.y, 0);
-        const bool ok = !pe.invalid & (fabsf(ixk - ixr) <= 0.00048828125f) & (fabsf(iyk - iyr) <= 0.00048828125f) &
-                        (fabsf(pe.x - xr) <= 3.814697265625e-6f) & (fabsf(pe.y - yr) <= 3.814697265625e-6f) &
-                        (ixr >= 1.5f) & (ixr <= (float)W - 2.5f) & (iyr >= 1.5f) & (iyr <= (float)H - 2.5f);
-        enc_ray = __all(ok) && !(q->ablate & 64);
-      }
-#endif
 
       float s_raw;
       if (__builtin_expect(__any(pe_needs_exact(v3, q->freq_factor)), 0)) {
@@ -956,21 +680,6 @@ __global__ __launch_bounds__(256, 2) void render_kernel_p(const FwdParams p) {
       BTS_TICK(0)
       // ---------------- h = bilinear(G) + W_pe . PE + b: gather two stages ahead, blend between the octaves
       f32x16 acc[HT][2];
-#ifdef BTS_ENC_RAY
-      bool done = false;
-      if constexpr (ONE_RAY && F16) {
-        if (enc_ray) {
-          int lane4e = lane * 4;
-          asm volatile("" : "+v"(lane4e));
-          done = enc_ray_lin_in<C, HD, NB>(acc, lds, lh, G, W, lane, h, wave, ixr, iyr, xr, yr, ixk, iyk, pe.x, pe.y, v3[2], q->freq_factor,
-                                           scale, lane4e);
-#ifdef BTS_PROBE
-          if (done && lane == 0 && q->dbg) atomicAdd(q->dbg + 63, 1ull);   // how many rays took the path (BTS_DBG_PTR buffer, slot 63)
-#endif
-        }
-      }
-      if (!done) {
-#endif
 #ifdef BTS_GATHER_LDS
       static_assert(F16, "the LDS gather is wired into the f16 path only");
       unsigned off_next[4];
@@ -1022,17 +731,6 @@ __global__ __launch_bounds__(256, 2) void render_kernel_p(const FwdParams p) {
 #else
         region_seq<HD, 0>(acc, ba, bb, G, o, wq, h, lh + LH::W_F16 + lane4, LH::TERM_STRIDE, raw, v3, q->freq_factor, bias, nosin, nomfma);
 #endif
-      } else {
-#ifndef BTS_GATHER_LDS
-        const float* wl = lds + L::W_IN + lane_off;
-        kstep_first<HD>(acc, wl, 0, v3[0], v3[1]);
-        kstep<HD>(acc, wl + 2 * HD, 0, v3[2], 1.0f, nomfma);
-        SinCos3 raw;
-        __builtin_amdgcn_sched_barrier(0);
-        pe_direct(raw, v3, q->freq_factor);
-        __builtin_amdgcn_sched_barrier(0);
-        octave_seq<HD, 0>(acc, ba, bb, G, o, wq, h, wl + 4 * HD, raw, v3, q->freq_factor, nomfma, nosin, nogather);
-#endif
       }
 #ifndef BTS_GATHER_LDS
       if constexpr (NS > kNumFreqs) {  // HD = 64: stages 6 and 7 are still in the buffers
@@ -1040,9 +738,6 @@ __global__ __launch_bounds__(256, 2) void render_kernel_p(const FwdParams p) {
           stage_blend<HD, 6>(acc, ba, wq);
           stage_blend<HD, 7>(acc, bb, wq);
         }
-      }
-#endif
-#ifdef BTS_ENC_RAY
       }
 #endif
       if (q->learn_empty && __any(use_empty)) {
@@ -1106,6 +801,7 @@ __global__ __launch_bounds__(256, 2) void render_kernel_p(const FwdParams p) {
       }
       float sigma = softplus(s_raw);
       if (q->empty_empty) sigma = pe.invalid ? 0.0f : sigma;
+      if (q->sigma_noise) sigma += q->sigma_noise[ray * K + min(k, K - 1)];   // nerf.py:279-280, the caller drew it
       BTS_TICK(2)
 
       // ---------------- colours (models_bts.py:218-264): projection into each render view + 4-tap fetch of the rgb0-packed frame.
@@ -1239,19 +935,8 @@ static int launch_render_p_nv(const FwdParams& p, int grid, hipStream_t s) {
   return launch_render_p_one<C, HD, NB, 8, EPI>(p, grid, s);
 }
 
-#if defined(BTS_PROBE) && !defined(BTS_GATHER_LDS)
-// A/B only (probe build with -DBTS_GATHER_REGS, BTS_RENDER_F32MFMA=1): the same pipeline with lin_in on the fp32-input MFMA, benchmark shape only
-inline int launch_render_p_f32mfma(const FwdParams& p, int grid, hipStream_t s) {
-  render_kernel_p<64, 64, 0, 1, true, false><<<grid, 256, 0, s>>>(p);
-  return hipGetLastError() == hipSuccess ? BTS_OK : BTS_E_LAUNCH;
-}
-#endif
-
 template <bool EPI>
 inline int launch_render_p(const FwdParams& p, int C, int HD, int NB, int grid, hipStream_t s) {
-#if defined(BTS_PROBE) && !defined(BTS_GATHER_LDS)
-  if (!EPI && C == 64 && HD == 64 && NB == 0 && p.nv <= 1 && p.lpr == 64 && getenv("BTS_RENDER_F32MFMA")) return launch_render_p_f32mfma(p, grid, s);
-#endif
   if (C == 64 && HD == 64 && NB == 0) return launch_render_p_nv<64, 64, 0, EPI>(p, grid, s);
   if (C == 32 && HD == 32 && NB == 1) return launch_render_p_nv<32, 32, 1, EPI>(p, grid, s);
   if (C == 32 && HD == 32 && NB == 0) return launch_render_p_nv<32, 32, 0, EPI>(p, grid, s);

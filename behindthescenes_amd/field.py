@@ -65,11 +65,13 @@ class BTSNet(nn.Module):
         self._scale = 0
         self._native = {}   # scale -> native.FieldTensors
         self._proj_ms = None
-        # an encoder that can compose the feature half of lin_in into its last convolution hands the
-        # renderer its projected, channels-last map G directly (monodepth2.Monodepth2.forward_projected); `fused_handover: false`
-        # keeps the generic route (encoder -> F (NCHW) -> bts_project_features)
+        # an encoder that can compose the feature half of lin_in into its last convolution can hand the
+        # renderer its projected, channels-last map G directly (monodepth2.Monodepth2.forward_projected: no F in HBM, no projection
+        # pass or backward).  MEASURED (profiles/r03g, exp_kitti_360.yaml shapes, ResNet-50, bs 16): MIOpen's composed channels-last
+        # convolution makes the step 1.4 ms SLOWER (49.9 vs 48.6 ms) than convolution + bts_project_features(_bwd) (0.9 ms together),
+        # for 0.57 GB less peak memory -- so the generic route is the default and `fused_handover: true` the opt-in.
         # (whether the CURRENT encoder can do that is looked up at every encode(): callers replace net.encoder after construction)
-        self.fused_handover = bool(conf.get("fused_handover", True))
+        self.fused_handover = bool(conf.get("fused_handover", False))
         self.spec = native.FieldSpec(C=self.encoder.latent_size, d_hidden=self.mlp_coarse.d_hidden,
                                      n_blocks=self.mlp_coarse.n_blocks, num_freqs=self.code_xyz.num_freqs,
                                      freq_factor=self.code_xyz.freq_factor, d_min=float(self.d_min), d_max=float(self.d_max),

@@ -304,15 +304,18 @@ def check_supported(spec: FieldSpec, nv: int = 1):
 _OUT_KEYS = ("rgb", "depth", "weights", "alphas", "invalid", "rgb_samps", "sigma_raw", "trans", "invalid_wsum", "invalid_any")
 
 
-def _render_args(ft: FieldTensors, rays, z_samp, hard_alpha_cap, white_bkgd, outs):
+def _render_args(ft: FieldTensors, rays, z_samp, hard_alpha_cap, white_bkgd, outs, sigma_noise=None):
+    if sigma_noise is not None:
+        _req(sigma_noise, "sigma_noise", tuple(z_samp.shape))
     return BtsRenderArgs(rays_per_sample=rays.shape[0] // ft.n, K=z_samp.shape[1], hard_alpha_cap=int(hard_alpha_cap),
                          white_bkgd=int(white_bkgd), rays=rays.data_ptr(), z_samp=z_samp.data_ptr(),
+                         sigma_noise=None if sigma_noise is None else sigma_noise.data_ptr(),
                          **{k: (None if outs.get(k) is None else outs[k].data_ptr()) for k in _OUT_KEYS})
 
 
 def render_fwd(ft: FieldTensors, mlp_params: torch.Tensor, rays: torch.Tensor, z_samp: torch.Tensor, *, hard_alpha_cap: bool,
                white_bkgd: bool = False, want_weights=False, want_alphas=False, want_invalid=True, want_rgb_samps=False,
-               want_saved=False, want_invalid_sums=False):
+               want_saved=False, want_invalid_sums=False, sigma_noise=None):
     """rays (n*Bp, 8), z_samp (n*Bp, K) -> dict of fresh tensors (bts_render_fwd).  want_saved adds the two per-sample
     activations the backward needs (sigma_raw, trans); want_invalid_sums the per-ray reductions the loss' invalid-ray policies need
     (invalid_wsum = sum_k weights * invalid, invalid_any = max_k invalid, (n*Bp, nv) each) -- with them a training step can leave
@@ -332,13 +335,14 @@ def render_fwd(ft: FieldTensors, mlp_params: torch.Tensor, rays: torch.Tensor, z
                 trans=new(B, K) if want_saved else None, invalid_wsum=new(B, nv) if want_invalid_sums else None,
                 invalid_any=new(B, nv) if want_invalid_sums else None)
     cfg, tens = ft.cfg(), ft.tensors(mlp_params)
-    args = _render_args(ft, rays, z_samp, hard_alpha_cap, white_bkgd, outs)
+    args = _render_args(ft, rays, z_samp, hard_alpha_cap, white_bkgd, outs, sigma_noise)
     _lib.check(_lib.load().bts_render_fwd(C.byref(cfg), C.byref(tens), C.byref(args), _stream(rays)), "bts_render_fwd")
     return outs
 
 
 def render_bwd(ft: FieldTensors, mlp_params, rays, z_samp, sigma_raw, trans, *, hard_alpha_cap, g_rgb=None, g_depth=None,
-               g_weights=None, g_alphas=None, need_proj=True, need_mlp=True, need_empty=False, white_bkgd=False, rgb_samps=None):
+               g_weights=None, g_alphas=None, need_proj=True, need_mlp=True, need_empty=False, white_bkgd=False, rgb_samps=None,
+               sigma_noise=None):
     """Returns (d_proj_nhwc | None, d_mlp_params | None, d_empty_proj | None) (bts_render_bwd)."""
     B, K = z_samp.shape
     for name, g in (("g_rgb", g_rgb), ("g_depth", g_depth), ("g_weights", g_weights), ("g_alphas", g_alphas)):
@@ -352,7 +356,7 @@ def render_bwd(ft: FieldTensors, mlp_params, rays, z_samp, sigma_raw, trans, *, 
     cfg, tens = ft.cfg(), ft.tensors(mlp_params)
     if rgb_samps is not None:
         _req(rgb_samps, "rgb_samps", (B, K, ft.nv * 3))
-    args = _render_args(ft, rays, z_samp, hard_alpha_cap, white_bkgd, dict(sigma_raw=sigma_raw, trans=trans, rgb_samps=rgb_samps))
+    args = _render_args(ft, rays, z_samp, hard_alpha_cap, white_bkgd, dict(sigma_raw=sigma_raw, trans=trans, rgb_samps=rgb_samps), sigma_noise)
 
     def dp(t):
         return None if t is None else t.data_ptr()
@@ -452,14 +456,15 @@ class RenderFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, proj_nhwc, mlp_params, empty_feature, ft: FieldTensors, rays, z_samp, hard_alpha_cap, white_bkgd,
-                want_weights, want_alphas, want_rgb_samps, grad_mode=True, want_invalid=True, want_invalid_sums=False):
+                want_weights, want_alphas, want_rgb_samps, grad_mode=True, want_invalid=True, want_invalid_sums=False, sigma_noise=None):
         # needs_input_grad reflects requires_grad even under torch.no_grad(), and inside forward() grad mode is always off: the
         # caller passes the mode it was invoked in, so that evaluation does not allocate / write the 8 B per sample of saved state
         needs_grad = any(ctx.needs_input_grad[:3]) and grad_mode
         out = render_fwd(ft, mlp_params, rays, z_samp, hard_alpha_cap=hard_alpha_cap, white_bkgd=white_bkgd,
                          want_weights=want_weights, want_alphas=want_alphas, want_invalid=want_invalid, want_rgb_samps=want_rgb_samps,
-                         want_saved=needs_grad, want_invalid_sums=want_invalid_sums)
+                         want_saved=needs_grad, want_invalid_sums=want_invalid_sums, sigma_noise=sigma_noise)
         ctx.ft, ctx.hard_alpha_cap, ctx.white_bkgd = ft, hard_alpha_cap, white_bkgd
+        ctx.sigma_noise = sigma_noise if needs_grad else None      # (a plain tensor without graph: kept on the context)
         if needs_grad:
             # rgb_samps is non-differentiable output the caller asked for: kept for the backward too (it then skips the colour taps)
             ctx.save_for_backward(mlp_params, rays, z_samp, out["sigma_raw"], out["trans"], *([out["rgb_samps"]] if want_rgb_samps else []))
@@ -484,7 +489,7 @@ class RenderFunction(torch.autograd.Function):
         d_proj, d_mlp, d_eproj = render_bwd(ft, mlp_params, rays, z_samp, sigma_raw, trans, hard_alpha_cap=ctx.hard_alpha_cap,
                                             g_rgb=prep(g_rgb), g_depth=prep(g_depth), g_weights=prep(g_weights, ctx.has[0]), white_bkgd=ctx.white_bkgd, rgb_samps=rgb_samps,
                                             g_alphas=prep(g_alphas, ctx.has[1]), need_proj=need_proj, need_mlp=need_mlp,
-                                            need_empty=need_empty or (need_mlp and ft.spec.learn_empty))
+                                            need_empty=need_empty or (need_mlp and ft.spec.learn_empty), sigma_noise=ctx.sigma_noise)
         d_empty = None
         if d_eproj is not None:
             # the projected empty feature is w_in[:, :C] @ empty_feature (a 64x64 GEMV): chain rule on parameter-sized tensors
@@ -494,4 +499,4 @@ class RenderFunction(torch.autograd.Function):
                 d_empty = w_f.t() @ d_eproj
             if need_mlp:
                 d_mlp[:spec.d_hidden * spec.d_in].view(spec.d_hidden, spec.d_in)[:, :spec.C] += torch.outer(d_eproj, ft.empty_feature.detach())
-        return (d_proj, d_mlp, d_empty) + (None,) * 11
+        return (d_proj, d_mlp, d_empty) + (None,) * 12

@@ -46,8 +46,6 @@ class NeRFRenderer(torch.nn.Module):
         # SURVEY 8f.1 (not a reference key): in training mode return only what a training step consumes -- rgb, depth and the
         # per-ray reductions behindthescenes_amd.ReconstructionLoss builds its invalid-ray mask from -- see forward()
         self.lean_training_outputs = bool(lean_training_outputs)
-        if noise_std > 0.0:
-            raise NotImplementedError("sigma noise (noise_std > 0) is disabled in every shipped config and is not implemented")
 
     # ---- sampling (nerf.py:103-208) ---------------------------------------------------------------------------------
     def sample_coarse(self, rays, u=None):
@@ -103,14 +101,16 @@ class NeRFRenderer(torch.nn.Module):
 
     # ---- the hot path (nerf.py:210-313) -------------------------------------------------------------------------------
     def composite(self, model, rays, z_samp, coarse=True, sb=0, want_weights=True, want_alphas=True, want_rgb_samps=True,
-                  want_invalid=True, want_invalid_sums=False):
+                  want_invalid=True, want_invalid_sums=False, sigma_noise=None):
         """rays (B, 8), z_samp (B, K) -> (weights, rgb, depth, alphas, invalid, z_samp, rgb_samps) like the reference.
         Entries that were not requested come back as ``None`` (the reference always materialises all of them).  With
         ``want_invalid_sums`` two more entries follow: (invalid_wsum, invalid_any), (B, nv) each."""
         with profiler.record_function("renderer_composite"):     # the reference's trace range (nerf.py:222); one fused kernel here
-            return self._composite(model, rays, z_samp, coarse, sb, want_weights, want_alphas, want_rgb_samps, want_invalid, want_invalid_sums)
+            return self._composite(model, rays, z_samp, coarse, sb, want_weights, want_alphas, want_rgb_samps, want_invalid, want_invalid_sums,
+                                   sigma_noise)
 
-    def _composite(self, model, rays, z_samp, coarse, sb, want_weights, want_alphas, want_rgb_samps, want_invalid, want_invalid_sums):
+    def _composite(self, model, rays, z_samp, coarse, sb, want_weights, want_alphas, want_rgb_samps, want_invalid, want_invalid_sums,
+                   sigma_noise=None):
         if not isinstance(model, BTSNet):
             raise native.BtsNativeError("composite() needs a behindthescenes_amd.BTSNet (the fused HIP kernel IS the field query)")
         if not coarse and model.mlp_fine is not None:
@@ -125,9 +125,14 @@ class NeRFRenderer(torch.nn.Module):
         z_samp = z_samp.float().contiguous()
         mlp_params = model.mlp_coarse.packed()
         empty = model.empty_feature if model.learn_empty else None
+        if sigma_noise is None and self.training and self.noise_std > 0.0:
+            # nerf.py:279-280: sigmas + randn_like(sigmas) * noise_std in training mode (no shipped config turns it on); drawn here with
+            # torch's generator, added inside the kernels (BtsRenderArgs.sigma_noise).  `sigma_noise` lets a caller inject the draw.
+            sigma_noise = torch.randn(z_samp.shape, device=z_samp.device, dtype=torch.float32) * self.noise_std
         rgb, depth, weights, alphas, invalid, rgb_samps, inv_wsum, inv_any = native.RenderFunction.apply(
             ft.proj_nhwc, mlp_params, empty, ft, rays, z_samp, bool(self.hard_alpha_cap), bool(self.white_bkgd),
-            bool(want_weights), bool(want_alphas), bool(want_rgb_samps), torch.is_grad_enabled(), bool(want_invalid), bool(want_invalid_sums))
+            bool(want_weights), bool(want_alphas), bool(want_rgb_samps), torch.is_grad_enabled(), bool(want_invalid), bool(want_invalid_sums),
+            None if sigma_noise is None else sigma_noise.float().contiguous())
         ret = (weights if want_weights else None, rgb, depth, alphas if want_alphas else None, invalid if want_invalid else None, z_samp,
                rgb_samps if want_rgb_samps else None)
         return ret + (inv_wsum, inv_any) if want_invalid_sums else ret

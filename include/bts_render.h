@@ -96,6 +96,9 @@ typedef struct BtsRenderArgs {
    * in the kernel's epilogue -- a training step then stores 8 B per ray and view instead of (1 + nv) * 4 * K B per ray */
   float* invalid_wsum;     /* (n*Bp, nv)       or NULL   sum_k weights_k * invalid_k,v   (policy weight_guided: > 0.9) */
   float* invalid_any;      /* (n*Bp, nv)       or NULL   max_k invalid_k,v               (policy strict) */
+  /* ABI 3: the density noise of a training step (nerf.py:279-280: sigmas + randn_like(sigmas) * noise_std, drawn by the caller),
+   * added to softplus(s) before relu / alpha -- INPUT of the forward and of the backward (which needs the sign of the sum) */
+  const float* sigma_noise;/* (n*Bp, K)        or NULL */
 } BtsRenderArgs;
 
 /* Gradients flowing into / out of the renderer (what torch.autograd would compute through nerf.py:283-299,

@@ -262,7 +262,7 @@ def field_forward(xyz: torch.Tensor, st: FieldState, mlp: MlpParams, cfg: FieldC
 # a5: alpha compositing (nerf.py:210-313)
 # ----------------------------------------------------------------------------------------------
 def composite(rays: torch.Tensor, z_samp: torch.Tensor, sb: int, st: FieldState, mlp: MlpParams, cfg: FieldConfig,
-              hard_alpha_cap: bool = True, white_bkgd: bool = False, chunk: int = 100000):
+              hard_alpha_cap: bool = True, white_bkgd: bool = False, chunk: int = 100000, sigma_noise: Optional[torch.Tensor] = None):
     """rays (sb*B', 8), z_samp (sb*B', K) -> (weights (B,K), rgb (B,nv*3), depth (B), alphas (B,K),
     invalid (B,K,nv), z_samp (B,K), rgb_samps (B,K,nv*3)).  Point queries are chunked like nerf.py:238-268 (chunking does
     not change any value, only peak memory)."""
@@ -278,6 +278,8 @@ def composite(rays: torch.Tensor, z_samp: torch.Tensor, sb: int, st: FieldState,
     invalid = torch.cat(invs, dim=1).reshape(B, K, -1)
     sigmas = torch.cat(sigs, dim=1).reshape(B, K)
 
+    if sigma_noise is not None:   # nerf.py:279-280: training-mode density noise (the draw randn_like(sigmas) * noise_std is injected)
+        sigmas = sigmas + sigma_noise
     alphas = 1 - torch.exp(-deltas.abs() * torch.relu(sigmas))
     if hard_alpha_cap:
         alphas = torch.cat((alphas[:, :-1], torch.ones_like(alphas[:, -1:])), dim=-1)

@@ -68,8 +68,11 @@ def test_forward_is_bit_deterministic(hip, name):
     n, v, H, W, C, Hd, nb, K, ids, n_rays, conf = CASES[name]
     net, renderer, rays, z = _scene(hip, n, v, H, W, C, Hd, nb, K, ids, n_rays, seed=40 + len(name), **conf)
     ref = None
+    # the RE10K instantiations are where the one order of the gather ring that is NOT shipped lost its run-to-run determinism in round 2
+    # (1 - 23 of 24 576 rays, i.e. ~1e-4 per ray and launch): 200 launches each instead of 20
+    runs = int(os.environ.get("BTS_DETERMINISM_RUNS", 200 if name.startswith("re10k") or name.endswith("re10k") else RUNS))
     with torch.no_grad():
-        for r in range(RUNS):
+        for r in range(runs):
             out = renderer.composite(net, rays, z, sb=n)
             out = [t for t in out if t is not None]
             if ref is None:

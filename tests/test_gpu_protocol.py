@@ -114,3 +114,67 @@ def test_two_pass_forward_with_the_shared_mlp_end_to_end(hip):
     (out["coarse"]["rgb"].square().mean() + out["fine"]["rgb"].square().mean() + 0.01 * out["fine"]["depth"].mean()).backward()
     gw = net.mlp_coarse.lin_in.weight.grad
     assert gw is not None and torch.isfinite(gw).all() and float(gw.abs().sum()) > 0
+
+
+@pytest.mark.parametrize("model", ["kitti", "re10k"])
+def test_density_noise_forward_and_backward_vs_oracle(hip, model):
+    """SURVEY 8 row a16, nerf.py:279-280: in training mode the reference adds randn_like(sigmas) * noise_std to the densities before
+    relu / alpha (no shipped config turns it on).  The drop-in draws the noise and hands it to the kernels (BtsRenderArgs.sigma_noise):
+    with the draw injected, outputs and gradients against the oracle -- the relu cuts the gradient where sigma + noise <= 0, through
+    both backward paths (gate bits: KITTI MLP; rows: RE10K MLP)."""
+    from oracle import bts_oracle as O
+    from tests._cases import robust_ray_mask
+    from tests._hip_helpers import build_net
+    from tests.test_gpu_grad import _gate_safe_rays, _rel_to_max
+    g = torch.Generator().manual_seed(21)
+    kitti = model == "kitti"
+    cfg = O.FieldConfig() if kitti else O.FieldConfig(d_min=1.0, d_max=100.0, code_mode="distance")
+    C, nb, K, n, H, W = (64, 0, 32, 2, 48, 160) if kitti else (32, 1, 24, 2, 64, 96)
+    scene = O.synthetic_scene(n, 3, H, W, C, seed=21, intrinsics=O.K_KITTI360 if kitti else O.K_RE10K, baseline=0.5, smooth=True)
+    mlp = O.init_mlp(C + 39, C, nb, gen=g)
+    mlp.b_out = torch.tensor([-1.0])            # densities of ~0.3: noise of std 0.5 pushes a good part of them below zero
+    rays = O.image_rays(scene["poses"], scene["projs"], H, W, cfg.d_min, cfg.d_max)
+    rays = rays[:, torch.randperm(rays.shape[1], generator=g)[:1200].sort().values].contiguous()
+    z = O.sample_coarse(rays.reshape(-1, 8), K, True, torch.rand(n * 1200, K, generator=g))
+    keep = robust_ray_mask(O.make_state(scene, [1, 2], cfg), rays, z).view(n, -1)
+    safe, _ = _gate_safe_rays(scene, mlp, cfg, [1, 2], rays, z, None, margin=2e-5)
+    keep = keep & safe
+    NR = min(512, int(keep.sum(1).min()))
+    assert NR >= 256
+    idx = torch.stack([torch.nonzero(keep[i])[:NR, 0] for i in range(n)])
+    rays = torch.gather(rays, 1, idx.unsqueeze(-1).expand(-1, -1, 8)).contiguous()
+    z = torch.gather(z.view(n, -1, K), 1, idx.unsqueeze(-1).expand(-1, -1, K)).reshape(-1, K).contiguous()
+    noise = torch.randn(n * NR, K, generator=g) * 0.5
+    c_rgb = torch.randn(n * NR, 6, generator=g)
+    # oracle
+    params = [t.clone().requires_grad_(True) for t in mlp.tensors()]
+    feat = scene["feat"].clone().requires_grad_(True)
+    m = O.MlpParams(params[0], params[1], [tuple(params[2 + 4 * i: 6 + 4 * i]) for i in range(nb)], params[-2], params[-1])
+    st = O.make_state(dict(scene, feat=feat), [1, 2], cfg)
+    ow, orgb, odepth, oa, *_ = O.composite(rays.reshape(-1, 8), z, n, st, m, cfg, hard_alpha_cap=kitti, sigma_noise=noise)
+    cut = float((oa[:, :-1] == 0).float().mean())
+    assert 0.05 < cut < 0.95, cut               # the noise really switches a share of the samples off
+    ref = torch.autograd.grad((orgb * c_rgb).sum() + 0.05 * odepth.sum(), params + [feat])
+    # HIP: the renderer in training mode draws its own noise unless one is injected
+    net = build_net(cfg, mlp, scene, [1, 2], train=True)
+    renderer = hip.NeRFRenderer.from_conf(dict(n_coarse=K, lindisp=True, hard_alpha_cap=kitti, noise_std=0.5)).cuda().train()
+    w, rgb, depth, a, *_ = renderer.composite(net, rays.reshape(-1, 8).cuda(), z.cuda(), sb=n, sigma_noise=noise.cuda())
+    torch.testing.assert_close(depth.detach().cpu(), odepth.detach(), rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(rgb.detach().cpu(), orgb.detach(), rtol=0, atol=1e-5)
+    torch.testing.assert_close(a.detach().cpu(), oa.detach(), rtol=0, atol=1e-5)
+    ((rgb * c_rgb.cuda()).sum() + 0.05 * depth.sum()).backward()
+    mc = net.mlp_coarse
+    ours = [mc.lin_in.weight.grad, mc.lin_in.bias.grad] + sum([[b.fc_0.weight.grad, b.fc_0.bias.grad, b.fc_1.weight.grad, b.fc_1.bias.grad] for b in mc.blocks], []) \
+        + [mc.lin_out.weight.grad, mc.lin_out.bias.grad, net.encoder.feats[0].grad]
+    for i, (x, y) in enumerate(zip(ours, ref)):
+        err = _rel_to_max(x, y.view_as(x.cpu()))
+        assert err <= 1e-4, (i, err)
+    # without an injected draw two training-mode renders differ (fresh noise), two eval-mode renders do not (no noise)
+    with torch.no_grad():
+        r1 = renderer.composite(net, rays.reshape(-1, 8).cuda(), z.cuda(), sb=n)[2]
+        r2 = renderer.composite(net, rays.reshape(-1, 8).cuda(), z.cuda(), sb=n)[2]
+        assert not torch.equal(r1, r2)
+        renderer.eval()
+        e1 = renderer.composite(net, rays.reshape(-1, 8).cuda(), z.cuda(), sb=n)[2]
+        e2 = renderer.composite(net, rays.reshape(-1, 8).cuda(), z.cuda(), sb=n)[2]
+        assert torch.equal(e1, e2)
