@@ -91,7 +91,8 @@ def build_library(force: bool = False, verbose: bool = False, probe: bool = Fals
 
 
 # differently scheduled builds of the product sources (tests/test_gpu_determinism.py re-runs parity against them)
-SCHEDULE_VARIANTS = {"o2": ["-O2"], "regionbarrier": ["-DBTS_REGION_BARRIER"], "gatherregs": ["-DBTS_GATHER_REGS"]}
+SCHEDULE_VARIANTS = {"o2": ["-O2"], "regionbarrier": ["-DBTS_REGION_BARRIER"], "gatherregs": ["-DBTS_GATHER_REGS"],
+                     "fetchearly": ["-DBTS_GL_FETCH_EARLY"]}
 # the erratum on purpose: the round-1 flags (SLP vectoriser on) -- tests/test_gpu_determinism.py shows this build is NOT deterministic
 ERRATUM_VARIANT = ("slp", ["-fslp-vectorize", "-DBTS_ALLOW_PK_OPSEL"])
 

@@ -381,17 +381,32 @@ __device__ __forceinline__ void gl_offsets(const GatherLds& c, unsigned (&off)[4
     off[j] = (B::tap < 3 ? row[B::tap] : row[2] + row[1] - row[0]) + c.piece16;
   }
 }
+// what the overwrite of a slot must wait for: one value computed from EACH of the four row pieces (ds_read_b128) of the block that
+// lived there.  See gl_issue.
+struct GDep {
+  float d[4];
+};
 template <int HD, int T>
-__device__ __forceinline__ void gl_issue(const GatherLds& c, const float4* G, const unsigned (&off)[4], float dep) {
+__device__ __forceinline__ void gl_issue(const GatherLds& c, const float4* G, const unsigned (&off)[4], const GDep& dep) {
   using B = GBlock<HD, T>;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     // the instruction offset (ht * 128: the hidden tile's half of the row) is added to the global AND to the LDS address: take it
-    // back out of M0.  `dep` is a value computed FROM the rows of the block whose slot is overwritten: its ds_reads have returned
-    // before this can issue (the memory clobber alone orders the issue, not the completion, of those reads)
+    // back out of M0.
+    // `dep`: the DMA write into LDS does not queue behind this wave's ds_reads -- a ds_read_b128 of the slot's previous block that is
+    // still waiting in the LDS queue when the new rows arrive returns the NEW rows (seen on the RE10K shapes, where eight waves'
+    // weight reads keep the queue hundreds of cycles deep: a handful of rays per frame differed from run to run, r03i / r03j).  The
+    // memory clobber orders only the ISSUE of those reads, so the issue takes one input computed from each of the four pieces: the
+    // compiler has to wait for all four reads to RETURN before the first load of the block goes out.  (One value of the last piece
+    // is not enough: the scheduler reorders the four reads and sinks the blend of the others below the loads.)
     const unsigned m0v = c.ring_m0 + B::slot * 4096 + j * 1024 - B::ht * 128;
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2 offset:%3"
-                 :: "v"(off[j]), "s"(m0v), "s"(G), "n"(B::ht * 128), "v"(dep) : "memory", "m0");
+    if (j == 0)
+      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2 offset:%3"
+                   :: "v"(off[j]), "s"(m0v), "s"(G), "n"(B::ht * 128), "v"(dep.d[0]), "v"(dep.d[1]), "v"(dep.d[2]), "v"(dep.d[3])
+                   : "memory", "m0");
+    else
+      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2 offset:%3"
+                   :: "v"(off[j]), "s"(m0v), "s"(G), "n"(B::ht * 128) : "memory", "m0");
   }
 }
 struct GRows {
@@ -401,21 +416,19 @@ struct GRows {
 template <int HD, int T, int ISSUED>
 __device__ __forceinline__ void gl_fetch(const GatherLds& c, GRows& r) {
   using B = GBlock<HD, T>;
-#if defined(BTS_GL_WAIT_ALL)   // diagnostic: every DMA load and LDS operation drained before the rows are read (5 % slower)
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-#else
   asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * ISSUED) : "memory");
-#endif
 #pragma unroll
   for (int q = 0; q < 4; ++q) r.v[T & 1][q] = *reinterpret_cast<const float4*>(c.ring + B::slot * 4096 + c.rd[q]);
 }
-// one step: the rows of block T + 1 are requested from LDS, block T (requested one step ago) is blended (acc += w_tap * row, the order
-// of gblend), block T + 3 goes out into T's slot, the offsets of block T + 4 are fetched from the table
+// one step: block T (its rows requested from LDS one step ago) is blended (acc += w_tap * row, the order of gblend), block T + 3 goes
+// out into T's slot, the offsets of block T + 4 are fetched from the table, and the rows of block T + 1 are requested from LDS -- last,
+// when block T + 1 has had the whole step to land (two blocks may still be in flight behind it).  -DBTS_GL_FETCH_EARLY requests them
+// first instead (rounds 1 - 2 shipped that order; 3 % slower on the eval frame, profiles/r03k).
 template <int HD, int T>
 __device__ __forceinline__ void gl_consume(f32x16 (&acc)[HD / 32][2], const GatherLds& c, GRows& r, const float4* G, const float (&w)[2][4],
                                            unsigned (&off_next)[4]) {
   using B = GBlock<HD, T>;
-#if !defined(BTS_GL_FETCH_LATE)
+#ifdef BTS_GL_FETCH_EARLY
   if constexpr (T + 1 < B::NBLK) gl_fetch<HD, T + 1, (T + 2 < B::NBLK ? 1 : 0)>(c, r);   // issued so far: blocks 0 .. T + 2
 #endif
   const f32x2 wv = {w[B::pt][B::tap], w[B::pt][B::tap]};
@@ -431,16 +444,11 @@ __device__ __forceinline__ void gl_consume(f32x16 (&acc)[HD / 32][2], const Gath
     }
   }
   if constexpr (T + 3 < B::NBLK) {
-    gl_issue<HD, T + 3>(c, G, off_next, a[15]);
+    gl_issue<HD, T + 3>(c, G, off_next, GDep{{a[3], a[7], a[11], a[15]}});
     if constexpr (T + 4 < B::NBLK) gl_offsets<HD, T + 4>(c, off_next);
   }
-#ifdef BTS_GL_FETCH_LATE
-  // NOT SHIPPED: requesting block T + 1 only now (issued so far: blocks 0 .. T + 3) is 4 % faster on the eval frame, but the RE10K
-  // instantiations (d_hidden 32, one ResnetBlockFC) then differ between runs in 1 - 23 of 24 576 rays
-  // (tests/test_gpu_determinism.py::test_forward_is_bit_deterministic[re10k_*]) -- even with every counter drained before the
-  // reads (-DBTS_GL_WAIT_ALL), while requesting the rows BEFORE block T + 3 is issued (the shipped order) is
-  // clean over hundreds of runs.  What ds_read_b128 right behind a group of LDS-DMA loads gets wrong is open.
-  if constexpr (T + 1 < B::NBLK) gl_fetch<HD, T + 1, (T + 3 < B::NBLK ? 2 : (T + 2 < B::NBLK ? 1 : 0))>(c, r);
+#ifndef BTS_GL_FETCH_EARLY
+  if constexpr (T + 1 < B::NBLK) gl_fetch<HD, T + 1, (T + 3 < B::NBLK ? 2 : (T + 2 < B::NBLK ? 1 : 0))>(c, r);   // issued: blocks 0 .. T + 3
 #endif
 }
 // start of a ray: table written and fenced by the caller; blocks 0, 1, 2 go out, block 0 is requested from LDS, the offsets of block 3
@@ -449,7 +457,11 @@ template <int HD>
 __device__ __forceinline__ void gl_prologue(const GatherLds& c, GRows& r, const float4* G, unsigned (&off_next)[4]) {
   unsigned o0[4], o1[4], o2[4];
   gl_offsets<HD, 0>(c, o0), gl_offsets<HD, 1>(c, o1), gl_offsets<HD, 2>(c, o2);
-  gl_issue<HD, 0>(c, G, o0, 0.0f), gl_issue<HD, 1>(c, G, o1, 0.0f), gl_issue<HD, 2>(c, G, o2, 0.0f);
+  // nothing of the previous ray may still be queued in LDS when its slots are overwritten (gl_issue): the table reads above need the
+  // wait anyway, LDS returns in order
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  const GDep none = {{0.0f, 0.0f, 0.0f, 0.0f}};
+  gl_issue<HD, 0>(c, G, o0, none), gl_issue<HD, 1>(c, G, o1, none), gl_issue<HD, 2>(c, G, o2, none);
   gl_offsets<HD, 3>(c, off_next);
 }
 // region_seq with the gather through LDS: region R blends the blocks of stages 2R and 2R + 1 behind its MFMAs

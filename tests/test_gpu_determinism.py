@@ -105,11 +105,15 @@ def test_parity_holds_on_a_second_schedule(tag):
     assert re.search(r"\b\d+ passed", r.stdout), r.stdout[-500:]
 
 
-@pytest.mark.parametrize("tag", ["o2", "regionbarrier", "gatherregs"])
-def test_second_schedule_matches_the_shipped_build_bit_for_bit(hip, tag, tmp_path):
+@pytest.mark.parametrize("tag,name", [("o2", "cfg2_nv1_learn_empty"), ("regionbarrier", "cfg2_nv1_learn_empty"),
+                                      ("gatherregs", "cfg2_nv1_learn_empty"), ("fetchearly", "cfg2_nv1_learn_empty"),
+                                      ("fetchearly", "re10k_nv2")])
+def test_second_schedule_matches_the_shipped_build_bit_for_bit(hip, tag, name, tmp_path):
     """Same expression tree, -ffp-contract=off: a different instruction schedule must not change a single bit.  gatherregs: the
-    round-1 gather (two register buffers per lane) against the shipped gather through LDS -- same blend order, same bits."""
-    name = "cfg2_nv1_learn_empty"
+    round-1 gather (two register buffers per lane) against the shipped gather through LDS -- same blend order, same bits.
+    fetchearly: the other order of the gather ring's step (rows of block T + 1 requested before block T + 3 goes out, the order
+    rounds 1 - 2 shipped) -- on the RE10K shape too, where the late order used to differ from run to run before gl_issue took one
+    dependency per row piece (tools/ubench/lds_dma_overtake.hip)."""
     code = f"""
 import sys, torch
 sys.path.insert(0, {ROOT!r})

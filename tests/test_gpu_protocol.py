@@ -161,7 +161,9 @@ def test_density_noise_forward_and_backward_vs_oracle(hip, model):
     w, rgb, depth, a, *_ = renderer.composite(net, rays.reshape(-1, 8).cuda(), z.cuda(), sb=n, sigma_noise=noise.cuda())
     torch.testing.assert_close(depth.detach().cpu(), odepth.detach(), rtol=1e-4, atol=1e-6)
     torch.testing.assert_close(rgb.detach().cpu(), orgb.detach(), rtol=0, atol=1e-5)
-    torch.testing.assert_close(a.detach().cpu(), oa.detach(), rtol=0, atol=1e-5)
+    # (alphas amplify the last bits of sigma by delta exp(-delta sigma), delta up to 20 m here: the 3 x noise-floor bound of test_gpu_parity._check)
+    torch.testing.assert_close(a.detach().cpu(), oa.detach(), rtol=0, atol=1.5e-4)
+    assert ((a.detach().cpu() - oa.detach()).abs() > 1e-5).float().mean().item() <= 2e-4
     ((rgb * c_rgb.cuda()).sum() + 0.05 * depth.sum()).backward()
     mc = net.mlp_coarse
     ours = [mc.lin_in.weight.grad, mc.lin_in.bias.grad] + sum([[b.fc_0.weight.grad, b.fc_0.bias.grad, b.fc_1.weight.grad, b.fc_1.bias.grad] for b in mc.blocks], []) \

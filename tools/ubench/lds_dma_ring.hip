@@ -1,14 +1,14 @@
 // Does the gather ring of render_kernel_p (three 4 KB LDS slots per wave filled by global_load_lds_dwordx4, read back as ds_read_b128,
 // bts_render_kernel.h: GatherLds / gl_*) deliver the right rows under BOTH orders of its steady state?
-//   shipped order   (default build):        request block T + 1 from LDS, blend block T, issue block T + 3 into T's slot
-//   late order      (-DBTS_GL_FETCH_LATE):  blend block T, issue block T + 3 into T's slot, THEN request block T + 1 from LDS
-// Round 2 measured the late order 4 % faster on the eval frame and found the RE10K instantiations (d_hidden 32) no longer bit-identical
-// from run to run (1 - 23 of 24 576 rays), even with every counter drained before the reads; the shipped order is clean.  This
-// stand-alone reproducer drives the VERY SAME device functions (it includes the kernel header) with synthetic taps, unit blend
-// weights and a feature map whose rows are known, so that every accumulator value can be checked against the host -- not only compared
-// between runs -- and the surroundings can be varied: matrix-pipe traffic between the steps (MFMA = 1), extra wait states (NOPS), a
-// full drain before the row reads (-DBTS_GL_WAIT_ALL), one or two waves per SIMD.
-//   hipcc --offload-arch=gfx950 -O3 -fno-slp-vectorize -ffp-contract=off [-DBTS_GL_FETCH_LATE] [-DBTS_GL_WAIT_ALL] -DRING_HD=32 \
+//   late order   (default build):          blend block T, issue block T + 3 into T's slot, THEN request block T + 1 from LDS
+//   early order  (-DBTS_GL_FETCH_EARLY):   request block T + 1 from LDS, blend block T, issue block T + 3 into T's slot
+// This stand-alone driver runs the VERY SAME device functions (it includes the kernel header) with synthetic taps, unit blend weights
+// and a feature map whose rows are known, so that every accumulator value can be checked against the host -- not only compared
+// between runs -- with matrix-pipe traffic between the steps (MFMA = 1) and one or two waves per SIMD.
+// History: rounds 2 - 3 used it to hunt the run-to-run differences of the late order on the RE10K shapes.  It stayed clean in every
+// configuration: the hazard needs a deep LDS queue AND a compiler schedule that reorders the four row reads -- see
+// lds_dma_overtake.hip, which shows the hardware behaviour in isolation, and gl_issue, which now closes it by construction.
+//   hipcc --offload-arch=gfx950 -O3 -fno-slp-vectorize -ffp-contract=off [-DBTS_GL_FETCH_EARLY] -DRING_HD=32 \
 //         tools/ubench/lds_dma_ring.hip -o lds_dma_ring && ./lds_dma_ring
 #define BTS_NO_LAUNCH_GLUE
 #include "../../behindthescenes_amd/csrc/bts_render_kernel.h"
@@ -123,16 +123,12 @@ int main(int argc, char** argv) {
   hipMemcpy(dG, hG.data(), hG.size() * 4, hipMemcpyHostToDevice);
   const int dyn = 4 * kGatherLdsPerWave;
   hipFuncSetAttribute(reinterpret_cast<const void*>(ring_kernel<HD>), hipFuncAttributeMaxDynamicSharedMemorySize, dyn);
-#if defined(BTS_GL_FETCH_LATE)
+#if defined(BTS_GL_FETCH_EARLY)
+  const char* order = "early";
+#else
   const char* order = "late";
-#else
-  const char* order = "shipped";
 #endif
-#if defined(BTS_GL_WAIT_ALL)
-  const char* drain = " + full drain";
-#else
   const char* drain = "";
-#endif
   for (int wgs_per_cu = 1; wgs_per_cu <= 2; ++wgs_per_cu)
     for (int with_mfma = 0; with_mfma <= 1; ++with_mfma) {
       const int grid = cus * wgs_per_cu;
