@@ -9,7 +9,7 @@ import threading
 PKG = os.path.dirname(os.path.abspath(__file__))
 # BTS_RENDER_LIB lets the profiling tools load the instrumented probe build (libbts_probe.so); the product always loads libbts_render.so
 LIB_PATH = os.environ.get("BTS_RENDER_LIB") or os.path.join(PKG, "libbts_render.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 BTS_MAX_VIEWS = 8
 ERRORS = {-1: "BTS_E_INVALID", -2: "BTS_E_UNSUPPORTED", -3: "BTS_E_LAUNCH", -4: "BTS_E_WORKSPACE"}
@@ -22,7 +22,7 @@ class BtsNativeError(RuntimeError):
 class BtsFieldCfg(C.Structure):
     _fields_ = [(k, C.c_int32) for k in ("n", "H", "W", "C", "d_hidden", "n_blocks", "nv", "num_freqs", "code_mode", "inv_z",
                                          "learn_empty", "empty_empty")] + \
-               [("freq_factor", C.c_float), ("d_min", C.c_float), ("d_max", C.c_float)]
+               [("freq_factor", C.c_float), ("d_min", C.c_float), ("d_max", C.c_float), ("feat_shift", C.c_int32)]
 
 
 class BtsFieldTensors(C.Structure):

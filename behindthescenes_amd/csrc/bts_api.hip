@@ -37,6 +37,17 @@ int render_bwd_impl(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const BtsR
 
 using namespace bts;
 
+// feat_shift: 0 .. 6, H and W multiples of 2^feat_shift (the small map then IS the nearest-neighbour source of the H x W one)
+static int check_shift(const BtsFieldCfg* cfg, const char* who) {
+  const int fs = cfg->feat_shift;
+  if (fs < 0 || fs > 6 || (cfg->H & ((1 << fs) - 1)) != 0 || (cfg->W & ((1 << fs) - 1)) != 0) {
+    set_error("%s: feat_shift=%ld needs 0 <= feat_shift <= 6 and H=%ld, W=%ld multiples of 2^feat_shift", who, (long)fs, (long)cfg->H, (long)cfg->W);
+    return BTS_E_INVALID;
+  }
+  return BTS_OK;
+}
+static long feat_texels(const BtsFieldCfg* cfg) { return (long)(cfg->H >> cfg->feat_shift) * (cfg->W >> cfg->feat_shift); }
+
 static int check_cfg(const BtsFieldCfg* cfg, const BtsFieldTensors* t, bool need_imgs) {
   if (!cfg || !t) {
     set_error("%s: NULL cfg/tensors", "bts");
@@ -50,6 +61,11 @@ static int check_cfg(const BtsFieldCfg* cfg, const BtsFieldTensors* t, bool need
     set_error("%s: configuration outside the compiled envelope (C=%ld d_hidden=%ld n_blocks=%ld; also needs num_freqs=6, nv<=8)",
               "bts", cfg->C, cfg->d_hidden, cfg->n_blocks);
     return BTS_E_UNSUPPORTED;
+  }
+  if (int rc = check_shift(cfg, "bts")) return rc;
+  if (cfg->feat_shift && !t->proj_nhwc) {
+    set_error("%s: feat_shift > 0 needs the projected map (proj_nhwc)", "bts");
+    return BTS_E_INVALID;
   }
   if ((!t->feat_nhwc && !t->proj_nhwc) || !t->K_enc || !t->w2c_enc || !t->mlp_params) {
     set_error("%s: NULL field tensor", "bts");
@@ -134,7 +150,8 @@ int bts_project_features(const BtsFieldCfg* cfg, const float* feat_nchw, const f
               cfg->d_hidden, cfg->n_blocks);
     return BTS_E_UNSUPPORTED;
   }
-  int rc = project_features_impl(cfg->C, cfg->d_hidden, feat_nchw, mlp_params, N, cfg->H * cfg->W, proj_nhwc, (hipStream_t)stream);
+  if (int rc = check_shift(cfg, "bts_project_features")) return rc;
+  int rc = project_features_impl(cfg->C, cfg->d_hidden, feat_nchw, mlp_params, N, (int)feat_texels(cfg), proj_nhwc, (hipStream_t)stream);
   if (rc) set_error("%s: kernel launch failed", "bts_project_features");
   return rc;
 }
@@ -150,7 +167,8 @@ int bts_project_features_bwd(const BtsFieldCfg* cfg, const float* feat_nchw, con
               cfg->d_hidden, cfg->n_blocks);
     return BTS_E_UNSUPPORTED;
   }
-  int rc = project_features_bwd_impl(cfg->C, cfg->d_hidden, feat_nchw, d_proj_nhwc, mlp_params, N, cfg->H * cfg->W, d_feat_nchw,
+  if (int rc = check_shift(cfg, "bts_project_features_bwd")) return rc;
+  int rc = project_features_bwd_impl(cfg->C, cfg->d_hidden, feat_nchw, d_proj_nhwc, mlp_params, N, (int)feat_texels(cfg), d_feat_nchw,
                                      d_mlp_params, (hipStream_t)stream);
   if (rc) set_error("%s: kernel launch failed", "bts_project_features_bwd");
   return rc;

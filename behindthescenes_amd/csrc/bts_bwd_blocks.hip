@@ -148,14 +148,14 @@ __device__ __forceinline__ float half_reduce16(float (&w)[16], int col) {
 // Out of line: inlined, its 36 libm sines cost the hot path > 200 spilled VGPRs.
 template <int C, int HD, int NB>
 __device__ __attribute__((noinline)) void lin_in_exact(const float* lb, const float4* G, const float* w2c, const float* Kc, int H, int W,
-                                                       int code_mode, int inv_z, float inv_dmax, float inv_range, float d_min, float range,
+                                                       int fs, int code_mode, int inv_z, float inv_dmax, float inv_range, float d_min, float range,
                                                        float freq_factor, int learn_empty, float px, float py, float pz, float* tile, int pt_sel) {
   using L = LdsB<HD, NB>;
   constexpr int HT = HD / 32;
   const int lane = threadIdx.x & 63, h = lane >> 5, col = lane & 31;
   const Cam enc = load_cam(w2c, Kc);
   const Proj pe = code_mode == 1 ? project<true>(enc, px, py, pz) : project<false>(enc, px, py, pz);
-  const Taps tp = make_taps(pe.x, pe.y, H, W);
+  const Taps tp = make_taps(pe.x, pe.y, H, W, fs);
   float v3[3];
   v3[0] = pe.x, v3[1] = pe.y;
   v3[2] = depth_code(code_mode == 1 ? pe.dist : pe.z, inv_z != 0, inv_dmax, inv_range, d_min, range);
@@ -310,11 +310,11 @@ __global__ __launch_bounds__(256, 2) void rowsb_kernel(const BwdParams bp, const
   for (; g >= 0; idx += waves_per_xcd, g = group_of(idx)) {
     auto qb = kernarg_view<BwdParams>();   // this iteration's parameters, re-read where they are used (bts_common.h: kernarg_view)
     asm volatile("" : "+s"(qb));
-    const int H = qb->f.H, W = qb->f.W, nv = qb->f.nv;
+    const int H = qb->f.H, W = qb->f.W, nv = qb->f.nv, fs = qb->f.fs;
     const long ray = g;
     while (g >= sample_end) ++sample, sample_end += Bp;
     const Cam enc = load_cam(qb->f.w2c_enc + sample * 16, qb->f.K_enc + sample * 9);
-    const float4* __restrict__ G = reinterpret_cast<const float4*>(qb->f.proj) + (long)sample * H * W * (HD / 4);
+    const float4* __restrict__ G = reinterpret_cast<const float4*>(qb->f.proj) + (long)sample * (H >> fs) * (W >> fs) * (HD / 4);
     const cfp rp = as_const(qb->f.rays) + ray * 8;
     const float ox = rp[0], oy = rp[1], oz = rp[2], dx = rp[3], dy = rp[4], dz = rp[5];
     // upstream gradients of the ray
@@ -384,7 +384,7 @@ __global__ __launch_bounds__(256, 2) void rowsb_kernel(const BwdParams bp, const
 
       // ---------------- encoder view
       const Proj pe = qb->f.code_mode == 1 ? project<true>(enc, px, py, pz) : project<false>(enc, px, py, pz);
-      Taps tp = make_taps(pe.x, pe.y, H, W);
+      Taps tp = make_taps(pe.x, pe.y, H, W, fs);
       float v3[3];
       v3[0] = pe.x, v3[1] = pe.y;
       v3[2] = depth_code(qb->f.code_mode == 1 ? pe.dist : pe.z, qb->f.inv_z != 0, qb->f.inv_dmax, qb->f.inv_range, qb->f.d_min, qb->f.range);
@@ -450,7 +450,7 @@ __global__ __launch_bounds__(256, 2) void rowsb_kernel(const BwdParams bp, const
       if (__builtin_expect(cold, 0)) {
         // no gather is in flight (the prologue above was skipped).  One point tile per call: the tile lives in the wave's gather ring
         wave_lds_fence();
-        lin_in_exact<C, HD, NB>(lds, G, qb->f.w2c_enc + sample * 16, qb->f.K_enc + sample * 9, H, W, qb->f.code_mode, qb->f.inv_z, qb->f.inv_dmax, qb->f.inv_range,
+        lin_in_exact<C, HD, NB>(lds, G, qb->f.w2c_enc + sample * 16, qb->f.K_enc + sample * 9, H, W, fs, qb->f.code_mode, qb->f.inv_z, qb->f.inv_dmax, qb->f.inv_range,
                                 qb->f.d_min, qb->f.range, qb->f.freq_factor, qb->f.learn_empty, px, py, pz, tile_a, 0);
         wave_lds_fence();
 #pragma unroll
@@ -458,7 +458,7 @@ __global__ __launch_bounds__(256, 2) void rowsb_kernel(const BwdParams bp, const
 #pragma unroll
           for (int q = 0; q < 16; ++q) acc[ht][0][q] = tile_a[col * (HD + 1) + ht * 32 + mfma_row(q, h)] * scale;
         wave_lds_fence();
-        lin_in_exact<C, HD, NB>(lds, G, qb->f.w2c_enc + sample * 16, qb->f.K_enc + sample * 9, H, W, qb->f.code_mode, qb->f.inv_z, qb->f.inv_dmax, qb->f.inv_range,
+        lin_in_exact<C, HD, NB>(lds, G, qb->f.w2c_enc + sample * 16, qb->f.K_enc + sample * 9, H, W, fs, qb->f.code_mode, qb->f.inv_z, qb->f.inv_dmax, qb->f.inv_range,
                                 qb->f.d_min, qb->f.range, qb->f.freq_factor, qb->f.learn_empty, px, py, pz, tile_a, 1);
         wave_lds_fence();
 #pragma unroll

@@ -111,7 +111,7 @@ __device__ __forceinline__ void gates_and_dwout(const f32x16 (&acc)[HD / 32][2],
 // array crosses the call.
 template <int C, int HD>
 __device__ __attribute__((noinline)) void rows_exact(const float* lds, const float4* G, const float* w2c, const float* Kc, int H, int W,
-                                                     int code_mode, int inv_z, float inv_dmax, float inv_range, float d_min, float range,
+                                                     int fs, int code_mode, int inv_z, float inv_dmax, float inv_range, float d_min, float range,
                                                      float freq_factor, int learn_empty, float px, float py, float pz, float gs,
                                                      unsigned* mrow, uint2* prow, int K, float* dw_out /* [HD/32], per lane */) {
   using L = Lds<C, HD, 0, true>;
@@ -119,7 +119,7 @@ __device__ __attribute__((noinline)) void rows_exact(const float* lds, const flo
   const int lane = threadIdx.x & 63, h = lane >> 5;
   const Cam enc = load_cam(w2c, Kc);
   const Proj pe = code_mode == 1 ? project<true>(enc, px, py, pz) : project<false>(enc, px, py, pz);
-  const Taps tp = make_taps(pe.x, pe.y, H, W);
+  const Taps tp = make_taps(pe.x, pe.y, H, W, fs);
   float v3[3];
   v3[0] = pe.x, v3[1] = pe.y;
   v3[2] = depth_code(code_mode == 1 ? pe.dist : pe.z, inv_z != 0, inv_dmax, inv_range, d_min, range);
@@ -249,11 +249,11 @@ __global__ __launch_bounds__(256, 2) void rows_kernel(const BwdParams bp) {
   for (; g >= 0; idx += waves_per_xcd, g = group_of(idx)) {
     auto qb = kernarg_view<BwdParams>();   // this iteration's parameters, re-read where they are used (bts_common.h: kernarg_view)
     asm volatile("" : "+s"(qb));
-    const int H = qb->f.H, W = qb->f.W, nv = qb->f.nv;
+    const int H = qb->f.H, W = qb->f.W, nv = qb->f.nv, fs = qb->f.fs;
     const long ray = g;
     while (g >= sample_end) ++sample, sample_end += Bp;
     const Cam enc = load_cam(qb->f.w2c_enc + sample * 16, qb->f.K_enc + sample * 9);
-    const float4* __restrict__ G = reinterpret_cast<const float4*>(qb->f.proj) + (long)sample * H * W * (HD / 4);
+    const float4* __restrict__ G = reinterpret_cast<const float4*>(qb->f.proj) + (long)sample * (H >> fs) * (W >> fs) * (HD / 4);
     const cfp rp = as_const(qb->f.rays) + ray * 8;
     const float ox = rp[0], oy = rp[1], oz = rp[2], dx = rp[3], dy = rp[4], dz = rp[5];
     const float z = z_pre, z_nx = zn_pre, s_raw = s_pre, T = t_pre;
@@ -309,7 +309,7 @@ __global__ __launch_bounds__(256, 2) void rows_kernel(const BwdParams bp) {
 
     // ---------------- encoder view
     const Proj pe = qb->f.code_mode == 1 ? project<true>(enc, px, py, pz) : project<false>(enc, px, py, pz);
-    Taps tp = make_taps(pe.x, pe.y, H, W);
+    Taps tp = make_taps(pe.x, pe.y, H, W, fs);
     float v3[3];
     v3[0] = pe.x, v3[1] = pe.y;
     v3[2] = depth_code(qb->f.code_mode == 1 ? pe.dist : pe.z, qb->f.inv_z != 0, qb->f.inv_dmax, qb->f.inv_range, qb->f.d_min, qb->f.range);
@@ -382,7 +382,7 @@ __global__ __launch_bounds__(256, 2) void rows_kernel(const BwdParams bp) {
 
     if (__builtin_expect(__any(pe_needs_exact(v3, qb->f.freq_factor)), 0)) {
       float dwx[HT];   // through memory: no accumulator array may cross the call (it would be demoted to scratch on the hot path)
-      rows_exact<C, HD>(lds, G, qb->f.w2c_enc + sample * 16, qb->f.K_enc + sample * 9, H, W, qb->f.code_mode, qb->f.inv_z, qb->f.inv_dmax, qb->f.inv_range, qb->f.d_min,
+      rows_exact<C, HD>(lds, G, qb->f.w2c_enc + sample * 16, qb->f.K_enc + sample * 9, H, W, fs, qb->f.code_mode, qb->f.inv_z, qb->f.inv_dmax, qb->f.inv_range, qb->f.d_min,
                         qb->f.range, qb->f.freq_factor, qb->f.learn_empty, px, py, pz, g_s, mrow, prow, K, dwx);
 #pragma unroll
       for (int ht = 0; ht < HT; ++ht) dw_acc[ht] += dwx[ht];
@@ -539,7 +539,8 @@ __global__ __launch_bounds__(64) void scatter_kernel(const ScatterMaskParams sp)
   const int chg = wv * 32 + c;   // this lane's channel of the row
   const int sample = grp / sp.groups_per_sample;
   const int g_in = grp - sample * sp.groups_per_sample;
-  const int Bp = p.Bp, K = p.K, H = p.H, W = p.W;
+  const int Bp = p.Bp, K = p.K, fs = p.fs;
+  const int H = p.H >> fs, W = p.W >> fs;   // the map in memory (BtsFieldCfg.feat_shift); the taps are computed for p.H x p.W
   const int r_raw = g_in * 64 + lane;
   const bool ray_ok = r_raw < Bp;
   const int r = ray_ok ? r_raw : Bp - 1;
@@ -656,7 +657,11 @@ __global__ __launch_bounds__(64) void scatter_kernel(const ScatterMaskParams sp)
     if (__all(gs == 0.0f)) continue;   // e.g. the capped last sample of every ray: nothing to add
     const Proj pe = project<false>(enc, r0.x + z * r0.w, r0.y + z * r1.x, r0.z + z * r1.y);
     int x0, y0, x1, y1;
-    Taps tp = make_taps_xy(pe.x, pe.y, H, W, x0, y0, x1, y1);
+    Taps tp = make_taps_xy(pe.x, pe.y, p.H, p.W, x0, y0, x1, y1, fs);
+    // taps that name the same texel become one: at the far border the second one's weight is exactly 0 (adding it changes nothing),
+    // on a down-scaled map (fs > 0) both count
+    if (x1 == x0) tp.w00 += tp.w01, tp.w10 += tp.w11, tp.w01 = tp.w11 = 0.0f;
+    if (y1 == y0) tp.w00 += tp.w10, tp.w01 += tp.w11, tp.w10 = tp.w11 = 0.0f;
     const bool use_empty = (p.learn_empty != 0) & pe.invalid;
     if constexpr (!ROWS) tp.w00 *= gs, tp.w01 *= gs, tp.w10 *= gs, tp.w11 *= gs;   // ROWS: g_s is part of the rows
     bool fits = false;

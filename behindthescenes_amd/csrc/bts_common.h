@@ -136,7 +136,10 @@ struct Taps {
   float w00, w01, w10, w11;
 };
 
-__device__ __forceinline__ Taps make_taps_xy(float x, float y, int H, int W, int& x0, int& y0, int& x1, int& y1) {
+// fs > 0: the map in memory is (H >> fs, W >> fs) and stands for its nearest-neighbour resize to H x W (BtsFieldCfg.feat_shift): the
+// weights are those of the H x W map, the texel indices (and the x0 .. y1 handed back) those of the small one.  Two taps may then
+// name the same texel with non-zero weights.
+__device__ __forceinline__ Taps make_taps_xy(float x, float y, int H, int W, int& x0, int& y0, int& x1, int& y1, int fs = 0) {
   float ix = ((x + 1.0f) * (float)W - 1.0f) / 2.0f;
   float iy = ((y + 1.0f) * (float)H - 1.0f) / 2.0f;
   ix = fminf((float)(W - 1), fmaxf(ix, 0.0f));
@@ -153,6 +156,7 @@ __device__ __forceinline__ Taps make_taps_xy(float x, float y, int H, int W, int
   // NaN coordinates (never produced by finite inputs) would give x0 = INT_MIN: clamp for memory safety
   x0 = max(0, min(x0, W - 1));
   y0 = max(0, min(y0, H - 1));
+  x0 >>= fs, x1 >>= fs, y0 >>= fs, y1 >>= fs, W >>= fs;
   t.o00 = y0 * W + x0;
   t.o01 = y0 * W + x1;
   t.o10 = y1 * W + x0;
@@ -160,9 +164,9 @@ __device__ __forceinline__ Taps make_taps_xy(float x, float y, int H, int W, int
   return t;
 }
 
-__device__ __forceinline__ Taps make_taps(float x, float y, int H, int W) {
+__device__ __forceinline__ Taps make_taps(float x, float y, int H, int W, int fs = 0) {
   int x0, y0, x1, y1;
-  return make_taps_xy(x, y, H, W, x0, y0, x1, y1);
+  return make_taps_xy(x, y, H, W, x0, y0, x1, y1, fs);
 }
 
 // depth code in [-1,1] (models_bts.py:157-171)

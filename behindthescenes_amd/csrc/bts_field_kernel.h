@@ -36,6 +36,7 @@ struct FwdParams {
   const float* empty_feature;
   const float* mlp;
   int n, H, W, nv;
+  int fs;        // log2 of the feature map's downscale (BtsFieldCfg.feat_shift): G is (n, H >> fs, W >> fs, HD)
   int code_mode, inv_z, learn_empty, empty_empty;
   float freq_factor, d_min, d_max;
   float inv_dmax, inv_range, range;
@@ -410,7 +411,7 @@ __device__ __forceinline__ float eval_point(const FwdParams& p, const float* lds
   const int lane_off = (lane >> 5) * HD + (lane & 31);
   // ---------------- encoder view: projection, taps, depth code
   pe = p.code_mode == 1 ? project<true>(enc, px, py, pz) : project<false>(enc, px, py, pz);
-  const Taps tp = make_taps(pe.x, pe.y, H, W);
+  const Taps tp = make_taps(pe.x, pe.y, H, W, p.fs);
   float v3[3];
   v3[0] = pe.x, v3[1] = pe.y;
   v3[2] = depth_code(p.code_mode == 1 ? pe.dist : pe.z, p.inv_z != 0, p.inv_dmax, p.inv_range, p.d_min, p.range);

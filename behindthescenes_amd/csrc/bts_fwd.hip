@@ -35,7 +35,7 @@ FwdParams make_params(const BtsFieldCfg* cfg, const BtsFieldTensors* t) {
   p.feat = t->feat_nhwc, p.proj = t->proj_nhwc, p.K_enc = t->K_enc, p.w2c_enc = t->w2c_enc;
   p.imgs = t->imgs_nhwc4, p.K_r = t->K_r, p.w2c_r = t->w2c_r;
   p.empty_feature = t->empty_feature, p.mlp = t->mlp_params;
-  p.n = cfg->n, p.H = cfg->H, p.W = cfg->W, p.nv = cfg->nv;
+  p.n = cfg->n, p.H = cfg->H, p.W = cfg->W, p.nv = cfg->nv, p.fs = cfg->feat_shift;
   p.code_mode = cfg->code_mode, p.inv_z = cfg->inv_z, p.learn_empty = cfg->learn_empty, p.empty_empty = cfg->empty_empty;
   p.freq_factor = cfg->freq_factor, p.d_min = cfg->d_min, p.d_max = cfg->d_max;
   // python-double constants rounded once to fp32, as `1 / self.d_max` etc. enter the reference's tensor ops (models_bts.py:160-169)

@@ -105,13 +105,13 @@ __global__ __launch_bounds__(256, 2) void query_kernel_p(const QueryParams qp) {
   for (; g >= 0; idx += waves_per_xcd, g = group_of(idx)) {
     auto qq = kernarg_view<QueryParams>();   // this iteration's parameters, re-read where they are used (bts_common.h: kernarg_view)
     asm volatile("" : "+s"(qq));
-    const int H = qq->f.H, W = qq->f.W, nv = qq->f.nv;
+    const int H = qq->f.H, W = qq->f.W, nv = qq->f.nv, fs = qq->f.fs;
     while (g >= sample_end) ++sample, sample_end += groups_per_sample;
     const int g_in = g - (sample_end - groups_per_sample);
     bool valid;
     const long pidx = (long)sample * P + point_of(g_in, valid);
     const Cam enc = load_cam(qq->f.w2c_enc + sample * 16, qq->f.K_enc + sample * 9);
-    const float4* __restrict__ G = reinterpret_cast<const float4*>(qq->f.proj) + (long)sample * H * W * (HD / 4);
+    const float4* __restrict__ G = reinterpret_cast<const float4*>(qq->f.proj) + (long)sample * (H >> fs) * (W >> fs) * (HD / 4);
     const float px = xp, py = yp, pz = zp;
     {  // the next group's points land while this group is evaluated
       const int gn = group_of(idx + waves_per_xcd);
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256, 2) void query_kernel_p(const QueryParams qp) {
 
     // ---------------- encoder view: projection, taps, depth code
     const Proj pe = qq->f.code_mode == 1 ? project<true>(enc, px, py, pz) : project<false>(enc, px, py, pz);
-    Taps tp = make_taps(pe.x, pe.y, H, W);
+    Taps tp = make_taps(pe.x, pe.y, H, W, fs);
     float v3[3];
     v3[0] = pe.x, v3[1] = pe.y;
     v3[2] = depth_code(qq->f.code_mode == 1 ? pe.dist : pe.z, qq->f.inv_z != 0, qq->f.inv_dmax, qq->f.inv_range, qq->f.d_min, qq->f.range);
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256, 2) void query_kernel_p(const QueryParams qp) {
 
     float s_raw;
     if (__builtin_expect(__any(pe_needs_exact(v3, qq->f.freq_factor)), 0)) {
-      s_raw = eval_point_exact<C, HD, NB>(lds, G, qq->f.w2c_enc + sample * 16, qq->f.K_enc + sample * 9, H, W, qq->f.code_mode, qq->f.inv_z, qq->f.inv_dmax,
+      s_raw = eval_point_exact<C, HD, NB>(lds, G, qq->f.w2c_enc + sample * 16, qq->f.K_enc + sample * 9, H, W, fs, qq->f.code_mode, qq->f.inv_z, qq->f.inv_dmax,
                                           qq->f.inv_range, qq->f.d_min, qq->f.range, qq->f.freq_factor, qq->f.learn_empty, b_out, px, py, pz);
     } else {
       // ---------------- h = bilinear(G) + W_pe . PE + b (render_kernel_p's pipeline)

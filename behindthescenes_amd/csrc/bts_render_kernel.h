@@ -505,10 +505,10 @@ __device__ __forceinline__ void region_seq_l(f32x16 (&acc)[HD / 32][2], const Ga
 // Kept out of line -- inlining 36 libm sines next to the pipelined path costs ~240 spilled VGPRs on the HOT path.
 template <int C, int HD, int NB>
 __device__ __attribute__((noinline)) float eval_point_exact(const float* lds, const float4* G, const float* w2c, const float* Kc, int H, int W,
-                                                            int code_mode, int inv_z, float inv_dmax, float inv_range, float d_min, float range,
+                                                            int fs, int code_mode, int inv_z, float inv_dmax, float inv_range, float d_min, float range,
                                                             float freq_factor, int learn_empty, float b_out, float px, float py, float pz) {
   FwdParams q;
-  q.H = H, q.W = W, q.code_mode = code_mode, q.inv_z = inv_z, q.inv_dmax = inv_dmax, q.inv_range = inv_range, q.d_min = d_min;
+  q.H = H, q.W = W, q.fs = fs, q.code_mode = code_mode, q.inv_z = inv_z, q.inv_dmax = inv_dmax, q.inv_range = inv_range, q.d_min = d_min;
   q.range = range, q.freq_factor = freq_factor, q.learn_empty = learn_empty, q.ablate = 0;
   const Cam enc = load_cam(w2c, Kc);
   Proj pe;
@@ -606,13 +606,13 @@ __global__ __launch_bounds__(256, 2) void render_kernel_p(const FwdParams p) {
     // whole life of the kernel (bts_common.h: kernarg_view)
     auto q = kernarg_view<FwdParams>();
     asm volatile("" : "+s"(q));
-    const int K = q->K, H = q->H, W = q->W, nv = q->nv;
+    const int K = q->K, H = q->H, W = q->W, nv = q->nv, fs = q->fs;
     const long ray = (long)g * R + lane / lpr;
     // all rays of a group belong to one batch element; g only grows along a wave's chunk list, so the element is tracked by a
     // running boundary (the 64-bit division this replaces was ~140 dependent scalar instructions at the top of every iteration)
     while (g >= sample_end) ++sample, sample_end += groups_per_sample;
     const Cam enc = load_cam(q->w2c_enc + sample * 16, q->K_enc + sample * 9);
-    const float4* __restrict__ G = reinterpret_cast<const float4*>(q->proj) + (long)sample * H * W * (HD / 4);
+    const float4* __restrict__ G = reinterpret_cast<const float4*>(q->proj) + (long)sample * (H >> fs) * (W >> fs) * (HD / 4);
     float ox, oy, oz, dx, dy, dz;
     if constexpr (ONE_RAY) {  // wave-uniform ray: scalar loads
       const cfp rp = as_const(q->rays) + (long)g * 8;
@@ -655,7 +655,7 @@ __global__ __launch_bounds__(256, 2) void render_kernel_p(const FwdParams p) {
 
       // ---------------- encoder view: projection, taps, depth code
       const Proj pe = q->code_mode == 1 ? project<true>(enc, px, py, pz) : project<false>(enc, px, py, pz);
-      Taps tp = make_taps(pe.x, pe.y, H, W);
+      Taps tp = make_taps(pe.x, pe.y, H, W, fs);
       float v3[3];
       v3[0] = pe.x, v3[1] = pe.y;
       v3[2] = depth_code(q->code_mode == 1 ? pe.dist : pe.z, q->inv_z != 0, q->inv_dmax, q->inv_range, q->d_min, q->range);
@@ -686,7 +686,7 @@ __global__ __launch_bounds__(256, 2) void render_kernel_p(const FwdParams p) {
 
       float s_raw;
       if (__builtin_expect(__any(pe_needs_exact(v3, q->freq_factor)), 0)) {
-        s_raw = eval_point_exact<C, HD, NB>(lds, G, q->w2c_enc + sample * 16, q->K_enc + sample * 9, H, W, q->code_mode, q->inv_z, q->inv_dmax,
+        s_raw = eval_point_exact<C, HD, NB>(lds, G, q->w2c_enc + sample * 16, q->K_enc + sample * 9, H, W, fs, q->code_mode, q->inv_z, q->inv_dmax,
                                             q->inv_range, q->d_min, q->range, q->freq_factor, q->learn_empty, b_out, px, py, pz);
       } else {
       BTS_TICK(0)

@@ -72,6 +72,11 @@ class BTSNet(nn.Module):
         # for 0.57 GB less peak memory -- so the generic route is the default and `fused_handover: true` the opt-in.
         # (whether the CURRENT encoder can do that is looked up at every encode(): callers replace net.encoder after construction)
         self.fused_handover = bool(conf.get("fused_handover", False))
+        # models_bts.py:115-117 resizes the decoder's coarser scales to scale 0's size (F.interpolate, nearest) before the renderer
+        # samples them.  A nearest resize by 2^s only repeats texels: the kernels index the scale's own map (BtsFieldCfg.feat_shift)
+        # -- bit-identical results, no resized map (and none of its gradient) in HBM, the projection G = F . W^T runs on 1 / 4^s of
+        # the texels.  `native_scale_maps: false` materialises the resized maps as the reference does.
+        self.native_scale_maps = bool(conf.get("native_scale_maps", True))
         self.spec = native.FieldSpec(C=self.encoder.latent_size, d_hidden=self.mlp_coarse.d_hidden,
                                      n_blocks=self.mlp_coarse.n_blocks, num_freqs=self.code_xyz.num_freqs,
                                      freq_factor=self.code_xyz.freq_factor, d_min=float(self.d_min), d_max=float(self.d_max),
@@ -79,6 +84,29 @@ class BTSNet(nn.Module):
                                      empty_empty=bool(self.empty_empty))
         if not self.code_xyz.include_input:
             raise NotImplementedError("include_input=False is not used by any shipped config")
+
+    def _scale_shift(self, size, size0):
+        """s if a map of `size` is scale 0's size divided by 2^s (and may be handed over as it is), else None (resize it)."""
+        (h, w), (h0, w0) = size, size0
+        if (h, w) == (h0, w0):
+            return 0
+        if self.native_scale_maps:
+            for sh in range(1, 7):
+                if (h << sh, w << sh) == (h0, w0):
+                    return sh
+        return None
+
+    @property
+    def grid_f_features(self):
+        """models_bts.py:117, 128: the encoder's maps of every scale at scale 0's size, (n, nv_enc, C, H, W) each.  The renderer does
+        not need them (see native_scale_maps); built on first access for callers that do.  None on the fused hand-over route."""
+        if not getattr(self, "_has_latents", False):
+            return None
+        if self._grid_f_features is None:
+            h_, w_ = self._grid_size
+            self._grid_f_features = [il if il.shape[-2:] == (h_, w_) else
+                                     F.interpolate(il[:, 0], (h_, w_)).unsqueeze(1) for il in self._latents_ms]
+        return self._grid_f_features
 
     # ---- reference protocol -------------------------------------------------------------------------------------
     def set_scale(self, scale):
@@ -94,6 +122,7 @@ class BTSNet(nn.Module):
         """images (n,v,3,H,W) in [-1,1]; Ks (n,v,3,3) normalised intrinsics; poses_c2w (n,v,4,4)  (models_bts.py:65-136)."""
         if combine_ids is not None:
             raise NotImplementedError("combine_ids (waymo multi-encoder-view mode) is not part of the HIP render path")
+        self.mlp_coarse.invalidate_packed()     # a new step: a new autograd graph for the packed parameter vector
         poses_w2c = native.invert_small(poses_c2w)
         if ids_encoder is None:
             ids_encoder = list(range(images.shape[1]))
@@ -118,8 +147,9 @@ class BTSNet(nn.Module):
             if do_flip:
                 g_ms = [torch.flip(g, dims=(2,)) for g in g_ms]
             h_, w_ = g_ms[0].shape[1:3]
-            self._proj_ms = [(g if g.shape[1:3] == (h_, w_) else F.interpolate(g.permute(0, 3, 1, 2), (h_, w_)).permute(0, 2, 3, 1)).contiguous()
-                             for g in g_ms]
+            self._shift_ms = [self._scale_shift(g.shape[1:3], (h_, w_)) for g in g_ms]
+            self._proj_ms = [(g if sh is not None else F.interpolate(g.permute(0, 3, 1, 2), (h_, w_)).permute(0, 2, 3, 1)).contiguous()
+                             for g, sh in zip(g_ms, self._shift_ms)]
             # G was composed from lin_in.weight AS IT WAS NOW and under the grad mode of NOW: native_field() refuses to pair it with
             # other weights (an optimizer step / load_state_dict between encode() and the render) or to render under autograd from a
             # map that was encoded under no_grad (lin_in and the CNN would silently get no gradient through G)
@@ -130,10 +160,14 @@ class BTSNet(nn.Module):
             if do_flip:
                 image_latents_ms = [torch.flip(il, dims=(-1,)) for il in image_latents_ms]
             _, _, h_, w_ = image_latents_ms[0].shape
-            image_latents_ms = [(il if il.shape[-2:] == (h_, w_) else F.interpolate(il, (h_, w_))).view(n, nv_enc, c_l, h_, w_)
-                                for il in image_latents_ms]
-
-        self.grid_f_features = image_latents_ms
+            self._shift_ms = [self._scale_shift(il.shape[-2:], (h_, w_)) for il in image_latents_ms]
+            self._latents_ms = [(il if sh is not None else F.interpolate(il, (h_, w_))).unsqueeze(1)
+                                for il, sh in zip(image_latents_ms, self._shift_ms)]
+            image_latents_ms = True
+        self._shift_ms = [sh or 0 for sh in self._shift_ms]
+        self._grid_size = (h_, w_)
+        self._has_latents = image_latents_ms is not None
+        self._grid_f_features = None
         self.grid_f_Ks = Ks_encoder
         self.grid_f_poses_w2c = poses_w2c_encoder
         self.grid_f_combine = None
@@ -175,11 +209,11 @@ class BTSNet(nn.Module):
                                                 "map carries no graph, lin_in / the encoder would get no gradient -- encode() under grad mode")
                 proj = self._proj_ms[s].float()
             else:
-                f = self.grid_f_features[s]                        # (n, 1, C, H, W) -> (n, C, H, W): a pure view (selecting [:, 0] would
+                f = self._latents_ms[s]                            # (n, 1, C, h, w) -> (n, C, h, w): a pure view (selecting [:, 0] would
                 f = f.reshape(f.shape[0], *f.shape[2:]).float()    # cost a zero fill + a copy of the whole map in its backward)
                 proj = native.ProjectFunction.apply(f, self.mlp_coarse.packed(), self.spec)
             ft = native.FieldTensors(self.spec, proj, self._K_enc, self._w2c_enc, self._imgs_nhwc4, self._K_r, self._w2c_r,
-                                     self.empty_feature if self.learn_empty else None)
+                                     self.empty_feature if self.learn_empty else None, feat_shift=self._shift_ms[s])
             self._native[s] = (ft, version)
         return self._native[s][0]
 

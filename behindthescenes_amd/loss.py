@@ -7,6 +7,7 @@ reference become one launch, one reduction and one device-to-host copy for the l
 alpha / surfaceness / depth-smoothness / ray-entropy, all off in the shipped configs) are a few elementwise torch expressions on
 top.  Same constructor keys, same call signature, same ``(loss, loss_dict)`` result as the reference."""
 import math
+from collections.abc import Mapping
 
 import torch
 from torch.autograd import profiler
@@ -43,6 +44,42 @@ def _same_view(a, b):
     """True when a and b are the same values in the same memory (same storage offset, shape, strides, grad history)."""
     return a is b or (a.data_ptr() == b.data_ptr() and a.shape == b.shape and a.stride() == b.stride() and a.dtype == b.dtype
                       and a._base is not None and a._base is b._base)
+
+
+class LazyScalars(Mapping):
+    """The loss dict of loss.py:219-229 ({name: python float}) without its synchronisation: the values are copied to pinned host memory
+    asynchronously when the loss is computed and the host waits for that copy only when an entry is read (logging handlers read them
+    every N iterations; a step whose dict nobody reads never stalls, and the backward is launched while the forward still runs).  A
+    read-only Mapping: ``d["loss"]``, ``d.items()``, ``dict(d)`` behave like the reference's dict."""
+
+    def __init__(self, keys, values: torch.Tensor):
+        self._keys, self._vals = list(keys), None
+        if values.is_cuda:
+            self._host = torch.empty(values.shape, dtype=values.dtype, pin_memory=True)
+            self._host.copy_(values, non_blocking=True)
+            self._event = torch.cuda.Event()
+            self._event.record()
+        else:
+            self._host, self._event = values, None
+
+    def _dict(self):
+        if self._vals is None:
+            if self._event is not None:
+                self._event.synchronize()
+            self._vals = dict(zip(self._keys, self._host.tolist()))
+        return self._vals
+
+    def __getitem__(self, k):
+        return self._dict()[k]
+
+    def __iter__(self):
+        return iter(self._keys)
+
+    def __len__(self):
+        return len(self._keys)
+
+    def __repr__(self):
+        return repr(self._dict())
 
 
 class ReconstructionLoss:
@@ -197,9 +234,10 @@ class ReconstructionLoss:
             ent = (-(dens * torch.log(dens)).sum(-1) / math.log2(a.shape[-1]) * keep()).mean()
             loss = loss + ent * self.lambda_entropy
 
-        # one device-to-host copy for the whole logging dict (the reference pays one synchronisation per entry)
+        # one device-to-host copy for the whole logging dict (the reference pays one synchronisation per entry), and not even that one
+        # stalls the step: the copy is asynchronous, the host waits for it when somebody READS an entry (LazyScalars)
         vals = torch.stack([m["coarse"], m["fine"], ent.detach(), m["depth_reg"], m["alpha_reg"], m["eas"], m["dsmooth"], m["inv"],
-                            loss.detach()]).tolist()
+                            loss.detach()])
         keys = ["loss_rgb_coarse", "loss_rgb_fine", "loss_ray_entropy", "loss_depth_reg", "loss_alpha_reg", "loss_eas",
                 "loss_depth_smoothness", "loss_invalid_ratio", "loss"]
-        return loss, dict(zip(keys, vals))
+        return loss, LazyScalars(keys, vals)

@@ -52,12 +52,28 @@ class ResnetFC(nn.Module):
 
     def packed(self) -> torch.Tensor:
         """Flat fp32 parameter vector in the layout of include/bts_render.h (differentiable: autograd splits the gradient of the
-        packed vector back onto the individual nn.Parameters)."""
-        parts = [self.lin_in.weight.reshape(-1), self.lin_in.bias]
+        packed vector back onto the individual nn.Parameters).  Cached until a parameter changes (version counter / storage) or
+        ``invalidate_packed()`` (BTSNet.encode calls it: one vector -- and one split of its gradient -- per training step, however
+        many renders and projections of the step read it; a multiscale step has eight)."""
+        params = [self.lin_in.weight, self.lin_in.bias]
         for blk in self.blocks:
-            parts += [blk.fc_0.weight.reshape(-1), blk.fc_0.bias, blk.fc_1.weight.reshape(-1), blk.fc_1.bias]
-        parts += [self.lin_out.weight.reshape(-1), self.lin_out.bias]
-        return torch.cat(parts)
+            params += [blk.fc_0.weight, blk.fc_0.bias, blk.fc_1.weight, blk.fc_1.bias]
+        params += [self.lin_out.weight, self.lin_out.bias]
+        key = (torch.is_grad_enabled(),) + tuple((p._version, p.data_ptr(), p.requires_grad) for p in params)
+        hit = self.__dict__.get("_packed_cache")
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        out = torch.cat([p.reshape(-1) for p in params])
+        self.__dict__["_packed_cache"] = (key, out)
+        return out
+
+    def invalidate_packed(self):
+        self.__dict__["_packed_cache"] = None
+
+    def __getstate__(self):     # copy.deepcopy / pickle: the cached vector (a non-leaf tensor under autograd) stays behind
+        state = self.__dict__.copy()
+        state["_packed_cache"] = None
+        return state
 
     @classmethod
     def from_conf(cls, conf, d_in, **kwargs):

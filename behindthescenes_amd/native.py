@@ -215,10 +215,11 @@ def distance_to_z(depths: torch.Tensor, projs: torch.Tensor) -> torch.Tensor:
 # --------------------------------------------------------------------------------------------------------------
 # field state handed to the renderer
 # --------------------------------------------------------------------------------------------------------------
-def _spec_cfg(spec: FieldSpec, n=1, H=1, W=1, nv=0) -> BtsFieldCfg:
+def _spec_cfg(spec: FieldSpec, n=1, H=1, W=1, nv=0, feat_shift=0) -> BtsFieldCfg:
     return BtsFieldCfg(n=n, H=H, W=W, C=spec.C, d_hidden=spec.d_hidden, n_blocks=spec.n_blocks, nv=nv, num_freqs=spec.num_freqs,
                        code_mode={"z": 0, "distance": 1}[spec.code_mode], inv_z=int(spec.inv_z), learn_empty=int(spec.learn_empty),
-                       empty_empty=int(spec.empty_empty), freq_factor=spec.freq_factor, d_min=spec.d_min, d_max=spec.d_max)
+                       empty_empty=int(spec.empty_empty), freq_factor=spec.freq_factor, d_min=spec.d_min, d_max=spec.d_max,
+                       feat_shift=feat_shift)
 
 
 def proj_storage_order(d_hidden: int) -> torch.Tensor:
@@ -256,11 +257,16 @@ def project_features_bwd(spec: FieldSpec, feat_nchw, d_proj, mlp_params, need_fe
 
 class FieldTensors:
     """Device tensors in the layouts of include/bts_render.h.  ``proj_nhwc`` (G) may require grad: it is produced by
-    ``ProjectFunction`` from the encoder output and the MLP parameters inside autograd."""
+    ``ProjectFunction`` from the encoder output and the MLP parameters inside autograd.
+    ``feat_shift`` = s: the map is the decoder's scale-s output at ITS size (n, H >> s, W >> s, .) and is read as its nearest-neighbour
+    resize to H x W -- what models_bts.py:115-117 materialises -- without the resize (BtsFieldCfg.feat_shift)."""
 
-    def __init__(self, spec: FieldSpec, proj_nhwc, K_enc, w2c_enc, imgs_nhwc4, K_r, w2c_r, empty_feature=None, feat_nhwc=None):
+    def __init__(self, spec: FieldSpec, proj_nhwc, K_enc, w2c_enc, imgs_nhwc4, K_r, w2c_r, empty_feature=None, feat_nhwc=None, feat_shift=0):
         ref = proj_nhwc if proj_nhwc is not None else feat_nhwc
         n, H, W, ch = ref.shape
+        H, W = H << feat_shift, W << feat_shift
+        if feat_shift and proj_nhwc is None:
+            raise BtsNativeError("feat_shift > 0 needs the projected map")
         if proj_nhwc is not None and ch != spec.d_hidden:
             raise BtsNativeError(f"proj_nhwc has {ch} channels, spec says d_hidden={spec.d_hidden}")
         if proj_nhwc is None and ch != spec.C:
@@ -275,13 +281,13 @@ class FieldTensors:
             if empty_feature is None:
                 raise BtsNativeError("learn_empty needs empty_feature")
             _req(empty_feature.detach(), "empty_feature", (spec.C,))
-        self.spec, self.n, self.H, self.W, self.nv = spec, n, H, W, nv
+        self.spec, self.n, self.H, self.W, self.nv, self.feat_shift = spec, n, H, W, nv, feat_shift
         self.proj_nhwc, self.feat_nhwc, self.K_enc, self.w2c_enc = proj_nhwc, feat_nhwc, K_enc, w2c_enc
         self.imgs_nhwc4, self.K_r, self.w2c_r = imgs_nhwc4, K_r, w2c_r
         self.empty_feature = empty_feature
 
     def cfg(self, nv=None) -> BtsFieldCfg:
-        return _spec_cfg(self.spec, self.n, self.H, self.W, self.nv if nv is None else nv)
+        return _spec_cfg(self.spec, self.n, self.H, self.W, self.nv if nv is None else nv, self.feat_shift)
 
     def tensors(self, mlp_params: torch.Tensor) -> BtsFieldTensors:
         def dp(t):

@@ -115,7 +115,10 @@ class PatchRaySampler(RaySampler):
             for t, hi, nme in ((pv, v, "view"), (py, h - self.patch_size_y + 1, "y0"), (px, w - self.patch_size_x + 1, "x0")):
                 if t.numel() and (int(t.min()) < 0 or int(t.max()) >= hi):
                     raise ValueError(f"patch {nme} outside [0, {hi})")
-        idx = torch.stack((pv, py, px)).to(device=dev, dtype=torch.int32)          # one small host-to-device copy
+        # one small host-to-device copy, from pinned memory and asynchronous: a pageable source would make the host wait for everything
+        # the stream still holds (the previous step's backward) before the copy even starts
+        idx = torch.stack((pv, py, px)).to(torch.int32)
+        idx = idx.pin_memory().to(dev, non_blocking=True) if dev.type == "cuda" else idx.to(dev)
         all_rays, all_rgb_gt = native.patch_rays(poses.detach().float().contiguous(), projs.detach().float().contiguous(),
                                                  images.detach().float().contiguous(), idx[0], idx[1], idx[2],
                                                  self.patch_size_y, self.patch_size_x, self.z_near, self.z_far)

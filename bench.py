@@ -52,6 +52,8 @@ def parse():
                          "(SURVEY 8f.4) unless --no-fused-handover")
     ap.add_argument("--no-fused-handover", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--ops-profile", action="store_true",
+                    help="training workloads: run 3 steps under torch.profiler and print the host-side op table (no JSON line)")
     ap.add_argument("--full-outputs", action="store_true",
                     help="train workload: also materialise weights / alphas / invalid / rgb_samps per sample as the reference trainer's dict "
                          "has them (default: lean_training_outputs -- the loss reads per-ray reductions from the render kernel's epilogue)")
@@ -286,6 +288,15 @@ def train_workload(args, world, rank, dev):
 
     for _ in range(args.warmup):
         step()
+    if args.ops_profile:      # diagnostic: what the host issues around the HIP kernels (launch-bound steps)
+        from torch.profiler import profile, ProfilerActivity
+        torch.cuda.synchronize()
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+            for _ in range(3):
+                step()
+            torch.cuda.synchronize()
+        print(prof.key_averages().table(sort_by="self_cpu_time_total", row_limit=45, max_name_column_width=60), file=sys.stderr)
+        return
     native.render_fwd, native.render_bwd = timed(orig_fwd, "fwd"), timed(orig_bwd, "bwd")
     torch.cuda.synchronize()
     if torch.distributed.is_initialized():

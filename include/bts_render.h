@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define BTS_ABI_VERSION 3
+#define BTS_ABI_VERSION 4
 
 enum {
   BTS_OK = 0,
@@ -58,6 +58,12 @@ typedef struct BtsFieldCfg {
   int32_t empty_empty; /* 1 = sigma := 0 for out-of-frustum points (models_bts.py:323-324) */
   float freq_factor;   /* PE base frequency (1.5) */
   float d_min, d_max;  /* z_near, z_far of the field */
+  /* ABI 4: the feature map of decoder scale s handed over at ITS OWN size.  BTSNet.encode resizes every scale's map to scale 0's
+   * size with F.interpolate(mode="nearest") (models_bts.py:115-117) before the renderer samples it; for sizes that differ by 2^s that
+   * map is texel (y >> s, x >> s) of the small one, so the kernels index the small map directly: feat / proj / d_proj are
+   * (n, H >> feat_shift, W >> feat_shift, .) and every result is bit-identical to the resized map's.  H and W (the colour frames'
+   * size, and the size the bilinear taps are computed for) must be multiples of 2^feat_shift.  0 = a full-size map. */
+  int32_t feat_shift;
 } BtsFieldCfg;
 
 #define BTS_MAX_VIEWS 8

@@ -38,7 +38,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
         assert hasattr(lib, n), f"{n} declared in include/bts_render.h but not exported"
         assert n in _lib.SYMBOLS, f"{n} has no ctypes signature in _lib.SYMBOLS"
     assert set(_lib.SYMBOLS) == set(names)
-    assert lib.bts_abi_version() == _lib.ABI_VERSION == 3
+    assert lib.bts_abi_version() == _lib.ABI_VERSION == 4
 
 
 def test_ctypes_structs_match_the_c_layout():
@@ -52,6 +52,7 @@ int main(void) {
   printf("%zu %zu %zu %zu\n", offsetof(BtsFieldCfg, freq_factor), offsetof(BtsFieldTensors, mlp_params), offsetof(BtsRenderArgs, rays),
          offsetof(BtsRenderArgs, trans));
   printf("%zu %zu %zu\n", offsetof(BtsRenderArgs, invalid_wsum), offsetof(BtsRenderArgs, invalid_any), offsetof(BtsLossArgs, invalid_wsum));
+  printf("%zu %zu\n", offsetof(BtsRenderArgs, sigma_noise), offsetof(BtsFieldCfg, feat_shift));
   return 0;
 }'''
     with tempfile.TemporaryDirectory() as d:
@@ -65,8 +66,10 @@ int main(void) {
     out = out[2:]
     assert [int(x) for x in out[:4]] == sizes and [int(x) for x in out[4:8]] == offs
     # ABI 2: the loss epilogue's per-ray reductions, appended to both structs
-    assert [int(x) for x in out[8:]] == [_lib.BtsRenderArgs.invalid_wsum.offset, _lib.BtsRenderArgs.invalid_any.offset,
-                                         _lib.BtsLossArgs.invalid_wsum.offset]
+    assert [int(x) for x in out[8:11]] == [_lib.BtsRenderArgs.invalid_wsum.offset, _lib.BtsRenderArgs.invalid_any.offset,
+                                           _lib.BtsLossArgs.invalid_wsum.offset]
+    # ABI 3: the density noise; ABI 4: the feature map at its own scale -- both appended
+    assert [int(x) for x in out[11:]] == [_lib.BtsRenderArgs.sigma_noise.offset, _lib.BtsFieldCfg.feat_shift.offset]
 
 
 def test_host_only_entry_points(lib):
