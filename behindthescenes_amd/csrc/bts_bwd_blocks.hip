@@ -92,6 +92,31 @@ __device__ __forceinline__ void stage_weights_b(float* lb, const float* __restri
   }
 }
 
+// hidden_layer_h (bts_render_kernel.h) for ONE point tile: out += (W 2^S) . relu(in) 2^-S.  The tiles are independent columns of the
+// product and the three split terms enter in hidden_layer_h's order: bit-identical to the two-tile form.
+__device__ __forceinline__ void hidden_layer_h1(f32x16& out, const f32x16& in, const float* wl /* lane-resolved, this layer */, int term_stride,
+                                                float inv_scale) {
+#pragma unroll
+  for (int sl = 0; sl < 2; ++sl) {
+    const h8 ah = *reinterpret_cast<const h8*>(wl + sl * 256);
+    const h8 al = *reinterpret_cast<const h8*>(wl + term_stride + sl * 256);
+    _Float16 hi[8], lo[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float v = __builtin_amdgcn_fmed3f(in[8 * sl + i], 0.0f, 3.4028234663852886e38f) * inv_scale;
+      float vc = fminf(v, 6.0e4f);
+      asm("" : "+v"(vc));   // opaque fp32 value: both conversions below must see the same rounding (see f16_region)
+      hi[i] = (_Float16)vc;
+      lo[i] = (_Float16)(vc - (float)hi[i]);
+    }
+    const h8 bh = __builtin_bit_cast(h8, (u32x4){pack_h2(hi[0], hi[1]), pack_h2(hi[2], hi[3]), pack_h2(hi[4], hi[5]), pack_h2(hi[6], hi[7])});
+    const h8 bl = __builtin_bit_cast(h8, (u32x4){pack_h2(lo[0], lo[1]), pack_h2(lo[2], lo[3]), pack_h2(lo[4], lo[5]), pack_h2(lo[6], lo[7])});
+    out = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, out, 0, 0, 0);
+    out = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, out, 0, 0, 0);
+    out = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, out, 0, 0, 0);
+  }
+}
+
 // out += (W^T 2^S) . (in in_mul) for ONE point tile of one transposed ResnetBlockFC linear of width 32 on the f16 pipe (split precision,
 // the backward twin of hidden_layer_h): the lane's own 16 values of the tile in the C layout are the B operand of two 16-row k-slices.
 __device__ __forceinline__ void hidden_layer_ht(f32x16& out, const f32x16& in, const float* wl /* lane-resolved, this layer */, int term_stride,
@@ -210,7 +235,22 @@ __device__ __attribute__((noinline)) void lin_in_exact(const float* lb, const fl
 
 struct RowsbOut {
   float* u0_ws;   // (n*Bp, K, HD) g_h0 = gradient at lin_in's output, channels in the storage order of G
+#ifdef BTS_TICKS
+  unsigned long long* ticks;   // diagnostic build: [waves][16] cycles per section of the iteration (tools/rowsb_ticks.py)
+#endif
 };
+// diagnostic build (-DBTS_TICKS, behindthescenes_amd/variants): s_memtime at the section borders of rowsb_kernel.  Reading the counter
+// drains lgkmcnt, so the sections are somewhat longer than in the product; their shares are what the numbers are for.
+#ifdef BTS_TICKS
+#define RB_TICK(i)                                                   \
+  {                                                                  \
+    const unsigned long long t_now = __builtin_readcyclecounter();   \
+    t_acc[i] += t_now - t_last;                                      \
+    t_last = t_now;                                                  \
+  }
+#else
+#define RB_TICK(i)
+#endif
 
 // ---------------------------------------------------------------------------------------------------------------
 // pass A
@@ -306,25 +346,40 @@ __global__ __launch_bounds__(256, 2) void rowsb_kernel(const BwdParams bp, const
     s_pre = p.sigma_raw[pk], t_pre = p.trans[pk];
   };
   if (g >= 0) fetch_state(g, kc_last);
+#ifdef BTS_TICKS
+  unsigned long long t_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long t_last = __builtin_readcyclecounter();
+  const unsigned long long t_begin = t_last;
+  unsigned n_iter = 0;
+#endif
 
   for (; g >= 0; idx += waves_per_xcd, g = group_of(idx)) {
     auto qb = kernarg_view<BwdParams>();   // this iteration's parameters, re-read where they are used (bts_common.h: kernarg_view)
     asm volatile("" : "+s"(qb));
-    const int H = qb->f.H, W = qb->f.W, nv = qb->f.nv, fs = qb->f.fs;
+    IterHead ih(qb);   // (batching these scalar loads -- IterHeadT<true> -- changes nothing here either: 0.640 vs 0.634 ms, profiles/r03s)
+    const int H = ih.H, W = ih.W, nv = ih.nv, fs = ih.fs;
     const long ray = g;
     while (g >= sample_end) ++sample, sample_end += Bp;
-    const Cam enc = load_cam(qb->f.w2c_enc + sample * 16, qb->f.K_enc + sample * 9);
-    const float4* __restrict__ G = reinterpret_cast<const float4*>(qb->f.proj) + (long)sample * (H >> fs) * (W >> fs) * (HD / 4);
-    const cfp rp = as_const(qb->f.rays) + ray * 8;
+    const Cam enc = load_cam(ih.w2c_enc + sample * 16, ih.K_enc + sample * 9);
+    const float4* __restrict__ G = reinterpret_cast<const float4*>(ih.proj) + (long)sample * (H >> fs) * (W >> fs) * (HD / 4);
+    const cfp rp = as_const(ih.rays) + ray * 8;
     const float ox = rp[0], oy = rp[1], oz = rp[2], dx = rp[3], dy = rp[4], dz = rp[5];
     // upstream gradients of the ray
     float g_rgb[NVMAX * 3];
     float g_bkgd = 0.0f;
     {
-      const cfp gr = as_const(qb->g_rgb) + ray * (long)(nv * 3);
+      // one batch of scalar loads (index clamped, the entries beyond nv zeroed by selects): a condition per entry is a branch, a load and
+      // a wait per entry
+#pragma unroll
+      for (int i = 0; i < NVMAX * 3; ++i) g_rgb[i] = 0.0f;
+      if (qb->g_rgb) {
+        const cfp gr = as_const(qb->g_rgb) + ray * (long)(nv * 3);
+#pragma unroll
+        for (int i = 0; i < NVMAX * 3; ++i) g_rgb[i] = gr[min(i, nv * 3 - 1)];
+      }
 #pragma unroll
       for (int i = 0; i < NVMAX * 3; ++i) {
-        g_rgb[i] = (qb->g_rgb && i < nv * 3) ? gr[i] : 0.0f;
+        g_rgb[i] = i < nv * 3 ? g_rgb[i] : 0.0f;
         g_bkgd -= g_rgb[i];
       }
     }
@@ -350,20 +405,67 @@ __global__ __launch_bounds__(256, 2) void rowsb_kernel(const BwdParams bp, const
       asm volatile("" : "+v"(h));   // keep the weight reads inside the persistent loop (see render_kernel_p)
       const float px = ox + z * dx, py = oy + z * dy, pz = oz + z * dz;
 
+      // ---------------- the forward's per-sample colours (and the optional per-sample upstream gradients): loads issued here, used behind
+      // the geometry and the first gather blocks -- read where they are needed, each is a full memory round trip with the wave idle.
+      // (Issuing them one chunk ahead, in front of the previous chunk's row stores -- vmcnt retires in order, a load behind the stores
+      // is back when they are -- was tried: the nine registers it keeps alive cost more in spills than the wait, 0.676 vs 0.629 ms.)
+      float cs_v[NVMAX * 3];
+#ifdef BTS_ABL_B1   // timing ablation: no per-sample colour loads
+      const bool have_cs = false;
+#else
+      const bool have_cs = qb->f.rgb_samps != nullptr;
+#endif
+#pragma unroll
+      for (int i = 0; i < NVMAX * 3; ++i) cs_v[i] = 0.0f;
+      if (have_cs) {
+        const float* cs = qb->f.rgb_samps + pk * (long)(nv * 3);
+#pragma unroll
+        for (int i = 0; i < NVMAX * 3; ++i) cs_v[i] = cs[min(i, nv * 3 - 1)];   // entries beyond nv meet g_rgb = 0
+      }
+      const float gw_k = qb->g_weights ? qb->g_weights[pk] : 0.0f;
+      const float ga_k = qb->g_alphas ? qb->g_alphas[pk] : 0.0f;
+
+      // ---------------- encoder view
+      const Proj pe = ih.code_mode == 1 ? project<true>(enc, px, py, pz) : project<false>(enc, px, py, pz);
+      Taps tp = make_taps(pe.x, pe.y, H, W, fs);
+      float v3[3];
+      v3[0] = pe.x, v3[1] = pe.y;
+      v3[2] = depth_code(ih.code_mode == 1 ? pe.dist : pe.z, ih.inv_z != 0, ih.inv_dmax, ih.inv_range, ih.d_min, ih.range);
+      const bool use_empty = (ih.learn_empty != 0) & pe.invalid;
+      if (use_empty) tp.w00 = tp.w01 = tp.w10 = tp.w11 = 0.0f;
+      tp.w00 *= scale, tp.w01 *= scale, tp.w10 *= scale, tp.w11 *= scale;
+
+      float wq[2][4];
+      bool emp[2];
+      {
+        unsigned t0, t1;
+        bcast_tiles(__float_as_uint(tp.w00), t0, t1), wq[0][0] = __uint_as_float(t0), wq[1][0] = __uint_as_float(t1);
+        bcast_tiles(__float_as_uint(tp.w01), t0, t1), wq[0][1] = __uint_as_float(t0), wq[1][1] = __uint_as_float(t1);
+        bcast_tiles(__float_as_uint(tp.w10), t0, t1), wq[0][2] = __uint_as_float(t0), wq[1][2] = __uint_as_float(t1);
+        bcast_tiles(__float_as_uint(tp.w11), t0, t1), wq[0][3] = __uint_as_float(t0), wq[1][3] = __uint_as_float(t1);
+        bcast_tiles(use_empty ? 1u : 0u, t0, t1), emp[0] = t0 != 0, emp[1] = t1 != 0;
+      }
+      const bool cold = __any(pe_needs_exact(v3, ih.freq_factor));
+      unsigned off_next[4];
+      GRows rows;
+      if (__builtin_expect(!cold, 1)) {
+        // the previous iteration's tile reads have returned (s_waitcnt at its end): the ring may be overwritten
+        wave_lds_fence();
+        gl.tab[lane * 3 + 0] = (unsigned)tp.o00 * (HD * 4u), gl.tab[lane * 3 + 1] = (unsigned)tp.o01 * (HD * 4u), gl.tab[lane * 3 + 2] = (unsigned)tp.o10 * (HD * 4u);   // o11 = o10 + (o01 - o00)
+        wave_lds_fence();
+        gl_prologue<HD>(gl, rows, G, off_next);
+      }
+      RB_TICK(0)   // ray / gradient loads issued, geometry, taps, table, first three blocks out
+
       // ---------------- upstream gradient of this sample's weight: g_w = g_depth z + sum_j g_rgb_j . c_kj (+ g_weights_k)
       float g_w = g_depth * z;
       {
         if (qb->f.white_bkgd) g_w += g_bkgd;   // nerf.py:301-304: rgb = sum_k w_k c_k + 1 - sum_k w_k
-        if (qb->g_weights) g_w += qb->g_weights[pk];
-#ifdef BTS_ABL_B1   // timing ablation: no per-sample colour loads
-        if (false) {
-#else
-        if (qb->f.rgb_samps) {
-#endif
-          const float* cs = qb->f.rgb_samps + pk * (long)(nv * 3);
+        g_w += gw_k;
+        if (have_cs) {
 #pragma unroll
           for (int j = 0; j < NVMAX; ++j)
-            if (j < nv) g_w += g_rgb[3 * j] * cs[3 * j] + g_rgb[3 * j + 1] * cs[3 * j + 1] + g_rgb[3 * j + 2] * cs[3 * j + 2];
+            g_w += g_rgb[3 * j] * cs_v[3 * j] + g_rgb[3 * j + 1] * cs_v[3 * j + 1] + g_rgb[3 * j + 2] * cs_v[3 * j + 2];
         } else {
 #pragma unroll
           for (int j = 0; j < NVMAX; ++j) {
@@ -382,36 +484,6 @@ __global__ __launch_bounds__(256, 2) void rowsb_kernel(const BwdParams bp, const
         }
       }
 
-      // ---------------- encoder view
-      const Proj pe = qb->f.code_mode == 1 ? project<true>(enc, px, py, pz) : project<false>(enc, px, py, pz);
-      Taps tp = make_taps(pe.x, pe.y, H, W, fs);
-      float v3[3];
-      v3[0] = pe.x, v3[1] = pe.y;
-      v3[2] = depth_code(qb->f.code_mode == 1 ? pe.dist : pe.z, qb->f.inv_z != 0, qb->f.inv_dmax, qb->f.inv_range, qb->f.d_min, qb->f.range);
-      const bool use_empty = (qb->f.learn_empty != 0) & pe.invalid;
-      if (use_empty) tp.w00 = tp.w01 = tp.w10 = tp.w11 = 0.0f;
-      tp.w00 *= scale, tp.w01 *= scale, tp.w10 *= scale, tp.w11 *= scale;
-
-      float wq[2][4];
-      bool emp[2];
-      {
-        unsigned t0, t1;
-        bcast_tiles(__float_as_uint(tp.w00), t0, t1), wq[0][0] = __uint_as_float(t0), wq[1][0] = __uint_as_float(t1);
-        bcast_tiles(__float_as_uint(tp.w01), t0, t1), wq[0][1] = __uint_as_float(t0), wq[1][1] = __uint_as_float(t1);
-        bcast_tiles(__float_as_uint(tp.w10), t0, t1), wq[0][2] = __uint_as_float(t0), wq[1][2] = __uint_as_float(t1);
-        bcast_tiles(__float_as_uint(tp.w11), t0, t1), wq[0][3] = __uint_as_float(t0), wq[1][3] = __uint_as_float(t1);
-        bcast_tiles(use_empty ? 1u : 0u, t0, t1), emp[0] = t0 != 0, emp[1] = t1 != 0;
-      }
-      const bool cold = __any(pe_needs_exact(v3, qb->f.freq_factor));
-      unsigned off_next[4];
-      GRows rows;
-      if (__builtin_expect(!cold, 1)) {
-        // the previous iteration's tile reads have returned (s_waitcnt at its end): the ring may be overwritten
-        wave_lds_fence();
-        gl.tab[lane * 3 + 0] = (unsigned)tp.o00 * (HD * 4u), gl.tab[lane * 3 + 1] = (unsigned)tp.o01 * (HD * 4u), gl.tab[lane * 3 + 2] = (unsigned)tp.o10 * (HD * 4u);   // o11 = o10 + (o01 - o00)
-        wave_lds_fence();
-        gl_prologue<HD>(gl, rows, G, off_next);
-      }
 
       // ---------------- compositing gradient (nerf.py:283-299):  g_alpha_k = g_w_k T_k - (sum_{m>k} g_w_m w_m) / (1 - alpha_k + 1e-10)
       float g_s = 0.0f;
@@ -439,11 +511,12 @@ __global__ __launch_bounds__(256, 2) void rowsb_kernel(const BwdParams bp, const
         const float S = (lane == 63 ? 0.0f : below) + S_carry;
         S_carry += __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, incl)));
         float g_alpha = g_w * T - S / (capped ? 1e-10f : ex + 1e-10f);
-        if (qb->g_alphas) g_alpha += qb->g_alphas[pk];
+        g_alpha += ga_k;
         if (!capped && !dead && !cut && valid) g_s = g_alpha * fabsf(delta) * ex * (s_raw > 20.0f ? 1.0f : sigmoidf(s_raw));
         if (valid) qb->gs_ws[pk] = g_s;
       }
       db_acc += g_s;
+      RB_TICK(1)   // compositing gradient (waits for the per-sample loads above)
 
       // ---------------- h0 = bilinear(G) + W_pe . PE + b, exactly as render_kernel_p evaluates it (accumulators carry 2^S)
       f32x16 acc[HT][2];
@@ -479,11 +552,11 @@ __global__ __launch_bounds__(256, 2) void rowsb_kernel(const BwdParams bp, const
             }
         }
         SinCos3 raw;
-        pe_direct(raw, v3, qb->f.freq_factor);
+        pe_direct(raw, v3, ih.freq_factor);
         __builtin_amdgcn_sched_barrier(0);
         int lane4 = lane * 4;
         asm volatile("" : "+v"(lane4));
-        region_seq_l<HD, 0>(acc, gl, rows, G, wq, off_next, lh + LH::W_F16 + lane4, LH::TERM_STRIDE, raw, v3, qb->f.freq_factor, bias);
+        region_seq_l<HD, 0>(acc, gl, rows, G, wq, off_next, lh + LH::W_F16 + lane4, LH::TERM_STRIDE, raw, v3, ih.freq_factor, bias);
         if constexpr (NS > kNumFreqs) {
           gl_consume<HD, 12>(acc, gl, rows, G, wq, off_next), gl_consume<HD, 13>(acc, gl, rows, G, wq, off_next);
           gl_consume<HD, 14>(acc, gl, rows, G, wq, off_next), gl_consume<HD, 15>(acc, gl, rows, G, wq, off_next);
@@ -500,60 +573,64 @@ __global__ __launch_bounds__(256, 2) void rowsb_kernel(const BwdParams bp, const
         }
       }
 
-      // ---------------- ResnetBlockFC layers, forward (as render_kernel_p): keep the block's input h0 and its inner activation n
-      f32x16 hin[NB > 0 ? NB : 1][2], net[NB > 0 ? NB : 1][2];
-      int lane4b = lane * 4;
-      asm volatile("" : "+v"(lane4b));
-      if constexpr (NB > 0) {
-#pragma unroll
-      for (int b = 0; b < NB; ++b) {
-        hin[b][0] = acc[0][0], hin[b][1] = acc[0][1];
-        f32x16 nt[1][2];
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          const float bias = lh[LH::BIAS + b * 2 * HD + mfma_row(q, 0) + 4 * h];
-          nt[0][0][q] = bias, nt[0][1][q] = bias;
-        }
-        hidden_layer_h(nt, acc, lh + LH::W_BLK + (2 * b) * LH::BLK_LAYER_STRIDE + lane4b, LH::BLK_TERM_STRIDE, inv_scale);
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          const float bias = lh[LH::BIAS + b * 2 * HD + HD + mfma_row(q, 0) + 4 * h];
-          acc[0][0][q] += bias, acc[0][1][q] += bias;
-        }
-        hidden_layer_h(acc, nt, lh + LH::W_BLK + (2 * b + 1) * LH::BLK_LAYER_STRIDE + lane4b, LH::BLK_TERM_STRIDE, inv_scale);
-        net[b][0] = nt[0][0], net[b][1] = nt[0][1];
-      }
-      }
-
-      // ---------------- g_s of both point tiles; dw_out += relu(h1) g_s (2^S removed through g_s)
-      float gs_t[2];
+      RB_TICK(2)   // forward pipeline: gather + encoding + lin_in
+      // ---------------- g_s of both point tiles
+      float gs_t[2], gs_v[2];
       {
         unsigned t0, t1;
         bcast_tiles(__float_as_uint(g_s), t0, t1);
         gs_t[0] = __uint_as_float(t0), gs_t[1] = __uint_as_float(t1);
+        gs_v[0] = gs_t[0] * inv_s_v, gs_v[1] = gs_t[1] * inv_s_v;   // exact (a power of two): the vectors below carry s_v
       }
-#pragma unroll
-      for (int ht = 0; ht < HT; ++ht) {
-        float r[16];
-#pragma unroll
-        for (int q = 0; q < 16; ++q)
-          r[q] = __builtin_fmaf(relu1(acc[ht][1][q]), gs_t[1] * inv_scale, relu1(acc[ht][0][q]) * (gs_t[0] * inv_scale));
-        // dw_acc[ht] belongs to channel ht*32 + mfma_row(col >> 1, h), on both lanes of the pair
-#ifdef BTS_ABL_B4   // timing ablation: no butterfly
-        dw_acc[ht] += r[0] + r[5] + r[15];
-#else
-        dw_acc[ht] += half_reduce16(r, col);
-#endif
-      }
-      gs_t[0] *= inv_s_v, gs_t[1] *= inv_s_v;    // exact (a power of two): the vectors below carry s_v
-
-      // ---------------- one point tile (32 samples) at a time -- the transient vectors of the block backward are 16 registers each
-      // instead of 32: v = m1 . w_out, then back through the blocks (resnetfc.py:53-62: h1 = h0 + fc_1(relu(n)), n = fc_0(relu(h0))),
+      // ---------------- one point tile (32 samples) at a time, forward through the ResnetBlockFC layers AND back: the block's input
+      // h0, its inner activation n, its output h1 and the transient vectors of the backward are 16 registers each instead of 32 (both
+      // tiles at once cost 64 spilled VGPRs and 150 scratch accesses per ray).  The tiles are independent columns of every product, so
+      // the values -- and the relu gates -- are those of render_kernel_p bit for bit.
+      // Backward of a tile: v = m1 . w_out, then back through the blocks (resnetfc.py:53-62: h1 = h0 + fc_1(relu(n)), n = fc_0(relu(h0))),
       // the fc_0 / fc_1 weight gradients of the tile, and u0 = g_s v0, the gradient row at lin_in's output
+      int lane4b = lane * 4;
+      asm volatile("" : "+v"(lane4b));
       int lane4t = lane * 4;
       asm volatile("" : "+v"(lane4t));   // opaque per iteration: the A operands of the transposed products stay inside the persistent loop
+      float r_out[HT][16];   // dw_out += relu(h1) g_s (2^S removed through g_s), summed over the two tiles before the butterfly
 #pragma unroll
       for (int pt = 0; pt < 2; ++pt) {
+        f32x16 hin[NB > 0 ? NB : 1], net[NB > 0 ? NB : 1];
+        if constexpr (NB > 0) {
+#pragma unroll
+          for (int b = 0; b < NB; ++b) {
+            hin[b] = acc[0][pt];
+            f32x16 nt;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) nt[q] = lh[LH::BIAS + b * 2 * HD + mfma_row(q, 0) + 4 * h];
+            hidden_layer_h1(nt, acc[0][pt], lh + LH::W_BLK + (2 * b) * LH::BLK_LAYER_STRIDE + lane4b, LH::BLK_TERM_STRIDE, inv_scale);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[0][pt][q] += lh[LH::BIAS + b * 2 * HD + HD + mfma_row(q, 0) + 4 * h];
+            hidden_layer_h1(acc[0][pt], nt, lh + LH::W_BLK + (2 * b + 1) * LH::BLK_LAYER_STRIDE + lane4b, LH::BLK_TERM_STRIDE, inv_scale);
+            net[b] = nt;
+          }
+        }
+        RB_TICK(3)   // block forward of the tile
+#pragma unroll
+        for (int ht = 0; ht < HT; ++ht)
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            // (the order of the two-tile form: relu(h1[1]) g_s[1] + relu(h1[0]) g_s[0] as one fma on top of the first product)
+            if (pt == 0) r_out[ht][q] = relu1(acc[ht][0][q]) * (gs_t[0] * inv_scale);
+            else r_out[ht][q] = __builtin_fmaf(relu1(acc[ht][1][q]), gs_t[1] * inv_scale, r_out[ht][q]);
+          }
+        if (pt == 1) {   // both tiles are in: the butterfly now, so that its 16 registers are free during this tile's backward
+          // dw_acc[ht] belongs to channel ht*32 + mfma_row(col >> 1, h), on both lanes of the pair
+#pragma unroll
+          for (int ht = 0; ht < HT; ++ht) {
+#ifdef BTS_ABL_B4   // timing ablation: no butterfly
+            dw_acc[ht] += r_out[ht][0] + r_out[ht][5] + r_out[ht][15];
+#else
+            dw_acc[ht] += half_reduce16(r_out[ht], col);
+#endif
+          }
+          RB_TICK(4)   // dw_out
+        }
         f32x16 v[HT];   // the gate-dependent vector of the current layer times s_v (g_h = (g_s / s_v) v)
 #pragma unroll
         for (int ht = 0; ht < HT; ++ht)
@@ -574,7 +651,8 @@ __global__ __launch_bounds__(256, 2) void rowsb_kernel(const BwdParams bp, const
             hidden_layer_ht(vn, v[0], wt + L::BLK_LAYER_STRIDE, L::BLK_TERM_STRIDE, 1.0f);
 #endif
 #pragma unroll
-            for (int q = 0; q < 16; ++q) vn[q] = net[b][pt][q] > 0.0f ? vn[q] * inv_scale : 0.0f;
+            for (int q = 0; q < 16; ++q) vn[q] = net[b][q] > 0.0f ? vn[q] * inv_scale : 0.0f;
+            RB_TICK(5)   // v, vn = mn . W1^T v
 #ifdef BTS_ABL_B3   // timing ablation: no fc_0 / fc_1 weight gradients
             if (false) {
 #else
@@ -584,8 +662,8 @@ __global__ __launch_bounds__(256, 2) void rowsb_kernel(const BwdParams bp, const
               wave_lds_fence();
 #pragma unroll
               for (int q = 0; q < 16; ++q) {
-                tile_a[col * 33 + mfma_row(q, h)] = v[0][q] * gs_t[pt];
-                tile_b[col * 33 + mfma_row(q, h)] = relu1(net[b][pt][q]) * inv_scale;
+                tile_a[col * 33 + mfma_row(q, h)] = v[0][q] * gs_v[pt];
+                tile_b[col * 33 + mfma_row(q, h)] = relu1(net[b][q]) * inv_scale;
               }
               wave_lds_fence();
 #pragma unroll 4
@@ -596,6 +674,7 @@ __global__ __launch_bounds__(256, 2) void rowsb_kernel(const BwdParams bp, const
                 dwb[b][1] = mfma(a, tile_b[pnt * 33 + col], dwb[b][1]);
               }
             }
+            RB_TICK(6)   // dW1 tiles
             // t2 = W0^T vn;  v <- v + m0 . t2
             f32x16 t2 = zero_acc();
 #ifdef BTS_ABL_B5
@@ -609,11 +688,12 @@ __global__ __launch_bounds__(256, 2) void rowsb_kernel(const BwdParams bp, const
             if (qb->d_mlp) {
 #endif
               // dW0[out][in] += sum_p (g_s vn)[p][out] relu(h0)[p][in];  db0[out] += sum_p (g_s vn)[p][out]
+              RB_TICK(7)   // t2 = W0^T vn
               wave_lds_fence();
 #pragma unroll
               for (int q = 0; q < 16; ++q) {
-                tile_a[col * 33 + mfma_row(q, h)] = vn[q] * gs_t[pt];
-                tile_b[col * 33 + mfma_row(q, h)] = relu1(hin[b][pt][q]) * inv_scale;
+                tile_a[col * 33 + mfma_row(q, h)] = vn[q] * gs_v[pt];
+                tile_b[col * 33 + mfma_row(q, h)] = relu1(hin[b][q]) * inv_scale;
               }
               wave_lds_fence();
 #pragma unroll 4
@@ -625,7 +705,8 @@ __global__ __launch_bounds__(256, 2) void rowsb_kernel(const BwdParams bp, const
               }
             }
 #pragma unroll
-            for (int q = 0; q < 16; ++q) v[0][q] += hin[b][pt][q] > 0.0f ? t2[q] * inv_scale : 0.0f;
+            for (int q = 0; q < 16; ++q) v[0][q] += hin[b][q] > 0.0f ? t2[q] * inv_scale : 0.0f;
+            RB_TICK(8)   // dW0 tiles
           }
         }
         // u0 = g_s v: one row per sample in the storage order of G (this lane's 16 accumulator rows of a hidden tile are 64 contiguous
@@ -633,7 +714,7 @@ __global__ __launch_bounds__(256, 2) void rowsb_kernel(const BwdParams bp, const
         if (ro.u0_ws) {
           const int ks = kc + pt * 32 + col;
 #ifdef BTS_ABL_B2   // timing ablation: no row stores
-          if (ks < K && gs_t[pt] == 12345.0f) {
+          if (ks < K && gs_v[pt] == 12345.0f) {
 #else
           if (ks < K) {
 #endif
@@ -642,15 +723,27 @@ __global__ __launch_bounds__(256, 2) void rowsb_kernel(const BwdParams bp, const
             for (int ht = 0; ht < HT; ++ht)
 #pragma unroll
               for (int j = 0; j < 4; ++j)
-                dst[ht * 8 + 4 * h + j] = make_float4(v[ht][4 * j] * gs_t[pt], v[ht][4 * j + 1] * gs_t[pt], v[ht][4 * j + 2] * gs_t[pt],
-                                                      v[ht][4 * j + 3] * gs_t[pt]);
+                dst[ht * 8 + 4 * h + j] = make_float4(v[ht][4 * j] * gs_v[pt], v[ht][4 * j + 1] * gs_v[pt], v[ht][4 * j + 2] * gs_v[pt],
+                                                      v[ht][4 * j + 3] * gs_v[pt]);
           }
         }
       }
+      RB_TICK(9)   // u0 row stores issued
       // the tile reads of this iteration must have returned before the next iteration's gather lands in the ring
       if constexpr (NB > 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifdef BTS_TICKS
+      ++n_iter;
+#endif
     }
   }
+#ifdef BTS_TICKS
+  if (ro.ticks && lane == 0) {
+    unsigned long long* d = ro.ticks + ((long)blockIdx.x * 4 + wave) * 16;
+#pragma unroll
+    for (int i = 0; i < 10; ++i) d[i] = t_acc[i];
+    d[14] = n_iter, d[15] = __builtin_readcyclecounter() - t_begin;
+  }
+#endif
 
   // ---------------- flush: wave registers -> work-group LDS (the gather rings, idle now) -> one global atomic per parameter
   __syncthreads();
@@ -720,6 +813,10 @@ static int launch_rowsb(const BwdParams& bp, const RowsbOut& ro, int grid, hipSt
 int launch_bwd_blocks(const BwdParams& bp, float* u0_ws, int C, int HD, int NB, int n, int grid, hipStream_t s) {
   RowsbOut ro;
   ro.u0_ws = (bp.d_proj || bp.d_empty_proj || bp.d_mlp) ? u0_ws : nullptr;
+#ifdef BTS_TICKS
+  ro.ticks = nullptr;
+  if (const char* e = getenv("BTS_DBG_PTR")) ro.ticks = (unsigned long long*)strtoull(e, nullptr, 0);
+#endif
   int rc = BTS_E_UNSUPPORTED;
   if (C == 64 && HD == 64 && NB == 0) rc = launch_rowsb<64, 64, 0>(bp, ro, grid, s);
   else if (C == 32 && HD == 32 && NB == 1) rc = launch_rowsb<32, 32, 1>(bp, ro, grid, s);

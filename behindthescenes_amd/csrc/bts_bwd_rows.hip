@@ -270,42 +270,37 @@ __global__ __launch_bounds__(256, 2) void rows_kernel(const BwdParams bp) {
     const float px = ox + z * dx, py = oy + z * dy, pz = oz + z * dz;
     const long pk = ray * K + kk;
 
-    // ---------------- upstream gradient of this sample's weight: g_w = g_depth z + sum_j g_rgb_j . c_kj (+ g_weights_k)
-    float g_w = 0.0f;
+    // ---------------- the ray's upstream gradients (one batch of scalar loads: index clamped, the entries beyond nv zeroed by selects -- a
+    // condition per entry is a branch, a load and a wait per entry) and the forward's per-sample colours: issued here, used behind the
+    // geometry and the first gather blocks (read where they are needed, each is a full memory round trip with the wave idle)
+    float g_rgb[NVMAX * 3];
+    float g_bkgd = 0.0f;
     {
-      const cfp gr = as_const(qb->g_rgb) + ray * (long)(nv * 3);
-      float g_rgb[NVMAX * 3];
-      float g_bkgd = 0.0f;
+#pragma unroll
+      for (int i = 0; i < NVMAX * 3; ++i) g_rgb[i] = 0.0f;
+      if (qb->g_rgb) {
+        const cfp gr = as_const(qb->g_rgb) + ray * (long)(nv * 3);
+#pragma unroll
+        for (int i = 0; i < NVMAX * 3; ++i) g_rgb[i] = gr[min(i, nv * 3 - 1)];
+      }
 #pragma unroll
       for (int i = 0; i < NVMAX * 3; ++i) {
-        g_rgb[i] = (qb->g_rgb && i < nv * 3) ? gr[i] : 0.0f;
+        g_rgb[i] = i < nv * 3 ? g_rgb[i] : 0.0f;
         g_bkgd -= g_rgb[i];
       }
-      if (qb->g_depth) g_w = as_const(qb->g_depth)[ray] * z;
-      if (qb->f.white_bkgd) g_w += g_bkgd;   // nerf.py:301-304: rgb = sum_k w_k c_k + 1 - sum_k w_k
-      if (qb->g_weights) g_w += qb->g_weights[pk];
-      if (qb->f.rgb_samps) {
-        const float* cs = qb->f.rgb_samps + pk * (long)(nv * 3);
-#pragma unroll
-        for (int j = 0; j < NVMAX; ++j)
-          if (j < nv) g_w += g_rgb[3 * j] * cs[3 * j] + g_rgb[3 * j + 1] * cs[3 * j + 1] + g_rgb[3 * j + 2] * cs[3 * j + 2];
-      } else {
-#pragma unroll
-        for (int j = 0; j < NVMAX; ++j) {
-          if (j < nv) {
-            const Cam cj = load_cam(qb->f.w2c_r + ((long)sample * nv + j) * 16, qb->f.K_r + ((long)sample * nv + j) * 9);
-            const Proj pc = project<false>(cj, px, py, pz);
-            const Taps tc = make_taps(pc.x, pc.y, H, W);
-            const float4* img = reinterpret_cast<const float4*>(qb->f.imgs) + ((long)sample * nv + j) * H * W;
-            const float4 a = img[tc.o00], b = img[tc.o01], cc = img[tc.o10], d = img[tc.o11];
-            const float c0 = ((a.x * tc.w00 + b.x * tc.w01) + cc.x * tc.w10) + d.x * tc.w11;
-            const float c1 = ((a.y * tc.w00 + b.y * tc.w01) + cc.y * tc.w10) + d.y * tc.w11;
-            const float c2 = ((a.z * tc.w00 + b.z * tc.w01) + cc.z * tc.w10) + d.z * tc.w11;
-            g_w += g_rgb[3 * j] * c0 + g_rgb[3 * j + 1] * c1 + g_rgb[3 * j + 2] * c2;
-          }
-        }
-      }
     }
+    const float g_depth = qb->g_depth ? as_const(qb->g_depth)[ray] : 0.0f;
+    float cs_v[NVMAX * 3];
+    const bool have_cs = qb->f.rgb_samps != nullptr;
+#pragma unroll
+    for (int i = 0; i < NVMAX * 3; ++i) cs_v[i] = 0.0f;
+    if (have_cs) {
+      const float* cs = qb->f.rgb_samps + pk * (long)(nv * 3);
+#pragma unroll
+      for (int i = 0; i < NVMAX * 3; ++i) cs_v[i] = cs[min(i, nv * 3 - 1)];   // entries beyond nv meet g_rgb = 0
+    }
+    const float gw_k = qb->g_weights ? qb->g_weights[pk] : 0.0f;
+    const float ga_k = qb->g_alphas ? qb->g_alphas[pk] : 0.0f;
 
     // ---------------- encoder view
     const Proj pe = qb->f.code_mode == 1 ? project<true>(enc, px, py, pz) : project<false>(enc, px, py, pz);
@@ -354,6 +349,33 @@ __global__ __launch_bounds__(256, 2) void rows_kernel(const BwdParams bp) {
 #endif
 #endif
 
+    // ---------------- upstream gradient of this sample's weight: g_w = g_depth z + sum_j g_rgb_j . c_kj (+ g_weights_k)
+    float g_w = qb->g_depth ? g_depth * z : 0.0f;
+    {
+      if (qb->f.white_bkgd) g_w += g_bkgd;   // nerf.py:301-304: rgb = sum_k w_k c_k + 1 - sum_k w_k
+      g_w += gw_k;
+      if (have_cs) {
+#pragma unroll
+        for (int j = 0; j < NVMAX; ++j)
+          g_w += g_rgb[3 * j] * cs_v[3 * j] + g_rgb[3 * j + 1] * cs_v[3 * j + 1] + g_rgb[3 * j + 2] * cs_v[3 * j + 2];
+      } else {
+#pragma unroll
+        for (int j = 0; j < NVMAX; ++j) {
+          if (j < nv) {
+            const Cam cj = load_cam(qb->f.w2c_r + ((long)sample * nv + j) * 16, qb->f.K_r + ((long)sample * nv + j) * 9);
+            const Proj pc = project<false>(cj, px, py, pz);
+            const Taps tc = make_taps(pc.x, pc.y, H, W);
+            const float4* img = reinterpret_cast<const float4*>(qb->f.imgs) + ((long)sample * nv + j) * H * W;
+            const float4 a = img[tc.o00], b = img[tc.o01], cc = img[tc.o10], d = img[tc.o11];
+            const float c0 = ((a.x * tc.w00 + b.x * tc.w01) + cc.x * tc.w10) + d.x * tc.w11;
+            const float c1 = ((a.y * tc.w00 + b.y * tc.w01) + cc.y * tc.w10) + d.y * tc.w11;
+            const float c2 = ((a.z * tc.w00 + b.z * tc.w01) + cc.z * tc.w10) + d.z * tc.w11;
+            g_w += g_rgb[3 * j] * c0 + g_rgb[3 * j + 1] * c1 + g_rgb[3 * j + 2] * c2;
+          }
+        }
+      }
+    }
+
     // ---------------- compositing gradient (nerf.py:283-299):  g_alpha_k = g_w_k T_k - (sum_{m>k} g_w_m w_m) / (1 - alpha_k + 1e-10)
     float g_s = 0.0f;
     {
@@ -372,7 +394,7 @@ __global__ __launch_bounds__(256, 2) void rows_kernel(const BwdParams bp) {
       const float S = wave_suffix_excl(valid ? g_w * (alpha * T) : 0.0f, lane);
 #endif
       float g_alpha = g_w * T - S / (capped ? 1e-10f : ex + 1e-10f);
-      if (qb->g_alphas) g_alpha += qb->g_alphas[pk];
+      g_alpha += ga_k;
       if (!capped && !dead && !cut && valid) g_s = g_alpha * fabsf(delta) * ex * (s_raw > 20.0f ? 1.0f : sigmoidf(s_raw));
       if (valid) qb->gs_ws[pk] = g_s;
     }

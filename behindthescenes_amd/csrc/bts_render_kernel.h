@@ -515,6 +515,39 @@ __device__ __attribute__((noinline)) float eval_point_exact(const float* lds, co
   return eval_point<C, HD, NB, true>(q, lds, enc, G, (int)(threadIdx.x & 63), b_out, px, py, pz, pe);
 }
 
+// What the top of an iteration of the persistent kernels needs of the kernel parameters (cameras, ray, sample positions, projection,
+// depth code).  With PIN they are fetched from the kernarg segment in ONE batch (the empty asm takes every member as an
+// operand, so the compiler has to issue all the scalar loads in front of it and waits once) instead of in ten dependent round trips;
+// measured, that loses (below), so the product reads them where they are used like every other parameter.
+template <bool PIN>
+struct IterHeadT {
+  const float* w2c_enc;
+  const float* K_enc;
+  const float* proj;
+  const float* rays;
+  const float* z_samp;
+  int K, H, W, nv, fs, code_mode, inv_z, learn_empty;
+  float inv_dmax, inv_range, d_min, range, freq_factor;
+  template <typename Q>
+  __device__ __forceinline__ explicit IterHeadT(Q q) {
+    const FwdParams __attribute__((address_space(4)))* f = head_of(q);
+    w2c_enc = f->w2c_enc, K_enc = f->K_enc, proj = f->proj, rays = f->rays, z_samp = f->z_samp;
+    K = f->K, H = f->H, W = f->W, nv = f->nv, fs = f->fs, code_mode = f->code_mode, inv_z = f->inv_z, learn_empty = f->learn_empty;
+    inv_dmax = f->inv_dmax, inv_range = f->inv_range, d_min = f->d_min, range = f->range, freq_factor = f->freq_factor;
+    // A/B (profiles/r03q): with the pin the FORWARD is 1.5 % slower -- the second wave of the SIMD hides the scalar round trips, and
+    // the 22 more spilled SGPRs are VALU instructions in a VALU-bound loop.  Without it this struct is only a list of names: the
+    // compiler sinks every load to its use.  The backward's pass A is the other way round (it waits, it does not issue): PIN = true.
+    if constexpr (PIN)
+    asm volatile("" : "+s"(w2c_enc), "+s"(K_enc), "+s"(proj), "+s"(rays), "+s"(z_samp), "+s"(K), "+s"(H), "+s"(W), "+s"(nv), "+s"(fs),
+                 "+s"(code_mode), "+s"(inv_z), "+s"(learn_empty), "+s"(inv_dmax), "+s"(inv_range), "+s"(d_min), "+s"(range), "+s"(freq_factor));
+  }
+  // the FwdParams at the head of the parameter block: the block itself (forward) or its first member (backward / query blocks)
+  static __device__ __forceinline__ const FwdParams __attribute__((address_space(4)))* head_of(const FwdParams __attribute__((address_space(4)))* q) { return q; }
+  template <typename B>
+  static __device__ __forceinline__ const FwdParams __attribute__((address_space(4)))* head_of(const B __attribute__((address_space(4)))* q) { return &q->f; }
+};
+using IterHead = IterHeadT<false>;
+
 // EPI: also reduce weights * invalid and max invalid over each ray's samples (BtsRenderArgs.invalid_wsum / invalid_any).  A template
 // parameter, not a run-time test: the evaluation instantiations carry no trace of it (16 more spilled SGPRs otherwise).
 template <int C, int HD, int NB, int NVMAX, bool ONE_RAY, bool F16, bool EPI = false>
@@ -606,28 +639,29 @@ __global__ __launch_bounds__(256, 2) void render_kernel_p(const FwdParams p) {
     // whole life of the kernel (bts_common.h: kernarg_view)
     auto q = kernarg_view<FwdParams>();
     asm volatile("" : "+s"(q));
-    const int K = q->K, H = q->H, W = q->W, nv = q->nv, fs = q->fs;
+    IterHead ih(q);   // the geometry's share of the parameters (see IterHead: batching their loads was measured and not kept)
+    const int K = ih.K, H = ih.H, W = ih.W, nv = ih.nv, fs = ih.fs;
     const long ray = (long)g * R + lane / lpr;
     // all rays of a group belong to one batch element; g only grows along a wave's chunk list, so the element is tracked by a
     // running boundary (the 64-bit division this replaces was ~140 dependent scalar instructions at the top of every iteration)
     while (g >= sample_end) ++sample, sample_end += groups_per_sample;
-    const Cam enc = load_cam(q->w2c_enc + sample * 16, q->K_enc + sample * 9);
-    const float4* __restrict__ G = reinterpret_cast<const float4*>(q->proj) + (long)sample * (H >> fs) * (W >> fs) * (HD / 4);
+    const Cam enc = load_cam(ih.w2c_enc + sample * 16, ih.K_enc + sample * 9);
+    const float4* __restrict__ G = reinterpret_cast<const float4*>(ih.proj) + (long)sample * (H >> fs) * (W >> fs) * (HD / 4);
     float ox, oy, oz, dx, dy, dz;
     if constexpr (ONE_RAY) {  // wave-uniform ray: scalar loads
-      const cfp rp = as_const(q->rays) + (long)g * 8;
+      const cfp rp = as_const(ih.rays) + (long)g * 8;
       ox = rp[0], oy = rp[1], oz = rp[2], dx = rp[3], dy = rp[4], dz = rp[5];
     } else {
-      const float4 r0 = reinterpret_cast<const float4*>(q->rays)[ray * 2];
-      const float4 r1 = reinterpret_cast<const float4*>(q->rays)[ray * 2 + 1];
+      const float4 r0 = reinterpret_cast<const float4*>(ih.rays)[ray * 2];
+      const float4 r1 = reinterpret_cast<const float4*>(ih.rays)[ray * 2 + 1];
       ox = r0.x, oy = r0.y, oz = r0.z, dx = r0.w, dy = r1.x, dz = r1.y;
     }
-    const float* zrow = q->z_samp + ray * K;
+    const float* zrow = ih.z_samp + ray * K;
     float z_cur = z_pre, zn_cur = zn_pre;
     {  // prefetch the next group's samples; they land while this group is evaluated
       const int gn = group_of(idx + waves_per_xcd);
       if (gn >= 0) {
-        const float* zr = q->z_samp + ((long)gn * R + lane / lpr) * K;
+        const float* zr = ih.z_samp + ((long)gn * R + lane / lpr) * K;
         const int kk = min(kl, K - 1);
         z_pre = zr[kk], zn_pre = zr[min(kk + 1, K - 1)];
       }
@@ -654,12 +688,12 @@ __global__ __launch_bounds__(256, 2) void render_kernel_p(const FwdParams p) {
       const float px = ox + z * dx, py = oy + z * dy, pz = oz + z * dz;
 
       // ---------------- encoder view: projection, taps, depth code
-      const Proj pe = q->code_mode == 1 ? project<true>(enc, px, py, pz) : project<false>(enc, px, py, pz);
+      const Proj pe = ih.code_mode == 1 ? project<true>(enc, px, py, pz) : project<false>(enc, px, py, pz);
       Taps tp = make_taps(pe.x, pe.y, H, W, fs);
       float v3[3];
       v3[0] = pe.x, v3[1] = pe.y;
-      v3[2] = depth_code(q->code_mode == 1 ? pe.dist : pe.z, q->inv_z != 0, q->inv_dmax, q->inv_range, q->d_min, q->range);
-      const bool use_empty = (q->learn_empty != 0) & pe.invalid;
+      v3[2] = depth_code(ih.code_mode == 1 ? pe.dist : pe.z, ih.inv_z != 0, ih.inv_dmax, ih.inv_range, ih.d_min, ih.range);
+      const bool use_empty = (ih.learn_empty != 0) & pe.invalid;
       if (use_empty) tp.w00 = tp.w01 = tp.w10 = tp.w11 = 0.0f;  // the empty feature is added after the blend
       if constexpr (F16) tp.w00 *= scale, tp.w01 *= scale, tp.w10 *= scale, tp.w11 *= scale;  // exact: power of two
 
@@ -685,7 +719,7 @@ __global__ __launch_bounds__(256, 2) void render_kernel_p(const FwdParams p) {
 
 
       float s_raw;
-      if (__builtin_expect(__any(pe_needs_exact(v3, q->freq_factor)), 0)) {
+      if (__builtin_expect(__any(pe_needs_exact(v3, ih.freq_factor)), 0)) {
         s_raw = eval_point_exact<C, HD, NB>(lds, G, q->w2c_enc + sample * 16, q->K_enc + sample * 9, H, W, fs, q->code_mode, q->inv_z, q->inv_dmax,
                                             q->inv_range, q->d_min, q->range, q->freq_factor, q->learn_empty, b_out, px, py, pz);
       } else {
@@ -730,12 +764,12 @@ __global__ __launch_bounds__(256, 2) void render_kernel_p(const FwdParams p) {
             }
         }
         SinCos3 raw;
-        pe_direct(raw, v3, q->freq_factor);
+        pe_direct(raw, v3, ih.freq_factor);
         __builtin_amdgcn_sched_barrier(0);
         int lane4 = lane * 4;
         asm volatile("" : "+v"(lane4));  // keep the A-operand reads inside the loop (see lane_off above)
 #ifdef BTS_GATHER_LDS
-        region_seq_l<HD, 0>(acc, gl, rows, G, wq, off_next, lh + LH::W_F16 + lane4, LH::TERM_STRIDE, raw, v3, q->freq_factor, bias);
+        region_seq_l<HD, 0>(acc, gl, rows, G, wq, off_next, lh + LH::W_F16 + lane4, LH::TERM_STRIDE, raw, v3, ih.freq_factor, bias);
         if constexpr (NS > kNumFreqs) {   // HD = 64: the blocks of stages 6 and 7
           gl_consume<HD, 12>(acc, gl, rows, G, wq, off_next), gl_consume<HD, 13>(acc, gl, rows, G, wq, off_next);
           gl_consume<HD, 14>(acc, gl, rows, G, wq, off_next), gl_consume<HD, 15>(acc, gl, rows, G, wq, off_next);
