@@ -385,6 +385,7 @@ __global__ __launch_bounds__(256, 2) void rowsb_kernel(const BwdParams bp, const
     }
     const float g_depth = qb->g_depth ? as_const(qb->g_depth)[ray] : 0.0f;
     float S_carry = 0.0f;   // sum over the samples of the chunks behind this one of g_w w
+    RB_TICK(10)   // (part of 0) the ray's scalars are in
 
     for (int kc = kc_last; kc >= 0; kc -= 64) {
       const int k = kc + lane;
@@ -425,6 +426,7 @@ __global__ __launch_bounds__(256, 2) void rowsb_kernel(const BwdParams bp, const
       const float gw_k = qb->g_weights ? qb->g_weights[pk] : 0.0f;
       const float ga_k = qb->g_alphas ? qb->g_alphas[pk] : 0.0f;
 
+      RB_TICK(11)   // (part of 0) per-sample loads issued
       // ---------------- encoder view
       const Proj pe = ih.code_mode == 1 ? project<true>(enc, px, py, pz) : project<false>(enc, px, py, pz);
       Taps tp = make_taps(pe.x, pe.y, H, W, fs);
@@ -445,6 +447,7 @@ __global__ __launch_bounds__(256, 2) void rowsb_kernel(const BwdParams bp, const
         bcast_tiles(__float_as_uint(tp.w11), t0, t1), wq[0][3] = __uint_as_float(t0), wq[1][3] = __uint_as_float(t1);
         bcast_tiles(use_empty ? 1u : 0u, t0, t1), emp[0] = t0 != 0, emp[1] = t1 != 0;
       }
+      RB_TICK(12)   // (part of 0) projection, taps, tile broadcast
       const bool cold = __any(pe_needs_exact(v3, ih.freq_factor));
       unsigned off_next[4];
       GRows rows;
@@ -709,28 +712,42 @@ __global__ __launch_bounds__(256, 2) void rowsb_kernel(const BwdParams bp, const
             RB_TICK(8)   // dW0 tiles
           }
         }
-        // u0 = g_s v: one row per sample in the storage order of G (this lane's 16 accumulator rows of a hidden tile are 64 contiguous
-        // bytes of the row)
+        // u0 = g_s v: one row per sample in the storage order of G.  In the C layout a lane holds four 16-byte pieces of ITS sample's row:
+        // stored from there, every instruction drops 16 bytes into each of 32 different rows and the memory system sees quarter lines
+        // (WRITE_SIZE 2.4 x the bytes, and -- vmcnt retiring in order -- everything the next chunk loads waits behind them).  The tile
+        // goes through LDS instead, written in the gather ring's own row layout (gl.rd: the inverse of what the forward reads), and
+        // comes back as whole rows: eight lanes per 128-byte row, eight full rows per store instruction.
         if (ro.u0_ws) {
-          const int ks = kc + pt * 32 + col;
 #ifdef BTS_ABL_B2   // timing ablation: no row stores
-          if (ks < K && gs_v[pt] == 12345.0f) {
-#else
-          if (ks < K) {
+          if (gs_v[pt] == 12345.0f)
 #endif
-            float4* dst = reinterpret_cast<float4*>(ro.u0_ws + (ray * K + ks) * (long)HD);
+          {
+            char* const u0t = gather_lds + wave * kGatherLdsPerWave + (NB > 0 ? 2 * 32 * 33 * 4 : 0);   // behind the contraction tiles
+            static_assert((NB > 0 ? 2 * 32 * 33 * 4 : 0) + HT * 4096 <= kGatherLdsPerWave, "u0 tile must fit the wave's ring memory");
+            wave_lds_fence();
 #pragma unroll
             for (int ht = 0; ht < HT; ++ht)
 #pragma unroll
               for (int j = 0; j < 4; ++j)
-                dst[ht * 8 + 4 * h + j] = make_float4(v[ht][4 * j] * gs_v[pt], v[ht][4 * j + 1] * gs_v[pt], v[ht][4 * j + 2] * gs_v[pt],
-                                                      v[ht][4 * j + 3] * gs_v[pt]);
+                *reinterpret_cast<float4*>(u0t + ht * 4096 + gl.rd[j]) =
+                    make_float4(v[ht][4 * j] * gs_v[pt], v[ht][4 * j + 1] * gs_v[pt], v[ht][4 * j + 2] * gs_v[pt], v[ht][4 * j + 3] * gs_v[pt]);
+            wave_lds_fence();
+            // position (jj, m = lane >> 3, lane & 7) of a block holds piece gl.piece16 / 16 of row 8 jj + m (GatherLds)
+#pragma unroll
+            for (int ht = 0; ht < HT; ++ht)
+#pragma unroll
+              for (int jj = 0; jj < 4; ++jj) {
+                const float4 x = *reinterpret_cast<const float4*>(u0t + ht * 4096 + jj * 1024 + lane * 16);
+                const int ks = kc + pt * 32 + 8 * jj + gl.m;
+                if (ks < K)
+                  *reinterpret_cast<float4*>(reinterpret_cast<char*>(ro.u0_ws + (ray * K + ks) * (long)HD) + ht * 128 + gl.piece16) = x;
+              }
           }
         }
       }
       RB_TICK(9)   // u0 row stores issued
       // the tile reads of this iteration must have returned before the next iteration's gather lands in the ring
-      if constexpr (NB > 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #ifdef BTS_TICKS
       ++n_iter;
 #endif
@@ -740,7 +757,7 @@ __global__ __launch_bounds__(256, 2) void rowsb_kernel(const BwdParams bp, const
   if (ro.ticks && lane == 0) {
     unsigned long long* d = ro.ticks + ((long)blockIdx.x * 4 + wave) * 16;
 #pragma unroll
-    for (int i = 0; i < 10; ++i) d[i] = t_acc[i];
+    for (int i = 0; i < 13; ++i) d[i] = t_acc[i];
     d[14] = n_iter, d[15] = __builtin_readcyclecounter() - t_begin;
   }
 #endif

@@ -326,12 +326,16 @@ def train_workload(args, world, rank, dev):
         # HBM bytes and issue counters of every training kernel from the committed rocprofv3 PMC passes (tools/profile.sh <tag> <workload>)
         traffic, counters = None, {}
         pdir = os.path.join(ROOT, "profiles")
-        tname = "traffic_train.json" if args.workload == "train" else f"traffic_{args.workload}.json"
-        prof = sorted(d for d in os.listdir(pdir) if os.path.exists(os.path.join(pdir, d, tname))) if os.path.isdir(pdir) else []
+        # tools/profile.sh writes traffic_<mode>.json: mode "train" for configs[2], "bwd_re10k" / "bwd_kitti_raw" (bts_render_fwd +
+        # bts_render_bwd of the configs[4] / [3] shape) for the others
+        tnames = ["traffic_train.json"] if args.workload == "train" else [f"traffic_{args.workload}.json", f"traffic_bwd_{args.workload}.json"]
+        prof = sorted((d, t) for d in (os.listdir(pdir) if os.path.isdir(pdir) else []) for t in tnames if os.path.exists(os.path.join(pdir, d, t)))
         if prof:
+            tname = prof[-1][1]
+            prof = [prof[-1][0]]
             tj = json.load(open(os.path.join(pdir, prof[-1], tname)))
             render = [k for k in ("render_kernel_p", "rows_kernel", "scatter_kernel", "dwpe_kernel", "rowsb_kernel", "dwpe_rows_kernel") if k in tj and "fetch_bytes" in tj[k]]
-            traffic = sum(tj[k]["fetch_bytes"] + tj[k]["write_bytes"] for k in render) if render else None
+            traffic = sum(tj[k]["fetch_bytes"] + tj[k]["write_bytes"] for k in render) if render and not args.samples else None   # (the passes ran at the yaml's K)
             counters = {k: {f: v[f] for f in ("kernel_ms_rocprof", "fetch_bytes", "write_bytes", "valu_busy", "mfma_busy", "wait_frac", "l2_hit") if f in v}
                         for k, v in tj.items()}
             counters["source"] = (f"profiles/{prof[-1]}/{tname}: rocprofv3 --pmc passes of tools/train_probe.py (same shapes); `traffic` = "

@@ -3,7 +3,8 @@
     BTS_RENDER_LIB=behindthescenes_amd/variants/libbts_ticks.so python tools/rowsb_ticks.py [K]
 Sections (cycles per ray-chunk iteration, averaged over the waves):
  0 top: loads issued, geometry, taps, table, first blocks out   1 compositing gradient   2 forward pipeline (gather, encoding, lin_in)
- 3 block forward   4 dw_out   5 v, vn = mn.W1^T v   6 dW1 tiles   7 t2 = W0^T vn   8 dW0 tiles + v update   9 u0 row stores issued"""
+ 3 block forward   4 dw_out   5 v, vn = mn.W1^T v   6 dW1 tiles   7 t2 = W0^T vn   8 dW0 tiles + v update   9 u0 row stores issued
+ 10 - 12 split section 0 further: ray scalars in | per-sample loads issued | projection, taps, tile broadcast | (0 itself: table + first blocks)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -41,7 +42,7 @@ with torch.no_grad():
         torch.cuda.synchronize()
     d = dbg.view(-1, 16).double().cpu()
     d = d[d[:, 14] > 0]
-    per = d[:, :10].sum(0) / d[:, 14].sum()
+    per = d[:, :13].sum(0) / d[:, 14].sum()
     life = d[:, 15].mean()
     print(f"bts_render_bwd {e0.elapsed_time(e1):.3f} ms; {d.shape[0]} waves, {d[:, 14].mean():.1f} iterations each, wave lifetime {life:.0f} ticks (max {d[:, 15].max():.0f})")
     print("ticks per iteration by section:", " ".join(f"{i}:{x:.0f}" for i, x in enumerate(per.tolist())), f" sum {per.sum():.0f}")
