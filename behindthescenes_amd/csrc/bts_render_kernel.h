@@ -284,14 +284,40 @@ __device__ __forceinline__ void hidden_layer_h(f32x16 (&out)[1][2], const f32x16
   }
 }
 
+// The octave chain of the three encoding regions (region R = octaves 2R, 2R + 1).  Direct evaluations (Cody-Waite + polynomials, ~26
+// instructions per argument) at octaves 0 and 3 only; 1, 2 and 4, 5 by angle doubling (fl(v 2f) = 2 fl(v f) exactly; ~1e-7 absolute error
+// per doubling, two in a row at most).  -DBTS_PE_DIRECT3 restores rounds 1 - 2: direct at 0, 2, 4, one doubling each (+69 instructions
+// per ray).  `raw` = octave 2R on entry and octave 2R + 2 on exit; `pre` carries octave 3 from region 0 (where it is evaluated, a region
+// ahead of its use like every direct evaluation) to region 1.
+template <int R>
+__device__ __forceinline__ void pe_second_octave(SinCos3& r1, const SinCos3& raw, const SinCos3& pre) {
+#ifdef BTS_PE_DIRECT3
+  pe_double(r1, raw);
+#else
+  if constexpr (R == 1) r1 = pre;
+  else pe_double(r1, raw);
+#endif
+}
+template <int R>
+__device__ __forceinline__ void pe_advance(SinCos3& raw, SinCos3& pre, const SinCos3& r1, const float (&v3)[3], float ff) {
+  if constexpr (R + 1 < 3) {
+#ifdef BTS_PE_DIRECT3
+    pe_direct(raw, v3, ff * 4.0f);
+#else
+    pe_double(raw, r1);                                   // octave 2R + 2 from octave 2R + 1
+    if constexpr (R == 0) pe_direct(pre, v3, ff * 8.0f);  // octave 3
+#endif
+  }
+}
+
 // Region R = octaves 2R (sines computed directly, one region ahead) and 2R+1 (by angle doubling), with gather stages 2R and 2R+1
 // blended behind the region's MFMAs and stages 2R+2, 2R+3 issued.  The regions are no longer fenced from each other: the scheduler
 // may pull the next region's trigonometry under this region's MFMAs (3 % faster, +3 spilled VGPRs).
 template <int HD, int R>
-__device__ __forceinline__ void region_seq(f32x16 (&acc)[HD / 32][2], GBuf& ba, GBuf& bb, const float4* __restrict__ G,
-                                           const int (&o)[2][4], const float (&wq)[2][4], int h, const float* wf, int term_stride,
-                                           SinCos3& raw, const float (&v3)[3], float ff, const f32x16* bias, bool nosin = false,
-                                           bool nomfma = false) {
+__device__ __forceinline__ void region_seq_i(f32x16 (&acc)[HD / 32][2], GBuf& ba, GBuf& bb, const float4* __restrict__ G,
+                                             const int (&o)[2][4], const float (&wq)[2][4], int h, const float* wf, int term_stride,
+                                             SinCos3& raw, SinCos3& pre, const float (&v3)[3], float ff, const f32x16* bias, bool nosin = false,
+                                             bool nomfma = false) {
   constexpr int HT = HD / 32;
   constexpr int NS = 4 * HT;
   if constexpr (R < 3) {
@@ -306,16 +332,14 @@ __device__ __forceinline__ void region_seq(f32x16 (&acc)[HD / 32][2], GBuf& ba, 
 #pragma unroll
       for (int i = 0; i < 6; ++i) e[i] = t[i];
       SinCos3 r1;
-      pe_double(r1, raw);
+      pe_second_octave<R>(r1, raw, pre);
       pe_entries(t, r1, v3, ff * 2.0f);
 #pragma unroll
       for (int i = 0; i < 6; ++i) e[6 + i] = t[i];
+      pe_advance<R>(raw, pre, r1, v3, ff);
     }
     if constexpr (R == 0) e[12] = v3[0], e[13] = v3[1];
     if constexpr (R == 1) e[12] = v3[2];
-    if constexpr (R + 1 < 3) {
-      if (!nosin) pe_direct(raw, v3, ff * 4.0f);
-    }
     if (nomfma) {  // probe builds only: no split, no MFMAs
 #pragma unroll
       for (int i = 0; i < NE; ++i) acc[0][0][i] += e[i];
@@ -335,8 +359,17 @@ __device__ __forceinline__ void region_seq(f32x16 (&acc)[HD / 32][2], GBuf& ba, 
 #ifdef BTS_REGION_BARRIER   // one scheduling region per encoding region: was needed against spills in r01c, costs 3 % now (r01g A/B)
     __builtin_amdgcn_sched_barrier(0);
 #endif
-    region_seq<HD, R + 1>(acc, ba, bb, G, o, wq, h, wf, term_stride, raw, v3, ff * 4.0f, bias, nosin, nomfma);
+    region_seq_i<HD, R + 1>(acc, ba, bb, G, o, wq, h, wf, term_stride, raw, pre, v3, ff * 4.0f, bias, nosin, nomfma);
   }
+}
+template <int HD, int R>
+__device__ __forceinline__ void region_seq(f32x16 (&acc)[HD / 32][2], GBuf& ba, GBuf& bb, const float4* __restrict__ G,
+                                           const int (&o)[2][4], const float (&wq)[2][4], int h, const float* wf, int term_stride,
+                                           SinCos3& raw, const float (&v3)[3], float ff, const f32x16* bias, bool nosin = false,
+                                           bool nomfma = false) {
+  static_assert(R == 0, "entered at region 0");
+  SinCos3 pre;
+  region_seq_i<HD, 0>(acc, ba, bb, G, o, wq, h, wf, term_stride, raw, pre, v3, ff, bias, nosin, nomfma);
 }
 
 #ifdef BTS_GATHER_LDS
@@ -466,9 +499,9 @@ __device__ __forceinline__ void gl_prologue(const GatherLds& c, GRows& r, const 
 }
 // region_seq with the gather through LDS: region R blends the blocks of stages 2R and 2R + 1 behind its MFMAs
 template <int HD, int R>
-__device__ __forceinline__ void region_seq_l(f32x16 (&acc)[HD / 32][2], const GatherLds& gl, GRows& rows, const float4* __restrict__ G,
-                                             const float (&wq)[2][4], unsigned (&off_next)[4], const float* wf, int term_stride, SinCos3& raw,
-                                             const float (&v3)[3], float ff, const f32x16* bias) {
+__device__ __forceinline__ void region_seq_li(f32x16 (&acc)[HD / 32][2], const GatherLds& gl, GRows& rows, const float4* __restrict__ G,
+                                              const float (&wq)[2][4], unsigned (&off_next)[4], const float* wf, int term_stride, SinCos3& raw,
+                                              SinCos3& pre, const float (&v3)[3], float ff, const f32x16* bias) {
   constexpr int HT = HD / 32;
   constexpr int NS = 4 * HT;
   if constexpr (R < 3) {
@@ -479,13 +512,13 @@ __device__ __forceinline__ void region_seq_l(f32x16 (&acc)[HD / 32][2], const Ga
 #pragma unroll
     for (int i = 0; i < 6; ++i) e[i] = t[i];
     SinCos3 r1;
-    pe_double(r1, raw);
+    pe_second_octave<R>(r1, raw, pre);
     pe_entries(t, r1, v3, ff * 2.0f);
 #pragma unroll
     for (int i = 0; i < 6; ++i) e[6 + i] = t[i];
     if constexpr (R == 0) e[12] = v3[0], e[13] = v3[1];
     if constexpr (R == 1) e[12] = v3[2];
-    if constexpr (R + 1 < 3) pe_direct(raw, v3, ff * 4.0f);
+    pe_advance<R>(raw, pre, r1, v3, ff);
     f16_region<HD, NE, R == 0>(acc, wf + R * HT * 256, term_stride, e, bias);
     if constexpr (2 * R < NS) {
       if constexpr (R == 0) gl_fetch<HD, 0, 2>(gl, rows);   // blocks 1, 2 were issued after block 0
@@ -494,8 +527,16 @@ __device__ __forceinline__ void region_seq_l(f32x16 (&acc)[HD / 32][2], const Ga
       gl_consume<HD, 4 * R + 2>(acc, gl, rows, G, wq, off_next);
       gl_consume<HD, 4 * R + 3>(acc, gl, rows, G, wq, off_next);
     }
-    region_seq_l<HD, R + 1>(acc, gl, rows, G, wq, off_next, wf, term_stride, raw, v3, ff * 4.0f, bias);
+    region_seq_li<HD, R + 1>(acc, gl, rows, G, wq, off_next, wf, term_stride, raw, pre, v3, ff * 4.0f, bias);
   }
+}
+template <int HD, int R>
+__device__ __forceinline__ void region_seq_l(f32x16 (&acc)[HD / 32][2], const GatherLds& gl, GRows& rows, const float4* __restrict__ G,
+                                             const float (&wq)[2][4], unsigned (&off_next)[4], const float* wf, int term_stride, SinCos3& raw,
+                                             const float (&v3)[3], float ff, const f32x16* bias) {
+  static_assert(R == 0, "entered at region 0");
+  SinCos3 pre;
+  region_seq_li<HD, 0>(acc, gl, rows, G, wq, off_next, wf, term_stride, raw, pre, v3, ff, bias);
 }
 #endif  // BTS_GATHER_LDS
 
