@@ -75,10 +75,12 @@ def test_fused_handover_matches_the_generic_route(hip, flip):
         print(f"grad err {i} flip={flip}: {err:.2e}")
         # the two routes' G differ by rounding (1e-5 above); a relu gate that flips between them moves a weight gradient by one sample's
         # contribution -- the kink sensitivity tests/test_gpu_grad.py masks out.  Measured 1e-7 ... 2e-6 of the largest entry in most
-        # processes (r03m, three runs); the first ResNet convolution's weight gradient (i = 4) comes out 8.0e-4 off -- the same value
-        # every time it happens -- in about one process of three: MIOpen's find step settles on another backward-weights solver for
-        # the 7x7 stride-2 convolution of one of the two nets (not part of the render path).
-        assert err <= (2e-3 if i == 4 else 5e-4), (i, err)
+        # processes (profiles/r03m, three runs).  In about one process of three MIOpen's find step settles on other convolution solvers
+        # for one of the two nets (not part of the render path): the first ResNet convolution's weight gradient then comes out 8.0e-4
+        # off -- the same value every time -- and the gradients behind it (lin_in, the scale-3 output convolution) 3e-4 ... 6e-4
+        # (profiles/r03l, r03z).  The bound covers that case; the oracle-anchored test below shares ONE encoder between its two sides
+        # and holds 5e-4.
+        assert err <= 2e-3, (i, err)
 
 
 def test_fused_handover_vs_oracle_autograd(hip):
