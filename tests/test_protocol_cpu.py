@@ -76,3 +76,50 @@ def test_lean_training_outputs_reconstruct_and_config():
         assert torch.equal(c["invalid_wsum"].reshape(n, B, nv), lean["invalid_wsum"])
         assert "weights" not in c and "invalid" not in c
     assert out["rgb_gt"].shape == (n, pc, ps, ps, 3)
+
+
+def test_packed_parameter_vector_is_cached_until_a_parameter_changes():
+    """ResnetFC.packed(): one flat vector (and one autograd split of its gradient) however many renders of a step read it; a new one
+    after an optimizer step / load_state_dict (version counter), a change of grad mode, or invalidate_packed() (BTSNet.encode)."""
+    import copy
+    from behindthescenes_amd.mlp import ResnetFC
+    m = ResnetFC(71, n_blocks=1, d_hidden=32)
+    a = m.packed()
+    assert m.packed() is a and a.requires_grad
+    with torch.no_grad():
+        b = m.packed()
+    assert b is not a and not b.requires_grad
+    (a * torch.arange(a.numel(), dtype=a.dtype)).sum().backward()          # the split lands on the individual parameters
+    assert all(p.grad is not None for p in m.parameters())
+    n_in = m.lin_in.weight.numel()
+    torch.testing.assert_close(m.lin_in.weight.grad.reshape(-1), torch.arange(n_in, dtype=a.dtype))
+    with torch.no_grad():
+        m.lin_out.bias.add_(1.0)                                          # what an optimizer step does
+    c = m.packed()
+    assert c is not a and float(c[-1].detach()) == float(m.lin_out.bias[-1].detach())
+    m.invalidate_packed()
+    assert m.packed() is not c
+    m2 = copy.deepcopy(m)                                                 # the cache (a non-leaf tensor) stays behind
+    assert m2.__dict__["_packed_cache"] is None and torch.equal(m2.packed(), m.packed())
+
+
+def test_loss_dict_is_a_lazy_read_only_mapping():
+    from behindthescenes_amd.loss import LazyScalars
+    d = LazyScalars(["loss", "loss_rgb_coarse"], torch.tensor([1.5, 0.25]))
+    assert d["loss"] == 1.5 and dict(d) == {"loss": 1.5, "loss_rgb_coarse": 0.25} and len(d) == 2 and list(d) == ["loss", "loss_rgb_coarse"]
+    assert "loss" in d and "nope" not in d and isinstance(d["loss_rgb_coarse"], float)
+    with pytest.raises(TypeError):
+        d["loss"] = 2.0
+
+
+def test_scale_maps_keep_their_size_only_for_power_of_two_ratios():
+    """BTSNet._scale_shift: the decoder's scale s goes to the renderer at its own size (BtsFieldCfg.feat_shift = s) when scale 0 is
+    exactly 2^s times larger; any other ratio is resized like the reference does (models_bts.py:115-117)."""
+    conf = dict(z_near=3, z_far=80, code=dict(num_freqs=6, freq_factor=1.5, include_input=True),
+                encoder=dict(type="feature_map", size=(16, 32), d_out=64), mlp_coarse=dict(type="resnet", n_blocks=0, d_hidden=64),
+                mlp_fine=dict(type="empty"))
+    net = bts.BTSNet(conf)
+    assert net._scale_shift((16, 32), (16, 32)) == 0 and net._scale_shift((8, 16), (16, 32)) == 1 and net._scale_shift((2, 4), (16, 32)) == 3
+    assert net._scale_shift((8, 15), (16, 32)) is None and net._scale_shift((5, 10), (16, 32)) is None
+    net_r = bts.BTSNet(dict(conf, native_scale_maps=False))
+    assert net_r._scale_shift((8, 16), (16, 32)) is None and net_r._scale_shift((16, 32), (16, 32)) == 0
