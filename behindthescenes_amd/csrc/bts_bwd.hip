@@ -763,7 +763,7 @@ int render_bwd_impl(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const BtsR
   static const bool direct = getenv("BTS_BWD_DIRECT_ATOMICS") != nullptr;   // A/B (probe build): round-1 kernel, every tap update an L2 atomic
   static const bool v1 = getenv("BTS_BWD_V1") != nullptr || direct;         // A/B (probe build): the round-1 lane = ray pass for every shape
   static const bool rows_always = getenv("BTS_BWD_ROWS") != nullptr;        // A/B (probe build): the row passes for every shape
-  if (v1) {
+  if (v1 && !bp.f.fs) {   // (the round-1 pass knows full-size maps only)
     bp.gh_ws = (bp.d_proj && !direct) ? static_cast<float*>(workspace) : nullptr;
     const int grid = bp.f.tiles_per_sample * cfg->n;
     int rc = BTS_E_UNSUPPORTED;

@@ -92,7 +92,7 @@ int render_fwd_impl(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const BtsR
   p.sigma_noise = a->sigma_noise;
   p.tiles_per_sample = (a->rays_per_sample + 255) / 256;
 #ifdef BTS_PROBE   // A/B switches exist only in the probe build (python -m behindthescenes_amd.build --probe); the product has one path
-  if (getenv("BTS_LANE_IS_RAY")) {  // round-1a mapping (one lane = one ray)
+  if (getenv("BTS_LANE_IS_RAY") && !p.fs) {  // round-1a mapping (one lane = one ray); the legacy kernels know full-size maps only
     if (p.proj) return launch_field<false, true>(p, cfg->C, cfg->d_hidden, cfg->n_blocks, p.tiles_per_sample * cfg->n, s);
     return launch_field<false, false>(p, cfg->C, cfg->d_hidden, cfg->n_blocks, p.tiles_per_sample * cfg->n, s);
   }
@@ -109,7 +109,7 @@ int render_fwd_impl(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const BtsR
   const int grid = render_grid(p);
   p.chunk_log2 = render_chunk_log2(grid);
 #ifdef BTS_PROBE
-  if (p.proj && getenv("BTS_RENDER_V1")) return launch_render<true>(p, cfg->C, cfg->d_hidden, cfg->n_blocks, grid, s);  // compact lane = sample kernel
+  if (p.proj && !p.fs && getenv("BTS_RENDER_V1")) return launch_render<true>(p, cfg->C, cfg->d_hidden, cfg->n_blocks, grid, s);  // compact lane = sample kernel
 #endif
   if (p.proj) return launch_render_pipelined(p, cfg->C, cfg->d_hidden, cfg->n_blocks, grid, s);
   if (p.invalid_wsum || p.invalid_any) {
