@@ -60,3 +60,27 @@ class Case:
         _, z, _, _ = O.project(pts, st.w2c_r, st.K_r)                    # (n, nv, P, 1)
         K = self.z_samp.shape[1]
         return (z[..., 0] >= min_z).permute(0, 2, 1).reshape(rays.shape[0], K, -1)
+
+
+class ProfileCase:
+    """tests/golden/profile.npz: the reference's own get_pts / render_profile (scripts/inference_setup.py:84-97, 201-229, executed from
+    the reference's source text by tests/golden/gen_golden_profile.py) on a small grid and a seeded scene."""
+
+    def __init__(self):
+        z = np.load(os.path.join(GOLDEN, "profile.npz"))
+        self.t = {k: torch.from_numpy(z[k]) for k in z.files if not k.startswith("meta_")}
+        self.meta = {k[5:]: z[k].tolist() for k in z.files if k.startswith("meta_")}
+        self.cfg = O.FieldConfig(learn_empty=True)
+        self.mlp = O.MlpParams(self.t["w_in"], self.t["b_in"], [], self.t["w_out"], self.t["b_out"])
+        self.scene = dict(images=self.t["images"], feat=self.t["feat"], projs=self.t["projs"], poses=self.t["poses"])
+        self.state = O.make_state(self.scene, self.meta["ids_render"], self.cfg, self.t["empty_feature"])
+
+    def decided_columns(self, margin=2e-4):
+        """(Z, X) bool: columns none of whose running sums (of the REFERENCE's densities, invalid -> 1) comes within `margin` of the
+        threshold -- on the others a last-bit difference of one density may move the count by one level."""
+        q = self.t["q_pts"]
+        Y, Z, X, _ = q.shape
+        a = self.t["sigma"].clone()
+        a[self.t["invalid"].reshape(Y * Z * X, -1).any(-1)] = 1
+        cs = torch.cumsum(a.reshape(Y, Z, X).double(), 0)
+        return ((cs - self.meta["threshold"]).abs() > margin).all(0)

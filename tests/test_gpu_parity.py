@@ -385,6 +385,33 @@ def test_kitti360_training_batch_forward_vs_oracle(hip):
     _check_arbitrated(r, nv=4, K=64)
 
 
+def test_occupancy_profile_vs_reference_golden(hip):
+    """SURVEY 8f.3 against the REAL reference: tests/golden/profile.npz holds what the reference's own get_pts / render_profile
+    (scripts/inference_setup.py:84-97, 201-229, run from its source text by tests/golden/gen_golden_profile.py) produce on a
+    64 x 24 x 40 grid.  bts_occupancy_profile (one fused pass) and bts_field_query on the same points."""
+    from tests._cases import ProfileCase
+    from tests._hip_helpers import build_net
+    c = ProfileCase()
+    q = c.t["q_pts"]
+    Y, Z, X, _ = q.shape
+    net = build_net(c.cfg, c.mlp, c.scene, c.meta["ids_render"], empty_feature=c.t["empty_feature"])
+    pts = q.reshape(1, -1, 3).cuda().contiguous()
+    prof, sigma = net.occupancy_profile(pts, Y, threshold=c.meta["threshold"], want_sigma=True)
+    rgb_q, inv_q, sig_q = net(pts)
+    ref_sigma, ref_inv = c.t["sigma"], c.t["invalid"]
+    # frustum flags: equal except for points within rounding of a frustum border (3.6 % of this grid is outside some frustum)
+    flips = (inv_q[0].cpu() != ref_inv)
+    assert flips.float().mean().item() <= 2e-4, flips.sum().item()
+    for s_hip in (sigma.reshape(-1).cpu(), sig_q.reshape(-1).cpu()):
+        err = (s_hip - ref_sigma).abs() / ref_sigma.abs().clamp_min(1e-3)
+        assert err.max().item() <= 5e-4 and (err > 2e-5).float().mean().item() <= 1e-3, (err.max().item(), (err > 2e-5).float().mean().item())
+    ok = c.decided_columns(margin=2e-3) & ~flips.any(-1).reshape(Y, Z, X).any(0)
+    assert ok.float().mean() > 0.9
+    p_hip, p_ref = prof.reshape(Z, X).cpu(), c.t["profile"]
+    assert torch.equal(p_hip[ok], p_ref[ok]), ((p_hip - p_ref).abs()[ok] > 0).sum().item()
+    assert (p_hip - p_ref).abs().max().item() <= 2.0 / Y + 1e-6
+
+
 @pytest.mark.parametrize("only_density", [False, True])
 def test_occupancy_profile_at_the_reference_grid_size(hip, only_density):
     """SURVEY 8f.3 at size: the 64 x 256 x 256 = 4.19 M-point grid of scripts/inference_setup.py (render_profile, :201-229) on the

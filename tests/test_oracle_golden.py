@@ -148,3 +148,22 @@ def test_train_step_oracle_end_to_end_golden():
     for g, nme in zip(grads, ("g_w_in", "g_b_in", "g_w_out", "g_b_out", "g_feat")):
         ref = t[nme]
         assert (g - ref).abs().max().item() <= 2e-5 * (ref.abs().max().item() + 1e-12), nme
+
+
+def test_occupancy_profile_matches_the_reference_golden():
+    """oracle.profile_points / occupancy_profile against the reference's own get_pts / render_profile
+    (scripts/inference_setup.py:84-97, 201-229) -- same torch ops, so the grid is bit-identical and the profile equal wherever no
+    running sum sits on the threshold."""
+    from tests._cases import ProfileCase
+    c = ProfileCase()
+    m = c.meta
+    q = O.profile_points(tuple(m["x_range"]), tuple(m["y_range"]), tuple(m["z_range"]), m["x_res"], m["y_res"], m["z_res"])
+    assert torch.equal(q, c.t["q_pts"])
+    with torch.no_grad():
+        prof, sigma, invalid = O.occupancy_profile(q, c.state, c.mlp, c.cfg, threshold=m["threshold"], batch_size=50000)
+    assert torch.equal(invalid, c.t["invalid"])
+    torch.testing.assert_close(sigma, c.t["sigma"], rtol=2e-6, atol=1e-7)
+    ok = c.decided_columns()
+    assert ok.float().mean() > 0.95
+    assert torch.equal(prof[ok], c.t["profile"][ok])
+    assert (prof - c.t["profile"]).abs().max().item() <= 1.0 / m["y_res"] + 1e-6     # the others: one level at most
