@@ -180,3 +180,31 @@ def test_density_noise_forward_and_backward_vs_oracle(hip, model):
         e1 = renderer.composite(net, rays.reshape(-1, 8).cuda(), z.cuda(), sb=n)[2]
         e2 = renderer.composite(net, rays.reshape(-1, 8).cuda(), z.cuda(), sb=n)[2]
         assert torch.equal(e1, e2)
+
+
+def test_density_noise_vs_reference_golden(hip):
+    """nerf.py:279-280 against the REAL reference: tests/golden/noise.npz (gen_golden_noise.py) holds the outputs and autograd gradients
+    of the reference's renderer in train() mode with noise_std = 0.7 together with the noise tensor its seeded draw produced.  The HIP
+    forward and backward with that tensor in BtsRenderArgs.sigma_noise (17 % of the samples end up on relu's zero side)."""
+    from tests._cases import Case
+    from tests._hip_helpers import net_from_case
+    from tests.test_gpu_grad import _rel_to_max, GRAD_RTOL
+    c = Case("noise")
+    t = c.t
+    net = net_from_case(c, train=True)
+    renderer = hip.NeRFRenderer.from_conf(dict(n_coarse=c.meta["K"], lindisp=True, hard_alpha_cap=True, noise_std=c.meta["noise_std"])).cuda().train()
+    net.zero_grad(set_to_none=True)
+    w, rgb, depth, a, inv, *_ = renderer.composite(net, c.rays.reshape(-1, 8).cuda(), c.z_samp.cuda(), sb=c.rays.shape[0],
+                                                   sigma_noise=t["sigma_noise"].cuda())
+    assert torch.equal(inv.cpu(), t["out_invalid"])
+    torch.testing.assert_close(depth.detach().cpu(), t["out_depth"], rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(rgb.detach().cpu(), t["out_rgb"], rtol=0, atol=1e-5)
+    torch.testing.assert_close(w.detach().cpu(), t["out_weights"], rtol=0, atol=1e-5)
+    torch.testing.assert_close(a.detach().cpu(), t["out_alphas"], rtol=0, atol=2e-5)
+    ((rgb * t["gin_rgb"].cuda()).sum() + (depth * t["gin_depth"].cuda()).sum()).backward()
+    mc = net.mlp_coarse
+    ours = [mc.lin_in.weight.grad, mc.lin_in.bias.grad, mc.lin_out.weight.grad, mc.lin_out.bias.grad, net.encoder.feats[0].grad]
+    for g_, nme in zip(ours, ["g_w_in", "g_b_in", "g_w_out", "g_b_out", "g_feat"]):
+        assert g_ is not None, nme
+        err = _rel_to_max(g_, t[nme].view_as(g_.cpu()))
+        assert err <= GRAD_RTOL, (nme, err)

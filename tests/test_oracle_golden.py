@@ -167,3 +167,30 @@ def test_occupancy_profile_matches_the_reference_golden():
     assert ok.float().mean() > 0.95
     assert torch.equal(prof[ok], c.t["profile"][ok])
     assert (prof - c.t["profile"]).abs().max().item() <= 1.0 / m["y_res"] + 1e-6     # the others: one level at most
+
+
+def test_density_noise_matches_the_reference_golden():
+    """nerf.py:279-280: the reference renderer in train() mode with noise_std = 0.7 (tests/golden/gen_golden_noise.py: the generator is
+    seeded, so the tensor composite() drew is known).  oracle.composite(sigma_noise=...) reproduces outputs and autograd gradients; 17 %
+    of the samples of this case sit on relu's zero side because of the noise."""
+    c = Case("noise")
+    t = c.t
+    params = [p.clone().requires_grad_(True) for p in c.mlp.tensors()]
+    feat = c.state.feat.clone().requires_grad_(True)
+    mlp = O.MlpParams(params[0], params[1], [], params[-2], params[-1])
+    st = O.FieldState(feat, c.state.K_enc, c.state.w2c_enc, c.state.imgs, c.state.K_r, c.state.w2c_r)
+    w, rgb, depth, a, inv, *_ = O.composite(c.rays.reshape(-1, 8), c.z_samp, c.rays.shape[0], st, mlp, c.cfg, hard_alpha_cap=c.hard_cap,
+                                            sigma_noise=t["sigma_noise"])
+    assert torch.equal(inv, t["out_invalid"])
+    torch.testing.assert_close(depth, t["out_depth"], rtol=2e-6, atol=0)
+    torch.testing.assert_close(rgb, t["out_rgb"], rtol=0, atol=2e-6)
+    torch.testing.assert_close(w, t["out_weights"], rtol=0, atol=2e-6)
+    torch.testing.assert_close(a, t["out_alphas"], rtol=0, atol=2e-6)
+    # without the noise the same call is a different render: the fixture does exercise the branch
+    with torch.no_grad():
+        w0 = O.composite(c.rays.reshape(-1, 8), c.z_samp, c.rays.shape[0], c.state, c.mlp, c.cfg, hard_alpha_cap=c.hard_cap)[0]
+    assert (w0 - t["out_weights"]).abs().max().item() > 1e-2
+    grads = torch.autograd.grad((rgb * t["gin_rgb"]).sum() + (depth * t["gin_depth"]).sum(), params + [feat])
+    for g, nme in zip(grads, ["g_w_in", "g_b_in", "g_w_out", "g_b_out", "g_feat"]):
+        ref = t[nme]
+        assert (g - ref.view_as(g)).abs().max().item() <= 2e-5 * (ref.abs().max().item() + 1e-12), nme
