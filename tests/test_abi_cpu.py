@@ -221,3 +221,13 @@ def test_drop_in_emits_the_reference_profiler_ranges():
         src = inspect.getsource(mod)
         for nme in names:
             assert f'record_function("{nme}")' in src, nme
+
+
+def test_the_product_library_reads_no_environment_variables():
+    """A/B switches (BTS_RENDER_V1, BTS_BWD_V1, BTS_ABLATE, BTS_DBG_PTR ...) exist only in the probe and diagnostic builds: the shipped
+    library does not even import getenv.  (The loader's BTS_RENDER_LIB is Python-side and documented in README.md.)"""
+    import shutil
+    nm = shutil.which("nm") or "/opt/rocm/lib/llvm/bin/llvm-nm"
+    lib = os.path.join(ROOT, "behindthescenes_amd", "libbts_render.so")
+    out = subprocess.run([nm, "-D", "--undefined-only", lib], capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in out
