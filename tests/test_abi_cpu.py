@@ -106,6 +106,13 @@ def test_errors_are_codes_with_messages_never_exceptions(lib):
     assert lib.bts_render_fwd(C.byref(cfg), C.byref(tens), None, None) == -2      # BTS_E_UNSUPPORTED before anything is touched
     assert b"envelope" in lib.bts_last_error()
     assert lib.bts_invert_small(None, None, 1, 3, None) == -1
+    # ABI 4: a down-scaled feature map needs frame sizes that are multiples of 2^feat_shift (checked before anything is touched)
+    bad = native._spec_cfg(native.FieldSpec(C=64, d_hidden=64, n_blocks=0), n=1, H=36, W=100, feat_shift=3)
+    assert lib.bts_render_fwd(C.byref(bad), C.byref(tens), None, None) == -1 and b"feat_shift" in lib.bts_last_error()
+    assert lib.bts_project_features(C.byref(bad), 16, 16, 1, 16, None) == -1 and b"feat_shift" in lib.bts_last_error()
+    raw = _lib.BtsFieldTensors(1, None, 1, 1, 1, 1, 1, 1, 1)      # raw features only: the kernels that read them know full-size maps
+    ok_size = native._spec_cfg(native.FieldSpec(C=64, d_hidden=64, n_blocks=0), n=1, H=32, W=96, feat_shift=2)
+    assert lib.bts_render_fwd(C.byref(ok_size), C.byref(raw), None, None) == -1 and b"proj_nhwc" in lib.bts_last_error()
     with pytest.raises(bts.BtsNativeError):
         native.nchw_to_nhwc(torch.zeros(1, 4, 2, 2))                                # CPU tensor: no CPU path
     with pytest.raises(bts.BtsNativeError):
