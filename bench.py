@@ -11,7 +11,10 @@ rays (`renderer(all_rays, want_weights=True, want_alphas=True)`), `reconstruct`,
 resident in HBM before the timed region.  N > 1: every rank renders its own frame (frames are independent -> weak scaling,
 no collective on the data path); value = total rays of all ranks / max-over-ranks time.
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (bts::render_kernel_p = bts_render_fwd), timed live with HIP
+Prints ONE JSON line (rank 0).  Next to the headline it carries `others` (N = 1: BASELINE configs[2], [3], [4], [4] at K = 128 and the
+occupancy profile, each = `bench.py --workload X --steps 10 --warmup 3` run in-process) and, under torch.distributed.run, `ddp_train`
+(KITTI-Raw shapes with the Monodepth2 encoder through DistributedDataParallel: the path's one collective, with `allreduce_ms`);
+`--no-others` skips both.  `roofline` is for the dominant kernel (bts::render_kernel_p = bts_render_fwd), timed live with HIP
 events on the launch stream inside the timed region; `roofline.traffic` is the HBM byte count of the committed rocprofv3 PMC passes
 of the same workload (profiles/<round>/traffic.json, written by tools/profile.sh), null when absent; `cpu_baseline` times the CPU
 oracle port on a bounded sample of the same workload.
@@ -52,6 +55,9 @@ def parse():
                          "(SURVEY 8f.4) unless --no-fused-handover")
     ap.add_argument("--no-fused-handover", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-others", action="store_true",
+                    help="eval workload: skip the `others` sub-records (every other BASELINE config + the occupancy profile, 10 steps each) and, "
+                         "under torch.distributed.run, the `ddp_train` sub-record (KITTI-Raw shapes with the Monodepth2 encoder: the real gradient bucket)")
     ap.add_argument("--ops-profile", action="store_true",
                     help="training workloads: run 3 steps under torch.profiler and print the host-side op table (no JSON line)")
     ap.add_argument("--full-outputs", action="store_true",
@@ -280,7 +286,10 @@ def train_workload(args, world, rank, dev):
         # (in a real run it flows on into the local CNN backward); the all-reduce carries the MLP here and MLP + CNN in a real run
         torch.nn.parallel.DistributedDataParallel._set_params_and_buffers_to_ignore_for_model(
             task, [k for k, _ in task.named_parameters() if ".encoder.feats." in k])
-    model = parallel.wrap_ddp(task, dev)
+    # a real DistributedDataParallel whenever a process group exists (also at world size 1 under torch.distributed.run: the reducer and
+    # the RCCL all-reduce then run on the single-GPU box as they will on a node)
+    model = parallel.wrap_ddp(task, dev, force=True)
+    is_ddp = isinstance(model, torch.nn.parallel.DistributedDataParallel)
 
     def step():   # base_trainer.py:287-297
         net.zero_grad(set_to_none=True)
@@ -316,6 +325,21 @@ def train_workload(args, world, rank, dev):
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = t.item()
+    allreduce = None
+    if is_ddp:
+        # the gradient all-reduce under a profiler range: device time of the RCCL kernels of two more steps (outside the timed region)
+        from torch.profiler import profile, ProfilerActivity
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            step(), step()
+            torch.cuda.synchronize()
+        coll = [e for e in prof.key_averages() if any(t in e.key.lower() for t in ("nccl", "rccl"))]
+        dev_us = lambda e: getattr(e, "device_time_total", None) or getattr(e, "cuda_time_total", 0.0)
+        ignored = set(getattr(model, "parameters_to_ignore", ()) or ())
+        grad_bytes = sum(p.numel() * p.element_size() for k, p in model.module.named_parameters() if p.requires_grad and k not in ignored)
+        allreduce = dict(allreduce_ms=sum(dev_us(e) for e in coll) / 2 / 1e3, kernels=sorted({e.key[:60] for e in coll}), calls_per_step=sum(e.count for e in coll) / 2,
+                         bucket_bytes=grad_bytes, world=world, backend=torch.distributed.get_backend(),
+                         note="device time of the RCCL kernels per step (torch.profiler, two steps after the timed region); at world 1 the "
+                              "collective is a local copy -- the number says the path ran, not what xGMI costs")
     n_rays = n * cfg["rays"]
     # per STEP: the four scales of re10k are four launches each
     ms = {k: sum(a.elapsed_time(b) for a, b in v) / max(args.steps, 1) for k, v in kern.items()}
@@ -328,14 +352,17 @@ def train_workload(args, world, rank, dev):
         pdir = os.path.join(ROOT, "profiles")
         # tools/profile.sh writes traffic_<mode>.json: mode "train" for configs[2], "bwd_re10k" / "bwd_kitti_raw" (bts_render_fwd +
         # bts_render_bwd of the configs[4] / [3] shape) for the others
-        tnames = ["traffic_train.json"] if args.workload == "train" else [f"traffic_{args.workload}.json", f"traffic_bwd_{args.workload}.json"]
+        # (a pass at another K than the yaml's carries the K in its name: tools/profile.sh <tag> bwd_re10k 128 -> traffic_bwd_re10k_k128.json;
+        # a line never shows the counters of another K)
+        ksfx = f"_k{args.samples}" if args.samples and args.samples != TRAIN_WORKLOADS[args.workload]["K"] else ""
+        tnames = ["traffic_train.json"] if args.workload == "train" and not ksfx else [f"traffic_{args.workload}{ksfx}.json", f"traffic_bwd_{args.workload}{ksfx}.json"]
         prof = sorted((d, t) for d in (os.listdir(pdir) if os.path.isdir(pdir) else []) for t in tnames if os.path.exists(os.path.join(pdir, d, t)))
         if prof:
             tname = prof[-1][1]
             prof = [prof[-1][0]]
             tj = json.load(open(os.path.join(pdir, prof[-1], tname)))
             render = [k for k in ("render_kernel_p", "rows_kernel", "scatter_kernel", "dwpe_kernel", "rowsb_kernel", "dwpe_rows_kernel") if k in tj and "fetch_bytes" in tj[k]]
-            traffic = sum(tj[k]["fetch_bytes"] + tj[k]["write_bytes"] for k in render) if render and not args.samples else None   # (the passes ran at the yaml's K)
+            traffic = sum(tj[k]["fetch_bytes"] + tj[k]["write_bytes"] for k in render) if render else None
             counters = {k: {f: v[f] for f in ("kernel_ms_rocprof", "fetch_bytes", "write_bytes", "valu_busy", "mfma_busy", "wait_frac", "l2_hit") if f in v}
                         for k, v in tj.items()}
             counters["source"] = (f"profiles/{prof[-1]}/{tname}: rocprofv3 --pmc passes of tools/train_probe.py (same shapes); `traffic` = "
@@ -366,7 +393,10 @@ def train_workload(args, world, rank, dev):
         }
         if world == 1 and not args.no_cpu_baseline and args.encoder == "feature_map":
             out["cpu_baseline"] = train_cpu_baseline(cfg, net, scene, rank)
-        print(json.dumps(out))
+        if allreduce is not None:
+            out["allreduce"] = allreduce
+        return out
+    return None
 
 
 def profile_workload(args, world, rank, dev):
@@ -473,7 +503,8 @@ def profile_workload(args, world, rank, dev):
             torch.set_num_threads(prev)
             out["cpu_baseline"] = dict(value=small.numel() / 3 / best, unit="points/s", cores=threads, kind="port", host_cpus=os.cpu_count(),
                                        sample="64 x 64 x 64 = 262 144 points of the same grid, oracle render_profile (50 000-point chunks), best of 2")
-        print(json.dumps(out))
+        return out
+    return None
 
 
 def main():
@@ -499,7 +530,9 @@ def main():
 
     _lib.load()
     if args.workload != "eval":
-        (profile_workload if args.workload == "profile" else train_workload)(args, world, rank, dev)
+        out = (profile_workload if args.workload == "profile" else train_workload)(args, world, rank, dev)
+        if out is not None:
+            print(json.dumps(out))
         if launched:
             torch.distributed.destroy_process_group()
         return
@@ -608,9 +641,59 @@ def main():
                 ref = cpu_baseline(scene, net, 4 * args.cpu_rows, device=dev)
                 ref["ours_over_ref"] = value / ref["value"]
                 out["ref_gpu_baseline"] = ref
+    # ---- the other BASELINE configs on the same line (every rank runs them: their barriers are collectives)
+    del net, wrapped, scene, images
+    torch.cuda.empty_cache()
+    subs = sub_records(args, world, rank, dev, launched)
+    if rank == 0:
+        out.update(subs)
         print(json.dumps(out))
     if launched:
         torch.distributed.destroy_process_group()
+
+
+def _condense(rec):
+    """what a sub-record keeps of a workload's own JSON line"""
+    r = rec["roofline"]
+    keep = {"metric": rec["metric"], "value": rec["value"], "unit": rec["unit"], "steps": rec["steps"], "warmup": rec["warmup"],
+            "ms_per_step": rec["ms_per_step"], "workload": rec["config"]["workload"],
+            "roofline": {k: r[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms", "fwd_ms", "bwd_ms") if k in r}}
+    if "allreduce" in rec:
+        keep["allreduce"] = rec["allreduce"]
+    return keep
+
+
+def sub_records(args, world, rank, dev, launched):
+    """`others`: BASELINE configs[2..4] (+ configs[4] at BASELINE.json's K = 128) and the occupancy profile, each measured by the same
+    code as `bench.py --workload X` (10 steps after 3 warm-ups, no CPU baseline) so that the ONE line the driver records carries every
+    workload; N = 1 only.  `ddp_train` (whenever a process group exists, i.e. under torch.distributed.run): the KITTI-Raw training shapes
+    WITH the shipped Monodepth2 encoder -- the real ~140 MB gradient bucket through DistributedDataParallel's RCCL all-reduce, the one
+    exchange step of the path (trainer.py:418); the eval headline next to it is collective-free by construction (independent frames)."""
+    import copy
+    out = {}
+    if args.no_others:
+        return out
+
+    def run(workload, steps=10, warmup=3, **kw):
+        a = copy.copy(args)
+        a.workload, a.steps, a.warmup, a.no_cpu_baseline, a.samples, a.encoder, a.no_fused_handover = workload, steps, warmup, True, 0, "feature_map", True
+        for k, v in kw.items():
+            setattr(a, k, v)
+        try:
+            rec = (profile_workload if workload == "profile" else train_workload)(a, world, rank, dev)
+            return _condense(rec) if rec is not None else None
+        except Exception as e:      # a sub-record never costs the headline
+            return {"error": f"{type(e).__name__}: {e}"[:500]}
+        finally:
+            torch.cuda.empty_cache()
+
+    if world == 1:
+        others = {"train": run("train"), "kitti_raw": run("kitti_raw"), "re10k": run("re10k"), "re10k_k128": run("re10k", samples=128),
+                  "profile": run("profile")}
+        out["others"] = others
+    if launched:
+        out["ddp_train"] = run("kitti_raw", steps=5, warmup=2, encoder="monodepth2")
+    return out
 
 
 if __name__ == "__main__":

@@ -66,10 +66,12 @@ def main(out_dir):
     c_rgb = torch.randn(N_TOTAL, 512, 6, generator=g).cuda()
     s, e = parallel.shard_range(N_TOTAL, rank, world)
     task.net.encoder.rows = slice(s, e)
-    model = parallel.wrap_ddp(task, dev)
-    if world > 1:
+    # backend nccl: a real DistributedDataParallel even at world size 1 (force) -- reducer, bucket views and the RCCL all-reduce then run
+    # through RenderFunction / ProjectFunction on the single-GPU box exactly as they will on a node
+    model = parallel.wrap_ddp(task, dev, force=backend == "nccl")
+    if world > 1 or backend == "nccl":
         assert isinstance(model, torch.nn.parallel.DistributedDataParallel)
-    elif dist.is_initialized():    # one RCCL rank: exercise the collectives the multi-GPU paths use (barrier, all-reduce, all-gather)
+    if world == 1 and dist.is_initialized():    # one RCCL rank: exercise the collectives the multi-GPU paths use (barrier, all-reduce, all-gather)
         t = torch.ones(4, device=dev)
         dist.all_reduce(t), dist.barrier()
         assert parallel.all_gather_cat(t, 0, 4, 1) is t and float(t.sum()) == 4.0

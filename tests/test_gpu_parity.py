@@ -161,9 +161,10 @@ def test_layout_kernels_roundtrip(hip):
 
 
 def _oracle_vs_hip(hip, *, n, v, H, W, C, Hd, nb, K, ids_render, cfg, hard_cap, intr, n_rays, seed, norm_dir=True, smooth=False,
-                   want_fp64=False, views=None, patches=None, baseline=0.54):
+                   want_fp64=False, views=None, patches=None, baseline=0.54, direct=False):
     """views: render only the rays of these frames (default: all v); patches = (ids_loss, n_patches): PatchRaySampler-ordered 8x8
-    patch rays from the ids_loss frames instead of whole images (the training shapes)."""
+    patch rays from the ids_loss frames instead of whole images (the training shapes); direct: render through the raw-feature route
+    (BtsFieldTensors.feat_nhwc, lin_in evaluated per point: the PROJ = false kernels) instead of the projected map G."""
     from tests._cases import robust_ray_mask
     from tests._hip_helpers import build_net
     g = torch.Generator().manual_seed(seed)
@@ -188,7 +189,16 @@ def _oracle_vs_hip(hip, *, n, v, H, W, C, Hd, nb, K, ids_render, cfg, hard_cap, 
     net = build_net(cfg, mlp, scene, ids_render, empty_feature=empty)
     renderer = hip.NeRFRenderer(n_coarse=K, lindisp=True, hard_alpha_cap=hard_cap).cuda().eval()
     with torch.no_grad():
-        w, rgb, depth, a, inv, _, _ = renderer.composite(net, rays.reshape(-1, 8).cuda(), z.cuda(), sb=n)
+        if direct:
+            from behindthescenes_amd import native
+            ft = net.native_field()
+            feat_nhwc = native.nchw_to_nhwc(net.grid_f_features[0][:, 0].detach().contiguous())
+            ftd = native.FieldTensors(net.spec, None, ft.K_enc, ft.w2c_enc, ft.imgs_nhwc4, ft.K_r, ft.w2c_r, ft.empty_feature, feat_nhwc=feat_nhwc)
+            o = native.render_fwd(ftd, net.mlp_coarse.packed().detach(), rays.reshape(-1, 8).cuda(), z.cuda(), hard_alpha_cap=hard_cap,
+                                  want_weights=True, want_alphas=True)
+            w, rgb, depth, a, inv = o["weights"], o["rgb"], o["depth"], o["alphas"], o["invalid"] > 0
+        else:
+            w, rgb, depth, a, inv, _, _ = renderer.composite(net, rays.reshape(-1, 8).cuda(), z.cuda(), sb=n)
     flips = (inv.cpu() != oinv).any(-1).any(-1)
     robust = robust_ray_mask(st, rays, z)
     assert not flips[robust].any(), "invalid flag differs on a ray that keeps a 1e-4 margin from every frustum border"
@@ -289,6 +299,14 @@ def test_full_size_frame_learn_empty_vs_oracle(hip):
     _check(r)
 
 
+def test_full_size_frame_raw_feature_route_vs_oracle(hip):
+    """The raw-feature route (feat_nhwc: callers that cannot pre-project; the kernel that EXECUTES SURVEY 8d's 13 312 FLOP per sample) at
+    the BASELINE configs[1] size, learn_empty on -- the same bar as the default route."""
+    r = _oracle_vs_hip(hip, n=1, v=2, H=192, W=640, C=64, Hd=64, nb=0, K=64, ids_render=[0], cfg=O.FieldConfig(learn_empty=True),
+                       hard_cap=True, intr=O.K_KITTIRAW, n_rays=None, seed=24, smooth=True, direct=True)
+    _check(r)
+
+
 def test_white_noise_frames_vs_oracle(hip):
     """Worst-case conditioning: iid pixels AND iid feature texels (slopes of order 1 per pixel) at W = 640.  The tap position
     ix = ((x + 1) W - 1) / 2 carries ~4e-5 px of fp32 rounding in ANY implementation, so colours move by up to 2e-5 and the hidden
@@ -350,6 +368,27 @@ def test_ragged_and_training_shapes_vs_oracle(hip):
         r = _oracle_vs_hip(hip, n=2, v=3, H=64, W=96, C=32, Hd=32, nb=1, K=K, ids_render=[1, 2], cfg=re, hard_cap=False,
                            intr=O.K_RE10K, n_rays=777, seed=6 + K, smooth=True)
         _check(r, depth_floor=1e-3)
+
+
+@pytest.mark.parametrize("learn_empty", [False, True])
+def test_single_frame_k32_packed_rays_vs_oracle(hip, learn_empty):
+    """BASELINE configs[0] at full size: scripts/images/gen_img_custom.py:108-125 -- ONE 192x640 KITTI-360 frame rendered from its own
+    encoder view (v = 1, ids_render = [0]), `ImageRaySampler(..., norm_dir=False)` (z_samp are z-depths), K = 32 (BASELINE.json; the
+    script itself sets 64, covered by the full-size tests above), exp_kitti_360.yaml's `learn_empty: false` and BTSNet's default true.
+    K <= 32 is the PACKED mode of the lane = sample kernels: two rays share a wave iteration (render_geometry, csrc/bts_fwd.hip)."""
+    r = _oracle_vs_hip(hip, n=1, v=1, H=192, W=640, C=64, Hd=64, nb=0, K=32, ids_render=[0], cfg=O.FieldConfig(learn_empty=learn_empty),
+                       hard_cap=True, intr=O.K_KITTI360, n_rays=None, seed=31 + int(learn_empty), norm_dir=False, smooth=True)
+    assert r["depth"][0].numel() == 192 * 640
+    _check(r)
+
+
+@pytest.mark.parametrize("K,n_rays", [(16, 1000), (16, 1001), (8, 1000), (8, 1003), (32, 999)])
+def test_short_rays_packed_and_unpacked_vs_oracle(hip, K, n_rays):
+    """K = 16 / 8: four / eight rays per wave iteration when the per-sample ray count is a multiple of 64 / lpr (1000), one ray per
+    iteration otherwise (1001, 1003, 999: render_geometry falls back to lpr = 64); ragged against the 4-wave work-groups either way."""
+    r = _oracle_vs_hip(hip, n=2, v=3, H=48, W=160, C=64, Hd=64, nb=0, K=K, ids_render=[1, 2], cfg=O.FieldConfig(learn_empty=True),
+                       hard_cap=True, intr=O.K_KITTI360, n_rays=n_rays, seed=900 + K + n_rays, smooth=True)
+    _check(r)
 
 
 @pytest.mark.parametrize("K", [48, 128])
