@@ -9,7 +9,7 @@ import threading
 PKG = os.path.dirname(os.path.abspath(__file__))
 # BTS_RENDER_LIB lets the profiling tools load the instrumented probe build (libbts_probe.so); the product always loads libbts_render.so
 LIB_PATH = os.environ.get("BTS_RENDER_LIB") or os.path.join(PKG, "libbts_render.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 BTS_MAX_VIEWS = 8
 ERRORS = {-1: "BTS_E_INVALID", -2: "BTS_E_UNSUPPORTED", -3: "BTS_E_LAUNCH", -4: "BTS_E_WORKSPACE"}
@@ -22,7 +22,7 @@ class BtsNativeError(RuntimeError):
 class BtsFieldCfg(C.Structure):
     _fields_ = [(k, C.c_int32) for k in ("n", "H", "W", "C", "d_hidden", "n_blocks", "nv", "num_freqs", "code_mode", "inv_z",
                                          "learn_empty", "empty_empty")] + \
-               [("freq_factor", C.c_float), ("d_min", C.c_float), ("d_max", C.c_float), ("feat_shift", C.c_int32)]
+               [("freq_factor", C.c_float), ("d_min", C.c_float), ("d_max", C.c_float), ("feat_shift", C.c_int32), ("enc_render_view", C.c_int32)]
 
 
 class BtsFieldTensors(C.Structure):
@@ -33,7 +33,8 @@ class BtsFieldTensors(C.Structure):
 class BtsRenderArgs(C.Structure):
     _fields_ = [(k, C.c_int32) for k in ("rays_per_sample", "K", "hard_alpha_cap", "white_bkgd")] + \
                [(k, C.c_void_p) for k in ("rays", "z_samp", "rgb", "depth", "weights", "alphas", "invalid", "rgb_samps",
-                                          "sigma_raw", "trans", "invalid_wsum", "invalid_any", "sigma_noise")]
+                                          "sigma_raw", "trans", "invalid_wsum", "invalid_any", "sigma_noise", "jitter", "z_samp_out")] + \
+               [("lindisp", C.c_int32), ("reserved_", C.c_int32)]
 
 
 class BtsRenderGrads(C.Structure):
@@ -97,7 +98,10 @@ def load():
             except AttributeError as e:
                 raise BtsNativeError(f"{LIB_PATH} does not export {name}; rebuild it") from e
             fn.restype, fn.argtypes = res, args
-        if lib.bts_abi_version() != ABI_VERSION:
+        # (A/B tools load an older revision's kernels through BTS_RENDER_LIB: the structs only ever grew at their ends, so a library
+        # of an older ABI reads the prefix it knows -- opt-in, tools only)
+        if lib.bts_abi_version() != ABI_VERSION and not (os.environ.get("BTS_RENDER_LIB") and os.environ.get("BTS_ALLOW_OLDER_ABI") == "1"
+                                                         and lib.bts_abi_version() < ABI_VERSION):
             raise BtsNativeError(f"ABI mismatch: library {lib.bts_abi_version()} vs binding {ABI_VERSION}; rebuild")
         _lib = lib
     return _lib

@@ -79,6 +79,10 @@ static int check_cfg(const BtsFieldCfg* cfg, const BtsFieldTensors* t, bool need
     set_error("%s: learn_empty set but empty_feature is NULL", "bts");
     return BTS_E_INVALID;
   }
+  if (cfg->enc_render_view < -1 || cfg->enc_render_view >= cfg->nv) {
+    set_error("%s: enc_render_view=%ld must be -1 or a render view index below nv=%ld", "bts", cfg->enc_render_view, cfg->nv);
+    return BTS_E_INVALID;
+  }
   if (cfg->code_mode != 0 && cfg->code_mode != 1) {
     set_error("%s: unknown code_mode %ld", "bts", cfg->code_mode);
     return BTS_E_INVALID;
@@ -104,8 +108,8 @@ int64_t bts_mlp_param_count(const BtsFieldCfg* cfg) {
 int bts_render_fwd(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const BtsRenderArgs* a, void* stream) {
   int rc = check_cfg(cfg, t, true);
   if (rc) return rc;
-  if (!a || !a->rays || !a->z_samp || !a->rgb || !a->depth) {
-    set_error("%s: NULL render argument", "bts_render_fwd");
+  if (!a || !a->rays || (!a->z_samp && !a->jitter) || !a->rgb || !a->depth) {
+    set_error("%s: NULL render argument (rays, z_samp or jitter, rgb and depth are required)", "bts_render_fwd");
     return BTS_E_INVALID;
   }
   if (a->rays_per_sample <= 0 || a->K <= 0) {

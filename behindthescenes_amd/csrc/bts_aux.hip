@@ -72,11 +72,6 @@ int pack_rgb_launch(const float* src, float* dst, int N, int H, int W, float sca
   return hipGetLastError() == hipSuccess ? BTS_OK : BTS_E_LAUNCH;
 }
 
-// torch.linspace(start, end, steps)[i] as ATen's device kernel evaluates it (symmetric about the midpoint)
-__device__ __forceinline__ float linspace_at(float start, float end, int steps, int i) {
-  const float step = (end - start) / (float)(steps - 1);
-  return i < steps / 2 ? start + step * (float)i : end - step * (float)(steps - i - 1);
-}
 
 // the ray of pixel (x, y) of a view: [c2w translation, R @ unproj(pixel), near, far]  (util.py:113-149, 244-273)
 __device__ __forceinline__ void ray_of_pixel(const float* __restrict__ P, const float* __restrict__ Kp, int H, int W, int x, int y,
@@ -172,12 +167,7 @@ __global__ __launch_bounds__(256) void sample_coarse_kernel(const float* __restr
     const long b = i / K;
     const int k = (int)(i - b * K);
     const float near = rays[b * 8 + 6], far = rays[b * 8 + 7];
-    const float base = K > 1 ? linspace_at(0.0f, 1.0f - step, K, k) : 0.0f;
-    const float sv = base + u[i] * step;
-    float out;
-    if (!lindisp) out = near * (1.0f - sv) + far * sv;
-    else out = 1.0f / ((1.0f / near) * (1.0f - sv) + (1.0f / far) * sv);
-    z[i] = out;
+    z[i] = coarse_depth(u[i], coarse_base(K, k), step, near, far, lindisp != 0);   // the render kernel's own routine (BtsRenderArgs.jitter)
   }
 }
 

@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256, 1) void render_bwd_kernel(const BwdParams bp) 
     const Taps tp = make_taps(pe.x, pe.y, H, W);
     float v3[3];
     v3[0] = pe.x, v3[1] = pe.y;
-    v3[2] = depth_code(p.code_mode == 1 ? pe.dist : pe.z, p.inv_z != 0, p.inv_dmax, p.inv_range, p.d_min, p.range);
+    v3[2] = depth_code(pe, p.code_mode == 1, p.inv_z != 0, p.inv_dmax, p.inv_range, p.d_min, p.range);
     const bool use_empty = (p.learn_empty != 0) & pe.invalid;
 
     // ---------------- compositing gradient (nerf.py:283-299)
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256, 1) void render_bwd_kernel(const BwdParams bp) 
     if (dead) sigma = 0.0f;
     const bool last = (k == K - 1);
     const float delta = last ? 1e10f : (z_after - z);
-    const float ex = expf(-fabsf(delta) * fmaxf(sigma, 0.0f));
+    const float ex = transmittance(delta, sigma);
     const bool capped = (p.hard_cap != 0) & last;
     const float alpha = capped ? 1.0f : 1.0f - ex;
     const float wgt = alpha * T;

@@ -183,7 +183,7 @@ __device__ __attribute__((noinline)) void lin_in_exact(const float* lb, const fl
   const Taps tp = make_taps(pe.x, pe.y, H, W, fs);
   float v3[3];
   v3[0] = pe.x, v3[1] = pe.y;
-  v3[2] = depth_code(code_mode == 1 ? pe.dist : pe.z, inv_z != 0, inv_dmax, inv_range, d_min, range);
+  v3[2] = depth_code(pe, code_mode == 1, inv_z != 0, inv_dmax, inv_range, d_min, range);
   const bool use_empty = (learn_empty != 0) & pe.invalid;
   f32x16 acc[HT][2];
 #pragma unroll
@@ -432,7 +432,7 @@ __global__ __launch_bounds__(256, 2) void rowsb_kernel(const BwdParams bp, const
       Taps tp = make_taps(pe.x, pe.y, H, W, fs);
       float v3[3];
       v3[0] = pe.x, v3[1] = pe.y;
-      v3[2] = depth_code(ih.code_mode == 1 ? pe.dist : pe.z, ih.inv_z != 0, ih.inv_dmax, ih.inv_range, ih.d_min, ih.range);
+      v3[2] = depth_code(pe, ih.code_mode == 1, ih.inv_z != 0, ih.inv_dmax, ih.inv_range, ih.d_min, ih.range);
       const bool use_empty = (ih.learn_empty != 0) & pe.invalid;
       if (use_empty) tp.w00 = tp.w01 = tp.w10 = tp.w11 = 0.0f;
       tp.w00 *= scale, tp.w01 *= scale, tp.w10 *= scale, tp.w11 *= scale;
@@ -497,7 +497,7 @@ __global__ __launch_bounds__(256, 2) void rowsb_kernel(const BwdParams bp, const
         if (qb->f.sigma_noise) sigma += qb->f.sigma_noise[pk];   // nerf.py:279-280: relu(sigma + noise) -- no gradient where the sum is <= 0
         const bool cut = sigma <= 0.0f && qb->f.sigma_noise != nullptr;
         const float delta = last ? 1e10f : (z_nx - z);
-        const float ex = expf(-fabsf(delta) * fmaxf(sigma, 0.0f));
+        const float ex = transmittance(delta, sigma);
         const bool capped = (qb->f.hard_cap != 0) & last;
         const float alpha = capped ? 1.0f : 1.0f - ex;
         const float gww = valid ? g_w * (alpha * T) : 0.0f;

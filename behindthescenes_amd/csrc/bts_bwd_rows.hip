@@ -122,7 +122,7 @@ __device__ __attribute__((noinline)) void rows_exact(const float* lds, const flo
   const Taps tp = make_taps(pe.x, pe.y, H, W, fs);
   float v3[3];
   v3[0] = pe.x, v3[1] = pe.y;
-  v3[2] = depth_code(code_mode == 1 ? pe.dist : pe.z, inv_z != 0, inv_dmax, inv_range, d_min, range);
+  v3[2] = depth_code(pe, code_mode == 1, inv_z != 0, inv_dmax, inv_range, d_min, range);
   const bool use_empty = (learn_empty != 0) & pe.invalid;
   f32x16 acc[HT][2];
 #pragma unroll
@@ -307,7 +307,7 @@ __global__ __launch_bounds__(256, 2) void rows_kernel(const BwdParams bp) {
     Taps tp = make_taps(pe.x, pe.y, H, W, fs);
     float v3[3];
     v3[0] = pe.x, v3[1] = pe.y;
-    v3[2] = depth_code(qb->f.code_mode == 1 ? pe.dist : pe.z, qb->f.inv_z != 0, qb->f.inv_dmax, qb->f.inv_range, qb->f.d_min, qb->f.range);
+    v3[2] = depth_code(pe, qb->f.code_mode == 1, qb->f.inv_z != 0, qb->f.inv_dmax, qb->f.inv_range, qb->f.d_min, qb->f.range);
     const bool use_empty = (qb->f.learn_empty != 0) & pe.invalid;
     if (use_empty) tp.w00 = tp.w01 = tp.w10 = tp.w11 = 0.0f;
     tp.w00 *= scale, tp.w01 *= scale, tp.w10 *= scale, tp.w11 *= scale;
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(256, 2) void rows_kernel(const BwdParams bp) {
       if (qb->f.sigma_noise) sigma += qb->f.sigma_noise[pk];   // nerf.py:279-280: relu(sigma + noise) -- no gradient where the sum is <= 0
       const bool cut = sigma <= 0.0f && qb->f.sigma_noise != nullptr;
       const float delta = last ? 1e10f : (z_nx - z);
-      const float ex = expf(-fabsf(delta) * fmaxf(sigma, 0.0f));
+      const float ex = transmittance(delta, sigma);
       const bool capped = (qb->f.hard_cap != 0) & last;
       const float alpha = capped ? 1.0f : 1.0f - ex;
 #ifdef BTS_ABL_R2   // timing ablation: no scan
@@ -910,7 +910,7 @@ __global__ __launch_bounds__(256, 2) void dwpe_kernel(const DwpeParams dp) {
     const Proj pe = p.code_mode == 1 ? project<true>(enc, px, py, pz) : project<false>(enc, px, py, pz);
     float v3[3];
     v3[0] = pe.x, v3[1] = pe.y;
-    v3[2] = depth_code(p.code_mode == 1 ? pe.dist : pe.z, p.inv_z != 0, p.inv_dmax, p.inv_range, p.d_min, p.range);
+    v3[2] = depth_code(pe, p.code_mode == 1, p.inv_z != 0, p.inv_dmax, p.inv_range, p.d_min, p.range);
     // ---- the 40 inputs of lin_in's encoding part in kernel order (kernel_to_ref_input: x, y, code, 1, then per octave 3 sines and
     // 3 "cosines"), times g_s, cut into bf16 pieces
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1081,7 +1081,7 @@ __global__ __launch_bounds__(256, HD == 32 ? 3 : 2) void dwpe_rows_kernel(const 
     const Proj pe = p.code_mode == 1 ? project<true>(enc, px, py, pz) : project<false>(enc, px, py, pz);
     float v3[3];
     v3[0] = pe.x, v3[1] = pe.y;
-    v3[2] = depth_code(p.code_mode == 1 ? pe.dist : pe.z, p.inv_z != 0, p.inv_dmax, p.inv_range, p.d_min, p.range);
+    v3[2] = depth_code(pe, p.code_mode == 1, p.inv_z != 0, p.inv_dmax, p.inv_range, p.d_min, p.range);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     if (__builtin_expect(__any(pe_needs_exact(v3, p.freq_factor)), 0)) {

@@ -9,6 +9,7 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #define BTS_EPS 1e-3f  // models_bts.py:14
 
@@ -94,9 +95,57 @@ __device__ __forceinline__ Cam load_cam_v(const float* __restrict__ w2c, const f
 struct Proj {
   float x, y;     // normalised image coordinates
   float z;        // q.z  (depth after K)
+  float rz;       // 1 / max(q.z, EPS)
   float dist;     // |R p + t|   (only meaningful when requested)
   bool invalid;
 };
+
+// ---------------------------------------------------------------------------------------------------------------
+// Divisions and exponentials on the transcendental unit (v_rcp_f32 / v_exp_f32 / v_log_f32, 1 ulp each) with explicit correction
+// steps instead of the compiler's IEEE sequences (v_div_scale x2, v_rcp, 4 fma, v_div_fmas, v_div_fixup = 10 instructions per quotient)
+// and libm's expf / log1pf (~70 instructions each with their range handling).  The operands of this path are far inside the normal
+// range (depths clamped to >= 1e-3, |x| of exp <= 1e4 after the clamp), so the scaling steps those sequences exist for are not needed.
+// Accuracy against fp64 is measured on the device by tools/ubench/fast_math_check.hip (profiles/r04*/fast_math_check.txt).
+// ---------------------------------------------------------------------------------------------------------------
+// 1 / b: hardware reciprocal + one Newton step (error <= 0.5 ulp + 2^-46 relative: the IEEE quotient in all but near-tie cases)
+__device__ __forceinline__ float rcp_nr(float b) {
+  const float r = __builtin_amdgcn_rcpf(b);
+  return __builtin_fmaf(r, __builtin_fmaf(-b, r, 1.0f), r);
+}
+// a / b given rb ~ 1 / b (within 1 ulp): quotient estimate + one residual correction -- the correctly rounded quotient (Markstein)
+__device__ __forceinline__ float div_by(float a, float b, float rb) {
+  const float q = a * rb;
+  return __builtin_fmaf(__builtin_fmaf(-b, q, a), rb, q);
+}
+// e^x, x <= ~88: 2^(x log2 e) with the product's rounding error carried into a first-order correction.  <= 1.5 ulp; results below
+// 2^-126 flush to 0 (v_exp_f32 has no denormal results): 1e-38 against 1 in 1 - exp(.) and in log(1 + exp(.)).
+__device__ __forceinline__ float exp_fast(float x) {
+  constexpr float c = 1.44269502162933349609375f, cc = 1.925963033500011e-8f;   // log2(e) = c + cc
+  const float ph = x * c;
+  const float pl = __builtin_fmaf(x, cc, __builtin_fmaf(x, c, -ph));
+  const float r = __builtin_amdgcn_exp2f(ph);
+  return __builtin_fmaf(r * pl, 0.693147182464599609375f, r);   // 2^(ph + pl) = r (1 + ln2 pl)
+}
+// F.softplus (beta 1, threshold 20) = log1p(exp(s)):  u = fl(1 + e) with its exact rounding error err (= e - (u - 1): both differences
+// are exact in fp32), log(u + err) = ln2 log2(u) + err / u, the product with ln2 in two pieces.
+__device__ __forceinline__ float softplus(float s) {
+  const float e = exp_fast(s);
+  const float u = 1.0f + e;
+  const float err = e - (u - 1.0f);
+  const float L = __builtin_amdgcn_logf(u);   // v_log_f32 = log2
+  constexpr float c = 0.693147182464599609375f, cc = -1.904654323148236e-9f;   // ln 2 = c + cc
+  const float h = L * c;
+  float r = __builtin_fmaf(L, cc, __builtin_fmaf(L, c, -h));
+  r = __builtin_fmaf(err, __builtin_amdgcn_rcpf(u), r);
+  return s > 20.0f ? s : h + r;
+}
+// 1 - alpha of a sample: exp(-|delta| max(sigma, 0))  (nerf.py:283-285).  The clamp keeps the huge last interval (delta = 1e10) finite
+// through exp_fast's correction term; exp(-1e4) is 0 in fp32 anyway.
+__device__ __forceinline__ float transmittance(float delta, float sigma) {
+  return exp_fast(fmaxf(-fabsf(delta) * fmaxf(sigma, 0.0f), -1.0e4f));
+}
+// d softplus / d s = sigmoid(s) = 1 / (1 + e^-s)
+__device__ __forceinline__ float sigmoidf(float s) { return rcp_nr(1.0f + exp_fast(fminf(-s, 88.0f))); }
 
 // models_bts.py:144-155 / 220-231.  (n,nv,3,4)@(n,1,4,P) then K@: sequential-k fused multiply-adds like a BLAS
 // micro-kernel; divide and compares unfused.
@@ -121,9 +170,10 @@ __device__ __forceinline__ Proj project(const Cam& c, float px, float py, float 
   }
   Proj p;
   p.z = q[2];
-  float zc = fmaxf(q[2], BTS_EPS);
-  p.x = q[0] / zc;
-  p.y = q[1] / zc;
+  const float zc = fmaxf(q[2], BTS_EPS);
+  p.rz = rcp_nr(zc);
+  p.x = div_by(q[0], zc, p.rz);
+  p.y = div_by(q[1], zc, p.rz);
   p.invalid = (q[2] <= BTS_EPS) | (p.x < -1.0f) | (p.x > 1.0f) | (p.y < -1.0f) | (p.y > 1.0f);
   p.dist = WANT_DIST ? sqrtf(cam[0] * cam[0] + cam[1] * cam[1] + cam[2] * cam[2]) : 0.0f;
   return p;
@@ -169,15 +219,34 @@ __device__ __forceinline__ Taps make_taps(float x, float y, int H, int W, int fs
   return make_taps_xy(x, y, H, W, x0, y0, x1, y1, fs);
 }
 
-// depth code in [-1,1] (models_bts.py:157-171)
-__device__ __forceinline__ float depth_code(float v, bool inv_z, float inv_dmax, float inv_range, float d_min, float range) {
+// depth code in [-1,1] (models_bts.py:157-171) of the projected point's depth (code_mode z) or distance (by_distance)
+__device__ __forceinline__ float depth_code(const Proj& pe, bool by_distance, bool inv_z, float inv_dmax, float inv_range, float d_min, float range) {
+  const float v = by_distance ? pe.dist : pe.z;
   float r;
   if (inv_z) {
-    r = (1.0f / fmaxf(v, BTS_EPS) - inv_dmax) / inv_range;
+    const float vc = fmaxf(v, BTS_EPS);
+    const float rv = div_by(1.0f, vc, by_distance ? __builtin_amdgcn_rcpf(vc) : pe.rz);   // 1 / max(v, EPS)
+    r = div_by(rv - inv_dmax, inv_range, rcp_nr(inv_range));
   } else {
-    r = (v - d_min) / range;
+    r = div_by(v - d_min, range, rcp_nr(range));
   }
-  return 2.0f * r - 1.0f;
+  return __builtin_fmaf(2.0f, r, -1.0f);   // 2 r is exact: the same rounding as 2 * r - 1
+}
+
+// torch.linspace(start, end, steps)[i] as ATen's device kernel evaluates it (symmetric about the midpoint)
+__device__ __forceinline__ float linspace_at(float start, float end, int steps, int i) {
+  const float step = (end - start) / (float)(steps - 1);
+  return i < steps / 2 ? start + step * (float)i : end - step * (float)(steps - i - 1);
+}
+// NeRFRenderer.sample_coarse (nerf.py:103-123): z_steps[k] = linspace(0, 1 - 1/K, K)[k] + u / K, then depth- or disparity-linear
+// between near and far.  One routine for bts_sample_coarse and for the render kernels' in-kernel sampling: the two agree bit for bit.
+__device__ __forceinline__ float coarse_base(int K, int k) { return K > 1 ? linspace_at(0.0f, 1.0f - 1.0f / (float)K, K, k) : 0.0f; }
+__device__ __forceinline__ float coarse_depth(float u, float base, float step, float near, float far, bool lindisp) {
+  const float sv = base + u * step;
+  if (!lindisp) return near * (1.0f - sv) + far * sv;
+  const float inv_near = div_by(1.0f, near, __builtin_amdgcn_rcpf(near)), inv_far = div_by(1.0f, far, __builtin_amdgcn_rcpf(far));
+  const float den = inv_near * (1.0f - sv) + inv_far * sv;
+  return div_by(1.0f, den, __builtin_amdgcn_rcpf(den));
 }
 
 // PE entry i of [x, y, zn | per octave k: sin(f_k x), sin(f_k y), sin(f_k zn), sin(f_k x + pi/2), ... ] (code.py:30-42);
@@ -203,12 +272,10 @@ __device__ __forceinline__ float pe_entry(const float (&v)[3], float freq_factor
   }
 }
 
-__device__ __forceinline__ float softplus(float s) { return s > 20.0f ? s : log1pf(expf(s)); }  // F.softplus defaults
 // max(x, 0) as ONE instruction, v_med3_f32(x, 0, FLT_MAX) (= x clamped to [0, FLT_MAX]; hidden activations never reach 3.4e38).
 // fmaxf on an MFMA result costs two: hipcc puts a canonicalising v_max(x, x) in front.  Not inline asm either: hipcc does not insert
 // the MFMA-result -> VALU-read wait states around an asm statement.
 __device__ __forceinline__ float relu1(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, 3.4028234663852886e38f); }
-__device__ __forceinline__ float sigmoidf(float s) { return 1.0f / (1.0f + expf(-s)); }
 
 // XCD-aware work-group remap: hardware places block b on XCD b % 8; give each XCD one contiguous range of tiles so
 // that neighbouring rays (which share texels) hit the same L2.  Bijective for any nwg.

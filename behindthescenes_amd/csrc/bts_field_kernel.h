@@ -37,12 +37,16 @@ struct FwdParams {
   const float* mlp;
   int n, H, W, nv;
   int fs;        // log2 of the feature map's downscale (BtsFieldCfg.feat_shift): G is (n, H >> fs, W >> fs, HD)
+  int enc_view;  // render view whose camera is the encoder's (BtsFieldCfg.enc_render_view), -1: none (or fs > 0: other texel indices)
   int code_mode, inv_z, learn_empty, empty_empty;
   float freq_factor, d_min, d_max;
   float inv_dmax, inv_range, range;
   // render
   const float* rays;
   const float* z_samp;
+  const float* jitter;   // z_samp == null: stratified jitter u (n*Bp, K), the sample depths are computed in the kernel (BtsRenderArgs.jitter)
+  float* z_out;          // ... and written here when non-null (BtsRenderArgs.z_samp_out)
+  int lindisp;
   int Bp, K, hard_cap, white_bkgd;
   float* rgb;
   float* depth;
@@ -153,7 +157,6 @@ __device__ __forceinline__ void gload(GBuf& b, const float4* __restrict__ G, con
   }
 }
 
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // blend two taps into 16 accumulator rows with packed FMAs (v_pk_fma_f32); tap order nw, ne | sw, se as in ATen
 template <bool FIRST>
@@ -325,41 +328,79 @@ __device__ __forceinline__ void sincos_small(float arg, float& s, float& c) {
   c = ((q + 1) & 2) ? -cc : cc;
 }
 
+// The same for TWO arguments at once (x and y of a point; or one coordinate at two octaves): the argument reduction and both
+// polynomials are packed FP32 instructions (v_pk_mul_f32 / v_pk_fma_f32: two IEEE operations per lane and instruction, the rate the
+// 157 TF fp32 vector peak is quoted at), only rounding, conversion and the quadrant selects stay per element.  Element by element
+// the operation sequence is sincos_small's: the results are bit-identical to it.
+__device__ __forceinline__ void sincos_small2(f32x2 arg, f32x2& s, f32x2& c) {
+  const f32x2 t = arg * (f32x2){0.63661977236758134308f, 0.63661977236758134308f};
+  const f32x2 j = {rintf(t[0]), rintf(t[1])};
+  f32x2 r = __builtin_elementwise_fma(-j, (f32x2){1.57079625129699707031f, 1.57079625129699707031f}, arg);
+  r = __builtin_elementwise_fma(-j, (f32x2){7.54978941586159635335e-8f, 7.54978941586159635335e-8f}, r);
+  const f32x2 r2 = r * r;
+  auto k2 = [](float v) { return (f32x2){v, v}; };
+  const f32x2 sp = __builtin_elementwise_fma(r2, __builtin_elementwise_fma(r2, __builtin_elementwise_fma(r2, k2(2.6083159809786593541503e-06f), k2(-1.981069071916863322258e-04f)),
+                                                                            k2(8.333307858556509017944e-03f)), k2(-1.666666597127914428711e-01f));
+  const f32x2 sn = __builtin_elementwise_fma(r * r2, sp, r);
+  const f32x2 cp = __builtin_elementwise_fma(r2, __builtin_elementwise_fma(r2, __builtin_elementwise_fma(r2, k2(2.443315711809948e-5f), k2(-1.388731625493765e-3f)),
+                                                                            k2(4.166664568298827e-2f)), k2(-0.5f));
+  const f32x2 cs = __builtin_elementwise_fma(r2, cp, k2(1.0f));
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int q = (int)j[e];
+    const float ss = (q & 1) ? cs[e] : sn[e];
+    const float cc = (q & 1) ? sn[e] : cs[e];
+    s[e] = (q & 2) ? -ss : ss;
+    c[e] = ((q + 1) & 2) ? -cc : cc;
+  }
+}
+
 // one PE octave: sin(f x), sin(f y), sin(f code), then the same with the fl32(pi/2) phase (code.py:25-28, 38).
 // The reference's "cos" entry is sin(fl(arg + P)), P = fl32(pi/2): with the exact rounding error e of that addition (TwoSum),
 // fl(arg + P) = arg + pi/2 + d, d = (P - pi/2) - e, so the entry equals cos(arg + d) = cos(arg) - d sin(arg) + O(d^2), |d| < 4e-6:
 // one sincos gives both entries with the reference's argument rounding reproduced (max deviation from it 1.2e-7).
-// raw sine / cosine of the three encoding arguments of one octave
+// raw sine / cosine of the three encoding arguments of one octave; x and y travel as a packed pair (see sincos_small2), the depth
+// code on its own
 struct SinCos3 {
-  float s[3], c[3];
+  f32x2 sxy, cxy;
+  float sz, cz;
 };
 __device__ __forceinline__ void pe_direct(SinCos3& r, const float (&v)[3], float f) {
-#pragma unroll
-  for (int i = 0; i < 3; ++i) sincos_small(v[i] * f, r.s[i], r.c[i]);
+  sincos_small2((f32x2){v[0], v[1]} * (f32x2){f, f}, r.sxy, r.cxy);
+  sincos_small(v[2] * f, r.sz, r.cz);
 }
 // next octave by angle doubling: fl(v * 2f) = 2 fl(v * f) exactly, so sin / cos of the doubled ARGUMENT are 2sc and 1 - 2s^2 of the
 // previous octave's; one doubling costs ~1e-7 extra absolute error (max 2.7e-7 vs 1.2e-7 direct, rms 4e-8 vs 2e-8 on PE
 // arguments), which is why only every other octave is derived this way.
 __device__ __forceinline__ void pe_double(SinCos3& r, const SinCos3& q) {
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    const float t = q.s[i] + q.s[i];
-    r.s[i] = t * q.c[i];
-    r.c[i] = __builtin_fmaf(-t, q.s[i], 1.0f);
-  }
+  const f32x2 t = q.sxy + q.sxy;
+  r.sxy = t * q.cxy;
+  r.cxy = __builtin_elementwise_fma(-t, q.sxy, (f32x2){1.0f, 1.0f});
+  const float tz = q.sz + q.sz;
+  r.sz = tz * q.cz;
+  r.cz = __builtin_fmaf(-tz, q.sz, 1.0f);
 }
 // the six encoding entries of an octave from its raw sines / cosines: sin(arg), then the reference's "cos" = sin(fl(arg + P))
 __device__ __forceinline__ void pe_entries(float (&o)[6], const SinCos3& r, const float (&v)[3], float f) {
   constexpr float P = 1.57079637050628662109375f;
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    const float arg = v[i] * f;
+  {
+    const f32x2 Pv = {P, P};
+    const f32x2 arg = (f32x2){v[0], v[1]} * (f32x2){f, f};
+    const f32x2 sm = arg + Pv;
+    const f32x2 bb = sm - arg;
+    const f32x2 err = (arg - (sm - bb)) + (Pv - bb);   // arg + P = sm + err exactly
+    const f32x2 d = (f32x2){4.371139000186241e-08f, 4.371139000186241e-08f} - err;     // (P - pi/2) - err
+    const f32x2 ec = __builtin_elementwise_fma(-d, r.sxy, r.cxy);
+    o[0] = r.sxy[0], o[1] = r.sxy[1], o[3] = ec[0], o[4] = ec[1];
+  }
+  {
+    const float arg = v[2] * f;
     const float sm = arg + P;
     const float bb = sm - arg;
-    const float err = (arg - (sm - bb)) + (P - bb);   // arg + P = sm + err exactly
-    const float d = 4.371139000186241e-08f - err;     // (P - pi/2) - err
-    o[i] = r.s[i];
-    o[3 + i] = __builtin_fmaf(-d, r.s[i], r.c[i]);
+    const float err = (arg - (sm - bb)) + (P - bb);
+    const float d = 4.371139000186241e-08f - err;
+    o[2] = r.sz;
+    o[5] = __builtin_fmaf(-d, r.sz, r.cz);
   }
 }
 // scalar form of pe_entries: one argument's pair (sin, reference "cos" = sin(fl(arg + P)))
@@ -414,7 +455,7 @@ __device__ __forceinline__ float eval_point(const FwdParams& p, const float* lds
   const Taps tp = make_taps(pe.x, pe.y, H, W, p.fs);
   float v3[3];
   v3[0] = pe.x, v3[1] = pe.y;
-  v3[2] = depth_code(p.code_mode == 1 ? pe.dist : pe.z, p.inv_z != 0, p.inv_dmax, p.inv_range, p.d_min, p.range);
+  v3[2] = depth_code(pe, p.code_mode == 1, p.inv_z != 0, p.inv_dmax, p.inv_range, p.d_min, p.range);
   const bool use_empty = (p.learn_empty != 0) & pe.invalid;
 
   f32x16 acc[HT][2];
@@ -648,7 +689,7 @@ __global__ __launch_bounds__(256, 2) void field_kernel(const FwdParams p) {
     } else {
       // ---------------- alpha compositing (nerf.py:225-299)
       const float delta = (k + 1 < K) ? (z_next - z) : 1e10f;
-      float alpha = 1.0f - expf(-fabsf(delta) * fmaxf(sigma, 0.0f));
+      float alpha = 1.0f - transmittance(delta, sigma);
       if (p.hard_cap && k == K - 1) alpha = 1.0f;
       const float wgt = alpha * T;
       const float T_before = T;
@@ -766,7 +807,7 @@ __device__ __forceinline__ void render_group(const FwdParams& p, const float* ld
 
       // ---------------- alpha compositing (nerf.py:225-299) as a segmented scan over the lanes of each ray
       const float delta = (k + 1 < K) ? (z_nx - z) : 1e10f;
-      float alpha = 1.0f - expf(-fabsf(delta) * fmaxf(sigma, 0.0f));
+      float alpha = 1.0f - transmittance(delta, sigma);
       if (p.hard_cap && k == K - 1) alpha = 1.0f;
       const float t = valid ? (1.0f - alpha) + 1e-10f : 1.0f;
       float incl = t;  // inclusive prefix product of t over the ray's lanes

@@ -36,6 +36,7 @@ FwdParams make_params(const BtsFieldCfg* cfg, const BtsFieldTensors* t) {
   p.imgs = t->imgs_nhwc4, p.K_r = t->K_r, p.w2c_r = t->w2c_r;
   p.empty_feature = t->empty_feature, p.mlp = t->mlp_params;
   p.n = cfg->n, p.H = cfg->H, p.W = cfg->W, p.nv = cfg->nv, p.fs = cfg->feat_shift;
+  p.enc_view = cfg->feat_shift ? -1 : cfg->enc_render_view;
   p.code_mode = cfg->code_mode, p.inv_z = cfg->inv_z, p.learn_empty = cfg->learn_empty, p.empty_empty = cfg->empty_empty;
   p.freq_factor = cfg->freq_factor, p.d_min = cfg->d_min, p.d_max = cfg->d_max;
   // python-double constants rounded once to fp32, as `1 / self.d_max` etc. enter the reference's tensor ops (models_bts.py:160-169)
@@ -85,6 +86,7 @@ int render_chunk_log2(int grid) {
 int render_fwd_impl(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const BtsRenderArgs* a, hipStream_t s) {
   FwdParams p = make_params(cfg, t);
   p.rays = a->rays, p.z_samp = a->z_samp;
+  p.jitter = a->z_samp ? nullptr : a->jitter, p.z_out = a->z_samp ? nullptr : a->z_samp_out, p.lindisp = a->lindisp;
   p.Bp = a->rays_per_sample, p.K = a->K, p.hard_cap = a->hard_alpha_cap, p.white_bkgd = a->white_bkgd;
   p.rgb = a->rgb, p.depth = a->depth, p.weights = a->weights, p.alphas = a->alphas, p.invalid = a->invalid;
   p.rgb_samps = a->rgb_samps, p.sigma_raw = a->sigma_raw, p.trans = a->trans;
@@ -114,6 +116,10 @@ int render_fwd_impl(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const BtsR
   if (p.proj) return launch_render_pipelined(p, cfg->C, cfg->d_hidden, cfg->n_blocks, grid, s);
   if (p.invalid_wsum || p.invalid_any) {
     set_error("%s: invalid_wsum / invalid_any need the projected feature map (proj_nhwc)", "bts_render_fwd");
+    return BTS_E_UNSUPPORTED;
+  }
+  if (!p.z_samp) {
+    set_error("%s: sampling inside the kernel (z_samp NULL, jitter given) needs the projected feature map (proj_nhwc)", "bts_render_fwd");
     return BTS_E_UNSUPPORTED;
   }
   return launch_render<false>(p, cfg->C, cfg->d_hidden, cfg->n_blocks, grid, s);

@@ -131,8 +131,9 @@ __global__ __launch_bounds__(256, 2) void query_kernel_p(const QueryParams qp) {
     Taps tp = make_taps(pe.x, pe.y, H, W, fs);
     float v3[3];
     v3[0] = pe.x, v3[1] = pe.y;
-    v3[2] = depth_code(qq->f.code_mode == 1 ? pe.dist : pe.z, qq->f.inv_z != 0, qq->f.inv_dmax, qq->f.inv_range, qq->f.d_min, qq->f.range);
+    v3[2] = depth_code(pe, qq->f.code_mode == 1, qq->f.inv_z != 0, qq->f.inv_dmax, qq->f.inv_range, qq->f.d_min, qq->f.range);
     const bool use_empty = (qq->f.learn_empty != 0) & pe.invalid;
+    const Taps tp_enc = tp;   // grid_sample's own taps: a render view that IS the encoder view reuses them (FwdParams::enc_view)
     if (use_empty) tp.w00 = tp.w01 = tp.w10 = tp.w11 = 0.0f;
     tp.w00 *= scale, tp.w01 *= scale, tp.w10 *= scale, tp.w11 *= scale;
     float wq[2][4];
@@ -238,13 +239,17 @@ __global__ __launch_bounds__(256, 2) void query_kernel_p(const QueryParams qp) {
 #pragma unroll
       for (int j = 0; j < NVMAX; ++j) {
         if (j < nv) {
-          const Cam cj = load_cam(qq->f.w2c_r + ((long)sample * nv + j) * 16, qq->f.K_r + ((long)sample * nv + j) * 9);
-          const Proj pc = project<false>(cj, px, py, pz);
-          const bool inv = pc.invalid | pe.invalid;
+          Taps tc = tp_enc;
+          bool inv = pe.invalid;
+          if (j != qq->f.enc_view) {   // wave-uniform
+            const Cam cj = load_cam(qq->f.w2c_r + ((long)sample * nv + j) * 16, qq->f.K_r + ((long)sample * nv + j) * 9);
+            const Proj pc = project<false>(cj, px, py, pz);
+            inv = pc.invalid | pe.invalid;
+            if (qq->f.rgb) tc = make_taps(pc.x, pc.y, H, W);
+          }
           any_inv |= inv;
           if (valid && qq->f.invalid) qq->f.invalid[pidx * nv + j] = inv ? 1.0f : 0.0f;
           if (qq->f.rgb) {
-            const Taps tc = make_taps(pc.x, pc.y, H, W);
             const float4* img = reinterpret_cast<const float4*>(qq->f.imgs) + ((long)sample * nv + j) * H * W;
             const float4 a = img[tc.o00], b = img[tc.o01], cc = img[tc.o10], d = img[tc.o11];
             if (valid) {

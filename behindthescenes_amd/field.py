@@ -6,6 +6,8 @@ What stays PyTorch-ROCm: the CNN encoder call inside ``encode`` and the 4x4 pose
 the feature map / colour frames over to the renderer's HBM layouts (projected channels-last G = F . w_in[:, :C]^T, rgb0-packed
 frames) with HIP kernels; under autograd the hand-over is differentiable (per-pixel GEMMs), so gradients of the renderer reach
 the CNN and lin_in exactly as they do in the reference."""
+import dataclasses
+
 import torch
 import torch.nn.functional as F
 from torch import nn
@@ -57,9 +59,9 @@ class BTSNet(nn.Module):
         d_in = self.encoder.latent_size + self.code_xyz.d_out
         self._d_in, self._d_out = d_in, 1
         self.mlp_coarse = make_mlp(conf["mlp_coarse"], d_in, d_out=1)
+        # models_bts.py:45, 293-307: a separate MLP for the fine pass (`coarse=False`); every shipped config says `type: empty` and the
+        # coarse MLP serves both.  Here it is one more packed parameter vector (and its own projected map G) through the same kernels.
         self.mlp_fine = make_mlp(conf["mlp_fine"], d_in, d_out=1, allow_empty=True)
-        if self.mlp_fine is not None:
-            raise NotImplementedError("a separate fine MLP is not used by any shipped config (mlp_fine.type: empty)")
         if self.learn_empty:
             self.empty_feature = nn.Parameter(torch.randn((self.encoder.latent_size,), requires_grad=True))
         self._scale = 0
@@ -82,8 +84,14 @@ class BTSNet(nn.Module):
                                      freq_factor=self.code_xyz.freq_factor, d_min=float(self.d_min), d_max=float(self.d_max),
                                      inv_z=bool(self.inv_z), code_mode=self.code_mode, learn_empty=bool(self.learn_empty),
                                      empty_empty=bool(self.empty_empty))
+        self.spec_fine = self.spec if self.mlp_fine is None else \
+            dataclasses.replace(self.spec, d_hidden=self.mlp_fine.d_hidden, n_blocks=self.mlp_fine.n_blocks)
         if not self.code_xyz.include_input:
             raise NotImplementedError("include_input=False is not used by any shipped config")
+
+    def mlp(self, coarse=True):
+        """models_bts.py:293-307: the MLP of the coarse pass, or of the fine pass when a separate one was configured."""
+        return self.mlp_coarse if coarse or self.mlp_fine is None else self.mlp_fine
 
     def _scale_shift(self, size, size0):
         """s if a map of `size` is scale 0's size divided by 2^s (and may be handed over as it is), else None (resize it)."""
@@ -123,6 +131,8 @@ class BTSNet(nn.Module):
         if combine_ids is not None:
             raise NotImplementedError("combine_ids (waymo multi-encoder-view mode) is not part of the HIP render path")
         self.mlp_coarse.invalidate_packed()     # a new step: a new autograd graph for the packed parameter vector
+        if self.mlp_fine is not None:
+            self.mlp_fine.invalidate_packed()
         poses_w2c = native.invert_small(poses_c2w)
         if ids_encoder is None:
             ids_encoder = list(range(images.shape[1]))
@@ -190,16 +200,26 @@ class BTSNet(nn.Module):
             self._imgs_nhwc4 = self._K_r = self._w2c_r = None
         self._K_enc = Ks_encoder[:, 0].detach().float().contiguous()
         self._w2c_enc = poses_w2c_encoder[:, 0].detach().float().contiguous()
+        # a render view that IS the encoder frame (eval_depth: ids_render = [0]) shares its camera bit for bit: the kernels skip its
+        # second projection (BtsFieldCfg.enc_render_view)
+        ids_r, id_e = [int(i) for i in ids_render], int(ids_encoder[0])
+        self._enc_view = ids_r.index(id_e) if id_e in ids_r else -1
 
-    def native_field(self) -> "native.FieldTensors":
+    def native_field(self, coarse=True) -> "native.FieldTensors":
         """Field state of the current scale in the C-ABI layouts.  The projected feature map G = F . w_in[:, :C]^T is built lazily
         per scale (one HIP pass that also does the NCHW -> channels-last hand-over) and cached until the next ``encode`` or until
-        lin_in.weight changes.  Under autograd the projection is differentiable w.r.t. F and the MLP parameters."""
+        lin_in.weight changes.  Under autograd the projection is differentiable w.r.t. F and the MLP parameters.  ``coarse=False`` with
+        a separate fine MLP: the map projected with THAT MLP's lin_in."""
         s = self._scale
-        version = (self.mlp_coarse.lin_in.weight._version, torch.is_grad_enabled())
-        hit = self._native.get(s)
+        fine = not coarse and self.mlp_fine is not None
+        mlp, spec = (self.mlp_fine, self.spec_fine) if fine else (self.mlp_coarse, self.spec)
+        version = (mlp.lin_in.weight._version, torch.is_grad_enabled())
+        hit = self._native.get((s, fine))
         if hit is None or hit[1] != version:
             if self._proj_ms is not None:                          # fused hand-over: G came out of the encoder
+                if fine:
+                    raise NotImplementedError("fused_handover composes the projected map from mlp_coarse only: build the net with "
+                                              "fused_handover=False to render with a separate fine MLP")
                 w_version, grad_mode = self._proj_version
                 if w_version != version[0]:
                     raise native.BtsNativeError("lin_in.weight changed since encode(): the fused hand-over composed the projected feature map "
@@ -211,19 +231,19 @@ class BTSNet(nn.Module):
             else:
                 f = self._latents_ms[s]                            # (n, 1, C, h, w) -> (n, C, h, w): a pure view (selecting [:, 0] would
                 f = f.reshape(f.shape[0], *f.shape[2:]).float()    # cost a zero fill + a copy of the whole map in its backward)
-                proj = native.ProjectFunction.apply(f, self.mlp_coarse.packed(), self.spec)
-            ft = native.FieldTensors(self.spec, proj, self._K_enc, self._w2c_enc, self._imgs_nhwc4, self._K_r, self._w2c_r,
-                                     self.empty_feature if self.learn_empty else None, feat_shift=self._shift_ms[s])
-            self._native[s] = (ft, version)
-        return self._native[s][0]
+                proj = native.ProjectFunction.apply(f, mlp.packed(), spec)
+            ft = native.FieldTensors(spec, proj, self._K_enc, self._w2c_enc, self._imgs_nhwc4, self._K_r, self._w2c_r,
+                                     self.empty_feature if self.learn_empty else None, feat_shift=self._shift_ms[s], enc_view=self._enc_view)
+            self._native[(s, fine)] = (ft, version)
+        return self._native[(s, fine)][0]
 
     def forward(self, xyz, coarse=True, viewdirs=None, far=False, only_density=False):
         """xyz (n, P, 3) world points -> rgb (n,P,nv*3), invalid (n,P,nv) float, sigma (n,P,1)  (models_bts.py:266-338).
         Forward-only (the reference's callers of this entry point -- occupancy profiles, LiDAR / 3D-bbox evaluators -- run it
         under no_grad); training goes through the renderer's composite, which is differentiable."""
-        ft = self.native_field()
+        ft = self.native_field(coarse)
         with torch.no_grad(), profiler.record_function("model_inference"):   # models_bts.py:275
-            rgb, invalid, sigma = native.field_query(ft, self.mlp_coarse.packed().detach(), xyz.detach().float().contiguous(),
+            rgb, invalid, sigma = native.field_query(ft, self.mlp(coarse).packed().detach(), xyz.detach().float().contiguous(),
                                                      only_density=only_density)
         nv = self.grid_c_imgs.shape[1]
         if only_density:

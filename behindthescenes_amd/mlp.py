@@ -68,7 +68,18 @@ class ResnetFC(nn.Module):
         return out
 
     def invalidate_packed(self):
+        """Drops the cached vector.  ``packed()`` notices in-place edits that bump a parameter's version counter, a new storage and a
+        changed ``requires_grad``; edits through ``.data`` (``p.data.copy_()``, an EMA swap, weight clipping) bump nothing -- call this
+        after them.  ``load_state_dict`` / ``.to()`` / ``.cuda()`` call it themselves (the hooks below), ``BTSNet.encode`` too."""
         self.__dict__["_packed_cache"] = None
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self.invalidate_packed()
+        return super()._load_from_state_dict(*args, **kwargs)
+
+    def _apply(self, fn, *args, **kwargs):
+        self.invalidate_packed()
+        return super()._apply(fn, *args, **kwargs)
 
     def __getstate__(self):     # copy.deepcopy / pickle: the cached vector (a non-leaf tensor under autograd) stays behind
         state = self.__dict__.copy()

@@ -215,11 +215,11 @@ def distance_to_z(depths: torch.Tensor, projs: torch.Tensor) -> torch.Tensor:
 # --------------------------------------------------------------------------------------------------------------
 # field state handed to the renderer
 # --------------------------------------------------------------------------------------------------------------
-def _spec_cfg(spec: FieldSpec, n=1, H=1, W=1, nv=0, feat_shift=0) -> BtsFieldCfg:
+def _spec_cfg(spec: FieldSpec, n=1, H=1, W=1, nv=0, feat_shift=0, enc_view=-1) -> BtsFieldCfg:
     return BtsFieldCfg(n=n, H=H, W=W, C=spec.C, d_hidden=spec.d_hidden, n_blocks=spec.n_blocks, nv=nv, num_freqs=spec.num_freqs,
                        code_mode={"z": 0, "distance": 1}[spec.code_mode], inv_z=int(spec.inv_z), learn_empty=int(spec.learn_empty),
                        empty_empty=int(spec.empty_empty), freq_factor=spec.freq_factor, d_min=spec.d_min, d_max=spec.d_max,
-                       feat_shift=feat_shift)
+                       feat_shift=feat_shift, enc_render_view=enc_view if 0 <= enc_view < nv else -1)
 
 
 def proj_storage_order(d_hidden: int) -> torch.Tensor:
@@ -261,7 +261,9 @@ class FieldTensors:
     ``feat_shift`` = s: the map is the decoder's scale-s output at ITS size (n, H >> s, W >> s, .) and is read as its nearest-neighbour
     resize to H x W -- what models_bts.py:115-117 materialises -- without the resize (BtsFieldCfg.feat_shift)."""
 
-    def __init__(self, spec: FieldSpec, proj_nhwc, K_enc, w2c_enc, imgs_nhwc4, K_r, w2c_r, empty_feature=None, feat_nhwc=None, feat_shift=0):
+    def __init__(self, spec: FieldSpec, proj_nhwc, K_enc, w2c_enc, imgs_nhwc4, K_r, w2c_r, empty_feature=None, feat_nhwc=None, feat_shift=0,
+                 enc_view=-1):
+        """enc_view: index of the render view whose camera is the encoder camera (BtsFieldCfg.enc_render_view), -1 = none / unknown."""
         ref = proj_nhwc if proj_nhwc is not None else feat_nhwc
         n, H, W, ch = ref.shape
         H, W = H << feat_shift, W << feat_shift
@@ -282,12 +284,13 @@ class FieldTensors:
                 raise BtsNativeError("learn_empty needs empty_feature")
             _req(empty_feature.detach(), "empty_feature", (spec.C,))
         self.spec, self.n, self.H, self.W, self.nv, self.feat_shift = spec, n, H, W, nv, feat_shift
+        self.enc_view = enc_view
         self.proj_nhwc, self.feat_nhwc, self.K_enc, self.w2c_enc = proj_nhwc, feat_nhwc, K_enc, w2c_enc
         self.imgs_nhwc4, self.K_r, self.w2c_r = imgs_nhwc4, K_r, w2c_r
         self.empty_feature = empty_feature
 
     def cfg(self, nv=None) -> BtsFieldCfg:
-        return _spec_cfg(self.spec, self.n, self.H, self.W, self.nv if nv is None else nv, self.feat_shift)
+        return _spec_cfg(self.spec, self.n, self.H, self.W, self.nv if nv is None else nv, self.feat_shift, self.enc_view)
 
     def tensors(self, mlp_params: torch.Tensor) -> BtsFieldTensors:
         def dp(t):
@@ -310,24 +313,38 @@ def check_supported(spec: FieldSpec, nv: int = 1):
 _OUT_KEYS = ("rgb", "depth", "weights", "alphas", "invalid", "rgb_samps", "sigma_raw", "trans", "invalid_wsum", "invalid_any")
 
 
-def _render_args(ft: FieldTensors, rays, z_samp, hard_alpha_cap, white_bkgd, outs, sigma_noise=None):
+def _render_args(ft: FieldTensors, rays, z_samp, hard_alpha_cap, white_bkgd, outs, sigma_noise=None, jitter=None, lindisp=True):
+    K = (z_samp if z_samp is not None else jitter).shape[1]
     if sigma_noise is not None:
-        _req(sigma_noise, "sigma_noise", tuple(z_samp.shape))
-    return BtsRenderArgs(rays_per_sample=rays.shape[0] // ft.n, K=z_samp.shape[1], hard_alpha_cap=int(hard_alpha_cap),
-                         white_bkgd=int(white_bkgd), rays=rays.data_ptr(), z_samp=z_samp.data_ptr(),
+        _req(sigma_noise, "sigma_noise", (rays.shape[0], K))
+    return BtsRenderArgs(rays_per_sample=rays.shape[0] // ft.n, K=K, hard_alpha_cap=int(hard_alpha_cap),
+                         white_bkgd=int(white_bkgd), rays=rays.data_ptr(), z_samp=None if z_samp is None else z_samp.data_ptr(),
                          sigma_noise=None if sigma_noise is None else sigma_noise.data_ptr(),
+                         jitter=None if jitter is None else jitter.data_ptr(), lindisp=int(bool(lindisp)), reserved_=0,
+                         z_samp_out=None if outs.get("z_samp") is None else outs["z_samp"].data_ptr(),
                          **{k: (None if outs.get(k) is None else outs[k].data_ptr()) for k in _OUT_KEYS})
 
 
 def render_fwd(ft: FieldTensors, mlp_params: torch.Tensor, rays: torch.Tensor, z_samp: torch.Tensor, *, hard_alpha_cap: bool,
                white_bkgd: bool = False, want_weights=False, want_alphas=False, want_invalid=True, want_rgb_samps=False,
-               want_saved=False, want_invalid_sums=False, sigma_noise=None):
+               want_saved=False, want_invalid_sums=False, sigma_noise=None, jitter=None, lindisp=True, want_z=False):
     """rays (n*Bp, 8), z_samp (n*Bp, K) -> dict of fresh tensors (bts_render_fwd).  want_saved adds the two per-sample
     activations the backward needs (sigma_raw, trans); want_invalid_sums the per-ray reductions the loss' invalid-ray policies need
     (invalid_wsum = sum_k weights * invalid, invalid_any = max_k invalid, (n*Bp, nv) each) -- with them a training step can leave
-    weights / invalid / rgb_samps unrequested."""
-    B, K = z_samp.shape
-    _req(rays, "rays", (B, 8)), _req(z_samp, "z_samp"), _req(mlp_params.detach(), "mlp_params", (ft.spec.mlp_param_count(),))
+    weights / invalid / rgb_samps unrequested.
+    z_samp=None with ``jitter`` (n*Bp, K) in [0, 1): NeRFRenderer.sample_coarse runs inside the kernel (BtsRenderArgs.jitter, ``lindisp``
+    as the renderer's flag); the depths come back as out["z_samp"] when ``want_z`` (bit-identical to ``sample_coarse(rays, jitter)``)."""
+    if z_samp is None:
+        if jitter is None:
+            raise BtsNativeError("render_fwd needs z_samp or jitter")
+        if ft.proj_nhwc is None:
+            raise BtsNativeError("in-kernel sampling (jitter) needs the projected feature map")
+        _req(jitter, "jitter")
+    else:
+        _req(z_samp, "z_samp")
+        jitter = None
+    B, K = (z_samp if z_samp is not None else jitter).shape
+    _req(rays, "rays", (B, 8)), _req(mlp_params.detach(), "mlp_params", (ft.spec.mlp_param_count(),))
     if B % ft.n != 0:
         raise BtsNativeError(f"{B} rays do not split evenly over n={ft.n} samples")
     dev, nv = rays.device, ft.nv
@@ -339,10 +356,13 @@ def render_fwd(ft: FieldTensors, mlp_params: torch.Tensor, rays: torch.Tensor, z
                 alphas=new(B, K) if want_alphas else None, invalid=new(B, K, nv) if want_invalid else None,
                 rgb_samps=new(B, K, nv * 3) if want_rgb_samps else None, sigma_raw=new(B, K) if want_saved else None,
                 trans=new(B, K) if want_saved else None, invalid_wsum=new(B, nv) if want_invalid_sums else None,
-                invalid_any=new(B, nv) if want_invalid_sums else None)
+                invalid_any=new(B, nv) if want_invalid_sums else None,
+                z_samp=new(B, K) if (z_samp is None and want_z) else None)
     cfg, tens = ft.cfg(), ft.tensors(mlp_params)
-    args = _render_args(ft, rays, z_samp, hard_alpha_cap, white_bkgd, outs, sigma_noise)
+    args = _render_args(ft, rays, z_samp, hard_alpha_cap, white_bkgd, outs, sigma_noise, jitter, lindisp)
     _lib.check(_lib.load().bts_render_fwd(C.byref(cfg), C.byref(tens), C.byref(args), _stream(rays)), "bts_render_fwd")
+    if z_samp is not None:
+        outs["z_samp"] = z_samp
     return outs
 
 
@@ -462,28 +482,32 @@ class RenderFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, proj_nhwc, mlp_params, empty_feature, ft: FieldTensors, rays, z_samp, hard_alpha_cap, white_bkgd,
-                want_weights, want_alphas, want_rgb_samps, grad_mode=True, want_invalid=True, want_invalid_sums=False, sigma_noise=None):
+                want_weights, want_alphas, want_rgb_samps, grad_mode=True, want_invalid=True, want_invalid_sums=False, sigma_noise=None,
+                jitter=None, lindisp=True, want_z=False):
         # needs_input_grad reflects requires_grad even under torch.no_grad(), and inside forward() grad mode is always off: the
         # caller passes the mode it was invoked in, so that evaluation does not allocate / write the 8 B per sample of saved state
         needs_grad = any(ctx.needs_input_grad[:3]) and grad_mode
+        # z_samp None: sample_coarse inside the kernel from `jitter`; the depths are materialised only for the backward / on request
         out = render_fwd(ft, mlp_params, rays, z_samp, hard_alpha_cap=hard_alpha_cap, white_bkgd=white_bkgd,
                          want_weights=want_weights, want_alphas=want_alphas, want_invalid=want_invalid, want_rgb_samps=want_rgb_samps,
-                         want_saved=needs_grad, want_invalid_sums=want_invalid_sums, sigma_noise=sigma_noise)
+                         want_saved=needs_grad, want_invalid_sums=want_invalid_sums, sigma_noise=sigma_noise, jitter=jitter, lindisp=lindisp,
+                         want_z=want_z or needs_grad)
         ctx.ft, ctx.hard_alpha_cap, ctx.white_bkgd = ft, hard_alpha_cap, white_bkgd
         ctx.sigma_noise = sigma_noise if needs_grad else None      # (a plain tensor without graph: kept on the context)
         if needs_grad:
             # rgb_samps is non-differentiable output the caller asked for: kept for the backward too (it then skips the colour taps)
-            ctx.save_for_backward(mlp_params, rays, z_samp, out["sigma_raw"], out["trans"], *([out["rgb_samps"]] if want_rgb_samps else []))
+            ctx.save_for_backward(mlp_params, rays, out["z_samp"], out["sigma_raw"], out["trans"], *([out["rgb_samps"]] if want_rgb_samps else []))
         empty = rays.new_empty(0)
+        z_out = out["z_samp"] if (z_samp is None and out["z_samp"] is not None) else empty
         res = (out["rgb"], out["depth"], out["weights"] if want_weights else empty, out["alphas"] if want_alphas else empty,
                out["invalid"] if want_invalid else empty, out["rgb_samps"] if want_rgb_samps else empty,
-               out["invalid_wsum"] if want_invalid_sums else empty, out["invalid_any"] if want_invalid_sums else empty)
+               out["invalid_wsum"] if want_invalid_sums else empty, out["invalid_any"] if want_invalid_sums else empty, z_out)
         ctx.mark_non_differentiable(*res[4:])
         ctx.has = (want_weights, want_alphas)
         return res
 
     @staticmethod
-    def backward(ctx, g_rgb, g_depth, g_weights, g_alphas, _g_inv, _g_rs, _g_iw, _g_ia):
+    def backward(ctx, g_rgb, g_depth, g_weights, g_alphas, _g_inv, _g_rs, _g_iw, _g_ia, _g_z):
         mlp_params, rays, z_samp, sigma_raw, trans, *rest = ctx.saved_tensors
         rgb_samps = rest[0] if rest else None
 
@@ -505,4 +529,4 @@ class RenderFunction(torch.autograd.Function):
                 d_empty = w_f.t() @ d_eproj
             if need_mlp:
                 d_mlp[:spec.d_hidden * spec.d_in].view(spec.d_hidden, spec.d_in)[:, :spec.C] += torch.outer(d_eproj, ft.empty_feature.detach())
-        return (d_proj, d_mlp, d_empty) + (None,) * 12
+        return (d_proj, d_mlp, d_empty) + (None,) * 15

@@ -82,18 +82,22 @@ def render_sharded(render: Callable[..., Dict], rays: torch.Tensor, rank: Option
         return {part: {k: all_gather_cat(v, 1, total, world) for k, v in d.items()} for part, d in out.items()}
 
 
-def wrap_ddp(module: torch.nn.Module, device: Optional[torch.device] = None, bucket_cap_mb: int = 64, force: bool = False) -> torch.nn.Module:
+def wrap_ddp(module: torch.nn.Module, device: Optional[torch.device] = None, bucket_cap_mb: int = 64, force: bool = False,
+             find_unused_parameters: bool = False) -> torch.nn.Module:
     """DistributedDataParallel around the task wrapper, as ``idist.auto_model`` does.  64 MB buckets: the ~140 MB of CNN gradients go
     out as 2-3 large RCCL all-reduces (xGMI is point-to-point, large messages amortise the per-link latency); the renderer's 27 KB
     of MLP gradients ride in the last bucket.  At world size 1 the module comes back bare (like idist.auto_model) unless ``force``:
     then the reducer, the bucket views and the (one-rank) all-reduce run exactly as on a node -- what the single-GPU tests and
-    ``bench.py`` under ``torch.distributed.run`` use to execute the DDP path over RCCL before a multi-GPU box ever sees it."""
+    ``bench.py`` under ``torch.distributed.run`` use to execute the DDP path over RCCL before a multi-GPU box ever sees it.
+    ``find_unused_parameters``: for models with parameters outside the loss' graph -- Monodepth2's output convolutions of the scales a
+    ``prediction_mode: default`` step never renders (monodepth2.py:211-239 computes all four, trainer.py:243-259 uses scale 0)."""
     if not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
         return module
     if device is not None and device.type == "cuda":
         return torch.nn.parallel.DistributedDataParallel(module, device_ids=[device.index], output_device=device.index,
-                                                         bucket_cap_mb=bucket_cap_mb, gradient_as_bucket_view=True)
-    return torch.nn.parallel.DistributedDataParallel(module, bucket_cap_mb=bucket_cap_mb)
+                                                         bucket_cap_mb=bucket_cap_mb, gradient_as_bucket_view=True,
+                                                         find_unused_parameters=find_unused_parameters)
+    return torch.nn.parallel.DistributedDataParallel(module, bucket_cap_mb=bucket_cap_mb, find_unused_parameters=find_unused_parameters)
 
 
 def all_reduce_mean_(tensors: Sequence[torch.Tensor]) -> None:

@@ -110,29 +110,36 @@ class NeRFRenderer(torch.nn.Module):
                                    sigma_noise)
 
     def _composite(self, model, rays, z_samp, coarse, sb, want_weights, want_alphas, want_rgb_samps, want_invalid, want_invalid_sums,
-                   sigma_noise=None):
+                   sigma_noise=None, jitter=None, want_z=False):
+        """z_samp None: ``sample_coarse`` runs INSIDE the render kernel from the jitter ``jitter`` (B, K) ~ U[0, 1) (BtsRenderArgs.jitter:
+        the same routine, bit-identical depths, no z_samp round trip through HBM); entry 5 of the result is then the depth tensor only
+        when ``want_z`` or when autograd needs it (else None)."""
         if not isinstance(model, BTSNet):
             raise native.BtsNativeError("composite() needs a behindthescenes_amd.BTSNet (the fused HIP kernel IS the field query)")
-        if not coarse and model.mlp_fine is not None:
-            raise NotImplementedError("separate fine MLP")
-        ft = model.native_field()
+        ft = model.native_field(coarse)
         n = ft.n
         if sb > 0 and sb != n:
             raise native.BtsNativeError(f"super-batch {sb} does not match the encoded batch {n}")
         if sb <= 0 and n != 1:
             raise native.BtsNativeError("sb=0 (no super-batch) is only meaningful for an encoded batch of 1")
         rays = rays.float().contiguous()
-        z_samp = z_samp.float().contiguous()
-        mlp_params = model.mlp_coarse.packed()
+        if z_samp is not None:
+            z_samp, jitter = z_samp.float().contiguous(), None
+        else:
+            jitter = jitter.float().contiguous()
+        shape = (z_samp if z_samp is not None else jitter).shape
+        mlp_params = model.mlp(coarse).packed()      # models_bts.py:293-307: mlp_coarse, or mlp_fine when the fine pass has its own
         empty = model.empty_feature if model.learn_empty else None
         if sigma_noise is None and self.training and self.noise_std > 0.0:
             # nerf.py:279-280: sigmas + randn_like(sigmas) * noise_std in training mode (no shipped config turns it on); drawn here with
             # torch's generator, added inside the kernels (BtsRenderArgs.sigma_noise).  `sigma_noise` lets a caller inject the draw.
-            sigma_noise = torch.randn(z_samp.shape, device=z_samp.device, dtype=torch.float32) * self.noise_std
-        rgb, depth, weights, alphas, invalid, rgb_samps, inv_wsum, inv_any = native.RenderFunction.apply(
+            sigma_noise = torch.randn(shape, device=rays.device, dtype=torch.float32) * self.noise_std
+        rgb, depth, weights, alphas, invalid, rgb_samps, inv_wsum, inv_any, z_out = native.RenderFunction.apply(
             ft.proj_nhwc, mlp_params, empty, ft, rays, z_samp, bool(self.hard_alpha_cap), bool(self.white_bkgd),
             bool(want_weights), bool(want_alphas), bool(want_rgb_samps), torch.is_grad_enabled(), bool(want_invalid), bool(want_invalid_sums),
-            None if sigma_noise is None else sigma_noise.float().contiguous())
+            None if sigma_noise is None else sigma_noise.float().contiguous(), jitter, bool(self.lindisp), bool(want_z))
+        if z_samp is None:
+            z_samp = z_out if z_out.numel() else None
         ret = (weights if want_weights else None, rgb, depth, alphas if want_alphas else None, invalid if want_invalid else None, z_samp,
                rgb_samps if want_rgb_samps else None)
         return ret + (inv_wsum, inv_any) if want_invalid_sums else ret
@@ -150,8 +157,13 @@ class NeRFRenderer(torch.nn.Module):
         assert len(rays.shape) == 3
         sb = rays.shape[0]
         rays = rays.reshape(-1, 8)
+        jitter = None
         if sample_from_dist is None:
-            z_coarse = self.sample_coarse(rays)
+            if isinstance(model, BTSNet):
+                # nerf.py:103-123 inside the render kernel: only the jitter is drawn here (the reference's torch.rand_like, :112)
+                z_coarse, jitter = None, torch.rand((rays.shape[0], self.n_coarse), device=rays.device, dtype=torch.float32)
+            else:
+                z_coarse = self.sample_coarse(rays)
         else:
             prop_weights, prop_z = sample_from_dist
             ns = prop_weights.shape[-1]
@@ -164,17 +176,17 @@ class NeRFRenderer(torch.nn.Module):
             # even when the (reference) trainer asks for them.  Opt-in (`lean_training_outputs`), training mode only.
             # (rgb_samps is still written, as the backward's saved state only: the stores are free in the latency-bound forward and
             # spare the backward one projection + four taps per view and sample; it is not returned)
-            comp = self.composite(model, rays, z_coarse, coarse=True, sb=sb, want_weights=False, want_alphas=False, want_rgb_samps=True,
-                                  want_invalid=False, want_invalid_sums=True)
+            comp = self._composite(model, rays, z_coarse, True, sb, False, False, True, False, True, jitter=jitter)
             nv = comp[7].shape[-1]
             return dict(coarse=dict(rgb=comp[1].reshape(sb, -1, comp[1].shape[-1]), depth=comp[2].reshape(sb, -1),
                                     invalid_wsum=comp[7].reshape(sb, -1, nv), invalid_any=comp[8].reshape(sb, -1, nv)))
         need_w = want_weights or self.using_fine
-        comp = self.composite(model, rays, z_coarse, coarse=True, sb=sb, want_weights=need_w, want_alphas=want_alphas,
-                              want_rgb_samps=want_rgb_samps)
+        with profiler.record_function("renderer_composite"):
+            comp = self._composite(model, rays, z_coarse, True, sb, need_w, want_alphas, want_rgb_samps, True, False, jitter=jitter,
+                                   want_z=want_z_samps or self.using_fine)
         outputs = dict(coarse=self._format_outputs(comp, sb, want_weights, want_alphas, want_z_samps, want_rgb_samps))
         if self.using_fine:
-            all_samps = [z_coarse]
+            all_samps = [comp[5]]
             if self.n_fine - self.n_fine_depth > 0:
                 all_samps.append(self.sample_fine(rays, comp[0].detach()))
             if self.n_fine_depth > 0:
@@ -187,7 +199,7 @@ class NeRFRenderer(torch.nn.Module):
 
     def _format_outputs(self, rendered, sb, want_weights=False, want_alphas=False, want_z_samps=False, want_rgb_samps=False):
         weights, rgb, depth, alphas, invalid, z_samps, rgb_samps = rendered
-        K = z_samps.shape[-1]
+        K = invalid.shape[-2]
         if sb > 0:
             rgb = rgb.reshape(sb, -1, rgb.shape[-1])
             depth = depth.reshape(sb, -1)

@@ -288,7 +288,8 @@ def train_workload(args, world, rank, dev):
             task, [k for k, _ in task.named_parameters() if ".encoder.feats." in k])
     # a real DistributedDataParallel whenever a process group exists (also at world size 1 under torch.distributed.run: the reducer and
     # the RCCL all-reduce then run on the single-GPU box as they will on a node)
-    model = parallel.wrap_ddp(task, dev, force=True)
+    # (Monodepth2 with one rendered scale: the output convolutions of scales 1-3 run but stay outside the loss' graph)
+    model = parallel.wrap_ddp(task, dev, force=True, find_unused_parameters=args.encoder == "monodepth2" and n_scales == 1)
     is_ddp = isinstance(model, torch.nn.parallel.DistributedDataParallel)
 
     def step():   # base_trainer.py:287-297

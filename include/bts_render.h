@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define BTS_ABI_VERSION 4
+#define BTS_ABI_VERSION 5
 
 enum {
   BTS_OK = 0,
@@ -64,6 +64,12 @@ typedef struct BtsFieldCfg {
    * (n, H >> feat_shift, W >> feat_shift, .) and every result is bit-identical to the resized map's.  H and W (the colour frames'
    * size, and the size the bilinear taps are computed for) must be multiples of 2^feat_shift.  0 = a full-size map. */
   int32_t feat_shift;
+  /* ABI 5: index j of a render view whose camera IS the encoder camera of every batch element -- K_r[:, j] == K_enc and
+   * w2c_r[:, j] == w2c_enc bit for bit, i.e. ids_render[j] == ids_encoder[0] in BTSNet.encode (models_bts.py:84-97; the eval_depth
+   * configuration renders its colours from the encoder frame) -- or -1.  The forward and query kernels then take that view's
+   * projection, frustum flag and bilinear weights from the encoder view's instead of evaluating them a second time: same inputs, same
+   * instruction sequence, bit-identical results (tests/test_gpu_abi5.py).  A hint: -1 is always correct. */
+  int32_t enc_render_view;
 } BtsFieldCfg;
 
 #define BTS_MAX_VIEWS 8
@@ -88,7 +94,7 @@ typedef struct BtsRenderArgs {
   int32_t hard_alpha_cap;  /* nerf.py:285-286 */
   int32_t white_bkgd;      /* nerf.py:301-304: rgb += 1 - sum(weights); honoured by the forward AND the backward */
   const float* rays;       /* (n*Bp, 8) */
-  const float* z_samp;     /* (n*Bp, K) */
+  const float* z_samp;     /* (n*Bp, K), or NULL with `jitter` below */
   /* outputs; the per-sample ones may be NULL when not wanted */
   float* rgb;              /* (n*Bp, nv*3) */
   float* depth;            /* (n*Bp) */
@@ -105,6 +111,15 @@ typedef struct BtsRenderArgs {
   /* ABI 3: the density noise of a training step (nerf.py:279-280: sigmas + randn_like(sigmas) * noise_std, drawn by the caller),
    * added to softplus(s) before relu / alpha -- INPUT of the forward and of the backward (which needs the sign of the sum) */
   const float* sigma_noise;/* (n*Bp, K)        or NULL */
+  /* ABI 5: NeRFRenderer.sample_coarse (nerf.py:103-123) inside the forward kernel.  With z_samp == NULL the sample depths are computed
+   * from every ray's [near, far] and the stratified jitter `jitter` in [0, 1) (the caller's torch.rand_like draw, nerf.py:112) by the
+   * routine bts_sample_coarse runs -- bit-identical depths, one launch and 8 bytes per sample of HBM traffic less; `lindisp` selects
+   * disparity- (nerf.py:117) or depth-linear (:115) spacing; z_samp_out, when given, receives the depths (a training step hands them
+   * to bts_render_bwd as z_samp).  Ignored when z_samp is given.  Needs proj_nhwc. */
+  const float* jitter;     /* (n*Bp, K)        or NULL */
+  float* z_samp_out;       /* (n*Bp, K)        or NULL */
+  int32_t lindisp;
+  int32_t reserved_;       /* 0 */
 } BtsRenderArgs;
 
 /* Gradients flowing into / out of the renderer (what torch.autograd would compute through nerf.py:283-299,

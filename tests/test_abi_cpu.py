@@ -38,7 +38,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
         assert hasattr(lib, n), f"{n} declared in include/bts_render.h but not exported"
         assert n in _lib.SYMBOLS, f"{n} has no ctypes signature in _lib.SYMBOLS"
     assert set(_lib.SYMBOLS) == set(names)
-    assert lib.bts_abi_version() == _lib.ABI_VERSION == 4
+    assert lib.bts_abi_version() == _lib.ABI_VERSION == 5
 
 
 def test_ctypes_structs_match_the_c_layout():
@@ -53,6 +53,8 @@ int main(void) {
          offsetof(BtsRenderArgs, trans));
   printf("%zu %zu %zu\n", offsetof(BtsRenderArgs, invalid_wsum), offsetof(BtsRenderArgs, invalid_any), offsetof(BtsLossArgs, invalid_wsum));
   printf("%zu %zu\n", offsetof(BtsRenderArgs, sigma_noise), offsetof(BtsFieldCfg, feat_shift));
+  printf("%zu %zu %zu %zu\n", offsetof(BtsFieldCfg, enc_render_view), offsetof(BtsRenderArgs, jitter), offsetof(BtsRenderArgs, z_samp_out),
+         offsetof(BtsRenderArgs, lindisp));
   return 0;
 }'''
     with tempfile.TemporaryDirectory() as d:
@@ -69,7 +71,10 @@ int main(void) {
     assert [int(x) for x in out[8:11]] == [_lib.BtsRenderArgs.invalid_wsum.offset, _lib.BtsRenderArgs.invalid_any.offset,
                                            _lib.BtsLossArgs.invalid_wsum.offset]
     # ABI 3: the density noise; ABI 4: the feature map at its own scale -- both appended
-    assert [int(x) for x in out[11:]] == [_lib.BtsRenderArgs.sigma_noise.offset, _lib.BtsFieldCfg.feat_shift.offset]
+    assert [int(x) for x in out[11:13]] == [_lib.BtsRenderArgs.sigma_noise.offset, _lib.BtsFieldCfg.feat_shift.offset]
+    # ABI 5: the encoder-view hint and the in-kernel sample_coarse -- appended
+    assert [int(x) for x in out[13:]] == [_lib.BtsFieldCfg.enc_render_view.offset, _lib.BtsRenderArgs.jitter.offset,
+                                          _lib.BtsRenderArgs.z_samp_out.offset, _lib.BtsRenderArgs.lindisp.offset]
 
 
 def test_host_only_entry_points(lib):
@@ -113,6 +118,13 @@ def test_errors_are_codes_with_messages_never_exceptions(lib):
     raw = _lib.BtsFieldTensors(1, None, 1, 1, 1, 1, 1, 1, 1)      # raw features only: the kernels that read them know full-size maps
     ok_size = native._spec_cfg(native.FieldSpec(C=64, d_hidden=64, n_blocks=0), n=1, H=32, W=96, feat_shift=2)
     assert lib.bts_render_fwd(C.byref(ok_size), C.byref(raw), None, None) == -1 and b"proj_nhwc" in lib.bts_last_error()
+    # ABI 5: enc_render_view must name a render view (or be -1); a render call needs z_samp or the jitter
+    hint = native._spec_cfg(native.FieldSpec(C=64, d_hidden=64, n_blocks=0), n=1, H=32, W=96, nv=2)
+    hint.enc_render_view = 2
+    assert lib.bts_render_fwd(C.byref(hint), C.byref(tens), None, None) == -1 and b"enc_render_view" in lib.bts_last_error()
+    hint.enc_render_view = 1
+    args = _lib.BtsRenderArgs(rays_per_sample=8, K=4, rays=1, rgb=1, depth=1)       # neither z_samp nor jitter
+    assert lib.bts_render_fwd(C.byref(hint), C.byref(tens), C.byref(args), None) == -1 and b"jitter" in lib.bts_last_error()
     with pytest.raises(bts.BtsNativeError):
         native.nchw_to_nhwc(torch.zeros(1, 4, 2, 2))                                # CPU tensor: no CPU path
     with pytest.raises(bts.BtsNativeError):

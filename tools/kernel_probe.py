@@ -16,12 +16,12 @@ net = S.build_net(scene, 64, 0, [0], learn_empty=True)
 ft = net.native_field()
 params = net.mlp_coarse.packed().detach()
 rays = bts.ImageRaySampler(3.0, 80.0, H, W).sample(None, scene["poses"].cuda(), scene["projs"].cuda())[0].reshape(-1, 8).contiguous()
-z = native.sample_coarse(rays, torch.rand(rays.shape[0], K, device="cuda"), True)
+u = torch.rand(rays.shape[0], K, device="cuda")   # sample_coarse runs inside the kernel (BtsRenderArgs.jitter), as bench.py's step does
 ts = []
 for r in range(rounds + 1):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    native.render_fwd(ft, params, rays, z, hard_alpha_cap=True, want_weights=True, want_alphas=True, want_invalid=True)
+    native.render_fwd(ft, params, rays, None, jitter=u, lindisp=True, hard_alpha_cap=True, want_weights=True, want_alphas=True, want_invalid=True)
     e1.record()
     torch.cuda.synchronize()
     if r > 0:

@@ -1,6 +1,8 @@
 """A/B timing of differently built libraries on the BASELINE configs[1] kernel workload within ONE gpurun call (box-to-box spread is
 +-4 %): every library renders the same frame `rounds` times in its own subprocess, interleaved over `passes` passes.
-    python tools/lib_ab.py [--learn-empty] default noslp late_noslp ...      (names under behindthescenes_amd/variants/, or "default")"""
+    python tools/lib_ab.py [--learn-empty] default noslp late_noslp ...      (names under behindthescenes_amd/variants/, or "default")
+A name may carry modes after a colon: "default:jitter" = sample_coarse inside the kernel (BtsRenderArgs.jitter) instead of a z_samp
+tensor, "default:nohint" = without the encoder-view hint (BtsFieldCfg.enc_render_view)."""
 import os
 import subprocess
 import sys
@@ -9,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def child(rounds, learn_empty):
+def child(rounds, learn_empty, modes=()):
     import torch
     import behindthescenes_amd as bts
     from behindthescenes_amd import native, synthetic as S
@@ -19,12 +21,16 @@ def child(rounds, learn_empty):
     ft = net.native_field()
     params = net.mlp_coarse.packed().detach()
     rays = bts.ImageRaySampler(3.0, 80.0, H, W).sample(None, scene["poses"].cuda(), scene["projs"].cuda())[0].reshape(-1, 8).contiguous()
-    z = native.sample_coarse(rays, torch.rand(rays.shape[0], K, device="cuda"), True)
+    u = torch.rand(rays.shape[0], K, device="cuda")
+    z = native.sample_coarse(rays, u, True)
+    if "nohint" in modes:
+        ft = native.FieldTensors(ft.spec, ft.proj_nhwc, ft.K_enc, ft.w2c_enc, ft.imgs_nhwc4, ft.K_r, ft.w2c_r, ft.empty_feature, enc_view=-1)
+    kw = dict(jitter=u, lindisp=True) if "jitter" in modes else {}
     ts = []
     for r in range(rounds + 2):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        native.render_fwd(ft, params, rays, z, hard_alpha_cap=True, want_weights=True, want_alphas=True, want_invalid=True)
+        native.render_fwd(ft, params, rays, None if kw else z, hard_alpha_cap=True, want_weights=True, want_alphas=True, want_invalid=True, **kw)
         e1.record()
         torch.cuda.synchronize()
         if r >= 2:
@@ -40,9 +46,10 @@ def main():
     res = {a: [] for a in args}
     for _ in range(passes):
         for a in args:
-            lib = os.path.join(ROOT, "behindthescenes_amd", "libbts_render.so" if a == "default" else f"variants/libbts_{a}.so")
-            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", "15"] + (["--learn-empty"] if le else []),
-                               env=dict(os.environ, BTS_RENDER_LIB=lib), capture_output=True, text=True)
+            name, *modes = a.split(":")
+            lib = os.path.join(ROOT, "behindthescenes_amd", "libbts_render.so" if name == "default" else f"variants/libbts_{name}.so")
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", "15"] + (["--learn-empty"] if le else []) + ["--modes=" + ",".join(modes)],
+                               env=dict(os.environ, BTS_RENDER_LIB=lib, BTS_ALLOW_OLDER_ABI="1"), capture_output=True, text=True)
             if r.returncode:
                 print(a, "FAILED", r.stderr[-500:])
                 continue
@@ -54,6 +61,7 @@ def main():
 
 if __name__ == "__main__":
     if "--child" in sys.argv:
-        child(int(sys.argv[sys.argv.index("--child") + 1]), "--learn-empty" in sys.argv)
+        child(int(sys.argv[sys.argv.index("--child") + 1]), "--learn-empty" in sys.argv,
+              tuple(m for a in sys.argv if a.startswith("--modes=") for m in a[8:].split(",") if m))
     else:
         main()
