@@ -159,8 +159,10 @@ class NeRFRenderer(torch.nn.Module):
         rays = rays.reshape(-1, 8)
         jitter = None
         if sample_from_dist is None:
-            if isinstance(model, BTSNet):
-                # nerf.py:103-123 inside the render kernel: only the jitter is drawn here (the reference's torch.rand_like, :112)
+            if isinstance(model, BTSNet) and getattr(self.sample_coarse, "__func__", None) is NeRFRenderer.sample_coarse:
+                # nerf.py:103-123 inside the render kernel: only the jitter is drawn here (the reference's torch.rand_like, :112).
+                # (a subclass or an instance that overrides sample_coarse -- the reference's extension point -- is honoured: its depths
+                # are used as they come)
                 z_coarse, jitter = None, torch.rand((rays.shape[0], self.n_coarse), device=rays.device, dtype=torch.float32)
             else:
                 z_coarse = self.sample_coarse(rays)

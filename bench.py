@@ -12,7 +12,7 @@ resident in HBM before the timed region.  N > 1: every rank renders its own fram
 no collective on the data path); value = total rays of all ranks / max-over-ranks time.
 
 Prints ONE JSON line (rank 0).  Next to the headline it carries `others` (N = 1: BASELINE configs[2], [3], [4], [4] at K = 128 and the
-occupancy profile, each = `bench.py --workload X --steps 10 --warmup 3` run in-process) and, under torch.distributed.run, `ddp_train`
+occupancy profile, each = `bench.py --workload X --steps 10 --warmup 3` in a child process) and, under torch.distributed.run, `ddp_train`
 (KITTI-Raw shapes with the Monodepth2 encoder through DistributedDataParallel: the path's one collective, with `allreduce_ms`);
 `--no-others` skips both.  `roofline` is for the dominant kernel (bts::render_kernel_p = bts_render_fwd), timed live with HIP
 events on the launch stream inside the timed region; `roofline.traffic` is the HBM byte count of the committed rocprofv3 PMC passes
@@ -666,8 +666,8 @@ def _condense(rec):
 
 def sub_records(args, world, rank, dev, launched):
     """`others`: BASELINE configs[2..4] (+ configs[4] at BASELINE.json's K = 128) and the occupancy profile, each measured by the same
-    code as `bench.py --workload X` (10 steps after 3 warm-ups, no CPU baseline) so that the ONE line the driver records carries every
-    workload; N = 1 only.  `ddp_train` (whenever a process group exists, i.e. under torch.distributed.run): the KITTI-Raw training shapes
+    code as `bench.py --workload X` (its own process each, 10 steps after 3 warm-ups, no CPU baseline) so that the ONE line the driver
+    records carries every workload; N = 1 only.  `ddp_train` (whenever a process group exists, i.e. under torch.distributed.run): the KITTI-Raw training shapes
     WITH the shipped Monodepth2 encoder -- the real ~140 MB gradient bucket through DistributedDataParallel's RCCL all-reduce, the one
     exchange step of the path (trainer.py:418); the eval headline next to it is collective-free by construction (independent frames)."""
     import copy
@@ -688,9 +688,26 @@ def sub_records(args, world, rank, dev, launched):
         finally:
             torch.cuda.empty_cache()
 
+    def run_child(workload, samples=0):
+        """`python bench.py --workload X --steps 10 --warmup 3` in its own process -- the very command a reader would run by hand (in this
+        process the allocator and host state the previous workload leaves behind cost the next one up to a millisecond per step)."""
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK",
+                                                                  "LOCAL_WORLD_SIZE", "ROLE_RANK", "TORCHELASTIC_RUN_ID")}
+        cmd = [sys.executable, os.path.abspath(__file__), "--workload", workload, "--steps", "10", "--warmup", "3", "--no-cpu-baseline", "--no-others"]
+        if samples:
+            cmd += ["--samples", str(samples)]
+        try:
+            r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+            line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            if r.returncode != 0 or not line:
+                return {"error": (r.stderr or r.stdout)[-500:]}
+            return _condense(json.loads(line[-1]))
+        except Exception as e:
+            return {"error": f"{type(e).__name__}: {e}"[:500]}
+
     if world == 1:
-        others = {"train": run("train"), "kitti_raw": run("kitti_raw"), "re10k": run("re10k"), "re10k_k128": run("re10k", samples=128),
-                  "profile": run("profile")}
+        others = {"train": run_child("train"), "kitti_raw": run_child("kitti_raw"), "re10k": run_child("re10k"),
+                  "re10k_k128": run_child("re10k", 128), "profile": run_child("profile")}
         out["others"] = others
     if launched:
         out["ddp_train"] = run("kitti_raw", steps=5, warmup=2, encoder="monodepth2")
