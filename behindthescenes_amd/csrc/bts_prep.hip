@@ -16,9 +16,12 @@ void set_error(const char* fmt, const char* a = "", long b = 0, long c = 0, long
 // ---- forward: one wave = 64 pixels x all Hd outputs.  D[pix][hid] = A[pix][c] . B[c][hid]:
 // A operand = F (lane l: pixel l&31, channel parity l>>5) read straight from the NCHW rows, B = w_in^T from LDS (k-major),
 // D rows (pixels) sit in registers, columns (hidden) across lanes -> every store is a 128-byte row segment of G.
+// Persistent work-groups (the weights are staged once per work-group, not once per 256 pixels) and ALL of a tile's loads issued
+// before its first MFMA: round 3 kept 8 loads (2 KB) per wave in flight and ran at 45 % of HBM speed (latency-bound by Little's law);
+// 64 loads per wave keep 16 KB in flight.
 template <int C, int HD>
-__global__ __launch_bounds__(256) void project_kernel(const float* __restrict__ feat, const float* __restrict__ mlp, float* __restrict__ proj,
-                                                      int HW, int tiles_per_img) {
+__global__ __launch_bounds__(256, 2) void project_kernel(const float* __restrict__ feat, const float* __restrict__ mlp, float* __restrict__ proj,
+                                                      int HW, int tiles_per_img, int n_tiles) {
   constexpr int HT = HD / 32;
   constexpr int D_IN = C + kPeDim;
   __shared__ float wl[C * HD];  // wl[c*HD + s] = w_in[hidden_of_storage(s)][c]: G comes out in its storage channel order
@@ -29,199 +32,225 @@ __global__ __launch_bounds__(256) void project_kernel(const float* __restrict__ 
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int h = lane >> 5, col = lane & 31;
-  const int wg = blockIdx.x;
-  const int img = wg / tiles_per_img;
-  const int p0 = (wg - img * tiles_per_img) * 256 + wave * 64;
-  if (p0 >= HW) return;
-  const float* F = feat + (long)img * C * HW;
-  float* G = proj + (long)img * HW * HD;
-
-  f32x16 acc[2][HT];
+  for (int tile = blockIdx.x * 4 + wave; tile < n_tiles; tile += gridDim.x * 4) {   // tile = 64 pixels of one image
+    const int img = tile / tiles_per_img;
+    const int p0 = (tile - img * tiles_per_img) * 64;
+    const float* F = feat + (long)img * C * HW;
+    float* G = proj + (long)img * HW * HD;
+    // wave-uniform base + 32-bit lane offset (one image's map is far below 4 GB): scalar-base loads, no 64-bit address per load
+    const unsigned o0 = (unsigned)(h * HW + min(p0 + col, HW - 1)), o1 = (unsigned)(h * HW + min(p0 + 32 + col, HW - 1));
+    float a0[C / 2], a1[C / 2];
 #pragma unroll
-  for (int pt = 0; pt < 2; ++pt)
-#pragma unroll
-    for (int ht = 0; ht < HT; ++ht) acc[pt][ht] = zero_acc();
-  const int px0 = min(p0 + col, HW - 1), px1 = min(p0 + 32 + col, HW - 1);
-#pragma unroll 4
-  for (int s = 0; s < C / 2; ++s) {
-    const int c = 2 * s + h;
-    const float a0 = F[(long)c * HW + px0];
-    const float a1 = F[(long)c * HW + px1];
-#pragma unroll
-    for (int ht = 0; ht < HT; ++ht) {
-      const float b = wl[c * HD + ht * 32 + col];
-      acc[0][ht] = mfma(a0, b, acc[0][ht]);
-      acc[1][ht] = mfma(a1, b, acc[1][ht]);
+    for (int s = 0; s < C / 2; ++s) {
+      const float* row = F + (long)(2 * s) * HW;   // uniform
+      a0[s] = row[o0], a1[s] = row[o1];
     }
-  }
+    f32x16 acc[2][HT];
 #pragma unroll
-  for (int pt = 0; pt < 2; ++pt)
+    for (int pt = 0; pt < 2; ++pt)
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int pix = p0 + pt * 32 + mfma_row(q, h);
-      if (pix < HW) {
+      for (int ht = 0; ht < HT; ++ht) acc[pt][ht] = zero_acc();
 #pragma unroll
-        for (int ht = 0; ht < HT; ++ht) G[(long)pix * HD + ht * 32 + col] = acc[pt][ht][q];
+    for (int s = 0; s < C / 2; ++s) {
+      const int c = 2 * s + h;
+#pragma unroll
+      for (int ht = 0; ht < HT; ++ht) {
+        const float b = wl[c * HD + ht * 32 + col];
+        acc[0][ht] = mfma(a0[s], b, acc[0][ht]);
+        acc[1][ht] = mfma(a1[s], b, acc[1][ht]);
       }
     }
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int pix = p0 + pt * 32 + mfma_row(q, h);
+        if (pix < HW) {
+#pragma unroll
+          for (int ht = 0; ht < HT; ++ht) G[(unsigned)(pix * HD + ht * 32 + col)] = acc[pt][ht][q];
+        }
+      }
+  }
 }
 
-// ---- backward, feature gradient: D[c][pix] = A[c][hid] . B[hid][pix]; A = w_in^T[c][hid] from LDS, B = dG (lane l: pixel
-// l&31, hidden parity l>>5).  D rows (channels) in registers, columns (pixels) across lanes -> 128-byte NCHW row stores.
-// dG rows are read as float4 (4 consecutive hidden units per lane half) and consumed over 4 k-steps:
-// k-step (q, e) pairs hidden 8q + e (half 0) with 8q + 4 + e (half 1).
+// ---- backward: ONE kernel for both gradients, so that dG (the largest tensor of a training step: 503 MB at exp_kitti_360.yaml's
+// batch) leaves HBM once.  The waves of a work-group split the roles and walk the same tiles of 64 pixels:
+//   waves 0, 1 (when the weight gradient is wanted): dW[hid][c] += sum_pix dG[pix][hid] F[c][pix]   (contraction over pixels)
+//   waves 2, 3 (when the feature gradient is wanted): dF[c][pix] = sum_hid dG[pix][hid] w_in[hid][c]
+// so a tile of dG is fetched by one role and found in L2 by the other (round 3 ran two kernels: 2 x 503 MB of dG reads).
+//
+// dW: A[i = stored channel][k = pix] comes straight from dG (32 lanes = 32 consecutive channels of one pixel: a 128-byte row segment);
+//     B[k = pix][j = c] = F[c][pix]: lane (c, half h) reads FOUR consecutive pixels of its channel row as one float4 -- k-step (t, e)
+//     pairs pixel 8t + e (lane half 0) with pixel 8t + 4 + e (half 1), so a row's 32-byte piece is one request per lane and a 128-byte
+//     line serves four of them (round 3 staged every tile of F through 66 KB of LDS for this; the k order of an MFMA is free).
+// dF: D[c][pix] = A[c][hid] . B[hid][pix]; A = w_in^T[c][hid] from LDS, B = dG (lane l: pixel l&31, hidden parity l>>5), read as
+//     float4 rows and consumed over 4 k-steps: k-step (q, e) pairs hidden 8q + e (half 0) with 8q + 4 + e (half 1).  D rows
+//     (channels) in registers, columns (pixels) across lanes -> 128-byte NCHW row stores.
+// Every load of a tile is issued before its first MFMA.  The weight gradient is reduced registers -> LDS -> one atomic per (hid, c).
 template <int C, int HD>
-__global__ __launch_bounds__(256) void project_bwd_feat_kernel(const float* __restrict__ dproj, const float* __restrict__ mlp,
-                                                               float* __restrict__ dfeat, int HW, int tiles_per_img) {
-  constexpr int CT = C / 32;
-  constexpr int D_IN = C + kPeDim;
-  __shared__ float wl[HD * C];  // wl[hid*C + c] = w_in[hid][c]
-  for (int i = threadIdx.x; i < HD * C; i += blockDim.x) {
-    const int hid = i / C, c = i % C;
-    wl[i] = mlp[hid * D_IN + c];
-  }
-  __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int h = lane >> 5, col = lane & 31;
-  const int wg = blockIdx.x;
-  const int img = wg / tiles_per_img;
-  const int p0 = (wg - img * tiles_per_img) * 256 + wave * 64;
-  if (p0 >= HW) return;
-  const float4* dG = reinterpret_cast<const float4*>(dproj + (long)img * HW * HD);
-  float* dF = dfeat + (long)img * C * HW;
-  f32x16 acc[CT][2];
-#pragma unroll
-  for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-    for (int pt = 0; pt < 2; ++pt) acc[ct][pt] = zero_acc();
-  const int px0 = min(p0 + col, HW - 1), px1 = min(p0 + 32 + col, HW - 1);
-#pragma unroll 2
-  for (int qq = 0; qq < HD / 8; ++qq) {
-    // storage float4 (ht*8 + 4h + q) holds hidden ht*32 + 8q + 4h + e, e = 0..3  (proj_storage_index)
-    const int ht = qq >> 2, q = qq & 3;
-    const float4 v0 = dG[(long)px0 * (HD / 4) + ht * 8 + 4 * h + q];
-    const float4 v1 = dG[(long)px1 * (HD / 4) + ht * 8 + 4 * h + q];
-    const float* b0 = reinterpret_cast<const float*>(&v0);
-    const float* b1 = reinterpret_cast<const float*>(&v1);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int hid = ht * 32 + 8 * q + 4 * h + e;
-#pragma unroll
-      for (int ct = 0; ct < CT; ++ct) {
-        const float a = wl[hid * C + ct * 32 + col];
-        acc[ct][0] = mfma(a, b0[e], acc[ct][0]);
-        acc[ct][1] = mfma(a, b1[e], acc[ct][1]);
-      }
-    }
-  }
-#pragma unroll
-  for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-    for (int pt = 0; pt < 2; ++pt) {
-      const int pix = p0 + pt * 32 + col;
-      if (pix < HW) {
-#pragma unroll
-        for (int q = 0; q < 16; ++q) dF[(long)(ct * 32 + mfma_row(q, h)) * HW + pix] = acc[ct][pt][q];
-      }
-    }
-}
-
-// ---- backward, weight gradient: dW[hid][c] = sum_pix dG[pix][hid] * F[c][pix]  (contraction over pixels).
-// A[i = stored channel s][k = pix] comes straight from dG (32 lanes = 32 consecutive channels of one pixel: a 128-byte row segment);
-// B[k = pix][j = c] = F[c][pix] would be a 4-byte gather with stride H*W from the NCHW map, so every wave first stages its 64-pixel
-// tile of F through LDS: coalesced 256-byte rows in (lane = pixel), [c][pix] with an odd leading dimension out (conflict-free).
-// k-step s of a tile pairs pixel s (lane half 0) with pixel s + 32 (half 1).  Each work-group reduces a slab of pixels into
-// registers, then LDS, then one atomic per (hid, c) into d_mlp.  HBM-bound: reads 4*(C + Hd) bytes per pixel once.
-template <int C, int HD>
-__global__ __launch_bounds__(256) void project_bwd_weight_kernel(const float* __restrict__ feat, const float* __restrict__ dproj,
-                                                                 float* __restrict__ d_mlp, int HW, int slabs_per_img, int tiles_per_slab) {
+__global__ __launch_bounds__(256, 2) void project_bwd_kernel(const float* __restrict__ feat, const float* __restrict__ dproj, const float* __restrict__ mlp,
+                                                          float* __restrict__ dfeat, float* __restrict__ d_mlp, int HW, int tiles_per_img, int n_tiles) {
   constexpr int HT = HD / 32, CT = C / 32;
   constexpr int D_IN = C + kPeDim;
-  constexpr int LDF = 65;
-  static_assert(4 * C * LDF >= HD * C, "the reduction buffer aliases the staging tiles");
-  __shared__ float ftile[4 * C * LDF];
-  float* red = ftile;                            // reused after the pixel loop
+  __shared__ float wl[HD * C];  // wl[hid*C + c] = w_in[hid][c]; reused as the weight gradient's reduction buffer after the tile loop
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int h = lane >> 5, col = lane & 31;
-  const int img = blockIdx.x / slabs_per_img;
-  const int slab = blockIdx.x - img * slabs_per_img;
-  const float* F = feat + (long)img * C * HW;
-  const float* dG = dproj + (long)img * HW * HD;
-  float* ft = ftile + wave * C * LDF;
-  f32x16 acc[HT][CT];
+  if (dfeat) {
+    for (int i = threadIdx.x; i < HD * C; i += blockDim.x) {
+      const int hid = i / C, c = i % C;
+      wl[i] = mlp[hid * D_IN + c];
+    }
+  }
+  __syncthreads();
+  // roles: with both gradients wanted waves 0, 1 reduce dW and waves 2, 3 write dF, each pair walking ALL tiles of the work-group
+  // (role-local wave index rw of nr); with one gradient wanted all four waves take that role
+  const bool both = dfeat && d_mlp;
+  const bool role_w = d_mlp && (!both || wave < 2);
+  const int nr = both ? 2 : 4, rw = both ? (wave & 1) : wave;
+  const bool vec4 = (HW & 3) == 0;   // float4 reads of F rows need 16-byte aligned rows
+  f32x16 accw[HT][CT];
 #pragma unroll
   for (int ht = 0; ht < HT; ++ht)
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct) acc[ht][ct] = zero_acc();
-  for (int t = wave; t < tiles_per_slab; t += 4) {
-    const int p0 = (slab * tiles_per_slab + t) * 64;
-    if (p0 >= HW) break;
-    // every global load of the tile is issued before the first use (the wave is alone on its SIMD half the time)
-    const int px = min(p0 + lane, HW - 1);
-    const bool okl = p0 + lane < HW;
-    float fv[C], av[32][HT];
+    for (int ct = 0; ct < CT; ++ct) accw[ht][ct] = zero_acc();
+
+  for (int tile = blockIdx.x * nr + rw; tile < n_tiles; tile += gridDim.x * nr) {
+    const int img = tile / tiles_per_img;
+    const int p0 = (tile - img * tiles_per_img) * 64;
+    const float* dG = dproj + (long)img * HW * HD;
+    if (role_w) {
+      const float* F = feat + (long)img * C * HW;
+      // a tile = 8 groups of 8 pixels, taken as two halves of four groups: all loads of a half (a float4 of F per channel tile and four
+      // dG values per hidden tile and group: 64 registers) are issued before its first MFMA
 #pragma unroll
-    for (int c = 0; c < C; ++c) fv[c] = F[(long)c * HW + px];   // rows of F: 256-byte coalesced reads
+      for (int half = 0; half < 2; ++half) {
+        float4 fb[4][CT];
+        float av[4][4][HT];
 #pragma unroll
-    for (int s = 0; s < 32; ++s) {
-      const int pix = min(p0 + s + 32 * h, HW - 1);
+        for (int t = 0; t < 4; ++t) {
+          const int pix4 = p0 + 8 * (4 * half + t) + 4 * h;
 #pragma unroll
-      for (int ht = 0; ht < HT; ++ht) av[s][ht] = dG[(long)pix * HD + ht * 32 + col];   // stored channel ht*32 + col
+          for (int ct = 0; ct < CT; ++ct) {
+            const unsigned ro = (unsigned)((ct * 32 + col) * HW + pix4);     // element offset inside the image's map (< 2^32)
+            if (vec4 && pix4 + 3 < HW) fb[t][ct] = *reinterpret_cast<const float4*>(F + ro);
+            else fb[t][ct] = make_float4(pix4 < HW ? F[ro] : 0.0f, pix4 + 1 < HW ? F[ro + 1] : 0.0f, pix4 + 2 < HW ? F[ro + 2] : 0.0f,
+                                         pix4 + 3 < HW ? F[ro + 3] : 0.0f);
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int pix = pix4 + e;
+#pragma unroll
+            for (int ht = 0; ht < HT; ++ht) av[t][e][ht] = pix < HW ? dG[(unsigned)(pix * HD + ht * 32 + col)] : 0.0f;   // stored channel ht*32 + col
+          }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+#pragma unroll
+            for (int ht = 0; ht < HT; ++ht)
+#pragma unroll
+              for (int ct = 0; ct < CT; ++ct) {
+                const float* fp = reinterpret_cast<const float*>(&fb[t][ct]);
+                accw[ht][ct] = mfma(av[t][e][ht], fp[e], accw[ht][ct]);
+              }
+          }
+      }
+    } else {
+      const float4* dG4 = reinterpret_cast<const float4*>(dG);
+      float* dF = dfeat + (long)img * C * HW;
+      const int px0 = min(p0 + col, HW - 1), px1 = min(p0 + 32 + col, HW - 1);
+      float4 v0[HD / 8], v1[HD / 8];
+#pragma unroll
+      for (int qq = 0; qq < HD / 8; ++qq) {
+        // storage float4 (ht*8 + 4h + q) holds hidden ht*32 + 8q + 4h + e, e = 0..3  (proj_storage_index)
+        const int ht = qq >> 2, q = qq & 3;
+        v0[qq] = dG4[(unsigned)(px0 * (HD / 4) + ht * 8 + 4 * h + q)];
+        v1[qq] = dG4[(unsigned)(px1 * (HD / 4) + ht * 8 + 4 * h + q)];
+      }
+      f32x16 acc[CT][2];
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt) acc[ct][pt] = zero_acc();
+#pragma unroll
+      for (int qq = 0; qq < HD / 8; ++qq) {
+        const int ht = qq >> 2, q = qq & 3;
+        const float* b0 = reinterpret_cast<const float*>(&v0[qq]);
+        const float* b1 = reinterpret_cast<const float*>(&v1[qq]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int hid = ht * 32 + 8 * q + 4 * h + e;
+#pragma unroll
+          for (int ct = 0; ct < CT; ++ct) {
+            const float a = wl[hid * C + ct * 32 + col];
+            acc[ct][0] = mfma(a, b0[e], acc[ct][0]);
+            acc[ct][1] = mfma(a, b1[e], acc[ct][1]);
+          }
+        }
+      }
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt) {
+          const int pix = p0 + pt * 32 + col;
+          if (pix < HW) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) dF[(unsigned)((ct * 32 + mfma_row(q, h)) * HW + pix)] = acc[ct][pt][q];
+          }
+        }
     }
-#pragma unroll
-    for (int c = 0; c < C; ++c) ft[c * LDF + lane] = okl ? fv[c] : 0.0f;
-#pragma unroll
-    for (int s = 0; s < 32; ++s) {
-      const int pl = s + 32 * h;                 // pixel of this lane half inside the tile
-      const bool ok = p0 + pl < HW;
-      float b[CT];
-#pragma unroll
-      for (int ct = 0; ct < CT; ++ct) b[ct] = ft[(ct * 32 + col) * LDF + pl];
+  }
+  if (d_mlp) {
+    __syncthreads();
+    float* red = wl;
+    for (int i = threadIdx.x; i < HD * C; i += blockDim.x) red[i] = 0.0f;
+    __syncthreads();
+    if (role_w) {   // accumulator rows are STORED channels: map back to hidden units
 #pragma unroll
       for (int ht = 0; ht < HT; ++ht)
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) acc[ht][ct] = mfma(ok ? av[s][ht] : 0.0f, b[ct], acc[ht][ct]);
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+          for (int q = 0; q < 16; ++q) atomicAdd(&red[proj_hidden_of_storage(ht * 32 + mfma_row(q, h)) * C + ct * 32 + col], accw[ht][ct][q]);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < HD * C; i += blockDim.x) {
+      const int hid = i / C, c = i % C;
+      atomicAdd(&d_mlp[hid * D_IN + c], red[i]);
     }
   }
-  __syncthreads();
-  for (int i = threadIdx.x; i < HD * C; i += blockDim.x) red[i] = 0.0f;
-  __syncthreads();
-  // accumulator rows are STORED channels: map back to hidden units
-#pragma unroll
-  for (int ht = 0; ht < HT; ++ht)
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-      for (int q = 0; q < 16; ++q) atomicAdd(&red[proj_hidden_of_storage(ht * 32 + mfma_row(q, h)) * C + ct * 32 + col], acc[ht][ct][q]);
-  __syncthreads();
-  for (int i = threadIdx.x; i < HD * C; i += blockDim.x) {
-    const int hid = i / C, c = i % C;
-    atomicAdd(&d_mlp[hid * D_IN + c], red[i]);
+}
+
+static int prep_cus() {
+  static thread_local int cus[16] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+  if (!cus[dev]) {
+    hipDeviceProp_t prop;
+    cus[dev] = hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   }
+  return cus[dev];
 }
 
 template <int C, int HD>
 static int run_fwd(const float* feat, const float* mlp, int N, int HW, float* proj, hipStream_t s) {
-  const int tiles = (HW + 255) / 256;
-  project_kernel<C, HD><<<N * tiles, 256, 0, s>>>(feat, mlp, proj, HW, tiles);
+  const int tiles = (HW + 63) / 64;
+  const long n_tiles = (long)N * tiles;
+  const long want = (n_tiles + 3) / 4, cap = 4L * prep_cus();     // persistent: <= 4 work-groups per CU (16 KB of LDS each)
+  project_kernel<C, HD><<<(int)(want < cap ? want : cap), 256, 0, s>>>(feat, mlp, proj, HW, tiles, (int)n_tiles);
   return hipGetLastError() == hipSuccess ? BTS_OK : BTS_E_LAUNCH;
 }
 
 template <int C, int HD>
 static int run_bwd(const float* feat, const float* dproj, const float* mlp, int N, int HW, float* dfeat, float* d_mlp, hipStream_t s) {
-  if (dfeat) {
-    const int tiles = (HW + 255) / 256;
-    project_bwd_feat_kernel<C, HD><<<N * tiles, 256, 0, s>>>(dproj, mlp, dfeat, HW, tiles);
-    if (hipGetLastError() != hipSuccess) return BTS_E_LAUNCH;
-  }
-  if (d_mlp) {
-    const int tiles64 = (HW + 63) / 64;
-    const int tiles_per_slab = 32;  // 2048 pixels per work-group
-    const int slabs = (tiles64 + tiles_per_slab - 1) / tiles_per_slab;
-    project_bwd_weight_kernel<C, HD><<<N * slabs, 256, 0, s>>>(feat, dproj, d_mlp, HW, slabs, tiles_per_slab);
-    if (hipGetLastError() != hipSuccess) return BTS_E_LAUNCH;
-  }
-  return BTS_OK;
+  if (!dfeat && !d_mlp) return BTS_OK;
+  const int tiles = (HW + 63) / 64;
+  const long n_tiles = (long)N * tiles;
+  const int nr = (dfeat && d_mlp) ? 2 : 4;
+  const long want = (n_tiles + nr - 1) / nr, cap = 2L * prep_cus();   // <= 2 work-groups per CU: the roles hold up to 256 VGPRs
+  project_bwd_kernel<C, HD><<<(int)(want < cap ? want : cap), 256, 0, s>>>(feat, dproj, mlp, dfeat, d_mlp, HW, tiles, (int)n_tiles);
+  return hipGetLastError() == hipSuccess ? BTS_OK : BTS_E_LAUNCH;
 }
 
 int project_features_impl(int C, int HD, const float* feat, const float* mlp, int N, int HW, float* proj, hipStream_t s) {

@@ -454,7 +454,7 @@ def test_projection_kernels_vs_torch(hip):
     """bts_project_features / _bwd are plain GEMMs: check against torch matmul (fp64 accumulate) incl. ragged pixel counts."""
     from behindthescenes_amd import native
     g = torch.Generator().manual_seed(1)
-    for (C, Hd, N, H, W) in ((64, 64, 2, 24, 80), (32, 32, 3, 7, 13), (64, 64, 1, 192, 640)):
+    for (C, Hd, N, H, W) in ((64, 64, 2, 24, 80), (32, 32, 3, 7, 13), (64, 64, 1, 192, 640), (64, 64, 3, 5, 27), (32, 32, 2, 64, 96)):
         spec = native.FieldSpec(C=C, d_hidden=Hd, n_blocks=0)
         F_ = torch.randn(N, C, H, W, generator=g).cuda()
         mlp = torch.randn(spec.mlp_param_count(), generator=g).cuda() * 0.2
@@ -473,6 +473,11 @@ def test_projection_kernels_vs_torch(hip):
         dW = dM[:Hd * spec.d_in].view(Hd, spec.d_in)
         assert (dW[:, :C].double() - dW_ref).abs().max().item() <= 1e-4 * dW_ref.abs().max().item()
         assert float(dW[:, C:].abs().max()) == 0.0 and float(dM[Hd * spec.d_in:].abs().max()) == 0.0
+        # one gradient only: all four waves of a work-group take the one role (the fused kernel's other launch shapes)
+        dF1, none = native.project_features_bwd(spec, F_, dG, mlp, need_feat=True, need_mlp=False)
+        assert none is None and torch.equal(dF1, dF)
+        none, dM1 = native.project_features_bwd(spec, F_, dG, mlp, need_feat=False, need_mlp=True)
+        assert none is None and (dM1 - dM).abs().max().item() <= 1e-5 * dM.abs().max().item()       # atomics: summation order only
 
 
 def test_direct_feature_path_matches_projected_path(hip):
