@@ -43,7 +43,7 @@ for f in sorted(glob.glob("$OUT/trace/**/*kernel_stats.csv", recursive=True)):
         if len(dur) <= 10:
             print(f"{float(row['AverageNs']) / 1e6:9.4f} ms x {row['Calls']:>4s}  {row['Name'][:110]}")
 train = ["rows_kernel", "scatter_kernel", "dwpe_kernel", "render_bwd_kernel", "scatter_dg_kernel", "render_kernel_p", "project_kernel",
-         "project_bwd_feat_kernel", "project_bwd_weight_kernel", "photometric_loss_kernel"]
+         "project_bwd_kernel", "photometric_loss_kernel"]
 rows = ["rowsb_kernel", "scatter_kernel", "dwpe_rows_kernel", "render_kernel_p"]
 pats = {"fwd": ["render_kernel_p"], "train": train, "bwd": train[:3], "bwd_re10k": rows, "bwd_kitti_raw": train[:3] + ["render_kernel_p"],
         "profile": ["query_kernel_p"]}[mode]
