@@ -45,6 +45,7 @@ __global__ __launch_bounds__(256, 2) void project_kernel(const float* __restrict
       const float* row = F + (long)(2 * s) * HW;   // uniform
       a0[s] = row[o0], a1[s] = row[o1];
     }
+    __builtin_amdgcn_sched_barrier(0);   // the scheduler otherwise sinks every load to its MFMA (two loads in flight, measured 2.9 TB/s)
     f32x16 acc[2][HT];
 #pragma unroll
     for (int pt = 0; pt < 2; ++pt)
@@ -86,7 +87,8 @@ __global__ __launch_bounds__(256, 2) void project_kernel(const float* __restrict
 // dF: D[c][pix] = A[c][hid] . B[hid][pix]; A = w_in^T[c][hid] from LDS, B = dG (lane l: pixel l&31, hidden parity l>>5), read as
 //     float4 rows and consumed over 4 k-steps: k-step (q, e) pairs hidden 8q + e (half 0) with 8q + 4 + e (half 1).  D rows
 //     (channels) in registers, columns (pixels) across lanes -> 128-byte NCHW row stores.
-// Every load of a tile is issued before its first MFMA.  The weight gradient is reduced registers -> LDS -> one atomic per (hid, c).
+// Every load of a (half) tile is issued before its first MFMA (sched_barrier: the scheduler sinks loads to their uses otherwise; keeping
+// the NEXT unit's loads in flight as well -- a register double buffer -- measured slower, profiles/r04g).  The weight gradient is reduced registers -> LDS -> one atomic per (hid, c).
 template <int C, int HD>
 __global__ __launch_bounds__(256, 2) void project_bwd_kernel(const float* __restrict__ feat, const float* __restrict__ dproj, const float* __restrict__ mlp,
                                                           float* __restrict__ dfeat, float* __restrict__ d_mlp, int HW, int tiles_per_img, int n_tiles) {
@@ -122,27 +124,41 @@ __global__ __launch_bounds__(256, 2) void project_bwd_kernel(const float* __rest
       const float* F = feat + (long)img * C * HW;
       // a tile = 8 groups of 8 pixels, taken as two halves of four groups: all loads of a half (a float4 of F per channel tile and four
       // dG values per hidden tile and group: 64 registers) are issued before its first MFMA
+      const bool full = vec4 && p0 + 64 <= HW;   // wave-uniform: whole tile inside the image, rows 16-byte aligned -> no per-load guards
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
         float4 fb[4][CT];
         float av[4][4][HT];
+        if (full) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const int pix4 = p0 + 8 * (4 * half + t) + 4 * h;
+          for (int t = 0; t < 4; ++t) {
+            const int pix4 = p0 + 8 * (4 * half + t) + 4 * h;
 #pragma unroll
-          for (int ct = 0; ct < CT; ++ct) {
-            const unsigned ro = (unsigned)((ct * 32 + col) * HW + pix4);     // element offset inside the image's map (< 2^32)
-            if (vec4 && pix4 + 3 < HW) fb[t][ct] = *reinterpret_cast<const float4*>(F + ro);
-            else fb[t][ct] = make_float4(pix4 < HW ? F[ro] : 0.0f, pix4 + 1 < HW ? F[ro + 1] : 0.0f, pix4 + 2 < HW ? F[ro + 2] : 0.0f,
-                                         pix4 + 3 < HW ? F[ro + 3] : 0.0f);
+            for (int ct = 0; ct < CT; ++ct) fb[t][ct] = *reinterpret_cast<const float4*>(F + (unsigned)((ct * 32 + col) * HW + pix4));
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+              for (int ht = 0; ht < HT; ++ht) av[t][e][ht] = dG[(unsigned)((pix4 + e) * HD + ht * 32 + col)];   // stored channel ht*32 + col
           }
+        } else {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int pix = pix4 + e;
+          for (int t = 0; t < 4; ++t) {
+            const int pix4 = p0 + 8 * (4 * half + t) + 4 * h;
 #pragma unroll
-            for (int ht = 0; ht < HT; ++ht) av[t][e][ht] = pix < HW ? dG[(unsigned)(pix * HD + ht * 32 + col)] : 0.0f;   // stored channel ht*32 + col
+            for (int ct = 0; ct < CT; ++ct) {
+              const unsigned ro = (unsigned)((ct * 32 + col) * HW + pix4);     // element offset inside the image's map (< 2^32)
+              fb[t][ct] = make_float4(pix4 < HW ? F[ro] : 0.0f, pix4 + 1 < HW ? F[ro + 1] : 0.0f, pix4 + 2 < HW ? F[ro + 2] : 0.0f,
+                                      pix4 + 3 < HW ? F[ro + 3] : 0.0f);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int pix = pix4 + e;
+#pragma unroll
+              for (int ht = 0; ht < HT; ++ht) av[t][e][ht] = pix < HW ? dG[(unsigned)(pix * HD + ht * 32 + col)] : 0.0f;
+            }
           }
         }
+        __builtin_amdgcn_sched_barrier(0);   // all loads of the half are out before its first MFMA (the scheduler would sink them)
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -168,6 +184,7 @@ __global__ __launch_bounds__(256, 2) void project_bwd_kernel(const float* __rest
         v0[qq] = dG4[(unsigned)(px0 * (HD / 4) + ht * 8 + 4 * h + q)];
         v1[qq] = dG4[(unsigned)(px1 * (HD / 4) + ht * 8 + 4 * h + q)];
       }
+      __builtin_amdgcn_sched_barrier(0);   // all 16 row loads are out before the first MFMA
       f32x16 acc[CT][2];
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct)
