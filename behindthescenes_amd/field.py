@@ -116,6 +116,17 @@ class BTSNet(nn.Module):
                                      F.interpolate(il[:, 0], (h_, w_)).unsqueeze(1) for il in self._latents_ms]
         return self._grid_f_features
 
+    @property
+    def grid_c_imgs(self):
+        """models_bts.py:82, 129: the render views' frames in [0, 1], (n, nv, 3, H, W).  The renderer reads its own rgb0-packed copy
+        (x * .5 + .5 happens inside bts_pack_rgb); this tensor is built when somebody asks for it."""
+        src = getattr(self, "_grid_c_src", None)
+        if src is None:
+            return None
+        if self._grid_c_raw:
+            self._grid_c_src, self._grid_c_raw = src * .5 + .5, False
+        return self._grid_c_src
+
     # ---- reference protocol -------------------------------------------------------------------------------------
     def set_scale(self, scale):
         self._scale = scale
@@ -130,7 +141,9 @@ class BTSNet(nn.Module):
         """images (n,v,3,H,W) in [-1,1]; Ks (n,v,3,3) normalised intrinsics; poses_c2w (n,v,4,4)  (models_bts.py:65-136)."""
         if combine_ids is not None:
             raise NotImplementedError("combine_ids (waymo multi-encoder-view mode) is not part of the HIP render path")
-        self.mlp_coarse.invalidate_packed()     # a new step: a new autograd graph for the packed parameter vector
+        # a new step: a new autograd graph for the packed parameter vector -- and the one point where edits packed() cannot see
+        # (`p.data.copy_()`, an EMA swap: no version bump) are picked up, so also without autograd
+        self.mlp_coarse.invalidate_packed()
         if self.mlp_fine is not None:
             self.mlp_fine.invalidate_packed()
         poses_w2c = native.invert_small(poses_c2w)
@@ -183,17 +196,18 @@ class BTSNet(nn.Module):
         self.grid_f_combine = None
         # colours: (x*.5+.5) fused into the rgb0 packing kernel unless the caller supplies processed frames
         src = _take(colours if colours is not None else images, ids_render)
-        self.grid_c_imgs = src if colours is not None else src * .5 + .5
+        self._grid_c_src, self._grid_c_raw = src, colours is None     # grid_c_imgs (models_bts.py:82) is materialised on first access
         self.grid_c_Ks = _take(Ks, ids_render)
         self.grid_c_poses_w2c = _take(poses_w2c, ids_render)
         self.grid_c_combine = None
 
         # ---- hand-over into the renderer's HBM layouts
         self._native = {}
-        nv = self.grid_c_imgs.shape[1]
+        nv = src.shape[1]
         native.check_supported(self.spec, nv)
         if nv:
-            self._imgs_nhwc4 = native.pack_rgb(self.grid_c_imgs.detach().float().contiguous())
+            scale, shift = (0.5, 0.5) if self._grid_c_raw else (1.0, 0.0)   # x * .5 + .5 inside the packing kernel (mul, then add)
+            self._imgs_nhwc4 = native.pack_rgb(src.detach().float().contiguous(), scale, shift)
             self._K_r = self.grid_c_Ks.detach().float().contiguous()
             self._w2c_r = self.grid_c_poses_w2c.detach().float().contiguous()
         else:
@@ -245,7 +259,7 @@ class BTSNet(nn.Module):
         with torch.no_grad(), profiler.record_function("model_inference"):   # models_bts.py:275
             rgb, invalid, sigma = native.field_query(ft, self.mlp(coarse).packed().detach(), xyz.detach().float().contiguous(),
                                                      only_density=only_density)
-        nv = self.grid_c_imgs.shape[1]
+        nv = self._grid_c_src.shape[1]
         if only_density:
             rgb = torch.zeros((xyz.shape[0], xyz.shape[1], nv * 3), device=sigma.device)
             invalid = invalid.unsqueeze(1)   # the reference returns (n, nv_enc=1, P, 1) here (models_bts.py:337)
