@@ -717,10 +717,15 @@ static bool bits_path(const BtsFieldCfg* cfg, const BtsRenderArgs* a) { return c
 // workspace = what the passes hand each other per sample.  Gate-bit path: g_s (one float) + the relu gates as bits, once per sample
 // and once per channel -- 20 bytes at d_hidden 64.  Row path: the gradient row at lin_in's output (4 d_hidden bytes) + g_s.
 // (Round 1: 256-byte g_h rows per sample AND lane = ray; probe build only.)
+// + pass C's slot copies of dW_pe (bts_bwd.h: kFlushSlots x 40 x d_hidden floats, 80 KB at d_hidden 64), behind the per-sample part
+static size_t flush_bytes(const BtsFieldCfg* cfg) { return sizeof(float) * kFlushSlots * kFlushRows * (size_t)cfg->d_hidden; }
+static size_t align16(size_t b) { return (b + 15) & ~(size_t)15; }
 size_t render_bwd_workspace_impl(const BtsFieldCfg* cfg, const BtsRenderArgs* a) {
   const size_t rays = (size_t)cfg->n * (size_t)a->rays_per_sample;
-  const size_t bits = rays * ((size_t)a->K * (1 + (size_t)cfg->d_hidden / 32) + 2 * (size_t)cfg->d_hidden) * sizeof(float);
-  const size_t rows = rays * (size_t)a->K * ((size_t)cfg->d_hidden + 1) * sizeof(float);
+  // gate-bit path: g_s + the per-sample masks, rounded up to 8 bytes (the per-channel masks behind them are read as 64-bit words)
+  const size_t bits = align16(((rays * (size_t)a->K * (1 + (size_t)cfg->d_hidden / 32) + 1) & ~(size_t)1) * sizeof(float) +
+                              rays * 2 * (size_t)cfg->d_hidden * sizeof(float)) + flush_bytes(cfg);
+  const size_t rows = align16(rays * (size_t)a->K * ((size_t)cfg->d_hidden + 1) * sizeof(float)) + flush_bytes(cfg);
 #ifdef BTS_PROBE   // any path may serve the call (BTS_BWD_V1)
   const size_t groups = (size_t)cfg->n * ((a->rays_per_sample + 255) / 256) * 4;
   const size_t v1 = groups * (size_t)a->K * 64 * (size_t)cfg->d_hidden * sizeof(float);
@@ -758,7 +763,7 @@ int render_bwd_impl(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const BtsR
   bp.f.tiles_per_sample = (a->rays_per_sample + 255) / 256;
   bp.g_rgb = g->g_rgb, bp.g_depth = g->g_depth, bp.g_weights = g->g_weights, bp.g_alphas = g->g_alphas;
   bp.d_proj = g->d_proj_nhwc, bp.d_mlp = g->d_mlp_params, bp.d_empty_proj = g->d_empty_proj;
-  bp.gh_ws = nullptr, bp.gs_ws = nullptr, bp.mask_ws = nullptr, bp.pmask_ws = nullptr;
+  bp.gh_ws = nullptr, bp.gs_ws = nullptr, bp.mask_ws = nullptr, bp.pmask_ws = nullptr, bp.flush_ws = nullptr;
 #ifdef BTS_PROBE
   static const bool direct = getenv("BTS_BWD_DIRECT_ATOMICS") != nullptr;   // A/B (probe build): round-1 kernel, every tap update an L2 atomic
   static const bool v1 = getenv("BTS_BWD_V1") != nullptr || direct;         // A/B (probe build): the round-1 lane = ray pass for every shape
@@ -788,11 +793,15 @@ int render_bwd_impl(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const BtsR
   if (bits_path(cfg, a) && !rows_always) {
     bp.gs_ws = static_cast<float*>(workspace);
     bp.mask_ws = reinterpret_cast<unsigned*>(bp.gs_ws + samples);
-    bp.pmask_ws = reinterpret_cast<uint2*>(bp.mask_ws + samples * (cfg->d_hidden / 32));
+    const size_t head = (samples * (1 + (size_t)cfg->d_hidden / 32) + 1) & ~(size_t)1;   // dwords, even: the 64-bit masks stay 8-byte aligned
+    bp.pmask_ws = reinterpret_cast<uint2*>(bp.gs_ws + head);
+    bp.flush_ws = reinterpret_cast<float*>(static_cast<char*>(workspace) +
+                                           align16((head + (size_t)cfg->n * a->rays_per_sample * 2 * (size_t)cfg->d_hidden) * sizeof(float)));
     rc = launch_bwd_rows(bp, cfg->C, cfg->d_hidden, cfg->n, grid, s);
   } else {
     float* u0_ws = static_cast<float*>(workspace);          // (rays, K, d_hidden): rows first, they are read as 16-byte pieces
     bp.gs_ws = u0_ws + samples * (size_t)cfg->d_hidden;     // (rays, K)
+    bp.flush_ws = reinterpret_cast<float*>(static_cast<char*>(workspace) + align16(samples * ((size_t)cfg->d_hidden + 1) * sizeof(float)));
     rc = launch_bwd_blocks(bp, u0_ws, cfg->C, cfg->d_hidden, cfg->n_blocks, cfg->n, grid, s);
   }
   if (rc != BTS_E_UNSUPPORTED) return rc;

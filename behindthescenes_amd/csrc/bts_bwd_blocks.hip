@@ -338,14 +338,19 @@ __global__ __launch_bounds__(256, 2) void rowsb_kernel(const BwdParams bp, const
   int idx = lw;
   int g = group_of(idx);
   float z_pre = 0.0f, zn_pre = 0.0f, s_pre = 0.0f, t_pre = 0.0f;
-  auto fetch_state = [&](int gg, int kc) {   // the per-sample state of chunk kc of ray gg
+  // (per-sample tensors are addressed as a wave-uniform row base -- the ray's first sample, an SGPR pair -- plus a 32-bit lane offset:
+  // 64-bit per-lane addresses computed ahead of their loads were what this kernel spilled, and a reload from scratch waits with
+  // vmcnt(0): the four prefetch loads below ran as four serial memory round trips per iteration)
+  // (`f`: the parameter block as laundered for this iteration -- through the by-value copy `p` the compiler hoists the lane parts of the
+  // four addresses out of the loop, keeps them as 64-bit VGPR pairs and spills exactly those)
+  auto fetch_state = [&](const FwdParams __attribute__((address_space(4)))* f, int gg, int kc) {   // the per-sample state of chunk kc of ray gg
     const int k = kc + lane;
-    const int kk = k < K ? k : K - 1;
-    const long pk = (long)gg * K + kk;
-    z_pre = p.z_samp[pk], zn_pre = p.z_samp[(long)gg * K + min(kk + 1, K - 1)];
-    s_pre = p.sigma_raw[pk], t_pre = p.trans[pk];
+    const unsigned kk = (unsigned)(k < K ? k : K - 1);
+    const long row = (long)gg * K;   // uniform
+    z_pre = at32(f->z_samp + row, kk), zn_pre = at32(f->z_samp + row, min(kk + 1u, (unsigned)(K - 1)));
+    s_pre = at32(f->sigma_raw + row, kk), t_pre = at32(f->trans + row, kk);
   };
-  if (g >= 0) fetch_state(g, kc_last);
+  if (g >= 0) fetch_state(&kernarg_view<BwdParams>()->f, g, kc_last);
 #ifdef BTS_TICKS
   unsigned long long t_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long t_last = __builtin_readcyclecounter();
@@ -392,15 +397,14 @@ __global__ __launch_bounds__(256, 2) void rowsb_kernel(const BwdParams bp, const
       const bool valid = k < K;
       const int kk = valid ? k : K - 1;
       const bool last = k == K - 1;
-      const long pk = ray * K + kk;
+      const long rowk = ray * K;         // uniform: the ray's first sample
+      const unsigned kku = (unsigned)kk;
       const float z = z_pre, z_nx = zn_pre, s_raw = s_pre, T = t_pre;
-      {  // the state of the chunk evaluated next lands while this one is evaluated
-        if (kc > 0) {
-          fetch_state(g, kc - 64);
-        } else {
-          const int gn = group_of(idx + waves_per_xcd);
-          if (gn >= 0) fetch_state(gn, kc_last);
-        }
+      {  // the state of the chunk evaluated next lands while this one is evaluated (ONE call site: two get tail-merged into a block
+         // that rebuilds 64-bit lane addresses from spilled parts)
+        const int g_nx = kc > 0 ? g : group_of(idx + waves_per_xcd);
+        const int kc_nx = kc > 0 ? kc - 64 : kc_last;
+        if (g_nx >= 0) fetch_state(&qb->f, g_nx, kc_nx);
       }
       int h = h0;
       asm volatile("" : "+v"(h));   // keep the weight reads inside the persistent loop (see render_kernel_p)
@@ -419,12 +423,13 @@ __global__ __launch_bounds__(256, 2) void rowsb_kernel(const BwdParams bp, const
 #pragma unroll
       for (int i = 0; i < NVMAX * 3; ++i) cs_v[i] = 0.0f;
       if (have_cs) {
-        const float* cs = qb->f.rgb_samps + pk * (long)(nv * 3);
+        const float* cs = qb->f.rgb_samps + rowk * (long)(nv * 3);   // uniform
+        const unsigned co = kku * (unsigned)(nv * 3);
 #pragma unroll
-        for (int i = 0; i < NVMAX * 3; ++i) cs_v[i] = cs[min(i, nv * 3 - 1)];   // entries beyond nv meet g_rgb = 0
+        for (int i = 0; i < NVMAX * 3; ++i) cs_v[i] = at32(cs, co + (unsigned)min(i, nv * 3 - 1));   // entries beyond nv meet g_rgb = 0
       }
-      const float gw_k = qb->g_weights ? qb->g_weights[pk] : 0.0f;
-      const float ga_k = qb->g_alphas ? qb->g_alphas[pk] : 0.0f;
+      const float gw_k = qb->g_weights ? at32(qb->g_weights + rowk, kku) : 0.0f;
+      const float ga_k = qb->g_alphas ? at32(qb->g_alphas + rowk, kku) : 0.0f;
 
       RB_TICK(11)   // (part of 0) per-sample loads issued
       // ---------------- encoder view
@@ -494,7 +499,7 @@ __global__ __launch_bounds__(256, 2) void rowsb_kernel(const BwdParams bp, const
         float sigma = softplus(s_raw);
         const bool dead = (qb->f.empty_empty != 0) & pe.invalid;   // sigma forced to 0: no gradient
         if (dead) sigma = 0.0f;
-        if (qb->f.sigma_noise) sigma += qb->f.sigma_noise[pk];   // nerf.py:279-280: relu(sigma + noise) -- no gradient where the sum is <= 0
+        if (qb->f.sigma_noise) sigma += at32(qb->f.sigma_noise + rowk, kku);   // nerf.py:279-280: relu(sigma + noise) -- no gradient where the sum is <= 0
         const bool cut = sigma <= 0.0f && qb->f.sigma_noise != nullptr;
         const float delta = last ? 1e10f : (z_nx - z);
         const float ex = transmittance(delta, sigma);
@@ -516,7 +521,7 @@ __global__ __launch_bounds__(256, 2) void rowsb_kernel(const BwdParams bp, const
         float g_alpha = g_w * T - S / (capped ? 1e-10f : ex + 1e-10f);
         g_alpha += ga_k;
         if (!capped && !dead && !cut && valid) g_s = g_alpha * fabsf(delta) * ex * (s_raw > 20.0f ? 1.0f : sigmoidf(s_raw));
-        if (valid) qb->gs_ws[pk] = g_s;
+        if (valid) at32(qb->gs_ws + rowk, kku) = g_s;
       }
       db_acc += g_s;
       RB_TICK(1)   // compositing gradient (waits for the per-sample loads above)
@@ -740,7 +745,7 @@ __global__ __launch_bounds__(256, 2) void rowsb_kernel(const BwdParams bp, const
                 const float4 x = *reinterpret_cast<const float4*>(u0t + ht * 4096 + jj * 1024 + lane * 16);
                 const int ks = kc + pt * 32 + 8 * jj + gl.m;
                 if (ks < K)
-                  *reinterpret_cast<float4*>(reinterpret_cast<char*>(ro.u0_ws + (ray * K + ks) * (long)HD) + ht * 128 + gl.piece16) = x;
+                  *reinterpret_cast<float4*>(reinterpret_cast<char*>(ro.u0_ws + rowk * (long)HD) + (unsigned)(ks * HD * 4 + ht * 128) + gl.piece16) = x;
               }
           }
         }
@@ -793,14 +798,14 @@ __global__ __launch_bounds__(256, 2) void rowsb_kernel(const BwdParams bp, const
     const MlpLayout ml{C + kPeDim, HD, NB};
     for (int i = threadIdx.x; i <= HD; i += blockDim.x) {
       const float vv = red[i];
-      if (vv != 0.0f) atomic_add_f32(bp.d_mlp + (i < HD ? ml.w_out() + i : ml.b_out()), vv);
+      if (vv != 0.0f) flush_add_f32(bp.d_mlp + (i < HD ? ml.w_out() + i : ml.b_out()), vv);
     }
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
       const float* d = red + RED_BLK + b * RED_BLK_STRIDE;
       for (int i = threadIdx.x; i < RED_BLK_STRIDE; i += blockDim.x) {
         const float vv = d[i];
-        if (vv != 0.0f) atomic_add_f32(bp.d_mlp + ml.blk(b) + i, vv);   // packed order: w0, b0, w1, b1 = the LDS order
+        if (vv != 0.0f) flush_add_f32(bp.d_mlp + ml.blk(b) + i, vv);   // packed order: w0, b0, w1, b1 = the LDS order
       }
     }
   }
@@ -810,7 +815,7 @@ __global__ __launch_bounds__(256, 2) void rowsb_kernel(const BwdParams bp, const
 // launch
 // ---------------------------------------------------------------------------------------------------------------
 int launch_scatter_rows(const FwdParams& p, const float* gs_ws, const float* u0_ws, float* d_proj, float* d_empty_proj, int HD, int n, hipStream_t s);
-int launch_dwpe_rows(const FwdParams& p, const float* u0_ws, float* d_mlp, int C, int HD, int NB, int n, int grid, hipStream_t s);
+int launch_dwpe_rows(const FwdParams& p, const float* u0_ws, float* d_mlp, float* flush_ws, int C, int HD, int NB, int n, int grid, hipStream_t s);
 
 template <int C, int HD, int NB>
 static int launch_rowsb(const BwdParams& bp, const RowsbOut& ro, int grid, hipStream_t s) {
@@ -839,7 +844,7 @@ int launch_bwd_blocks(const BwdParams& bp, float* u0_ws, int C, int HD, int NB, 
   else if (C == 32 && HD == 32 && NB == 1) rc = launch_rowsb<32, 32, 1>(bp, ro, grid, s);
   else if (C == 32 && HD == 32 && NB == 0) rc = launch_rowsb<32, 32, 0>(bp, ro, grid, s);
   if (rc == BTS_OK && (bp.d_proj || bp.d_empty_proj)) rc = launch_scatter_rows(bp.f, bp.gs_ws, u0_ws, bp.d_proj, bp.d_empty_proj, HD, n, s);
-  if (rc == BTS_OK && bp.d_mlp) rc = launch_dwpe_rows(bp.f, u0_ws, bp.d_mlp, C, HD, NB, n, grid, s);
+  if (rc == BTS_OK && bp.d_mlp) rc = launch_dwpe_rows(bp.f, u0_ws, bp.d_mlp, bp.flush_ws, C, HD, NB, n, grid, s);
   if (rc == BTS_E_LAUNCH) set_error("%s: backward kernel launch failed (%ld)", hipGetErrorString(hipGetLastError()), 0);
   return rc;
 }

@@ -489,7 +489,7 @@ __global__ __launch_bounds__(256, 2) void rows_kernel(const BwdParams bp) {
     const MlpLayout ml{C + kPeDim, HD, 0};
     for (int i = threadIdx.x; i <= HD; i += blockDim.x) {
       const float v = red[i];
-      if (v != 0.0f) atomic_add_f32(bp.d_mlp + (i < HD ? ml.w_out() + i : ml.b_out()), v);
+      if (v != 0.0f) flush_add_f32(bp.d_mlp + (i < HD ? ml.w_out() + i : ml.b_out()), v);
     }
   }
 }
@@ -810,6 +810,7 @@ struct DwpeParams {
   const uint2* pmask_ws;   // (n*Bp, HD) per-channel gates over the ray's 64 samples
   const float* gs_ws;      // (n*Bp, K)
   float* d_mlp;
+  float* slots;            // kFlushSlots x (40 x HD): the work-groups' partial sums (bts_bwd.h), folded into d_mlp by dwpe_reduce_kernel
   long rays;               // n * Bp
 };
 
@@ -989,12 +990,26 @@ __global__ __launch_bounds__(256, 2) void dwpe_kernel(const DwpeParams dp) {
         if (kin < PE_ROWS) atomicAdd(&d_wpe[kin * HD + chn], dw[ht][kt][q]);
       }
   __syncthreads();
+  float* slot = dp.slots + (blockIdx.x % kFlushSlots) * (PE_ROWS * HD);
   for (int i = threadIdx.x; i < PE_ROWS * HD; i += blockDim.x) {
-    const int kin = i / HD, hid = proj_hidden_of_storage(i % HD);
-    const int src = kernel_to_ref_input<C>(kin + C);
-    const float v = d_wpe[i] * p.mlp[ml.w_out() + hid];
-    if (v != 0.0f) atomic_add_f32(dp.d_mlp + (src >= 0 ? ml.w_in() + hid * D_IN + src : ml.b_in() + hid), v);
+    const float v = d_wpe[i] * p.mlp[ml.w_out() + proj_hidden_of_storage(i % HD)];
+    if (v != 0.0f) flush_add_f32(slot + i, v);
   }
+}
+
+// slots [kFlushSlots][kin][stored channel] -> d_mlp (w_in's encoding columns and b_in: at the start of the packed parameters whatever
+// the number of blocks)
+template <int C, int HD>
+__global__ __launch_bounds__(256) void dwpe_reduce_kernel(const float* __restrict__ slots, float* __restrict__ d_mlp) {
+  constexpr int D_IN = C + kPeDim;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= kFlushRows * HD) return;
+  float v = 0.0f;
+#pragma unroll
+  for (int s = 0; s < kFlushSlots; ++s) v += slots[s * (kFlushRows * HD) + i];
+  const int kin = i / HD, hid = proj_hidden_of_storage(i % HD);
+  const int src = kernel_to_ref_input<C>(kin + C);
+  if (v != 0.0f) atomic_add_f32(d_mlp + (src >= 0 ? hid * D_IN + src : HD * D_IN + hid), v);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1008,6 +1023,7 @@ struct DwpeRowsParams {
   FwdParams f;
   const float* u0_ws;   // (n*Bp, K, HD), channels in the storage order of G
   float* d_mlp;
+  float* slots;         // kFlushSlots x (40 x HD), see DwpeParams
   long rays;            // n * Bp
 };
 
@@ -1058,18 +1074,8 @@ __global__ __launch_bounds__(256, HD == 32 ? 3 : 2) void dwpe_rows_kernel(const 
     const int sample = (int)(unit / units_per_sample);
     const int s0 = (int)(unit - (long)sample * units_per_sample) * 64;     // first sample of the unit inside its batch element
     const int n_valid = min(64, per_sample - s0);                          // wave-uniform
-    // ---- A operand: channel ht*32 + col of samples s0 + 2 s2 + h, all k-steps up front (they land under the trigonometry)
-    float a[HT][32];
-    {
-      const float* ur = dp.u0_ws + ((long)sample * per_sample + s0 + h) * (long)HD + col;
-#pragma unroll
-      for (int s2 = 0; s2 < 32; ++s2) {
-        const bool ok = 2 * s2 + h < n_valid;
-#pragma unroll
-        for (int ht = 0; ht < HT; ++ht) a[ht][s2] = ok ? ur[(long)(2 * s2) * HD + ht * 32] : 0.0f;
-      }
-    }
-    // ---- B operand: the 40 inputs of lin_in's encoding part in kernel order (x, y, code, 1, then per octave 3 sines and 3 "cosines")
+    // ---- this lane's sample: ray and depth.  Issued BEFORE the row loads below: vmcnt retires in order, so the geometry -- which needs
+    // only these three -- would otherwise wait for all 32 row loads as well and nothing would run under their latency
     const Cam enc = load_cam(p.w2c_enc + sample * 16, p.K_enc + sample * 9);
     const int si = min(s0 + lane, per_sample - 1);
     const int r_in = si / K;
@@ -1077,6 +1083,28 @@ __global__ __launch_bounds__(256, HD == 32 ? 3 : 2) void dwpe_rows_kernel(const 
     const float4 r0 = reinterpret_cast<const float4*>(p.rays)[ray * 2];
     const float4 r1 = reinterpret_cast<const float4*>(p.rays)[ray * 2 + 1];
     const float z = p.z_samp[(long)sample * per_sample + si];
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- A operand: channel ht*32 + col of samples s0 + 2 s2 + h, all k-steps up front: they land under the trigonometry
+    // (wave-uniform base + 32-bit lane offset; whole units -- all but a batch element's last -- need no per-load guard)
+    float a[HT][32];
+    {
+      const float* ur = dp.u0_ws + ((long)sample * per_sample + s0) * (long)HD;   // uniform
+      // (no branch around the loads -- clamped rows, zeroed below: behind a merge of two paths the compiler waits with vmcnt(0), i.e.
+      // for every row, before the geometry may start)
+#pragma unroll
+      for (int s2 = 0; s2 < 32; ++s2) {
+        const unsigned row = (unsigned)min(2 * s2 + h, n_valid - 1);
+#pragma unroll
+        for (int ht = 0; ht < HT; ++ht)
+#ifdef BTS_ABL_E3   // timing ablation: no row loads
+          a[ht][s2] = (float)(s2 + lane);
+#else
+          a[ht][s2] = ur[row * (unsigned)HD + (unsigned)(ht * 32 + col)];
+#endif
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);   // (the scheduler would sink the row loads to their MFMAs)
+    // ---- B operand: the 40 inputs of lin_in's encoding part in kernel order (x, y, code, 1, then per octave 3 sines and 3 "cosines")
     const float px = r0.x + z * r0.w, py = r0.y + z * r1.x, pz = r0.z + z * r1.y;
     const Proj pe = p.code_mode == 1 ? project<true>(enc, px, py, pz) : project<false>(enc, px, py, pz);
     float v3[3];
@@ -1090,6 +1118,11 @@ __global__ __launch_bounds__(256, HD == 32 ? 3 : 2) void dwpe_rows_kernel(const 
       float* row = tile + lane * kPeLd;
       row[0] = v3[0], row[1] = v3[1], row[2] = v3[2], row[3] = 1.0f;
       float ff = p.freq_factor;
+#ifdef BTS_ABL_E2   // timing ablation: no trigonometry
+#pragma unroll
+      for (int i = 4; i < 40; ++i) row[i] = v3[i % 3] * (float)i;
+      if (false)
+#endif
 #pragma unroll
       for (int r = 0; r < kNumFreqs / 2; ++r) {   // octaves 2r (direct) and 2r + 1 (angle doubling), as the forward's regions
         SinCos3 raw, dbl;
@@ -1109,6 +1142,15 @@ __global__ __launch_bounds__(256, HD == 32 ? 3 : 2) void dwpe_rows_kernel(const 
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     // ---- 32 k-steps of two samples each
+#ifdef BTS_ABL_E1   // timing ablation: no MFMA block (one accumulate keeps the operands alive)
+    {
+      float acc1 = 0.0f;
+#pragma unroll
+      for (int s2 = 0; s2 < 32; ++s2) acc1 += a[0][s2] * tile[(2 * s2 + h) * kPeLd + col];
+      dw[0][0][0] += acc1;
+    }
+    if (false)
+#endif
 #pragma unroll
     for (int s2 = 0; s2 < 32; ++s2) {
       const float* brow = tile + (2 * s2 + h) * kPeLd;
@@ -1116,8 +1158,9 @@ __global__ __launch_bounds__(256, HD == 32 ? 3 : 2) void dwpe_rows_kernel(const 
       const float b1 = col < PE_ROWS - 32 ? brow[32 + col] : 0.0f;
 #pragma unroll
       for (int ht = 0; ht < HT; ++ht) {
-        dw[ht][0] = mfma(a[ht][s2], b0, dw[ht][0]);
-        dw[ht][1] = mfma(a[ht][s2], b1, dw[ht][1]);
+        const float av = 2 * s2 + h < n_valid ? a[ht][s2] : 0.0f;   // rows past the batch element's end were loads of its last row
+        dw[ht][0] = mfma(av, b0, dw[ht][0]);
+        dw[ht][1] = mfma(av, b1, dw[ht][1]);
       }
     }
   }
@@ -1137,12 +1180,10 @@ __global__ __launch_bounds__(256, HD == 32 ? 3 : 2) void dwpe_rows_kernel(const 
         if (kin < PE_ROWS) atomicAdd(&d_wpe[kin * HD + chn], dw[ht][kt][q]);
       }
   __syncthreads();
+  float* slot = dp.slots + (blockIdx.x % kFlushSlots) * (PE_ROWS * HD);
   for (int i = threadIdx.x; i < PE_ROWS * HD; i += blockDim.x) {
-    const int kin = i / HD, hid = proj_hidden_of_storage(i % HD);
-    const int src = kernel_to_ref_input<C>(kin + C);
     const float v = d_wpe[i];
-    // w_in / b_in sit at the start of the packed parameters whatever the number of blocks
-    if (v != 0.0f) atomic_add_f32(dp.d_mlp + (src >= 0 ? hid * D_IN + src : HD * D_IN + hid), v);
+    if (v != 0.0f) flush_add_f32(slot + i, v);
   }
 }
 
@@ -1180,11 +1221,13 @@ static int launch_rows(const BwdParams& bp, int n, int grid, hipStream_t s) {
   }
   if (e == hipSuccess && bp.d_mlp) {
     DwpeParams dp;
-    dp.f = p, dp.pmask_ws = bp.pmask_ws, dp.gs_ws = bp.gs_ws, dp.d_mlp = bp.d_mlp, dp.rays = (long)n * p.Bp;
+    dp.f = p, dp.pmask_ws = bp.pmask_ws, dp.gs_ws = bp.gs_ws, dp.d_mlp = bp.d_mlp, dp.slots = bp.flush_ws, dp.rays = (long)n * p.Bp;
     const long wgs = (dp.rays + 3) / 4;
     auto kern = dwpe_kernel<C, HD>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, DwpeLds::TOTAL);
+    (void)hipMemsetAsync(bp.flush_ws, 0, sizeof(float) * kFlushSlots * kFlushRows * HD, s);
     kern<<<(int)(wgs < grid ? wgs : grid), 256, DwpeLds::TOTAL, s>>>(dp);   // grid = 2 work-groups per CU
+    dwpe_reduce_kernel<C, HD><<<(kFlushRows * HD + 255) / 256, 256, 0, s>>>(bp.flush_ws, bp.d_mlp);
     e = hipGetLastError();
   }
   if (e != hipSuccess) {
@@ -1217,18 +1260,23 @@ int launch_scatter_rows(const FwdParams& p, const float* gs_ws, const float* u0_
   return hipGetLastError() == hipSuccess ? BTS_OK : BTS_E_LAUNCH;
 }
 
-int launch_dwpe_rows(const FwdParams& p, const float* u0_ws, float* d_mlp, int C, int HD, int NB, int n, int grid, hipStream_t s) {
+int launch_dwpe_rows(const FwdParams& p, const float* u0_ws, float* d_mlp, float* flush_ws, int C, int HD, int NB, int n, int grid, hipStream_t s) {
   DwpeRowsParams dp;
-  dp.f = p, dp.u0_ws = u0_ws, dp.d_mlp = d_mlp, dp.rays = (long)n * p.Bp;
+  dp.f = p, dp.u0_ws = u0_ws, dp.d_mlp = d_mlp, dp.slots = flush_ws, dp.rays = (long)n * p.Bp;
   if ((long)p.Bp * p.K > 0x7FFFFF00L) return BTS_E_UNSUPPORTED;
   dp.f.n = n;
   const long units = (long)n * (((long)p.Bp * p.K + 63) / 64);
   const long wgs = (units + 3) / 4;
   const long cap = HD == 32 ? (long)grid / 2 * 3 : grid;   // grid = 2 work-groups per CU; this kernel fits 3 at d_hidden 32
   const int g = (int)(wgs < cap ? wgs : cap);
-  if (C == 64 && HD == 64) dwpe_rows_kernel<64, 64><<<g, 256, 0, s>>>(dp);
-  else if (C == 32 && HD == 32) dwpe_rows_kernel<32, 32><<<g, 256, 0, s>>>(dp);
-  else return BTS_E_UNSUPPORTED;
+  (void)hipMemsetAsync(flush_ws, 0, sizeof(float) * kFlushSlots * kFlushRows * HD, s);
+  if (C == 64 && HD == 64) {
+    dwpe_rows_kernel<64, 64><<<g, 256, 0, s>>>(dp);
+    dwpe_reduce_kernel<64, 64><<<(kFlushRows * 64 + 255) / 256, 256, 0, s>>>(flush_ws, d_mlp);
+  } else if (C == 32 && HD == 32) {
+    dwpe_rows_kernel<32, 32><<<g, 256, 0, s>>>(dp);
+    dwpe_reduce_kernel<32, 32><<<(kFlushRows * 32 + 255) / 256, 256, 0, s>>>(flush_ws, d_mlp);
+  } else return BTS_E_UNSUPPORTED;
   (void)NB;
   return hipGetLastError() == hipSuccess ? BTS_OK : BTS_E_LAUNCH;
 }

@@ -82,6 +82,19 @@ __device__ __forceinline__ const T __attribute__((address_space(4)))* kernarg_vi
   return (const T __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
 }
 
+// Element `idx` (a 32-bit lane value) of an array whose base is WAVE-UNIFORM: the byte offset is formed in 32 bits, so the access is
+// the scalar-base form `global_load v, v_off32, s[base:base+1]` -- no 64-bit per-lane address (two VGPRs per access, computed ahead of
+// the load and, in the register-starved kernels, spilled: a reload from scratch waits with vmcnt(0) for every load in flight).
+// base[idx] written plainly is base + (zext(idx) << 2), which the compiler cannot narrow to 32 bits.  Arrays far below 4 GB only.
+template <class T>
+__device__ __forceinline__ T& at32(T* base, unsigned idx) {
+  return *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + idx * (unsigned)sizeof(T));
+}
+template <class T>
+__device__ __forceinline__ const T& at32(const T* base, unsigned idx) {
+  return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + idx * (unsigned)sizeof(T));
+}
+
 // same through ordinary (vector) loads: the values land in VGPRs
 __device__ __forceinline__ Cam load_cam_v(const float* __restrict__ w2c, const float* __restrict__ K) {
   Cam c;

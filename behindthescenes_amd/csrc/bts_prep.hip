@@ -234,7 +234,11 @@ __global__ __launch_bounds__(256, 2) void project_bwd_kernel(const float* __rest
     __syncthreads();
     for (int i = threadIdx.x; i < HD * C; i += blockDim.x) {
       const int hid = i / C, c = i % C;
+#ifndef BTS_ABL_NOFLUSH
       atomicAdd(&d_mlp[hid * D_IN + c], red[i]);
+#else
+      if (red[i] == 1.2345e-30f) d_mlp[hid * D_IN + c] = red[i];
+#endif
     }
   }
 }

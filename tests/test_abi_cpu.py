@@ -91,16 +91,25 @@ def test_host_only_entry_points(lib):
 def test_backward_workspace_is_what_the_passes_hand_each_other(lib):
     """bts_render_bwd_workspace: 20 B per sample for the plain MLP with K <= 64 (g_s + the relu gates as bits, per sample and per
     channel); the gradient row at lin_in's output (4 * d_hidden B) + g_s per sample for the ResnetBlockFC model and for K > 64 (the
-    row passes of bts_bwd_blocks.hip) -- per SAMPLE, no rounding of the ray count to work-group tiles any more."""
+    row passes of bts_bwd_blocks.hip) -- per SAMPLE, no rounding of the ray count to work-group tiles any more; behind it the slot
+    copies pass C reduces dW_pe through (csrc/bts_bwd.h: kFlushSlots)."""
     def ws(spec, n, rays_per_sample, K, nv=2):
         cfg = native._spec_cfg(spec, n=n, H=8, W=8, nv=nv)
         args = _lib.BtsRenderArgs(rays_per_sample=rays_per_sample, K=K, hard_alpha_cap=1, white_bkgd=0)
         return lib.bts_render_bwd_workspace(C.byref(cfg), C.byref(args))
     kitti, re10k = native.FieldSpec(C=64, d_hidden=64, n_blocks=0), native.FieldSpec(C=32, d_hidden=32, n_blocks=1)
-    assert ws(kitti, 16, 4096, 64) == 16 * 4096 * (64 * (1 + 2) + 2 * 64) * 4 == 16 * 4096 * 64 * 20        # 84 MB, not 1.07 GB
-    assert ws(kitti, 2, 320, 16) == 2 * 320 * (16 * 3 + 128) * 4
-    assert ws(kitti, 1, 300, 128) == 300 * 128 * (64 + 1) * 4                                               # K > 64: rows
-    assert ws(re10k, 24, 1024, 48) == 24 * 1024 * 48 * (32 + 1) * 4                                          # one ResnetBlockFC: rows
+
+    def a16(b):
+        return (b + 15) // 16 * 16
+
+    def slots(hd):      # + pass C's eight slot copies of dW_pe / db_in (40 x d_hidden floats each): 80 KB at d_hidden 64
+        return 8 * 40 * hd * 4
+    assert ws(kitti, 16, 4096, 64) == 16 * 4096 * 64 * 20 + slots(64)                                        # 84 MB, not 1.07 GB
+    assert ws(kitti, 2, 320, 16) == a16(2 * 320 * (16 * 3 + 128) * 4) + slots(64)
+    assert ws(kitti, 1, 300, 128) == a16(300 * 128 * (64 + 1) * 4) + slots(64)                              # K > 64: rows
+    assert ws(re10k, 24, 1024, 48) == a16(24 * 1024 * 48 * (32 + 1) * 4) + slots(32)                        # one ResnetBlockFC: rows
+    # an odd number of samples: the per-sample dwords are rounded up to 8 bytes (the 64-bit per-channel masks start there)
+    assert ws(kitti, 1, 3, 5) == a16((3 * 5 * 3 + 1) * 4 + 3 * 128 * 4) + slots(64)
 
 
 def test_errors_are_codes_with_messages_never_exceptions(lib):
