@@ -66,14 +66,10 @@ class BTSNet(nn.Module):
             self.empty_feature = nn.Parameter(torch.randn((self.encoder.latent_size,), requires_grad=True))
         self._scale = 0
         self._native = {}   # scale -> native.FieldTensors
-        self._proj_ms = None
-        # an encoder that can compose the feature half of lin_in into its last convolution can hand the
-        # renderer its projected, channels-last map G directly (monodepth2.Monodepth2.forward_projected: no F in HBM, no projection
-        # pass or backward).  MEASURED (profiles/r03g, exp_kitti_360.yaml shapes, ResNet-50, bs 16): MIOpen's composed channels-last
-        # convolution makes the step 1.4 ms SLOWER (49.9 vs 48.6 ms) than convolution + bts_project_features(_bwd) (0.9 ms together),
-        # for 0.57 GB less peak memory -- so the generic route is the default and `fused_handover: true` the opt-in.
-        # (whether the CURRENT encoder can do that is looked up at every encode(): callers replace net.encoder after construction)
-        self.fused_handover = bool(conf.get("fused_handover", False))
+        if conf.get("fused_handover", False):
+            # rounds 2 - 3 let the decoder's last convolution write G; measured slower than convolution + projection
+            # passes and removed in round 4
+            raise NotImplementedError("fused_handover was removed: the projection passes (bts_project_features / _bwd) are the hand-over")
         # models_bts.py:115-117 resizes the decoder's coarser scales to scale 0's size (F.interpolate, nearest) before the renderer
         # samples them.  A nearest resize by 2^s only repeats texels: the kernels index the scale's own map (BtsFieldCfg.feat_shift)
         # -- bit-identical results, no resized map (and none of its gradient) in HBM, the projection G = F . W^T runs on 1 / 4^s of
@@ -107,7 +103,7 @@ class BTSNet(nn.Module):
     @property
     def grid_f_features(self):
         """models_bts.py:117, 128: the encoder's maps of every scale at scale 0's size, (n, nv_enc, C, H, W) each.  The renderer does
-        not need them (see native_scale_maps); built on first access for callers that do.  None on the fused hand-over route."""
+        not need them (see native_scale_maps); built on first access for callers that do."""
         if not getattr(self, "_has_latents", False):
             return None
         if self._grid_f_features is None:
@@ -156,40 +152,21 @@ class BTSNet(nn.Module):
         n, nv_enc, c, h, w = images_encoder.shape
         if nv_enc != 1:
             raise NotImplementedError("the HIP render path takes exactly one encoder view (ids_encoder=[0] in every shipped mode)")
-        c_l = self.encoder.latent_size
 
         do_flip = bool(self.flip_augmentation and self.training and (torch.rand(1) > .5).item())
         if do_flip:
             images_encoder = torch.flip(images_encoder, dims=(-1,))
         enc_in = images_encoder.reshape(n * nv_enc, c, h, w)
-        self._proj_ms = None
-        if self.fused_handover and hasattr(self.encoder, "forward_projected"):
-            # G_s = F_s . w_in[:, :C]^T straight out of the decoder's last convolutions, channels-last (no F in HBM, no projection pass)
-            order = native.proj_storage_order(self.spec.d_hidden).to(images.device)
-            g_ms = self.encoder.forward_projected(enc_in, self.mlp_coarse.lin_in.weight[:, :c_l][order])
-            if do_flip:
-                g_ms = [torch.flip(g, dims=(2,)) for g in g_ms]
-            h_, w_ = g_ms[0].shape[1:3]
-            self._shift_ms = [self._scale_shift(g.shape[1:3], (h_, w_)) for g in g_ms]
-            self._proj_ms = [(g if sh is not None else F.interpolate(g.permute(0, 3, 1, 2), (h_, w_)).permute(0, 2, 3, 1)).contiguous()
-                             for g, sh in zip(g_ms, self._shift_ms)]
-            # G was composed from lin_in.weight AS IT WAS NOW and under the grad mode of NOW: native_field() refuses to pair it with
-            # other weights (an optimizer step / load_state_dict between encode() and the render) or to render under autograd from a
-            # map that was encoded under no_grad (lin_in and the CNN would silently get no gradient through G)
-            self._proj_version = (self.mlp_coarse.lin_in.weight._version, torch.is_grad_enabled())
-            image_latents_ms = None    # the feature map itself is never materialised on this route
-        else:
-            image_latents_ms = self.encoder(enc_in)
-            if do_flip:
-                image_latents_ms = [torch.flip(il, dims=(-1,)) for il in image_latents_ms]
-            _, _, h_, w_ = image_latents_ms[0].shape
-            self._shift_ms = [self._scale_shift(il.shape[-2:], (h_, w_)) for il in image_latents_ms]
-            self._latents_ms = [(il if sh is not None else F.interpolate(il, (h_, w_))).unsqueeze(1)
-                                for il, sh in zip(image_latents_ms, self._shift_ms)]
-            image_latents_ms = True
+        image_latents_ms = self.encoder(enc_in)
+        if do_flip:
+            image_latents_ms = [torch.flip(il, dims=(-1,)) for il in image_latents_ms]
+        _, _, h_, w_ = image_latents_ms[0].shape
+        self._shift_ms = [self._scale_shift(il.shape[-2:], (h_, w_)) for il in image_latents_ms]
+        self._latents_ms = [(il if sh is not None else F.interpolate(il, (h_, w_))).unsqueeze(1)
+                            for il, sh in zip(image_latents_ms, self._shift_ms)]
         self._shift_ms = [sh or 0 for sh in self._shift_ms]
         self._grid_size = (h_, w_)
-        self._has_latents = image_latents_ms is not None
+        self._has_latents = True
         self._grid_f_features = None
         self.grid_f_Ks = Ks_encoder
         self.grid_f_poses_w2c = poses_w2c_encoder
@@ -230,22 +207,9 @@ class BTSNet(nn.Module):
         version = (mlp.lin_in.weight._version, torch.is_grad_enabled())
         hit = self._native.get((s, fine))
         if hit is None or hit[1] != version:
-            if self._proj_ms is not None:                          # fused hand-over: G came out of the encoder
-                if fine:
-                    raise NotImplementedError("fused_handover composes the projected map from mlp_coarse only: build the net with "
-                                              "fused_handover=False to render with a separate fine MLP")
-                w_version, grad_mode = self._proj_version
-                if w_version != version[0]:
-                    raise native.BtsNativeError("lin_in.weight changed since encode(): the fused hand-over composed the projected feature map "
-                                                "from the old weights -- call encode() again (or build the net with fused_handover=False)")
-                if version[1] and not grad_mode and any(p.requires_grad for p in self.encoder.parameters()):
-                    raise native.BtsNativeError("encode() ran under torch.no_grad() but the render runs under autograd: the projected feature "
-                                                "map carries no graph, lin_in / the encoder would get no gradient -- encode() under grad mode")
-                proj = self._proj_ms[s].float()
-            else:
-                f = self._latents_ms[s]                            # (n, 1, C, h, w) -> (n, C, h, w): a pure view (selecting [:, 0] would
-                f = f.reshape(f.shape[0], *f.shape[2:]).float()    # cost a zero fill + a copy of the whole map in its backward)
-                proj = native.ProjectFunction.apply(f, mlp.packed(), spec)
+            f = self._latents_ms[s]                            # (n, 1, C, h, w) -> (n, C, h, w): a pure view (selecting [:, 0] would
+            f = f.reshape(f.shape[0], *f.shape[2:]).float()    # cost a zero fill + a copy of the whole map in its backward)
+            proj = native.ProjectFunction.apply(f, mlp.packed(), spec)
             ft = native.FieldTensors(spec, proj, self._K_enc, self._w2c_enc, self._imgs_nhwc4, self._K_r, self._w2c_r,
                                      self.empty_feature if self.learn_empty else None, feat_shift=self._shift_ms[s], enc_view=self._enc_view)
             self._native[(s, fine)] = (ft, version)

@@ -4,11 +4,11 @@ load unchanged:  ``encoder.encoder.{conv1,bn1,layer1..4.*,fc}``, ``decoder.decod
 ConvBlocks, scale 4 down to 0) and ``decoder.decoder.{10..13}.conv.{weight,bias}`` (the per-scale output convolutions).
 
 The CNN is NOT part of the render path and stays PyTorch-ROCm (MIOpen) -- written here without torchvision, which the image lacks.
-What IS on the path is the hand-over: the renderer does not consume the feature map F but the projected
-map  G = F . w_in[:, :C]^T  in channels-last order.  F is the output of a 3x3 convolution and G a per-pixel linear map of it, so
-G is itself a 3x3 convolution of the decoder's last activation with the COMPOSED weights  W' = w_f . W_conv,  b' = w_f . b_conv:
-``forward_projected`` runs the network in ``torch.channels_last`` and lets that last convolution write G directly -- no F in HBM, no
-projection pass, no projection backward (autograd differentiates the composition, a 64 x 64 x 576 GEMM, for lin_in and the conv).
+Its output F goes to the renderer through ``bts_project_features`` (G = F . w_in[:, :C]^T, channels-last, one streaming HIP pass and
+its fused backward).  SURVEY.md section 8 row f4 asked whether the decoder's last convolution should write G itself: rounds 2 - 3
+built that (the composed weights W' = w_f . W_conv handed to MIOpen) and measured it 1.4 ms per step SLOWER than convolution +
+projection passes (49.9 vs 48.6 ms, profiles/r03g); with the round-4 projection kernels (0.21 + 0.45 ms per step at bs 16) the
+projection is 1.3 % of the step, and the route was removed.
 """
 import warnings
 
@@ -135,10 +135,8 @@ class Conv3x3(nn.Module):
         self.pad = nn.ReflectionPad2d(1) if use_refl else nn.ZeroPad2d(1)
         self.conv = nn.Conv2d(int(in_channels), int(out_channels), 3)
 
-    def forward(self, x, weight=None, bias=None):
-        """weight / bias override the module's own (the composed projection weights of ``forward_projected``)."""
-        x = self.pad(x)
-        return self.conv(x) if weight is None else F.conv2d(x, weight, bias)
+    def forward(self, x):
+        return self.conv(self.pad(x))
 
 
 class ConvBlock(nn.Module):
@@ -223,20 +221,6 @@ class Monodepth2(nn.Module):
         """images (B, 3, H, W) in [-1, 1] -> [features (B, d_out, H / 2^s, W / 2^s) for s in scales]  (monodepth2.py:279-291)."""
         feats = self._trunk(x)
         return [self.decoder.decoder[self.decoder.decoder_keys[("dispconv", s)]](feats[s]) for s in self.scales]
-
-    def forward_projected(self, x, w_rows):
-        """The renderer's hand-over fused into the decoder tail: w_rows (R, d_out) -- the feature columns of lin_in in the
-        renderer's storage order -- composed into each scale's output convolution.  -> [G_s (B, h_s, w_s, R) channels-last
-        CONTIGUOUS for s in scales], G_s = F_s . w_rows^T with F_s what forward() returns.  Differentiable w.r.t. everything."""
-        feats = self._trunk(x)
-        out = []
-        for s in self.scales:
-            conv = self.decoder.decoder[self.decoder.decoder_keys[("dispconv", s)]]
-            w = torch.einsum("rc,cikl->rikl", w_rows, conv.conv.weight)
-            b = w_rows @ conv.conv.bias
-            g = conv(feats[s], w.contiguous(memory_format=torch.channels_last), b)
-            out.append(g.permute(0, 2, 3, 1))          # channels-last storage -> (B, h, w, R), a contiguous view
-        return out
 
     @classmethod
     def from_conf(cls, conf, **kw):

@@ -51,9 +51,7 @@ def parse():
     ap.add_argument("--samples", type=int, default=0, help="re10k: samples per ray (default 48 = the yaml; BASELINE.json quotes 128)")
     ap.add_argument("--encoder", choices=("feature_map", "monodepth2"), default="feature_map",
                     help="training workloads: feature_map (default) = learnable stand-in for the CNN output (the renderer's share of the step); "
-                         "monodepth2 = the shipped Monodepth2 (ResNet of the yaml, random weights): whole step incl. the CNN, fused hand-over "
-                         "(SURVEY 8f.4) unless --no-fused-handover")
-    ap.add_argument("--no-fused-handover", action="store_true")
+                         "monodepth2 = the shipped Monodepth2 (ResNet of the yaml, random weights): whole step incl. the CNN")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-others", action="store_true",
                     help="eval workload: skip the `others` sub-records (every other BASELINE config + the occupancy profile, 10 steps each) and, "
@@ -222,7 +220,6 @@ def train_workload(args, world, rank, dev):
     conf = S.field_conf(Cc, Hd, Nb, Hh, Ww, z_near=cfg["z"][0], z_far=cfg["z"][1], code_mode=cfg["code_mode"])
     if args.encoder == "monodepth2":
         conf["encoder"] = dict(type="monodepth2", freeze=False, pretrained=False, resnet_layers=cfg["resnet"], num_ch_dec=cfg["num_ch_dec"], d_out=Cc)
-        conf["fused_handover"] = not args.no_fused_handover
         torch.manual_seed(99)
         net = bts.BTSNet(conf)
         if n_scales == 1:
@@ -373,7 +370,7 @@ def train_workload(args, world, rank, dev):
                 + (f"{n_scales} renders per step (multiscale, trainer.py:220-242), " if n_scales > 1 else "")
                 + ("everything after the CNN (feature-map encoder stand-in): " if args.encoder == "feature_map" else
                    f"whole step incl. the shipped Monodepth2 (ResNet-{cfg['resnet']}, random weights), "
-                   + ("fused hand-over (the decoder's last convolution writes G, SURVEY 8f.4): " if not args.no_fused_handover else "generic hand-over (F -> bts_project_features): "))
+                   + "hand-over F -> bts_project_features: ")
                 + "sample, render, photometric loss, backward; "
                 + ("every per-sample output of the reference trainer's dict materialised (--full-outputs)" if args.full_outputs else
                    "lean_training_outputs: the loss' invalid-ray mask reads per-ray reductions from the render epilogue (SURVEY 8f.1)"))
@@ -677,7 +674,7 @@ def sub_records(args, world, rank, dev, launched):
 
     def run(workload, steps=10, warmup=3, **kw):
         a = copy.copy(args)
-        a.workload, a.steps, a.warmup, a.no_cpu_baseline, a.samples, a.encoder, a.no_fused_handover = workload, steps, warmup, True, 0, "feature_map", True
+        a.workload, a.steps, a.warmup, a.no_cpu_baseline, a.samples, a.encoder = workload, steps, warmup, True, 0, "feature_map"
         for k, v in kw.items():
             setattr(a, k, v)
         try:

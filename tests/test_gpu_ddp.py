@@ -73,7 +73,7 @@ def test_bench_runs_under_torch_distributed_run(workload):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    extra = ["--workload", "train", "--encoder", "monodepth2", "--no-fused-handover"] if workload == "train_monodepth2" else ["--workload", workload]
+    extra = ["--workload", "train", "--encoder", "monodepth2"] if workload == "train_monodepth2" else ["--workload", workload]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port",
            str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"] + extra
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))

@@ -1,6 +1,5 @@
 """CPU: the shipped Monodepth2 encoder (behindthescenes_amd/monodepth2.py): state-dict layout of the reference / torchvision so that
-reference checkpoints load, numerical identity with the reference's own Decoder (when the reference tree is present), and the fused
-hand-over: forward_projected(x, w) == forward(x) . w^T without ever forming F."""
+reference checkpoints load, numerical identity with the reference's own Decoder (when the reference tree is present)."""
 import pytest
 import torch
 
@@ -19,7 +18,8 @@ KITTI360_MODEL_CONF = dict(   # configs/exp_kitti_360.yaml model_conf (the keys 
 def test_btsnet_builds_from_the_shipped_kitti360_config_with_reference_state_dict_keys():
     net = bts.BTSNet(KITTI360_MODEL_CONF)
     assert isinstance(net.encoder, Monodepth2) and net.encoder.latent_size == 64 and list(net.encoder.scales) == [0, 1, 2, 3]
-    assert not net.fused_handover      # the fused hand-over is opt-in (measured slower than conv + project, field.py)
+    with pytest.raises(NotImplementedError):      # rounds 2 - 3's opt-in fused hand-over: measured slower, removed
+        bts.BTSNet(dict(KITTI360_MODEL_CONF, fused_handover=True))
     sd = net.state_dict()
     for k in ("encoder.encoder.encoder.conv1.weight", "encoder.encoder.encoder.bn1.running_mean", "encoder.encoder.encoder.layer1.0.conv3.weight",
               "encoder.encoder.encoder.layer1.0.downsample.0.weight", "encoder.encoder.encoder.layer4.2.bn3.weight", "encoder.encoder.encoder.fc.weight",
@@ -36,28 +36,13 @@ def test_btsnet_builds_from_the_shipped_kitti360_config_with_reference_state_dic
                                              ).encoder.encoder.encoder.parameters()) == 11689512
 
 
-def test_forward_shapes_and_fused_handover_equals_projection_of_the_feature_map():
+def test_forward_shapes():
     torch.manual_seed(0)
     enc = Monodepth2(resnet_layers=18, num_ch_dec=[32, 32, 64, 128, 256], d_out=64, pretrained=False).eval()
-    for m in enc.modules():   # make the batch-norm statistics non-trivial
-        if isinstance(m, torch.nn.BatchNorm2d):
-            m.running_mean.normal_(0, 0.1), m.running_var.uniform_(0.5, 1.5)
     x = torch.rand(2, 3, 64, 96) * 2 - 1
-    w = torch.randn(64, 64) * 0.2
     with torch.no_grad():
         feats = enc(x)
-        proj = enc.forward_projected(x, w)
     assert [tuple(f.shape) for f in feats] == [(2, 64, 64 >> s, 96 >> s) for s in range(4)]
-    for f, g in zip(feats, proj):
-        assert g.shape == (f.shape[0], f.shape[2], f.shape[3], 64) and g.is_contiguous()
-        want = torch.einsum("nchw,rc->nhwr", f, w)
-        assert (g - want).abs().max().item() <= 2e-5 * want.abs().max().item()
-    # gradients reach the projection rows and the composed convolution alike
-    x.requires_grad_(False)
-    w2 = w.clone().requires_grad_(True)
-    enc.forward_projected(x, w2)[0].square().mean().backward()
-    head = enc.decoder.decoder[enc.decoder.decoder_keys[("dispconv", 0)]].conv
-    assert w2.grad is not None and head.weight.grad is not None and float(w2.grad.abs().sum()) > 0 and float(head.weight.grad.abs().sum()) > 0
 
 
 def test_unused_classifier_head_is_frozen_and_missing_pretrained_weights_are_announced(tmp_path):
