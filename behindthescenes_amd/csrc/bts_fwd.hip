@@ -53,9 +53,11 @@ void render_geometry(FwdParams& p, int n) {
   if (p.K <= 32) {
     lpr = p.K <= 8 ? 8 : (p.K <= 16 ? 16 : 32);
     if (p.Bp % (64 / lpr) != 0) lpr = 64;
+  } else if (p.K <= 48 && p.Bp % 4 == 0) {
+    lpr = 48;   // four rays in three wave iterations (render_kernel_p's 48-lane mode): exp_re10k.yaml's 48 samples per ray
   }
   p.lpr = lpr;
-  p.groups = (long)n * p.Bp / (64 / lpr);
+  p.groups = lpr == 48 ? (long)n * p.Bp / 4 : (long)n * p.Bp / (64 / lpr);
 }
 
 // persistent grid: 2 work-groups (8 waves) per CU of the current device, multiple of 8 so that every XCD owns an equal contiguous
@@ -104,6 +106,7 @@ int render_fwd_impl(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const BtsR
   if (const char* e = getenv("BTS_DBG_PTR")) p.dbg = (unsigned long long*)strtoull(e, nullptr, 0);
 #endif
   render_geometry(p, cfg->n);
+  if (!p.proj && p.lpr == 48) p.lpr = 64, p.groups = (long)cfg->n * p.Bp;   // (the raw-feature route's compact kernel knows power-of-two groups only)
   if (p.groups > 0x7FF00000L) {   // the kernels index ray groups with 32 bits
     set_error("%s: too many rays in one call (%ld groups)", "bts_render_fwd", p.groups);
     return BTS_E_UNSUPPORTED;

@@ -51,6 +51,15 @@ constexpr int kDppBcast31 = 0x143;  // lane 31 -> rows 2, 3
 // lanes, which share a row with a neighbour group, mask the steps.
 __device__ __forceinline__ float seg_scan_mul(float x, int lpr, int kl) {
   float y;
+  if (lpr == 48) {   // lanes 0-47 one segment (rows 0, 1, 2), lanes 48-63 (row 3) another: see render_kernel_p's 48-lane mode
+    x *= dpp_f<kDppRowShr + 1>(1.0f, x);
+    x *= dpp_f<kDppRowShr + 2>(1.0f, x);
+    x *= dpp_f<kDppRowShr + 4>(1.0f, x);
+    x *= dpp_f<kDppRowShr + 8>(1.0f, x);
+    x *= dpp_f<kDppBcast15, 0x2>(1.0f, x);   // row 1 <- row 0's total
+    x *= dpp_f<kDppBcast31, 0x4>(1.0f, x);   // row 2 <- the scan through row 1
+    return x;
+  }
   if (lpr >= 16) {
     x *= dpp_f<kDppRowShr + 1>(1.0f, x);
     x *= dpp_f<kDppRowShr + 2>(1.0f, x);
@@ -68,6 +77,15 @@ __device__ __forceinline__ float seg_scan_mul(float x, int lpr, int kl) {
 // inclusive prefix sum; the LAST lane of each group holds the group's total
 __device__ __forceinline__ float seg_scan_add(float x, int lpr, int kl) {
   float y;
+  if (lpr == 48) {
+    x += dpp_f<kDppRowShr + 1>(0.0f, x);
+    x += dpp_f<kDppRowShr + 2>(0.0f, x);
+    x += dpp_f<kDppRowShr + 4>(0.0f, x);
+    x += dpp_f<kDppRowShr + 8>(0.0f, x);
+    x += dpp_f<kDppBcast15, 0x2>(0.0f, x);
+    x += dpp_f<kDppBcast31, 0x4>(0.0f, x);
+    return x;
+  }
   if (lpr >= 16) {
     x += dpp_f<kDppRowShr + 1>(0.0f, x);
     x += dpp_f<kDppRowShr + 2>(0.0f, x);
@@ -654,8 +672,17 @@ __global__ __launch_bounds__(256, 2) void render_kernel_p(const FwdParams p) {
   const int xcd = wg / wg_per_xcd;
   const int lw = (wg - xcd * wg_per_xcd) * 4 + wave;  // wave index inside its XCD
   const int waves_per_xcd = wg_per_xcd * 4;
-  const int lpr = ONE_RAY ? 64 : p.lpr, R = 64 / lpr;
-  const int kl = lane & (lpr - 1);
+  // 48-lane mode (render_geometry: 32 < K <= 48 and the rays of a batch element a multiple of four -- exp_re10k.yaml's n_coarse = 48):
+  // a wave takes FOUR rays in THREE iterations -- lanes 0-47 one whole ray per iteration, lanes 48-63 one 16-sample row of the
+  // fourth -- instead of idling a quarter of its lanes on every instruction.  The fourth ray's transmittance and partial sums cross
+  // the three iterations (the chunk loop below, reused); everything per sample is lane-local anyway.
+  const int lpr = ONE_RAY ? 64 : p.lpr;
+  const bool pk48 = !ONE_RAY && lpr == 48;
+  const bool mainl = lane < 48;
+  const int R = pk48 ? 4 : 64 / lpr;   // rays per group
+  const int kl = pk48 ? (mainl ? lane : lane - 48) : lane & (lpr - 1);
+  auto lane_ray = [&](int gg, int it) -> long { return pk48 ? (long)gg * 4 + (mainl ? it : 3) : (long)gg * R + lane / lpr; };
+  auto lane_k = [&](int it) -> int { return pk48 && !mainl ? 16 * it + kl : kl; };
   // Work distribution.  Ray groups are cut into chunks of 2^chunk_log2 consecutive groups; chunk c belongs to XCD c % 8, and the
   // waves of an XCD walk its chunks in order (consecutive waves = consecutive rays, so the texel footprints of the waves resident
   // on an XCD still overlap in its L2).  Round 1 gave every XCD ONE contiguous eighth of the rays: with the two stereo views of
@@ -690,8 +717,8 @@ __global__ __launch_bounds__(256, 2) void render_kernel_p(const FwdParams p) {
   float z_pre = 0.0f, zn_pre = 0.0f;
   if (g >= 0) {
     const int K = p.K;
-    const long row = ((long)g * R + lane / lpr) * K;
-    const int kk = min(kl, K - 1);
+    const long row = lane_ray(g, 0) * K;
+    const int kk = min(lane_k(0), K - 1);
     if (p.z_samp) z_pre = p.z_samp[row + kk], zn_pre = p.z_samp[row + min(kk + 1, K - 1)];
     else z_pre = p.jitter[row + kk];
   }
@@ -705,7 +732,7 @@ __global__ __launch_bounds__(256, 2) void render_kernel_p(const FwdParams p) {
     asm volatile("" : "+s"(q));
     IterHead ih(q);   // the geometry's share of the parameters (see IterHead: batching their loads was measured and not kept)
     const int K = ih.K, H = ih.H, W = ih.W, nv = ih.nv, fs = ih.fs;
-    const long ray = (long)g * R + lane / lpr;
+    long ray = lane_ray(g, 0);   // (48-lane mode: lanes 0-47 move on to the group's next ray with every chunk of the loop below)
     // all rays of a group belong to one batch element; g only grows along a wave's chunk list, so the element is tracked by a
     // running boundary (the 64-bit division this replaces was ~140 dependent scalar instructions at the top of every iteration)
     while (g >= sample_end) ++sample, sample_end += groups_per_sample;
@@ -722,31 +749,46 @@ __global__ __launch_bounds__(256, 2) void render_kernel_p(const FwdParams p) {
       const float4 r1 = reinterpret_cast<const float4*>(ih.rays)[ray * 2 + 1];
       ox = r0.x, oy = r0.y, oz = r0.z, dx = r0.w, dy = r1.x, dz = r1.y, near = r1.z, far = r1.w;
     }
-    const float* zrow = (from_jitter ? ih.jitter : ih.z_samp) + ray * K;
+    const float* zsrc = from_jitter ? ih.jitter : ih.z_samp;
+    const float* zrow = zsrc + ray * K;
     float z_cur = z_pre, zn_cur = zn_pre;
-    {  // prefetch the next group's samples (or jitter); they land while this group is evaluated
-      const int gn = group_of(idx + waves_per_xcd);
-      if (gn >= 0) {
-        const long row = ((long)gn * R + lane / lpr) * K;
-        const int kk = min(kl, K - 1);
-        if (from_jitter) z_pre = ih.jitter[row + kk];
-        else z_pre = ih.z_samp[row + kk], zn_pre = ih.z_samp[row + min(kk + 1, K - 1)];
-      }
-    }
+    // the samples (or the jitter) of what this wave evaluates next: they land while the current unit is evaluated
+    auto prefetch_z = [&](int gg, int it) {
+      const long row = lane_ray(gg, it) * K;
+      const int kk = min(lane_k(it), K - 1);
+      if (from_jitter) z_pre = ih.jitter[row + kk];
+      else z_pre = ih.z_samp[row + kk], zn_pre = ih.z_samp[row + min(kk + 1, K - 1)];
+    };
+    const int g_next = group_of(idx + waves_per_xcd);
+    if (!pk48 && g_next >= 0) prefetch_z(g_next, 0);
 
     float T_carry = 1.0f, depth_part = 0.0f, w_part = 0.0f;
+    float Tc_D = 1.0f;   // 48-lane mode: transmittance in front of the fourth ray's current row
     float rgb_part[NVMAX * 3];
 #pragma unroll
     for (int i = 0; i < NVMAX * 3; ++i) rgb_part[i] = 0.0f;
 
-    for (int kc = 0; kc < K; kc += 64) {
-      const int k = kc + kl;
+    for (int kc = 0; kc < (pk48 ? 192 : K); kc += 64) {
+      const int it = kc >> 6;
+      const int k = pk48 ? lane_k(it) : kc + kl;
       const bool valid = k < K;
+      if (pk48) {
+        ray = lane_ray(g, it);
+        zrow = zsrc + ray * K;
+        if (it > 0) z_cur = z_pre, zn_cur = zn_pre;
+        if (it < 2) prefetch_z(g, it + 1);
+        else if (g_next >= 0) prefetch_z(g_next, 0);
+        if (mainl && it > 0) {   // lanes 0-47 start a new ray
+          depth_part = 0.0f, w_part = 0.0f;
+#pragma unroll
+          for (int i = 0; i < NVMAX * 3; ++i) rgb_part[i] = 0.0f;
+        }
+      }
       // The weights in LDS are the same for every ray: without this the compiler hoists all ~150 weight reads out of the persistent
       // loop and keeps them in VGPRs (then spills the gather buffers).  Make the LDS offsets opaque per iteration.
       int lane_off = lane_off0, h = h0;
       asm volatile("" : "+v"(lane_off), "+v"(h));
-      if (kc > 0) {
+      if (kc > 0 && !pk48) {
         const int kk = valid ? k : K - 1;
         z_cur = zrow[kk];
         if (!from_jitter) zn_cur = zrow[min(kk + 1, K - 1)];
@@ -757,14 +799,22 @@ __global__ __launch_bounds__(256, 2) void render_kernel_p(const FwdParams p) {
         // samples: computed from its own jitter, the neighbour of lane 63 belongs to the next chunk).
         const int kk = valid ? k : K - 1;
         const bool lindisp = q->lindisp != 0;
-        z_cur = coarse_depth(z_cur, kc == 0 ? base0 : coarse_base(K, kk), step0, near, far, lindisp);
+        z_cur = coarse_depth(z_cur, (kc == 0 && !pk48) ? base0 : coarse_base(K, kk), step0, near, far, lindisp);
         zn_cur = dpp_f<kDppWaveShl1>(z_cur, z_cur);
-        if (K > 64) zn_cur = coarse_depth(zrow[min(kk + 1, K - 1)], coarse_base(K, min(kk + 1, K - 1)), step0, near, far, lindisp);
+        if (K > 64 || pk48) zn_cur = coarse_depth(zrow[min(kk + 1, K - 1)], coarse_base(K, min(kk + 1, K - 1)), step0, near, far, lindisp);
         if (q->z_out && valid) q->z_out[ray * K + k] = z_cur;
       }
       const float z = z_cur, z_nx = zn_cur;
       // nerf.py:231  points = o + z * d   (mul, then add)
       const float px = ox + z * dx, py = oy + z * dy, pz = oz + z * dz;
+      if constexpr (!ONE_RAY) {
+        if (pk48 && it < 2) {   // the next iteration's ray (lanes 0-47 change theirs): its registers are free from here on
+          const long rn = lane_ray(g, it + 1);
+          const float4 r0 = reinterpret_cast<const float4*>(ih.rays)[rn * 2];
+          const float4 r1 = reinterpret_cast<const float4*>(ih.rays)[rn * 2 + 1];
+          ox = r0.x, oy = r0.y, oz = r0.z, dx = r0.w, dy = r1.x, dz = r1.y, near = r1.z, far = r1.w;
+        }
+      }
 
       // ---------------- encoder view: projection, taps, depth code
       const Proj pe = ih.code_mode == 1 ? project<true>(enc, px, py, pz) : project<false>(enc, px, py, pz);
@@ -966,8 +1016,9 @@ __global__ __launch_bounds__(256, 2) void render_kernel_p(const FwdParams p) {
       const float t = valid ? (1.0f - alpha) + 1e-10f : 1.0f;
       const float incl = seg_scan_mul(t, lpr, kl);
       float excl = dpp_f<kDppWaveShr1>(1.0f, incl);
-      if (kl == 0) excl = 1.0f;
-      const float T = T_carry * excl;
+      if (kl == 0) excl = 1.0f;   // (48-lane mode: lanes 0 and 48)
+      const float T = (pk48 ? (mainl ? 1.0f : Tc_D) : T_carry) * excl;
+      if (pk48) Tc_D = Tc_D * __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, incl), 63));
       if (ONE_RAY && K > 64) T_carry = T_carry * __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, incl), 63));
       const float wgt = valid ? alpha * T : 0.0f;
       BTS_TICK(3)
@@ -978,12 +1029,14 @@ __global__ __launch_bounds__(256, 2) void render_kernel_p(const FwdParams p) {
           if (j < nv) {
             const float ws = seg_scan_add((valid && inv[j]) ? wgt : 0.0f, lpr, kl);       // the last lane of each ray has the sum
             const unsigned long long hit = __ballot(valid && inv[j]);
-            if (kl == lpr - 1) {
+            if (pk48 ? (lane == 47 || lane == 63) : kl == lpr - 1) {
               const long idx = ray * nv + j;
-              const unsigned long long seg = lpr == 64 ? ~0ull : (((1ull << lpr) - 1ull) << (lane - (lpr - 1)));
+              const unsigned long long seg = pk48 ? (mainl ? 0x0000FFFFFFFFFFFFull : 0xFFFF000000000000ull)
+                                                  : (lpr == 64 ? ~0ull : (((1ull << lpr) - 1ull) << (lane - (lpr - 1))));
               const float any = (hit & seg) ? 1.0f : 0.0f;
-              if (q->invalid_wsum) q->invalid_wsum[idx] = (kc > 0 ? q->invalid_wsum[idx] : 0.0f) + ws;   // K > 64: chunk after chunk
-              if (q->invalid_any) q->invalid_any[idx] = kc > 0 ? fmaxf(q->invalid_any[idx], any) : any;
+              const bool more = pk48 ? (!mainl && it > 0) : kc > 0;   // K > 64: chunk after chunk; 48-lane mode: the fourth ray's rows
+              if (q->invalid_wsum) q->invalid_wsum[idx] = (more ? q->invalid_wsum[idx] : 0.0f) + ws;
+              if (q->invalid_any) q->invalid_any[idx] = more ? fmaxf(q->invalid_any[idx], any) : any;
             }
           }
       }
@@ -1012,19 +1065,35 @@ __global__ __launch_bounds__(256, 2) void render_kernel_p(const FwdParams p) {
             }
         }
       }
+      if (pk48) {
+        // per-ray sums of this iteration: lane 47 has the totals of lanes 0-47's ray; lane 63 those of the fourth ray's rows so far
+        // (its lanes keep accumulating), written after its last row
+        const float dsum = seg_scan_add(depth_part, 48, kl), wsum = seg_scan_add(w_part, 48, kl);
+        float csum[NVMAX * 3];
+#pragma unroll
+        for (int i = 0; i < NVMAX * 3; ++i) csum[i] = i < nv * 3 ? seg_scan_add(rgb_part[i], 48, kl) : 0.0f;
+        if (lane == 47 || (lane == 63 && it == 2)) {
+          q->depth[ray] = dsum;
+#pragma unroll
+          for (int i = 0; i < NVMAX * 3; ++i)
+            if (i < nv * 3) q->rgb[ray * nv * 3 + i] = q->white_bkgd ? (csum[i] + 1.0f) - wsum : csum[i];  // nerf.py:301-304
+        }
+      }
     }
     BTS_TICK(4)
     // ---------------- per-ray sums: the last lane of each ray ends up with the totals
-    depth_part = seg_scan_add(depth_part, lpr, kl);
-    w_part = seg_scan_add(w_part, lpr, kl);
-#pragma unroll
-    for (int i = 0; i < NVMAX * 3; ++i)
-      if (i < nv * 3) rgb_part[i] = seg_scan_add(rgb_part[i], lpr, kl);
-    if (kl == lpr - 1) {
-      q->depth[ray] = depth_part;
+    if (!pk48) {
+      depth_part = seg_scan_add(depth_part, lpr, kl);
+      w_part = seg_scan_add(w_part, lpr, kl);
 #pragma unroll
       for (int i = 0; i < NVMAX * 3; ++i)
-        if (i < nv * 3) q->rgb[ray * nv * 3 + i] = q->white_bkgd ? (rgb_part[i] + 1.0f) - w_part : rgb_part[i];  // nerf.py:301-304
+        if (i < nv * 3) rgb_part[i] = seg_scan_add(rgb_part[i], lpr, kl);
+      if (kl == lpr - 1) {
+        q->depth[ray] = depth_part;
+#pragma unroll
+        for (int i = 0; i < NVMAX * 3; ++i)
+          if (i < nv * 3) q->rgb[ray * nv * 3 + i] = q->white_bkgd ? (rgb_part[i] + 1.0f) - w_part : rgb_part[i];  // nerf.py:301-304
+      }
     }
     BTS_TICK(5)
   }

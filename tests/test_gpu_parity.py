@@ -404,6 +404,46 @@ def test_short_rays_packed_and_unpacked_vs_oracle(hip, K, n_rays):
     _check(r)
 
 
+@pytest.mark.parametrize("K,nv_ids,epi", [(48, [1, 2], False), (40, [1], False), (48, [1, 2], True), (33, [0, 1, 2], True)])
+def test_48_lane_mode_matches_the_one_ray_mode(hip, K, nv_ids, epi):
+    """32 < K <= 48 with a ray count that is a multiple of four runs four rays in three wave iterations (lanes 0-47 a whole ray, lanes
+    48-63 one 16-sample row of the fourth: render_kernel_p's 48-lane mode, exp_re10k.yaml's n_coarse = 48); one ray more per batch
+    element and the same rays run one per iteration.  Per-sample outputs must agree bit for bit (the compositing products are formed
+    in the same order), per-ray sums to rounding (the fourth ray's are accumulated per lane over its three rows first)."""
+    from behindthescenes_amd import native
+    from tests._hip_helpers import build_net
+    cfg = O.FieldConfig(d_min=1.0, d_max=100.0, code_mode="distance")
+    g = torch.Generator().manual_seed(480 + K)
+    n, H, W = 2, 64, 96
+    scene = O.synthetic_scene(n, 3, H, W, 32, seed=48, intrinsics=O.K_RE10K, smooth=True, baseline=0.2)
+    mlp = O.init_mlp(32 + 39, 32, 1, gen=g)
+    net = build_net(cfg, mlp, scene, nv_ids)
+    rays = O.image_rays(scene["poses"], scene["projs"], H, W, cfg.d_min, cfg.d_max)
+    idx = torch.randperm(rays.shape[1], generator=g)[:1001].sort().values
+    rays = rays[:, idx].contiguous().cuda()                                   # (2, 1001, 8)
+    u = torch.rand(n, 1001, K, generator=g).cuda()
+    ft, params = net.native_field(), net.mlp_coarse.packed().detach()
+    kw = dict(hard_alpha_cap=False, want_weights=True, want_alphas=True, want_rgb_samps=True, want_saved=True, want_invalid_sums=epi)
+    outs = []
+    for m in (1000, 1001):                                                     # 1000 = 4 * 250: the 48-lane mode; 1001: one ray per iteration
+        r, uu = rays[:, :m].reshape(-1, 8).contiguous(), u[:, :m].reshape(-1, K).contiguous()
+        z = native.sample_coarse(r, uu, True)
+        o = native.render_fwd(ft, params, r, z, **kw)
+        oj = native.render_fwd(ft, params, r, None, jitter=uu, lindisp=True, want_z=True, **kw)      # and sample_coarse in the kernel
+        assert torch.equal(oj["z_samp"], z)
+        for k_ in ("weights", "alphas", "depth", "rgb", "sigma_raw", "trans"):
+            assert torch.equal(o[k_], oj[k_]), k_
+        outs.append({k_: v.view(n, m, *v.shape[1:])[:, :1000] for k_, v in o.items() if v is not None})
+    a, b = outs
+    for k_ in ("weights", "alphas", "invalid", "rgb_samps", "sigma_raw", "trans"):
+        assert torch.equal(a[k_], b[k_]), k_
+    torch.testing.assert_close(a["depth"], b["depth"], rtol=2e-6, atol=0)
+    torch.testing.assert_close(a["rgb"], b["rgb"], rtol=0, atol=2e-6)
+    if epi:
+        torch.testing.assert_close(a["invalid_wsum"], b["invalid_wsum"], rtol=0, atol=2e-6)
+        assert torch.equal(a["invalid_any"], b["invalid_any"])
+
+
 @pytest.mark.parametrize("K", [48, 128])
 def test_re10k_full_frame_vs_oracle(hip, K):
     """BASELINE configs[4] field at full frame size: exp_re10k.yaml (C = 32, one ResnetBlockFC of width 32, distance code, z in [1, 100],
