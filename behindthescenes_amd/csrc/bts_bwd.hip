@@ -706,7 +706,7 @@ static int launch_bwd(const BwdParams& bp, int grid, hipStream_t s) {
 
 FwdParams make_params(const BtsFieldCfg* cfg, const BtsFieldTensors* t);
 int render_grid(const FwdParams& p);
-int render_chunk_log2(int grid);
+int render_chunk_log2(int grid, long groups);
 int launch_bwd_rows(const BwdParams& bp, int C, int HD, int n, int grid, hipStream_t s);
 int launch_bwd_blocks(const BwdParams& bp, float* u0_ws, int C, int HD, int NB, int n, int grid, hipStream_t s);
 
@@ -787,7 +787,7 @@ int render_bwd_impl(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const BtsR
     return BTS_E_UNSUPPORTED;
   }
   const int grid = render_grid(bp.f);
-  bp.f.chunk_log2 = render_chunk_log2(grid);
+  bp.f.chunk_log2 = render_chunk_log2(grid, bp.f.groups);
   const size_t samples = (size_t)cfg->n * a->rays_per_sample * a->K;
   int rc;
   if (bits_path(cfg, a) && !rows_always) {

@@ -278,7 +278,7 @@ __global__ __launch_bounds__(256, 2) void query_kernel_p(const QueryParams qp) {
 
 FwdParams make_params(const BtsFieldCfg* cfg, const BtsFieldTensors* t);
 int render_grid(const FwdParams& p);
-int render_chunk_log2(int grid);
+int render_chunk_log2(int grid, long groups);
 
 template <int C, int HD, int NB>
 static int launch_query_nv(const QueryParams& qp, int grid, hipStream_t s) {
@@ -315,7 +315,7 @@ int query_impl(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const float* xy
     return BTS_E_UNSUPPORTED;
   }
   const int grid = render_grid(qp.f);
-  qp.f.chunk_log2 = render_chunk_log2(grid);
+  qp.f.chunk_log2 = render_chunk_log2(grid, qp.f.groups);
   const int C = cfg->C, HD = cfg->d_hidden, NB = cfg->n_blocks;
   if (C == 64 && HD == 64 && NB == 0) return launch_query_nv<64, 64, 0>(qp, grid, s);
   if (C == 32 && HD == 32 && NB == 1) return launch_query_nv<32, 32, 1>(qp, grid, s);

@@ -408,8 +408,7 @@ def test_short_rays_packed_and_unpacked_vs_oracle(hip, K, n_rays):
 def test_48_lane_mode_matches_the_one_ray_mode(hip, K, nv_ids, epi):
     """32 < K <= 48 with a ray count that is a multiple of four runs four rays in three wave iterations (lanes 0-47 a whole ray, lanes
     48-63 one 16-sample row of the fourth: render_kernel_p's 48-lane mode, exp_re10k.yaml's n_coarse = 48); one ray more per batch
-    element and the same rays run one per iteration.  Per-sample outputs must agree bit for bit (the compositing products are formed
-    in the same order), per-ray sums to rounding (the fourth ray's are accumulated per lane over its three rows first)."""
+    element and the same rays run one per iteration: the two must agree -- to the bit on the rays that keep their lanes."""
     from behindthescenes_amd import native
     from tests._hip_helpers import build_net
     cfg = O.FieldConfig(d_min=1.0, d_max=100.0, code_mode="distance")
@@ -435,12 +434,22 @@ def test_48_lane_mode_matches_the_one_ray_mode(hip, K, nv_ids, epi):
             assert torch.equal(o[k_], oj[k_]), k_
         outs.append({k_: v.view(n, m, *v.shape[1:])[:, :1000] for k_, v in o.items() if v is not None})
     a, b = outs
-    for k_ in ("weights", "alphas", "invalid", "rgb_samps", "sigma_raw", "trans"):
-        assert torch.equal(a[k_], b[k_]), k_
-    torch.testing.assert_close(a["depth"], b["depth"], rtol=2e-6, atol=0)
-    torch.testing.assert_close(a["rgb"], b["rgb"], rtol=0, atol=2e-6)
+    # rays 0, 1, 2 of every four keep their lanes (0-47) in both modes: everything per sample is the same instruction sequence on the
+    # same lanes -> bit for bit.  The fourth ray's samples sit in lanes 48-63 here and in lanes 0-47 there: a sample's summation order
+    # depends on its point tile (lanes 0-31 / 32-63 meet the gather blocks and the MFMA regions in another interleaving, DESIGN.md
+    # section 3), so those agree to rounding.
+    main = (torch.arange(1000, device="cuda") % 4 != 3)
+    for k_ in ("alphas", "weights", "trans", "invalid", "rgb_samps", "sigma_raw"):
+        assert torch.equal(a[k_][:, main], b[k_][:, main]), k_
+    assert torch.equal(a["invalid"], b["invalid"]) and torch.equal(a["rgb_samps"], b["rgb_samps"])
+    torch.testing.assert_close(a["sigma_raw"], b["sigma_raw"], rtol=1e-4, atol=2e-5)
+    for k_ in ("weights", "alphas"):
+        assert (a[k_] - b[k_]).abs().max().item() <= 1e-5, k_
+    torch.testing.assert_close(a["depth"], b["depth"], rtol=1e-5, atol=0)
+    torch.testing.assert_close(a["rgb"], b["rgb"], rtol=0, atol=1e-5)
+    torch.testing.assert_close(a["depth"][:, main], b["depth"][:, main], rtol=2e-6, atol=0)
     if epi:
-        torch.testing.assert_close(a["invalid_wsum"], b["invalid_wsum"], rtol=0, atol=2e-6)
+        torch.testing.assert_close(a["invalid_wsum"], b["invalid_wsum"], rtol=0, atol=1e-5)
         assert torch.equal(a["invalid_any"], b["invalid_any"])
 
 
