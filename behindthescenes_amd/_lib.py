@@ -9,7 +9,7 @@ import threading
 PKG = os.path.dirname(os.path.abspath(__file__))
 # BTS_RENDER_LIB lets the profiling tools load the instrumented probe build (libbts_probe.so); the product always loads libbts_render.so
 LIB_PATH = os.environ.get("BTS_RENDER_LIB") or os.path.join(PKG, "libbts_render.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 BTS_MAX_VIEWS = 8
 ERRORS = {-1: "BTS_E_INVALID", -2: "BTS_E_UNSUPPORTED", -3: "BTS_E_LAUNCH", -4: "BTS_E_WORKSPACE"}
@@ -39,7 +39,7 @@ class BtsRenderArgs(C.Structure):
 
 class BtsRenderGrads(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in ("g_rgb", "g_depth", "g_weights", "g_alphas", "d_proj_nhwc", "d_mlp_params",
-                                          "d_empty_proj")]
+                                          "d_empty_proj", "d_proj_tiles")]
 
 
 class BtsLossArgs(C.Structure):
@@ -62,6 +62,8 @@ SYMBOLS = {
                                  C.POINTER(BtsRenderGrads), _P, C.c_size_t, _P]),
     "bts_project_features": (C.c_int, [C.POINTER(BtsFieldCfg), _P, _P, _I, _P, _P]),
     "bts_project_features_bwd": (C.c_int, [C.POINTER(BtsFieldCfg), _P, _P, _P, _I, _P, _P, _P]),
+    "bts_proj_tile_count": (C.c_int64, [C.POINTER(BtsFieldCfg)]),
+    "bts_project_features_bwd_tiles": (C.c_int, [C.POINTER(BtsFieldCfg), _P, _P, _P, _P, _I, _P, _P, _I, _P]),
     "bts_field_query": (C.c_int, [C.POINTER(BtsFieldCfg), C.POINTER(BtsFieldTensors), _P, _I, _I, _P, _P, _P, _P]),
     "bts_occupancy_profile": (C.c_int, [C.POINTER(BtsFieldCfg), C.POINTER(BtsFieldTensors), _P, _I, _I, C.c_float, _I, _P, _P, _P]),
     "bts_nchw_to_nhwc": (C.c_int, [_P, _P, _I, _I, _I, _I, _P]),

@@ -23,6 +23,8 @@ int distance_to_z_launch(const float* depths, const float* invK, int N, int H, i
 int invert_small_launch(const float* src, float* dst, int N, int dim, hipStream_t s);
 
 int project_features_impl(int C, int HD, const float* feat, const float* mlp, int N, int HW, float* proj, hipStream_t s);
+int project_features_bwd_tiles_impl(int C, int HD, const float* feat, float* dproj, unsigned char* tiles, const float* mlp, int N, int HW, float* dfeat,
+                                    float* d_mlp, int clear, hipStream_t s);
 int project_features_bwd_impl(int C, int HD, const float* feat, const float* dproj, const float* mlp, int N, int HW, float* dfeat,
                               float* d_mlp, hipStream_t s);
 int render_fwd_impl(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const BtsRenderArgs* a, hipStream_t s);
@@ -175,6 +177,29 @@ int bts_project_features_bwd(const BtsFieldCfg* cfg, const float* feat_nchw, con
   int rc = project_features_bwd_impl(cfg->C, cfg->d_hidden, feat_nchw, d_proj_nhwc, mlp_params, N, (int)feat_texels(cfg), d_feat_nchw,
                                      d_mlp_params, (hipStream_t)stream);
   if (rc) set_error("%s: kernel launch failed", "bts_project_features_bwd");
+  return rc;
+}
+
+int64_t bts_proj_tile_count(const BtsFieldCfg* cfg) {
+  if (!cfg || cfg->H <= 0 || cfg->W <= 0 || cfg->feat_shift < 0 || cfg->feat_shift > 3) return 0;
+  return (feat_texels(cfg) + 63) / 64;
+}
+
+int bts_project_features_bwd_tiles(const BtsFieldCfg* cfg, const float* feat_nchw, float* d_proj_nhwc, uint8_t* tiles, const float* mlp_params,
+                                   int32_t N, float* d_feat_nchw, float* d_mlp_params, int32_t clear_after, void* stream) {
+  if (!cfg || !d_proj_nhwc || !tiles || !mlp_params || N <= 0 || cfg->H <= 0 || cfg->W <= 0 || (d_mlp_params && !feat_nchw)) {
+    set_error("%s: NULL pointer or non-positive size", "bts_project_features_bwd_tiles");
+    return BTS_E_INVALID;
+  }
+  if (!bts_supported(cfg)) {
+    set_error("%s: configuration outside the compiled envelope (C=%ld d_hidden=%ld n_blocks=%ld)", "bts_project_features_bwd_tiles", cfg->C,
+              cfg->d_hidden, cfg->n_blocks);
+    return BTS_E_UNSUPPORTED;
+  }
+  if (int rc = check_shift(cfg, "bts_project_features_bwd_tiles")) return rc;
+  int rc = project_features_bwd_tiles_impl(cfg->C, cfg->d_hidden, feat_nchw, d_proj_nhwc, tiles, mlp_params, N, (int)feat_texels(cfg), d_feat_nchw,
+                                           d_mlp_params, clear_after, (hipStream_t)stream);
+  if (rc) set_error("%s: kernel launch failed", "bts_project_features_bwd_tiles");
   return rc;
 }
 

@@ -17,6 +17,8 @@ struct BwdParams {
   float* gs_ws;           // lane = sample path (bts_bwd_rows.hip): (n*Bp, K) gradient at the pre-softplus density
   unsigned* mask_ws;      //                    (n*Bp, HD/32, K) relu gates of lin_in's output per sample, one bit per channel
   uint2* pmask_ws;        //                    (n*Bp, HD) the same gates per channel, one bit per sample of the ray
+  unsigned char* tiles;   // (n, tiles_per_img) dirty flags of d_proj's 64-texel tiles (BtsRenderGrads.d_proj_tiles), or null
+  int tiles_per_img;
   float* flush_ws;        // kFlushSlots x (40 x HD) floats, zeroed by the launcher: pass C's dW_pe partial sums (dwpe_flush below)
 };
 

@@ -764,11 +764,13 @@ int render_bwd_impl(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const BtsR
   bp.g_rgb = g->g_rgb, bp.g_depth = g->g_depth, bp.g_weights = g->g_weights, bp.g_alphas = g->g_alphas;
   bp.d_proj = g->d_proj_nhwc, bp.d_mlp = g->d_mlp_params, bp.d_empty_proj = g->d_empty_proj;
   bp.gh_ws = nullptr, bp.gs_ws = nullptr, bp.mask_ws = nullptr, bp.pmask_ws = nullptr, bp.flush_ws = nullptr;
+  bp.tiles = bp.d_proj ? g->d_proj_tiles : nullptr;
+  bp.tiles_per_img = (int)((((long)(cfg->H >> cfg->feat_shift) * (cfg->W >> cfg->feat_shift)) + 63) / 64);
 #ifdef BTS_PROBE
   static const bool direct = getenv("BTS_BWD_DIRECT_ATOMICS") != nullptr;   // A/B (probe build): round-1 kernel, every tap update an L2 atomic
   static const bool v1 = getenv("BTS_BWD_V1") != nullptr || direct;         // A/B (probe build): the round-1 lane = ray pass for every shape
   static const bool rows_always = getenv("BTS_BWD_ROWS") != nullptr;        // A/B (probe build): the row passes for every shape
-  if (v1 && !bp.f.fs) {   // (the round-1 pass knows full-size maps only)
+  if (v1 && !bp.f.fs && !bp.tiles) {   // (the round-1 pass knows full-size maps only, and no tile flags)
     bp.gh_ws = (bp.d_proj && !direct) ? static_cast<float*>(workspace) : nullptr;
     const int grid = bp.f.tiles_per_sample * cfg->n;
     int rc = BTS_E_UNSUPPORTED;
@@ -786,6 +788,10 @@ int render_bwd_impl(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const BtsR
     set_error("%s: too many rays in one call (%ld)", "bts_render_bwd", bp.f.groups);
     return BTS_E_UNSUPPORTED;
   }
+  // the RE10K model at its own sample count (32 < K <= 48, exp_re10k.yaml: 48): four rays in three wave iterations (rowsb_kernel<PK>)
+  const bool pack48 = !(bits_path(cfg, a) && !rows_always) && cfg->C == 32 && cfg->d_hidden == 32 && cfg->n_blocks == 1 && a->K > 32 &&
+                      a->K <= 48 && a->rays_per_sample % 4 == 0;
+  if (pack48) bp.f.lpr = 48, bp.f.groups /= 4;
   const int grid = render_grid(bp.f);
   bp.f.chunk_log2 = render_chunk_log2(grid, bp.f.groups);
   const size_t samples = (size_t)cfg->n * a->rays_per_sample * a->K;

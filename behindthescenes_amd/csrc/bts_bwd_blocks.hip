@@ -255,7 +255,13 @@ struct RowsbOut {
 // ---------------------------------------------------------------------------------------------------------------
 // pass A
 // ---------------------------------------------------------------------------------------------------------------
-template <int C, int HD, int NB, int NVMAX>
+// PK: the 48-lane mode of render_kernel_p for the backward (32 < K <= 48 and the rays of a batch element a multiple of four --
+// exp_re10k.yaml's n_coarse = 48): a group is FOUR rays taken in THREE iterations, walked back to front like the chunks of a long ray --
+// lanes 0-47 one whole ray (ray it of the group) per iteration, lanes 48-63 the 16-sample row `it` of the fourth -- so that no
+// instruction runs with a quarter of its lanes idle.  Everything per sample is lane-local; what belongs to a RAY (origin, direction,
+// upstream gradients: wave-uniform scalars in the one-ray mode) becomes a per-lane select between the iteration's two rays, the suffix
+// sum of the compositing gradient is segmented (lanes 0-47 | 48-63), and the fourth ray's carries over its three rows.
+template <int C, int HD, int NB, int NVMAX, bool PK = false>
 __global__ __launch_bounds__(256, 2) void rowsb_kernel(const BwdParams bp, const RowsbOut ro) {
   static_assert(NB == 0 || HD == 32, "ResnetBlockFC layers are laid out for d_hidden = 32 (the RE10K model)");
   const FwdParams& p = bp.f;
@@ -320,7 +326,13 @@ __global__ __launch_bounds__(256, 2) void rowsb_kernel(const BwdParams bp, const
     return (c < n_chunks && gg < n_groups) ? gg : -1;
   };
   const int Bp = p.Bp, K = p.K;
-  const int kc_last = ((K - 1) >> 6) << 6;   // first sample of the last 64-sample chunk of a ray: chunks are walked back to front
+  const int kc_last = PK ? 128 : ((K - 1) >> 6) << 6;   // first sample of the last 64-sample chunk of a ray: chunks are walked back to front
+                                                        // (PK: kc >> 6 is the iteration of the group, 2 .. 0)
+  const bool mainl = !PK || lane < 48;
+  // this lane's sample in iteration kc: its index in the ray (may be >= K: an idle lane) ...
+  auto k_of = [&](int kc) -> int { return PK ? (mainl ? lane : 16 * (kc >> 6) + lane - 48) : kc + lane; };
+  // ... and the row of (ray, sample) tables it indexes, relative to the group's first ray
+  auto row_of = [&](int kc, int kk) -> unsigned { return PK ? (unsigned)((mainl ? (kc >> 6) : 3) * K + kk) : (unsigned)kk; };
 
   // persistent per-wave gradient state
   float dw_acc[HT], db_acc = 0.0f;   // this lane's share of dw_out (see dw_out below) and of db_out
@@ -343,12 +355,13 @@ __global__ __launch_bounds__(256, 2) void rowsb_kernel(const BwdParams bp, const
   // vmcnt(0): the four prefetch loads below ran as four serial memory round trips per iteration)
   // (`f`: the parameter block as laundered for this iteration -- through the by-value copy `p` the compiler hoists the lane parts of the
   // four addresses out of the loop, keeps them as 64-bit VGPR pairs and spills exactly those)
-  auto fetch_state = [&](const FwdParams __attribute__((address_space(4)))* f, int gg, int kc) {   // the per-sample state of chunk kc of ray gg
-    const int k = kc + lane;
-    const unsigned kk = (unsigned)(k < K ? k : K - 1);
-    const long row = (long)gg * K;   // uniform
-    z_pre = at32(f->z_samp + row, kk), zn_pre = at32(f->z_samp + row, min(kk + 1u, (unsigned)(K - 1)));
-    s_pre = at32(f->sigma_raw + row, kk), t_pre = at32(f->trans + row, kk);
+  auto fetch_state = [&](const FwdParams __attribute__((address_space(4)))* f, int gg, int kc) {   // the per-sample state of chunk kc of ray (group) gg
+    const int k = k_of(kc);
+    const int kk = k < K ? k : K - 1;
+    const long row = (long)gg * (PK ? 4 : 1) * K;   // uniform
+    const unsigned r = row_of(kc, kk);
+    z_pre = at32(f->z_samp + row, r), zn_pre = at32(f->z_samp + row, kk + 1 < K ? r + 1u : r);
+    s_pre = at32(f->sigma_raw + row, r), t_pre = at32(f->trans + row, r);
   };
   if (g >= 0) fetch_state(&kernarg_view<BwdParams>()->f, g, kc_last);
 #ifdef BTS_TICKS
@@ -363,43 +376,61 @@ __global__ __launch_bounds__(256, 2) void rowsb_kernel(const BwdParams bp, const
     asm volatile("" : "+s"(qb));
     IterHead ih(qb);   // (batching these scalar loads -- IterHeadT<true> -- changes nothing here either: 0.640 vs 0.634 ms, profiles/r03s)
     const int H = ih.H, W = ih.W, nv = ih.nv, fs = ih.fs;
-    const long ray = g;
-    while (g >= sample_end) ++sample, sample_end += Bp;
+    const long ray0 = PK ? (long)g * 4 : (long)g;   // the (first) ray of the group
+    while (ray0 >= sample_end) ++sample, sample_end += Bp;
     const Cam enc = load_cam(ih.w2c_enc + sample * 16, ih.K_enc + sample * 9);
     const float4* __restrict__ G = reinterpret_cast<const float4*>(ih.proj) + (long)sample * (H >> fs) * (W >> fs) * (HD / 4);
-    const cfp rp = as_const(ih.rays) + ray * 8;
-    const float ox = rp[0], oy = rp[1], oz = rp[2], dx = rp[3], dy = rp[4], dz = rp[5];
-    // upstream gradients of the ray
-    float g_rgb[NVMAX * 3];
-    float g_bkgd = 0.0f;
-    {
-      // one batch of scalar loads (index clamped, the entries beyond nv zeroed by selects): a condition per entry is a branch, a load and
-      // a wait per entry
+    // a ray's scalars: origin, direction, upstream gradients -- one batch of scalar loads (index clamped, the entries beyond nv zeroed by
+    // selects: a condition per entry is a branch, a load and a wait per entry)
+    struct RayIn {
+      float o[3], d[3], g_rgb[NVMAX * 3], g_bkgd, g_depth;
+    };
+    auto load_ray = [&](long ray) -> RayIn {
+      RayIn r;
+      const cfp rp = as_const(ih.rays) + ray * 8;
+      r.o[0] = rp[0], r.o[1] = rp[1], r.o[2] = rp[2], r.d[0] = rp[3], r.d[1] = rp[4], r.d[2] = rp[5];
+      r.g_bkgd = 0.0f;
 #pragma unroll
-      for (int i = 0; i < NVMAX * 3; ++i) g_rgb[i] = 0.0f;
+      for (int i = 0; i < NVMAX * 3; ++i) r.g_rgb[i] = 0.0f;
       if (qb->g_rgb) {
         const cfp gr = as_const(qb->g_rgb) + ray * (long)(nv * 3);
 #pragma unroll
-        for (int i = 0; i < NVMAX * 3; ++i) g_rgb[i] = gr[min(i, nv * 3 - 1)];
+        for (int i = 0; i < NVMAX * 3; ++i) r.g_rgb[i] = gr[min(i, nv * 3 - 1)];
       }
 #pragma unroll
       for (int i = 0; i < NVMAX * 3; ++i) {
-        g_rgb[i] = i < nv * 3 ? g_rgb[i] : 0.0f;
-        g_bkgd -= g_rgb[i];
+        r.g_rgb[i] = i < nv * 3 ? r.g_rgb[i] : 0.0f;
+        r.g_bkgd -= r.g_rgb[i];
       }
-    }
-    const float g_depth = qb->g_depth ? as_const(qb->g_depth)[ray] : 0.0f;
-    float S_carry = 0.0f;   // sum over the samples of the chunks behind this one of g_w w
+      r.g_depth = qb->g_depth ? as_const(qb->g_depth)[ray] : 0.0f;
+      return r;
+    };
+    RayIn rin = load_ray(PK ? ray0 + 3 : ray0);   // PK: the fourth ray's, selected into lanes 48-63 of every iteration below
+    float S_carry = 0.0f;   // sum over the samples of the chunks behind this one of g_w w (PK: of the fourth ray's rows behind this one)
     RB_TICK(10)   // (part of 0) the ray's scalars are in
 
     for (int kc = kc_last; kc >= 0; kc -= 64) {
-      const int k = kc + lane;
+      const int k = k_of(kc);
       const bool valid = k < K;
       const int kk = valid ? k : K - 1;
       const bool last = k == K - 1;
-      const long rowk = ray * K;         // uniform: the ray's first sample
-      const unsigned kku = (unsigned)kk;
+      const long rowk = ray0 * K;         // uniform: the first sample of the group's first ray
+      const unsigned kku = row_of(kc, kk);
       const float z = z_pre, z_nx = zn_pre, s_raw = s_pre, T = t_pre;
+      float ox, oy, oz, dx, dy, dz, g_rgb[NVMAX * 3], g_bkgd, g_depth;
+      if constexpr (PK) {
+        const RayIn rm = load_ray(ray0 + (kc >> 6));
+        ox = mainl ? rm.o[0] : rin.o[0], oy = mainl ? rm.o[1] : rin.o[1], oz = mainl ? rm.o[2] : rin.o[2];
+        dx = mainl ? rm.d[0] : rin.d[0], dy = mainl ? rm.d[1] : rin.d[1], dz = mainl ? rm.d[2] : rin.d[2];
+#pragma unroll
+        for (int i = 0; i < NVMAX * 3; ++i) g_rgb[i] = mainl ? rm.g_rgb[i] : rin.g_rgb[i];
+        g_bkgd = mainl ? rm.g_bkgd : rin.g_bkgd, g_depth = mainl ? rm.g_depth : rin.g_depth;
+      } else {
+        ox = rin.o[0], oy = rin.o[1], oz = rin.o[2], dx = rin.d[0], dy = rin.d[1], dz = rin.d[2];
+#pragma unroll
+        for (int i = 0; i < NVMAX * 3; ++i) g_rgb[i] = rin.g_rgb[i];
+        g_bkgd = rin.g_bkgd, g_depth = rin.g_depth;
+      }
       {  // the state of the chunk evaluated next lands while this one is evaluated (ONE call site: two get tail-merged into a block
          // that rebuilds 64-bit lane addresses from spilled parts)
         const int g_nx = kc > 0 ? g : group_of(idx + waves_per_xcd);
@@ -509,15 +540,16 @@ __global__ __launch_bounds__(256, 2) void rowsb_kernel(const BwdParams bp, const
         // exclusive suffix sum over the wave + the chunks behind; the wave's total moves on to the chunk in front
         float incl = gww;
 #ifndef BTS_ABL_B6   // timing ablation: no suffix scan
+        const int seg_end = mainl && PK ? 48 : 64;   // one past the last lane of this lane's ray
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
           const float y = __shfl_down(incl, off, 64);
-          incl += (lane + off < 64) ? y : 0.0f;
+          incl += (lane + off < seg_end) ? y : 0.0f;
         }
 #endif
         const float below = __shfl_down(incl, 1, 64);
-        const float S = (lane == 63 ? 0.0f : below) + S_carry;
-        S_carry += __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, incl)));
+        const float S = (lane == seg_end - 1 ? 0.0f : below) + (mainl && PK ? 0.0f : S_carry);
+        S_carry += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, incl), PK ? 48 : 0));
         float g_alpha = g_w * T - S / (capped ? 1e-10f : ex + 1e-10f);
         g_alpha += ga_k;
         if (!capped && !dead && !cut && valid) g_s = g_alpha * fabsf(delta) * ex * (s_raw > 20.0f ? 1.0f : sigmoidf(s_raw));
@@ -743,9 +775,11 @@ __global__ __launch_bounds__(256, 2) void rowsb_kernel(const BwdParams bp, const
 #pragma unroll
               for (int jj = 0; jj < 4; ++jj) {
                 const float4 x = *reinterpret_cast<const float4*>(u0t + ht * 4096 + jj * 1024 + lane * 16);
-                const int ks = kc + pt * 32 + 8 * jj + gl.m;
+                const int pos = pt * 32 + 8 * jj + gl.m;   // the wave position (= lane) of the sample this row belongs to
+                const int ks = PK ? (pos < 48 ? pos : 16 * (kc >> 6) + pos - 48) : kc + pos;
+                const int kr = PK ? (pos < 48 ? (kc >> 6) : 3) * K + ks : ks;
                 if (ks < K)
-                  *reinterpret_cast<float4*>(reinterpret_cast<char*>(ro.u0_ws + rowk * (long)HD) + (unsigned)(ks * HD * 4 + ht * 128) + gl.piece16) = x;
+                  *reinterpret_cast<float4*>(reinterpret_cast<char*>(ro.u0_ws + rowk * (long)HD) + (unsigned)(kr * HD * 4 + ht * 128) + gl.piece16) = x;
               }
           }
         }
@@ -814,7 +848,7 @@ __global__ __launch_bounds__(256, 2) void rowsb_kernel(const BwdParams bp, const
 // ---------------------------------------------------------------------------------------------------------------
 // launch
 // ---------------------------------------------------------------------------------------------------------------
-int launch_scatter_rows(const FwdParams& p, const float* gs_ws, const float* u0_ws, float* d_proj, float* d_empty_proj, int HD, int n, hipStream_t s);
+int launch_scatter_rows(const BwdParams& bp, const float* u0_ws, int HD, int n, hipStream_t s);
 int launch_dwpe_rows(const FwdParams& p, const float* u0_ws, float* d_mlp, float* flush_ws, int C, int HD, int NB, int n, int grid, hipStream_t s);
 
 template <int C, int HD, int NB>
@@ -824,6 +858,16 @@ static int launch_rowsb(const BwdParams& bp, const RowsbOut& ro, int grid, hipSt
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, dyn);
     kern<<<grid, 256, dyn, s>>>(bp, ro);
   };
+  if constexpr (NB == 1) {   // the 48-lane mode is built for the RE10K model (rowsb_packs_48 in bts_bwd.hip names the same condition)
+    if (bp.f.lpr == 48) {
+      if (bp.f.nv <= 1) go(rowsb_kernel<C, HD, NB, 1, true>);
+      else if (bp.f.nv <= 2) go(rowsb_kernel<C, HD, NB, 2, true>);
+      else if (bp.f.nv <= 4) go(rowsb_kernel<C, HD, NB, 4, true>);
+      else go(rowsb_kernel<C, HD, NB, 8, true>);
+      return hipGetLastError() == hipSuccess ? BTS_OK : BTS_E_LAUNCH;
+    }
+  }
+  if (bp.f.lpr != 64) return BTS_E_UNSUPPORTED;
   if (bp.f.nv <= 1) go(rowsb_kernel<C, HD, NB, 1>);
   else if (bp.f.nv <= 2) go(rowsb_kernel<C, HD, NB, 2>);
   else if (bp.f.nv <= 4) go(rowsb_kernel<C, HD, NB, 4>);
@@ -843,7 +887,7 @@ int launch_bwd_blocks(const BwdParams& bp, float* u0_ws, int C, int HD, int NB, 
   if (C == 64 && HD == 64 && NB == 0) rc = launch_rowsb<64, 64, 0>(bp, ro, grid, s);
   else if (C == 32 && HD == 32 && NB == 1) rc = launch_rowsb<32, 32, 1>(bp, ro, grid, s);
   else if (C == 32 && HD == 32 && NB == 0) rc = launch_rowsb<32, 32, 0>(bp, ro, grid, s);
-  if (rc == BTS_OK && (bp.d_proj || bp.d_empty_proj)) rc = launch_scatter_rows(bp.f, bp.gs_ws, u0_ws, bp.d_proj, bp.d_empty_proj, HD, n, s);
+  if (rc == BTS_OK && (bp.d_proj || bp.d_empty_proj)) rc = launch_scatter_rows(bp, u0_ws, HD, n, s);
   if (rc == BTS_OK && bp.d_mlp) rc = launch_dwpe_rows(bp.f, u0_ws, bp.d_mlp, bp.flush_ws, C, HD, NB, n, grid, s);
   if (rc == BTS_E_LAUNCH) set_error("%s: backward kernel launch failed (%ld)", hipGetErrorString(hipGetLastError()), 0);
   return rc;

@@ -515,6 +515,8 @@ struct ScatterMaskParams {
   const float* gs_ws;        // (n*Bp, K)
   float* d_proj;             // or null: only d_empty
   float* d_empty_proj;       // or null
+  unsigned char* tiles;      // or null.  (n, tiles_per_img) dirty flags of d_proj (BtsRenderGrads.d_proj_tiles): the byte of every 64-texel
+  int tiles_per_img;         // tile that receives a contribution is set to 1
   int groups_per_sample;
   int w_out_off;             // offset of w_out in the packed parameter vector
   int nseg, kseg;            // the K steps of a ray group are cut into nseg segments of kseg steps, one wave each (own window, own flush):
@@ -577,6 +579,7 @@ __global__ __launch_bounds__(64) void scatter_kernel(const ScatterMaskParams sp)
   const float* gsrow = sp.gs_ws + ray * K;
   const unsigned* mrow = ROWS ? nullptr : sp.mask_ws + (ray * NW + wv) * K;
   float* __restrict__ dG = sp.d_proj + (long)sample * H * W * HD + chg;
+  unsigned char* __restrict__ const dirty = sp.tiles ? sp.tiles + (long)sample * sp.tiles_per_img : nullptr;
   const float w_out_ch = ROWS ? 0.0f : p.mlp[sp.w_out_off + proj_hidden_of_storage(chg)];
   // ROWS: channel chg of point i of this lane's half at step k is urow[(i K + k) HD]
   const float* urow = ROWS ? sp.u0_ws + ((long)sample * Bp + g_in * 64 + 32 * h) * K * HD + chg : nullptr;
@@ -592,6 +595,7 @@ __global__ __launch_bounds__(64) void scatter_kernel(const ScatterMaskParams sp)
     const float v = *cc;
     if (v != 0.0f) {
       atomic_add_f32(dG + ((long)ty * W + tx) * HD, v);
+      if (dirty) dirty[(unsigned)(ty * W + tx) >> 6] = 1;   // (same byte from every lane that added something: one request)
       *cc = 0.0f;
     }
   };
@@ -780,6 +784,9 @@ __global__ __launch_bounds__(64) void scatter_kernel(const ScatterMaskParams sp)
           atomic_add_f32(dG + (ya + xb) * HD, w01 * gv);
           atomic_add_f32(dG + (yb + xa) * HD, w10 * gv);
           atomic_add_f32(dG + (yb + xb) * HD, w11 * gv);
+          if (dirty)
+            dirty[(unsigned)(ya + xa) >> 6] = 1, dirty[(unsigned)(ya + xb) >> 6] = 1, dirty[(unsigned)(yb + xa) >> 6] = 1,
+            dirty[(unsigned)(yb + xb) >> 6] = 1;
         }
       }
     }
@@ -1213,6 +1220,7 @@ static int launch_rows(const BwdParams& bp, int n, int grid, hipStream_t s) {
     const MlpLayout ml{C + kPeDim, HD, 0};
     ScatterMaskParams sp;
     sp.f = p, sp.mask_ws = bp.mask_ws, sp.u0_ws = nullptr, sp.gs_ws = bp.gs_ws, sp.d_proj = bp.d_proj, sp.d_empty_proj = bp.d_empty_proj;
+    sp.tiles = bp.tiles, sp.tiles_per_img = bp.tiles_per_img;
     sp.groups_per_sample = (p.Bp + 63) / 64, sp.w_out_off = ml.w_out();
     const long units = (long)n * sp.groups_per_sample * (HD / 32);
     scatter_segments(sp, units, p.K);
@@ -1248,9 +1256,11 @@ static void scatter_segments(ScatterMaskParams& sp, long units, int K) {
 }
 
 // ROWS form of pass B / pass C for bts_bwd_blocks.hip
-int launch_scatter_rows(const FwdParams& p, const float* gs_ws, const float* u0_ws, float* d_proj, float* d_empty_proj, int HD, int n, hipStream_t s) {
+int launch_scatter_rows(const BwdParams& bp, const float* u0_ws, int HD, int n, hipStream_t s) {
+  const FwdParams& p = bp.f;
   ScatterMaskParams sp;
-  sp.f = p, sp.mask_ws = nullptr, sp.u0_ws = u0_ws, sp.gs_ws = gs_ws, sp.d_proj = d_proj, sp.d_empty_proj = d_empty_proj;
+  sp.f = p, sp.mask_ws = nullptr, sp.u0_ws = u0_ws, sp.gs_ws = bp.gs_ws, sp.d_proj = bp.d_proj, sp.d_empty_proj = bp.d_empty_proj;
+  sp.tiles = bp.tiles, sp.tiles_per_img = bp.tiles_per_img;
   sp.groups_per_sample = (p.Bp + 63) / 64, sp.w_out_off = 0;
   const long units = (long)n * sp.groups_per_sample * (HD / 32);
   scatter_segments(sp, units, p.K);

@@ -89,6 +89,172 @@ __global__ __launch_bounds__(256, 2) void project_kernel(const float* __restrict
 //     (channels) in registers, columns (pixels) across lanes -> 128-byte NCHW row stores.
 // Every load of a (half) tile is issued before its first MFMA (sched_barrier: the scheduler sinks loads to their uses otherwise; keeping
 // the NEXT unit's loads in flight as well -- a register double buffer -- measured slower, profiles/r04g).  The weight gradient is reduced registers -> LDS -> one atomic per (hid, c).
+// dW += dG^T F over one tile of 64 pixels (p0 ..): a tile = 8 groups of 8 pixels, taken as two halves of four groups: all loads of a
+// half (a float4 of F per channel tile and four dG values per hidden tile and group: 64 registers) are issued before its first MFMA
+template <int C, int HD>
+__device__ __forceinline__ void project_dw_tile(const float* __restrict__ F, const float* __restrict__ dG, int p0, int HW, bool vec4, int h, int col,
+                                                f32x16 (&accw)[HD / 32][C / 32]) {
+  constexpr int HT = HD / 32, CT = C / 32;
+  const bool full = vec4 && p0 + 64 <= HW;   // wave-uniform: whole tile inside the image, rows 16-byte aligned -> no per-load guards
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    float4 fb[4][CT];
+    float av[4][4][HT];
+    if (full) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int pix4 = p0 + 8 * (4 * half + t) + 4 * h;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) fb[t][ct] = *reinterpret_cast<const float4*>(F + (unsigned)((ct * 32 + col) * HW + pix4));
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int ht = 0; ht < HT; ++ht) av[t][e][ht] = dG[(unsigned)((pix4 + e) * HD + ht * 32 + col)];   // stored channel ht*32 + col
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int pix4 = p0 + 8 * (4 * half + t) + 4 * h;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+          const unsigned ro = (unsigned)((ct * 32 + col) * HW + pix4);     // element offset inside the image's map (< 2^32)
+          fb[t][ct] = make_float4(pix4 < HW ? F[ro] : 0.0f, pix4 + 1 < HW ? F[ro + 1] : 0.0f, pix4 + 2 < HW ? F[ro + 2] : 0.0f,
+                                  pix4 + 3 < HW ? F[ro + 3] : 0.0f);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int pix = pix4 + e;
+#pragma unroll
+          for (int ht = 0; ht < HT; ++ht) av[t][e][ht] = pix < HW ? dG[(unsigned)(pix * HD + ht * 32 + col)] : 0.0f;
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);   // all loads of the half are out before its first MFMA (the scheduler would sink them)
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+#pragma unroll
+        for (int ht = 0; ht < HT; ++ht)
+#pragma unroll
+          for (int ct = 0; ct < CT; ++ct) {
+            const float* fp = reinterpret_cast<const float*>(&fb[t][ct]);
+            accw[ht][ct] = mfma(av[t][e][ht], fp[e], accw[ht][ct]);
+          }
+      }
+  }
+}
+
+// dF = dG w_in[:, :C] over one tile of 64 pixels; wl[hid*C + c] = w_in[hid][c] in LDS
+template <int C, int HD>
+__device__ __forceinline__ void project_df_tile(const float* __restrict__ dG, float* __restrict__ dF, const float* wl, int p0, int HW, int h, int col) {
+  constexpr int CT = C / 32;
+  const float4* dG4 = reinterpret_cast<const float4*>(dG);
+  const int px0 = min(p0 + col, HW - 1), px1 = min(p0 + 32 + col, HW - 1);
+  float4 v0[HD / 8], v1[HD / 8];
+#pragma unroll
+  for (int qq = 0; qq < HD / 8; ++qq) {
+    // storage float4 (ht*8 + 4h + q) holds hidden ht*32 + 8q + 4h + e, e = 0..3  (proj_storage_index)
+    const int ht = qq >> 2, q = qq & 3;
+    v0[qq] = dG4[(unsigned)(px0 * (HD / 4) + ht * 8 + 4 * h + q)];
+    v1[qq] = dG4[(unsigned)(px1 * (HD / 4) + ht * 8 + 4 * h + q)];
+  }
+  __builtin_amdgcn_sched_barrier(0);   // all 16 row loads are out before the first MFMA
+  f32x16 acc[CT][2];
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt) acc[ct][pt] = zero_acc();
+#pragma unroll
+  for (int qq = 0; qq < HD / 8; ++qq) {
+    const int ht = qq >> 2, q = qq & 3;
+    const float* b0 = reinterpret_cast<const float*>(&v0[qq]);
+    const float* b1 = reinterpret_cast<const float*>(&v1[qq]);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int hid = ht * 32 + 8 * q + 4 * h + e;
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+        const float a = wl[hid * C + ct * 32 + col];
+        acc[ct][0] = mfma(a, b0[e], acc[ct][0]);
+        acc[ct][1] = mfma(a, b1[e], acc[ct][1]);
+      }
+    }
+  }
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt) {
+      const int pix = p0 + pt * 32 + col;
+      if (pix < HW) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) dF[(unsigned)((ct * 32 + mfma_row(q, h)) * HW + pix)] = acc[ct][pt][q];
+      }
+    }
+}
+
+// the same, one half of the tile (32 pixels) after the other: half the registers, for the kernel whose waves hold the weight
+// gradient's accumulators as well
+template <int C, int HD>
+__device__ __forceinline__ void project_df_half_tiles(const float* __restrict__ dG, float* __restrict__ dF, const float* wl, int p0, int HW, int h, int col) {
+  constexpr int CT = C / 32;
+  const float4* dG4 = reinterpret_cast<const float4*>(dG);
+#pragma unroll 1
+  for (int pt = 0; pt < 2; ++pt) {
+    const int pix = p0 + pt * 32 + col;
+    const int px = min(pix, HW - 1);
+    float4 v[HD / 8];
+#pragma unroll
+    for (int qq = 0; qq < HD / 8; ++qq) v[qq] = dG4[(unsigned)(px * (HD / 4) + (qq >> 2) * 8 + 4 * h + (qq & 3))];
+    __builtin_amdgcn_sched_barrier(0);
+    f32x16 acc[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) acc[ct] = zero_acc();
+#pragma unroll
+    for (int qq = 0; qq < HD / 8; ++qq) {
+      const float* b = reinterpret_cast<const float*>(&v[qq]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int hid = (qq >> 2) * 32 + 8 * (qq & 3) + 4 * h + e;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) acc[ct] = mfma(wl[hid * C + ct * 32 + col], b[e], acc[ct]);
+      }
+    }
+    if (pix < HW) {
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) dF[(unsigned)((ct * 32 + mfma_row(q, h)) * HW + pix)] = acc[ct][q];
+    }
+  }
+}
+
+// the weight gradient's way out: registers -> work-group LDS (red = HD x C floats, reused from the staged weights) -> one atomic per (hid, c)
+template <int C, int HD>
+__device__ __forceinline__ void project_dw_flush(float* red, const f32x16 (&accw)[HD / 32][C / 32], bool has_acc, float* __restrict__ d_mlp, int h, int col) {
+  constexpr int HT = HD / 32, CT = C / 32, D_IN = C + kPeDim;
+  __syncthreads();
+  for (int i = threadIdx.x; i < HD * C; i += blockDim.x) red[i] = 0.0f;
+  __syncthreads();
+  if (has_acc) {   // accumulator rows are STORED channels: map back to hidden units
+#pragma unroll
+    for (int ht = 0; ht < HT; ++ht)
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) atomicAdd(&red[proj_hidden_of_storage(ht * 32 + mfma_row(q, h)) * C + ct * 32 + col], accw[ht][ct][q]);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < HD * C; i += blockDim.x) {
+    const int hid = i / C, c = i % C;
+#ifndef BTS_ABL_NOFLUSH
+    if (red[i] != 0.0f) atomicAdd(&d_mlp[hid * D_IN + c], red[i]);
+#else
+    if (red[i] == 1.2345e-30f) d_mlp[hid * D_IN + c] = red[i];
+#endif
+  }
+}
+
 template <int C, int HD>
 __global__ __launch_bounds__(256, 2) void project_bwd_kernel(const float* __restrict__ feat, const float* __restrict__ dproj, const float* __restrict__ mlp,
                                                           float* __restrict__ dfeat, float* __restrict__ d_mlp, int HW, int tiles_per_img, int n_tiles) {
@@ -120,127 +286,73 @@ __global__ __launch_bounds__(256, 2) void project_bwd_kernel(const float* __rest
     const int img = tile / tiles_per_img;
     const int p0 = (tile - img * tiles_per_img) * 64;
     const float* dG = dproj + (long)img * HW * HD;
-    if (role_w) {
-      const float* F = feat + (long)img * C * HW;
-      // a tile = 8 groups of 8 pixels, taken as two halves of four groups: all loads of a half (a float4 of F per channel tile and four
-      // dG values per hidden tile and group: 64 registers) are issued before its first MFMA
-      const bool full = vec4 && p0 + 64 <= HW;   // wave-uniform: whole tile inside the image, rows 16-byte aligned -> no per-load guards
-#pragma unroll
-      for (int half = 0; half < 2; ++half) {
-        float4 fb[4][CT];
-        float av[4][4][HT];
-        if (full) {
-#pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            const int pix4 = p0 + 8 * (4 * half + t) + 4 * h;
-#pragma unroll
-            for (int ct = 0; ct < CT; ++ct) fb[t][ct] = *reinterpret_cast<const float4*>(F + (unsigned)((ct * 32 + col) * HW + pix4));
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-              for (int ht = 0; ht < HT; ++ht) av[t][e][ht] = dG[(unsigned)((pix4 + e) * HD + ht * 32 + col)];   // stored channel ht*32 + col
-          }
-        } else {
-#pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            const int pix4 = p0 + 8 * (4 * half + t) + 4 * h;
-#pragma unroll
-            for (int ct = 0; ct < CT; ++ct) {
-              const unsigned ro = (unsigned)((ct * 32 + col) * HW + pix4);     // element offset inside the image's map (< 2^32)
-              fb[t][ct] = make_float4(pix4 < HW ? F[ro] : 0.0f, pix4 + 1 < HW ? F[ro + 1] : 0.0f, pix4 + 2 < HW ? F[ro + 2] : 0.0f,
-                                      pix4 + 3 < HW ? F[ro + 3] : 0.0f);
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const int pix = pix4 + e;
-#pragma unroll
-              for (int ht = 0; ht < HT; ++ht) av[t][e][ht] = pix < HW ? dG[(unsigned)(pix * HD + ht * 32 + col)] : 0.0f;
-            }
-          }
-        }
-        __builtin_amdgcn_sched_barrier(0);   // all loads of the half are out before its first MFMA (the scheduler would sink them)
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-#pragma unroll
-            for (int ht = 0; ht < HT; ++ht)
-#pragma unroll
-              for (int ct = 0; ct < CT; ++ct) {
-                const float* fp = reinterpret_cast<const float*>(&fb[t][ct]);
-                accw[ht][ct] = mfma(av[t][e][ht], fp[e], accw[ht][ct]);
-              }
-          }
-      }
-    } else {
-      const float4* dG4 = reinterpret_cast<const float4*>(dG);
-      float* dF = dfeat + (long)img * C * HW;
-      const int px0 = min(p0 + col, HW - 1), px1 = min(p0 + 32 + col, HW - 1);
-      float4 v0[HD / 8], v1[HD / 8];
-#pragma unroll
-      for (int qq = 0; qq < HD / 8; ++qq) {
-        // storage float4 (ht*8 + 4h + q) holds hidden ht*32 + 8q + 4h + e, e = 0..3  (proj_storage_index)
-        const int ht = qq >> 2, q = qq & 3;
-        v0[qq] = dG4[(unsigned)(px0 * (HD / 4) + ht * 8 + 4 * h + q)];
-        v1[qq] = dG4[(unsigned)(px1 * (HD / 4) + ht * 8 + 4 * h + q)];
-      }
-      __builtin_amdgcn_sched_barrier(0);   // all 16 row loads are out before the first MFMA
-      f32x16 acc[CT][2];
-#pragma unroll
-      for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-        for (int pt = 0; pt < 2; ++pt) acc[ct][pt] = zero_acc();
-#pragma unroll
-      for (int qq = 0; qq < HD / 8; ++qq) {
-        const int ht = qq >> 2, q = qq & 3;
-        const float* b0 = reinterpret_cast<const float*>(&v0[qq]);
-        const float* b1 = reinterpret_cast<const float*>(&v1[qq]);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int hid = ht * 32 + 8 * q + 4 * h + e;
-#pragma unroll
-          for (int ct = 0; ct < CT; ++ct) {
-            const float a = wl[hid * C + ct * 32 + col];
-            acc[ct][0] = mfma(a, b0[e], acc[ct][0]);
-            acc[ct][1] = mfma(a, b1[e], acc[ct][1]);
-          }
-        }
-      }
-#pragma unroll
-      for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-        for (int pt = 0; pt < 2; ++pt) {
-          const int pix = p0 + pt * 32 + col;
-          if (pix < HW) {
-#pragma unroll
-            for (int q = 0; q < 16; ++q) dF[(unsigned)((ct * 32 + mfma_row(q, h)) * HW + pix)] = acc[ct][pt][q];
-          }
-        }
-    }
+    if (role_w) project_dw_tile<C, HD>(feat + (long)img * C * HW, dG, p0, HW, vec4, h, col, accw);
+    else project_df_tile<C, HD>(dG, dfeat + (long)img * C * HW, wl, p0, HW, h, col);
   }
-  if (d_mlp) {
-    __syncthreads();
-    float* red = wl;
-    for (int i = threadIdx.x; i < HD * C; i += blockDim.x) red[i] = 0.0f;
-    __syncthreads();
-    if (role_w) {   // accumulator rows are STORED channels: map back to hidden units
-#pragma unroll
-      for (int ht = 0; ht < HT; ++ht)
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-          for (int q = 0; q < 16; ++q) atomicAdd(&red[proj_hidden_of_storage(ht * 32 + mfma_row(q, h)) * C + ct * 32 + col], accw[ht][ct][q]);
-    }
-    __syncthreads();
+  if (d_mlp) project_dw_flush<C, HD>(wl, accw, role_w, d_mlp, h, col);
+}
+
+// ---- the same backward over a SPARSE dG: `tiles` holds one byte per tile of 64 pixels, set by bts_render_bwd's scatter pass for every
+// tile it added into (BtsRenderGrads.d_proj_tiles); everything else of dproj is zero by contract and is never read.  A training step
+// renders a few thousand 8 x 8 patches: 8-15 % of the tiles (exp_re10k.yaml / exp_kitti_360.yaml's batches), so the pass costs the
+// dense write of dF plus a tenth of the reads.  Every wave takes whole tiles: a dirty one gets both contractions (the second read of
+// its dG rows comes from L1 / L2), a clean one 16 wide zero stores.  With `clear` the wave then writes zeros over the dirty tile and
+// resets its byte -- the (dproj, tiles) pair is all zero again when the kernel ends, and the caller never fills 503 MB before a step.
+template <int C, int HD>
+__global__ __launch_bounds__(256, 2) void project_bwd_tiles_kernel(const float* __restrict__ feat, float* dproj, unsigned char* tiles, const float* __restrict__ mlp,
+                                                                float* __restrict__ dfeat, float* __restrict__ d_mlp, int HW, int tiles_per_img, int n_tiles,
+                                                                int clear) {
+  constexpr int HT = HD / 32, CT = C / 32;
+  constexpr int D_IN = C + kPeDim;
+  __shared__ float wl[HD * C];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int h = lane >> 5, col = lane & 31;
+  if (dfeat) {
     for (int i = threadIdx.x; i < HD * C; i += blockDim.x) {
       const int hid = i / C, c = i % C;
-#ifndef BTS_ABL_NOFLUSH
-      atomicAdd(&d_mlp[hid * D_IN + c], red[i]);
-#else
-      if (red[i] == 1.2345e-30f) d_mlp[hid * D_IN + c] = red[i];
-#endif
+      wl[i] = mlp[hid * D_IN + c];
     }
   }
+  __syncthreads();
+  const bool vec4 = (HW & 3) == 0;
+  f32x16 accw[HT][CT];
+#pragma unroll
+  for (int ht = 0; ht < HT; ++ht)
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) accw[ht][ct] = zero_acc();
+  const float4 z4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+
+  const int tile0 = blockIdx.x * 4 + wave, stride = gridDim.x * 4;
+  int flag_n = tile0 < n_tiles ? (int)tiles[tile0] : 0;   // a tile's flag is fetched one tile ahead
+  for (int tile = tile0; tile < n_tiles; tile += stride) {
+    const int img = tile / tiles_per_img;
+    const int p0 = (tile - img * tiles_per_img) * 64;
+    const bool dirty = __builtin_amdgcn_readfirstlane(flag_n) != 0;
+    flag_n = tile + stride < n_tiles ? (int)tiles[tile + stride] : 0;
+    if (dirty) {
+      float* dG = dproj + (long)img * HW * HD;
+      if (d_mlp) project_dw_tile<C, HD>(feat + (long)img * C * HW, dG, p0, HW, vec4, h, col, accw);
+      if (dfeat) project_df_half_tiles<C, HD>(dG, dfeat + (long)img * C * HW, wl, p0, HW, h, col);
+      if (clear) {
+        // (this wave is the only reader of the tile and its loads have returned: their values went through the MFMAs above)
+        __builtin_amdgcn_sched_barrier(0);
+        const int npx = min(64, HW - p0);
+        float4* row = reinterpret_cast<float4*>(dG + (long)p0 * HD);   // 64 pixels x HD floats, contiguous
+        for (int i = lane; i < npx * (HD / 4); i += 64) row[i] = z4;
+        if (lane == 0) tiles[tile] = 0;
+      }
+    } else if (dfeat) {
+      float* dF = dfeat + (long)img * C * HW;
+      if (vec4 && p0 + 64 <= HW) {   // 16 stores of 4 channel rows x 64 pixels
+#pragma unroll
+        for (int i = 0; i < C / 4; ++i) *reinterpret_cast<float4*>(dF + (unsigned)((4 * i + (lane >> 4)) * HW + p0 + 4 * (lane & 15))) = z4;
+      } else if (p0 + lane < HW) {
+#pragma unroll 8
+        for (int c = 0; c < C; ++c) dF[(unsigned)(c * HW + p0 + lane)] = 0.0f;
+      }
+    }
+  }
+  if (d_mlp) project_dw_flush<C, HD>(wl, accw, true, d_mlp, h, col);
 }
 
 static int prep_cus() {
@@ -274,6 +386,17 @@ static int run_bwd(const float* feat, const float* dproj, const float* mlp, int 
   return hipGetLastError() == hipSuccess ? BTS_OK : BTS_E_LAUNCH;
 }
 
+template <int C, int HD>
+static int run_bwd_tiles(const float* feat, float* dproj, unsigned char* tiles, const float* mlp, int N, int HW, float* dfeat, float* d_mlp, int clear,
+                         hipStream_t s) {
+  if (!dfeat && !d_mlp && !clear) return BTS_OK;
+  const int tpi = (HW + 63) / 64;
+  const long n_tiles = (long)N * tpi;
+  const long want = (n_tiles + 3) / 4, cap = 2L * prep_cus();
+  project_bwd_tiles_kernel<C, HD><<<(int)(want < cap ? want : cap), 256, 0, s>>>(feat, dproj, tiles, mlp, dfeat, d_mlp, HW, tpi, (int)n_tiles, clear);
+  return hipGetLastError() == hipSuccess ? BTS_OK : BTS_E_LAUNCH;
+}
+
 int project_features_impl(int C, int HD, const float* feat, const float* mlp, int N, int HW, float* proj, hipStream_t s) {
   if (C == 64 && HD == 64) return run_fwd<64, 64>(feat, mlp, N, HW, proj, s);
   if (C == 32 && HD == 32) return run_fwd<32, 32>(feat, mlp, N, HW, proj, s);
@@ -284,6 +407,13 @@ int project_features_bwd_impl(int C, int HD, const float* feat, const float* dpr
                               float* d_mlp, hipStream_t s) {
   if (C == 64 && HD == 64) return run_bwd<64, 64>(feat, dproj, mlp, N, HW, dfeat, d_mlp, s);
   if (C == 32 && HD == 32) return run_bwd<32, 32>(feat, dproj, mlp, N, HW, dfeat, d_mlp, s);
+  return BTS_E_UNSUPPORTED;
+}
+
+int project_features_bwd_tiles_impl(int C, int HD, const float* feat, float* dproj, unsigned char* tiles, const float* mlp, int N, int HW, float* dfeat,
+                                    float* d_mlp, int clear, hipStream_t s) {
+  if (C == 64 && HD == 64) return run_bwd_tiles<64, 64>(feat, dproj, tiles, mlp, N, HW, dfeat, d_mlp, clear, s);
+  if (C == 32 && HD == 32) return run_bwd_tiles<32, 32>(feat, dproj, tiles, mlp, N, HW, dfeat, d_mlp, clear, s);
   return BTS_E_UNSUPPORTED;
 }
 

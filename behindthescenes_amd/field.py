@@ -209,9 +209,11 @@ class BTSNet(nn.Module):
         if hit is None or hit[1] != version:
             f = self._latents_ms[s]                            # (n, 1, C, h, w) -> (n, C, h, w): a pure view (selecting [:, 0] would
             f = f.reshape(f.shape[0], *f.shape[2:]).float()    # cost a zero fill + a copy of the whole map in its backward)
-            proj = native.ProjectFunction.apply(f, mlp.packed(), spec)
+            link = native.ProjLink()   # lets a single render of this map hand its (sparse) gradient to the projection's backward as tiles
+            proj = native.ProjectFunction.apply(f, mlp.packed(), spec, link)
             ft = native.FieldTensors(spec, proj, self._K_enc, self._w2c_enc, self._imgs_nhwc4, self._K_r, self._w2c_r,
                                      self.empty_feature if self.learn_empty else None, feat_shift=self._shift_ms[s], enc_view=self._enc_view)
+            ft.proj_link = link
             self._native[(s, fine)] = (ft, version)
         return self._native[(s, fine)][0]
 

@@ -20,6 +20,7 @@ class _PhotometricSums(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, rgb, depth, weights, invalid, rgb_gt, ph, pw, policy, eas, invalid_wsum=None, invalid_any=None):
+        ctx.set_materialize_grads(False)
         need = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
         parts, g_rgb, g_depth = native.photometric_loss(rgb, depth if eas else None, weights, invalid, rgb_gt, ph, pw, policy, eas, 1.0, 1.0,
                                                         need_grad=need, invalid_wsum=invalid_wsum, invalid_any=invalid_any)
@@ -30,6 +31,8 @@ class _PhotometricSums(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         g_rgb, g_depth = ctx.saved_tensors
+        if g is None:
+            return (None,) * 11
         d_rgb = g_rgb * g[0] if (g_rgb is not None and ctx.needs_input_grad[0]) else None
         d_depth = g_depth * g[1] if (g_depth is not None and ctx.needs_input_grad[1]) else None
         return d_rgb, d_depth, None, None, None, None, None, None, None, None, None
@@ -104,6 +107,7 @@ class ReconstructionLoss:
         self.alpha_reg_fraction = config.get("alpha_reg_fraction", 1 / 8)
         if self.alpha_reg_reduction not in ("ray", "slice"):
             raise ValueError(f"Unknown reduction for alpha regularization: {self.alpha_reg_reduction}")
+        self._lin = {}    # (scales, rays per scale, fine present, device) -> the (9 x 3 S) matrix of _call_photometric_only
         if self.criterion_str != "l1+ssim" or use_automasking or self.median_thresholding or self.invalid_policy == "weight_guided_diverse":
             raise NotImplementedError("the fused HIP loss covers criterion 'l1+ssim' with invalid_policy strict / weight_guided / none, "
                                       "without automasking / median thresholding (every shipped config); got "
@@ -114,8 +118,9 @@ class ReconstructionLoss:
     def get_loss_metric_names():
         return ["loss", "loss_rgb_coarse", "loss_rgb_fine", "loss_ray_entropy", "loss_depth_reg"]
 
-    def _photometric(self, level, level0, rgb_gt, eas):
-        """-> (mean rgb term, mean smoothness term, invalid-ray ratio) of one set of renderer outputs in patch layout."""
+    def _sums(self, level, level0, rgb_gt, eas):
+        """-> ((sum of the rgb term, sum of the smoothness term, number of invalid rays) as one (3,) tensor, number of rays) of one set
+        of renderer outputs in patch layout."""
         rgb = level["rgb"]                                   # (n, pc, h, w, nv, 3)
         n, pc, h, w, nv, c = rgb.shape
         if c != 3:
@@ -126,19 +131,65 @@ class ReconstructionLoss:
                                           _flat(rgb_gt, (3,)).detach(), h, w, self.invalid_policy, eas,
                                           _flat(level0["invalid_wsum"], (nv,)).detach() if self.invalid_policy == "weight_guided" else None,
                                           _flat(level0["invalid_any"], (nv,)).detach() if self.invalid_policy == "strict" else None)
-            return sums[0] / B, sums[1] / B, sums[2] / B
+            return sums, B
         K = level0["weights"].shape[-1]
         sums = _PhotometricSums.apply(_flat(rgb, (nv * 3,)), _flat(level["depth"], ()) if eas else None,
                                       _flat(level0["weights"], (K,)).detach() if self.invalid_policy == "weight_guided" else None,
                                       _flat(level0["invalid"], (K, nv)).detach() if self.ignore_invalid else None,
                                       _flat(rgb_gt, (3,)).detach(), h, w, self.invalid_policy, eas)
+        return sums, B
+
+    def _photometric(self, level, level0, rgb_gt, eas):
+        """-> (mean rgb term, mean smoothness term, invalid-ray ratio)"""
+        sums, B = self._sums(level, level0, rgb_gt, eas)
         return sums[0] / B, sums[1] / B, sums[2] / B
+
+    _KEYS = ["loss_rgb_coarse", "loss_rgb_fine", "loss_ray_entropy", "loss_depth_reg", "loss_alpha_reg", "loss_eas",
+             "loss_depth_smoothness", "loss_invalid_ratio", "loss"]
+
+    def _call_photometric_only(self, data):
+        """The shipped configs' loss -- photometric term (coarse + the fine dict trainer.py:247-248 aliases to it) and edge-aware
+        smoothness, no optional regulariser -- is LINEAR in the per-scale sums the HIP pass returns: loss and the whole logging dict are
+        one (9 x 3 S) matrix applied to them.  The general path below spells the same algebra with ~25 zero-dimensional torch ops per
+        scale (each a kernel launch, plus their autograd nodes and the zero fills of SelectBackward): ~190 launches and 0.5 ms of a
+        3.7 ms exp_re10k.yaml step.  Returns None when the data needs the general path."""
+        coarse_0, fine_0 = data["coarse"][0], data["fine"][0]
+        S = len(data["coarse"])
+        mask_keys = ("weights", "invalid") if "weights" in coarse_0 else ("invalid_wsum", "invalid_any")
+        has_fine = []
+        for coarse, fine in zip(data["coarse"], data["fine"]):
+            if len(fine) > 0 and not (_same_view(fine["rgb"], coarse["rgb"]) and all(_same_view(fine_0[k], coarse_0[k]) for k in mask_keys)):
+                return None
+            has_fine.append(len(fine) > 0)
+        eas_on = self.lambda_edge_aware_smoothness > 0
+        sums, Bs = zip(*(self._sums(c, coarse_0, data["rgb_gt"], eas_on) for c in data["coarse"]))
+        st = torch.stack(sums).reshape(-1)                      # (3 S): rgb, eas, invalid count per scale
+        key = (S, Bs, tuple(has_fine), st.device)
+        M = self._lin.get(key)
+        if M is None:
+            M = torch.zeros(9, 3 * S, dtype=torch.float64)
+            for s in range(S):
+                lam = self.lambda_coarse + self.lambda_fine if has_fine[s] else 1.0    # (without a fine dict the rgb term enters unscaled)
+                M[0, 3 * s] = self.lambda_coarse / Bs[s]
+                M[1, 3 * s] = (self.lambda_fine if has_fine[s] else 0) / Bs[s]
+                M[5, 3 * s + 1] = 1.0 / Bs[s]
+                M[8, 3 * s] = lam / Bs[s] / S
+                M[8, 3 * s + 1] = (self.lambda_edge_aware_smoothness / 2 ** s if eas_on else 0) / Bs[s] / S
+            M[7, 2] = 1.0 / Bs[0]
+            M = self._lin[key] = M.float().to(st.device)
+        loss = torch.dot(M[8], st)
+        return loss, LazyScalars(self._KEYS, torch.mv(M, st.detach()))
 
     def __call__(self, data):
         with profiler.record_function("loss_computation"):       # loss.py:84
             return self._call(data)
 
     def _call(self, data):
+        if not (self.lambda_depth_reg > 0 or self.lambda_alpha_reg > 0 or self.lambda_surfaceness_reg > 0 or self.lambda_depth_smoothness > 0
+                or self.lambda_entropy > 0):
+            res = self._call_photometric_only(data)
+            if res is not None:
+                return res
         n_scales = len(data["coarse"])
         coarse_0, fine_0 = data["coarse"][0], data["fine"][0]
         dev = coarse_0["rgb"].device
@@ -238,6 +289,4 @@ class ReconstructionLoss:
         # stalls the step: the copy is asynchronous, the host waits for it when somebody READS an entry (LazyScalars)
         vals = torch.stack([m["coarse"], m["fine"], ent.detach(), m["depth_reg"], m["alpha_reg"], m["eas"], m["dsmooth"], m["inv"],
                             loss.detach()])
-        keys = ["loss_rgb_coarse", "loss_rgb_fine", "loss_ray_entropy", "loss_depth_reg", "loss_alpha_reg", "loss_eas",
-                "loss_depth_smoothness", "loss_invalid_ratio", "loss"]
-        return loss, LazyScalars(keys, vals)
+        return loss, LazyScalars(self._KEYS, vals)

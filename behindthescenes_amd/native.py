@@ -243,16 +243,31 @@ def project_features(spec: FieldSpec, feat_nchw: torch.Tensor, mlp_params: torch
     return out
 
 
-def project_features_bwd(spec: FieldSpec, feat_nchw, d_proj, mlp_params, need_feat=True, need_mlp=True):
-    """-> (d_feat_nchw | None, d_mlp_params | None) (bts_project_features_bwd)."""
+def project_features_bwd(spec: FieldSpec, feat_nchw, d_proj, mlp_params, need_feat=True, need_mlp=True, tiles=None, clear_after=False):
+    """-> (d_feat_nchw | None, d_mlp_params | None) (bts_project_features_bwd).  With ``tiles`` (N, proj_tile_count) uint8 -- the flags
+    ``render_bwd`` set next to a d_proj that was all zero before -- only the flagged 64-texel tiles of d_proj are read
+    (bts_project_features_bwd_tiles); ``clear_after`` returns the pair to all zero."""
     N, Cc, H, W = feat_nchw.shape
     _req(feat_nchw, "feat_nchw"), _req(d_proj, "d_proj", (N, H, W, spec.d_hidden)), _req(mlp_params, "mlp_params")
     d_feat = torch.empty_like(feat_nchw) if need_feat else None
     d_mlp = torch.zeros_like(mlp_params) if need_mlp else None
     cfg = _spec_cfg(spec, N, H, W)
-    _lib.check(_lib.load().bts_project_features_bwd(C.byref(cfg), _ptr(feat_nchw), _ptr(d_proj), _ptr(mlp_params), N, _ptr(d_feat),
-                                                    _ptr(d_mlp), _stream(d_proj)), "bts_project_features_bwd")
+    lib = _lib.load()
+    if tiles is not None:
+        if tiles.dtype != torch.uint8 or not tiles.is_contiguous() or tiles.numel() != N * proj_tile_count(spec, H, W) or tiles.device != d_proj.device:
+            raise ValueError("tiles: expected a contiguous uint8 tensor of (N, proj_tile_count) on d_proj's device")
+        _lib.check(lib.bts_project_features_bwd_tiles(C.byref(cfg), _ptr(feat_nchw), _ptr(d_proj), _ptr(tiles), _ptr(mlp_params), N, _ptr(d_feat),
+                                                      _ptr(d_mlp), 1 if clear_after else 0, _stream(d_proj)), "bts_project_features_bwd_tiles")
+    else:
+        _lib.check(lib.bts_project_features_bwd(C.byref(cfg), _ptr(feat_nchw), _ptr(d_proj), _ptr(mlp_params), N, _ptr(d_feat),
+                                                _ptr(d_mlp), _stream(d_proj)), "bts_project_features_bwd")
     return d_feat, d_mlp
+
+
+def proj_tile_count(spec: FieldSpec, H: int, W: int) -> int:
+    """Tiles (64 consecutive texels) per image of an (H, W) projected map (bts_proj_tile_count)."""
+    cfg = _spec_cfg(spec, 1, H, W)
+    return int(_lib.load().bts_proj_tile_count(C.byref(cfg)))
 
 
 class FieldTensors:
@@ -288,6 +303,7 @@ class FieldTensors:
         self.proj_nhwc, self.feat_nhwc, self.K_enc, self.w2c_enc = proj_nhwc, feat_nhwc, K_enc, w2c_enc
         self.imgs_nhwc4, self.K_r, self.w2c_r = imgs_nhwc4, K_r, w2c_r
         self.empty_feature = empty_feature
+        self.proj_link = None   # ProjLink when proj_nhwc came out of ProjectFunction (field.py): see SPARSE_PROJ_GRAD
 
     def cfg(self, nv=None) -> BtsFieldCfg:
         return _spec_cfg(self.spec, self.n, self.H, self.W, self.nv if nv is None else nv, self.feat_shift, self.enc_view)
@@ -368,15 +384,22 @@ def render_fwd(ft: FieldTensors, mlp_params: torch.Tensor, rays: torch.Tensor, z
 
 def render_bwd(ft: FieldTensors, mlp_params, rays, z_samp, sigma_raw, trans, *, hard_alpha_cap, g_rgb=None, g_depth=None,
                g_weights=None, g_alphas=None, need_proj=True, need_mlp=True, need_empty=False, white_bkgd=False, rgb_samps=None,
-               sigma_noise=None):
-    """Returns (d_proj_nhwc | None, d_mlp_params | None, d_empty_proj | None) (bts_render_bwd)."""
+               sigma_noise=None, proj_grad=None):
+    """Returns (d_proj_nhwc | None, d_mlp_params | None, d_empty_proj | None) (bts_render_bwd).  ``proj_grad`` = (d_proj, tiles): add
+    into THIS d_proj (the caller vouches that it is zero wherever ``tiles`` is) and flag the 64-texel tiles that received something
+    (BtsRenderGrads.d_proj_tiles) -- no fill of a map-sized tensor."""
     B, K = z_samp.shape
     for name, g in (("g_rgb", g_rgb), ("g_depth", g_depth), ("g_weights", g_weights), ("g_alphas", g_alphas)):
         if g is not None:
             _req(g, name)
     _req(sigma_raw, "sigma_raw", (B, K)), _req(trans, "trans", (B, K))
     dev = rays.device
-    d_proj = torch.zeros(ft.proj_nhwc.shape, device=dev, dtype=torch.float32) if need_proj else None
+    tiles = None
+    if need_proj and proj_grad is not None:
+        d_proj, tiles = proj_grad
+        _req(d_proj, "proj_grad[0]", tuple(ft.proj_nhwc.shape))
+    else:
+        d_proj = torch.zeros(ft.proj_nhwc.shape, device=dev, dtype=torch.float32) if need_proj else None
     d_mlp = torch.zeros(ft.spec.mlp_param_count(), device=dev, dtype=torch.float32) if need_mlp else None
     d_empty = torch.zeros(ft.spec.d_hidden, device=dev, dtype=torch.float32) if need_empty else None
     cfg, tens = ft.cfg(), ft.tensors(mlp_params)
@@ -387,7 +410,7 @@ def render_bwd(ft: FieldTensors, mlp_params, rays, z_samp, sigma_raw, trans, *, 
     def dp(t):
         return None if t is None else t.data_ptr()
     grads = BtsRenderGrads(g_rgb=dp(g_rgb), g_depth=dp(g_depth), g_weights=dp(g_weights), g_alphas=dp(g_alphas),
-                           d_proj_nhwc=dp(d_proj), d_mlp_params=dp(d_mlp), d_empty_proj=dp(d_empty))
+                           d_proj_nhwc=dp(d_proj), d_mlp_params=dp(d_mlp), d_empty_proj=dp(d_empty), d_proj_tiles=dp(tiles))
     lib = _lib.load()
     ws_bytes = lib.bts_render_bwd_workspace(C.byref(cfg), C.byref(args))
     ws = _workspace(dev, int(ws_bytes))
@@ -457,22 +480,78 @@ def occupancy_profile(ft: FieldTensors, mlp_params: torch.Tensor, xyz: torch.Ten
 # --------------------------------------------------------------------------------------------------------------
 # autograd glue
 # --------------------------------------------------------------------------------------------------------------
+# The gradient of a projected map G is SPARSE in a training step: the rays of a few thousand 8 x 8 patches reach 8-15 % of its texels,
+# yet as a dense autograd tensor it costs a map-sized zero fill, and a full read in the projection's backward (at exp_kitti_360.yaml's
+# batch 503 MB each -- as much as everything else the backward moves).  When exactly ONE render reads a map that ProjectFunction made,
+# RenderFunction.backward therefore adds into a kept (d_proj, tile flags) pair that is all zero between steps, and
+# ProjectFunction.backward reads the flagged tiles only and returns the pair to zero (bts_project_features_bwd_tiles).  Every other
+# constellation -- several renders of one map, a hook or retain_grad on G, somebody touching the gradient on its way -- takes the dense
+# path; the results are the same either way (tests/test_gpu_sparse_grad.py).
+SPARSE_PROJ_GRAD = True
+
+
+class ProjLink:
+    """Ties a map made by ProjectFunction to the RenderFunction calls that read it (FieldTensors.proj_link)."""
+    __slots__ = ("renders", "entry")
+
+    def __init__(self):
+        self.renders, self.entry = 0, None
+
+
+class _SparseGrad:
+    __slots__ = ("buf", "tiles", "busy", "version")
+
+
+_SPARSE = {}
+
+
+def _sparse_grad(ft: "FieldTensors"):
+    g = ft.proj_nhwc
+    key = (g.device, tuple(g.shape), torch.cuda.current_stream(g.device).cuda_stream)
+    e = _SPARSE.get(key)
+    if e is None:
+        e = _SparseGrad()
+        e.buf = torch.zeros(g.shape, device=g.device, dtype=torch.float32)
+        e.tiles = torch.zeros((g.shape[0], proj_tile_count(ft.spec, g.shape[1], g.shape[2])), device=g.device, dtype=torch.uint8)
+        e.busy = False
+        _SPARSE[key] = e
+    return e
+
+
+def release_sparse_grads():
+    """Drops the kept (d_proj, tile flags) pairs (one map-sized buffer per map shape, device and stream)."""
+    _SPARSE.clear()
+
+
 class ProjectFunction(torch.autograd.Function):
-    """(F nchw, packed mlp params) -> G nhwc.  Backward: per-pixel GEMMs in bts_project_features_bwd."""
+    """(F nchw, packed mlp params) -> G nhwc.  Backward: per-pixel GEMMs in bts_project_features_bwd (_tiles)."""
 
     @staticmethod
-    def forward(ctx, feat_nchw, mlp_params, spec):
+    def forward(ctx, feat_nchw, mlp_params, spec, link=None):
         feat_nchw = feat_nchw.contiguous()
-        ctx.spec = spec
+        ctx.set_materialize_grads(False)
+        ctx.spec, ctx.link = spec, link
         ctx.save_for_backward(feat_nchw, mlp_params)
         return project_features(spec, feat_nchw, mlp_params.contiguous())
 
     @staticmethod
     def backward(ctx, g):
+        if g is None:
+            return None, None, None, None
         feat_nchw, mlp_params = ctx.saved_tensors
-        d_feat, d_mlp = project_features_bwd(ctx.spec, feat_nchw, g.contiguous(), mlp_params, ctx.needs_input_grad[0],
-                                             ctx.needs_input_grad[1])
-        return d_feat, d_mlp, None
+        need = ctx.needs_input_grad[:2]
+        entry = ctx.link.entry if ctx.link is not None else None
+        if entry is not None:
+            ctx.link.entry = None
+            if g.data_ptr() == entry.buf.data_ptr() and entry.buf._version == entry.version and g.shape == entry.buf.shape:
+                d_feat, d_mlp = project_features_bwd(ctx.spec, feat_nchw, entry.buf, mlp_params, *need, tiles=entry.tiles, clear_after=True)
+                entry.busy = False
+                return d_feat, d_mlp, None, None
+        d_feat, d_mlp = project_features_bwd(ctx.spec, feat_nchw, g.contiguous(), mlp_params, *need)
+        if entry is not None:   # the kept pair was replaced or modified on its way here: dense on what arrived, and the pair starts over
+            entry.buf.zero_(), entry.tiles.zero_()
+            entry.busy = False
+        return d_feat, d_mlp, None, None
 
 
 class RenderFunction(torch.autograd.Function):
@@ -486,6 +565,9 @@ class RenderFunction(torch.autograd.Function):
                 jitter=None, lindisp=True, want_z=False):
         # needs_input_grad reflects requires_grad even under torch.no_grad(), and inside forward() grad mode is always off: the
         # caller passes the mode it was invoked in, so that evaluation does not allocate / write the 8 B per sample of saved state
+        # (outputs nobody differentiates through arrive as None in backward, not as zero-filled tensors of their size: in a lean training
+        # step that was four fills per render -- rgb_samps, z_samp, the two per-ray reductions)
+        ctx.set_materialize_grads(False)
         needs_grad = any(ctx.needs_input_grad[:3]) and grad_mode
         # z_samp None: sample_coarse inside the kernel from `jitter`; the depths are materialised only for the backward / on request
         out = render_fwd(ft, mlp_params, rays, z_samp, hard_alpha_cap=hard_alpha_cap, white_bkgd=white_bkgd,
@@ -493,6 +575,9 @@ class RenderFunction(torch.autograd.Function):
                          want_saved=needs_grad, want_invalid_sums=want_invalid_sums, sigma_noise=sigma_noise, jitter=jitter, lindisp=lindisp,
                          want_z=want_z or needs_grad)
         ctx.ft, ctx.hard_alpha_cap, ctx.white_bkgd = ft, hard_alpha_cap, white_bkgd
+        ctx.link = getattr(ft, "proj_link", None) if (needs_grad and ctx.needs_input_grad[0]) else None
+        if ctx.link is not None:
+            ctx.link.renders += 1
         ctx.sigma_noise = sigma_noise if needs_grad else None      # (a plain tensor without graph: kept on the context)
         if needs_grad:
             # rgb_samps is non-differentiable output the caller asked for: kept for the backward too (it then skips the colour taps)
@@ -516,10 +601,17 @@ class RenderFunction(torch.autograd.Function):
 
         ft = ctx.ft
         need_proj, need_mlp, need_empty = ctx.needs_input_grad[:3]
+        pg, link, G = None, ctx.link, ft.proj_nhwc
+        if (need_proj and SPARSE_PROJ_GRAD and link is not None and link.renders == 1 and link.entry is None and not G.retains_grad
+                and not G._backward_hooks):
+            entry = _sparse_grad(ft)
+            if not entry.busy:
+                entry.busy, entry.version, link.entry = True, entry.buf._version, entry
+                pg = (entry.buf, entry.tiles)
         d_proj, d_mlp, d_eproj = render_bwd(ft, mlp_params, rays, z_samp, sigma_raw, trans, hard_alpha_cap=ctx.hard_alpha_cap,
                                             g_rgb=prep(g_rgb), g_depth=prep(g_depth), g_weights=prep(g_weights, ctx.has[0]), white_bkgd=ctx.white_bkgd, rgb_samps=rgb_samps,
                                             g_alphas=prep(g_alphas, ctx.has[1]), need_proj=need_proj, need_mlp=need_mlp,
-                                            need_empty=need_empty or (need_mlp and ft.spec.learn_empty), sigma_noise=ctx.sigma_noise)
+                                            need_empty=need_empty or (need_mlp and ft.spec.learn_empty), sigma_noise=ctx.sigma_noise, proj_grad=pg)
         d_empty = None
         if d_eproj is not None:
             # the projected empty feature is w_in[:, :C] @ empty_feature (a 64x64 GEMV): chain rule on parameter-sized tensors

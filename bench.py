@@ -53,6 +53,12 @@ def parse():
                     help="training workloads: feature_map (default) = learnable stand-in for the CNN output (the renderer's share of the step); "
                          "monodepth2 = the shipped Monodepth2 (ResNet of the yaml, random weights): whole step incl. the CNN")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dense-proj-grad", action="store_true",
+                    help="training workloads, A/B: the gradient of the projected map as a dense autograd tensor (zero fill + full read) instead of "
+                         "the kept (d_proj, tile flags) pair (native.SPARSE_PROJ_GRAD)")
+    ap.add_argument("--tile-stats", action="store_true",
+                    help="training workloads, diagnostic: how much of the projected map's gradient a step touches (texels, 16-texel segments, "
+                         "64-texel tiles, 8 x 8 blocks); prints to stderr and exits")
     ap.add_argument("--no-others", action="store_true",
                     help="eval workload: skip the `others` sub-records (every other BASELINE config + the occupancy profile, 10 steps each) and, "
                          "under torch.distributed.run, the `ddp_train` sub-record (KITTI-Raw shapes with the Monodepth2 encoder: the real gradient bucket)")
@@ -293,16 +299,52 @@ def train_workload(args, world, rank, dev):
         net.zero_grad(set_to_none=True)
         model(images, projs, poses).backward()
 
+    native.SPARSE_PROJ_GRAD = not args.dense_proj_grad
     for _ in range(args.warmup):
         step()
+    if args.tile_stats:
+        orig_pb = native.project_features_bwd
+
+        def spy(spec, feat, d_proj, mlp_params, *a, tiles=None, **kw):
+            on = (d_proj != 0).any(dim=-1)                                  # (N, H, W)
+            N, Hm, Wm = on.shape
+            flat = on.reshape(N, -1)
+            pad = (-flat.shape[1]) % 64
+            flat = torch.nn.functional.pad(flat, (0, pad))
+            blk = on[:, :Hm // 8 * 8, :Wm // 8 * 8].reshape(N, Hm // 8, 8, Wm // 8, 8)
+            print(f"map {tuple(d_proj.shape)}: texels {on.float().mean().item():.3f}  16-texel segments "
+                  f"{flat.reshape(N, -1, 16).any(-1).float().mean().item():.3f}  64-texel tiles {flat.reshape(N, -1, 64).any(-1).float().mean().item():.3f}"
+                  f"  flagged {'-' if tiles is None else round(tiles.float().mean().item(), 3)}  8x8 blocks {blk.any(4).any(2).float().mean().item():.3f}"
+                  f"  16x4 blocks {on[:, :Hm // 4 * 4, :Wm // 16 * 16].reshape(N, Hm // 4, 4, Wm // 16, 16).any(4).any(2).float().mean().item():.3f}",
+                  file=sys.stderr)
+            return orig_pb(spec, feat, d_proj, mlp_params, *a, tiles=tiles, **kw)
+        native.project_features_bwd = spy
+        step()
+        torch.cuda.synchronize()
+        native.project_features_bwd = orig_pb
+        return
     if args.ops_profile:      # diagnostic: what the host issues around the HIP kernels (launch-bound steps)
         from torch.profiler import profile, ProfilerActivity
         torch.cuda.synchronize()
-        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=True) as prof:
             for _ in range(3):
                 step()
             torch.cuda.synchronize()
         print(prof.key_averages().table(sort_by="self_cpu_time_total", row_limit=45, max_name_column_width=60), file=sys.stderr)
+        # who issues the small torch kernels: ops that launch something, grouped by the innermost frames of this repository
+        by = {}
+        for e in prof.events():
+            if e.device_time_total <= 0 or not e.name.startswith("aten::") or e.cpu_parent is not None and e.cpu_parent.name.startswith("aten::"):
+                continue
+            frames = [f for f in (e.stack or []) if ROOT in f][:2] or ["(no python frame)"]
+            parent = e.cpu_parent.name if e.cpu_parent is not None else "-"
+            k = (e.name, f"shapes {e.input_shapes}  under {parent}  " + " <- ".join(f.replace(ROOT + "/", "") for f in frames))
+            c = by.setdefault(k, [0, 0.0])
+            c[0] += 1
+            c[1] += e.device_time_total
+        print("\nop, calls per step, device us per step, issued from", file=sys.stderr)
+        for (name, where), (cnt, us) in sorted(by.items(), key=lambda kv: -kv[1][1]):
+            print(f"{name:28s} {cnt / 3:6.1f} {us / 3:9.1f}  {where}", file=sys.stderr)
         return
     native.render_fwd, native.render_bwd = timed(orig_fwd, "fwd"), timed(orig_bwd, "bwd")
     torch.cuda.synchronize()

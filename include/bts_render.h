@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define BTS_ABI_VERSION 5
+#define BTS_ABI_VERSION 6
 
 enum {
   BTS_OK = 0,
@@ -132,6 +132,10 @@ typedef struct BtsRenderGrads {
   float* d_proj_nhwc;      /* (n, H, W, Hd) gradient w.r.t. proj_nhwc, ACCUMULATED into (caller zero-fills), or NULL to skip */
   float* d_mlp_params;     /* packed like mlp_params, ACCUMULATED into (caller zero-fills), or NULL to skip */
   float* d_empty_proj;     /* (Hd) gradient w.r.t. the PROJECTED empty feature (w_in[:, :C] . empty_feature), accumulated, or NULL */
+  /* ABI 6: which parts of d_proj_nhwc received anything.  (n, bts_proj_tile_count(cfg)) bytes, one per tile of 64 consecutive texels
+   * of an image's (flattened, row-major) map: the backward SETS the byte of every tile it adds into (it never clears one), or NULL.
+   * A training step's rays touch 8-15 % of the tiles; bts_project_features_bwd_tiles reads only those. */
+  uint8_t* d_proj_tiles;
 } BtsRenderGrads;
 
 int bts_abi_version(void);
@@ -167,6 +171,17 @@ int bts_project_features(const BtsFieldCfg* cfg, const float* feat_nchw, const f
  * gradient the render backward accumulated for the projected empty feature; d_empty_feature (C) += w_in[:, :C]^T d_empty_proj. */
 int bts_project_features_bwd(const BtsFieldCfg* cfg, const float* feat_nchw, const float* d_proj_nhwc, const float* mlp_params,
                              int32_t N, float* d_feat_nchw, float* d_mlp_params, void* stream);
+
+/* ABI 6: the same backward over a SPARSE d_proj.  `tiles` (N, bts_proj_tile_count(cfg)) is the flag array bts_render_bwd filled
+ * (BtsRenderGrads.d_proj_tiles): only flagged tiles of d_proj_nhwc are read, every other texel is taken as zero (it must BE zero if
+ * clear_after is set, see below).  d_feat_nchw is written densely (zeros where nothing arrived), d_mlp_params accumulated.  With
+ * clear_after != 0 the call also writes zeros over the flagged tiles of d_proj_nhwc and resets their flags: a caller that keeps one
+ * (d_proj, tiles) pair per map shape zero-fills it once and never again (the fill of a training step's d_proj is as large as the
+ * gradient's whole HBM traffic otherwise: 503 MB at exp_kitti_360.yaml's batch). */
+int64_t bts_proj_tile_count(const BtsFieldCfg* cfg);
+int bts_project_features_bwd_tiles(const BtsFieldCfg* cfg, const float* feat_nchw, float* d_proj_nhwc, uint8_t* tiles,
+                                   const float* mlp_params, int32_t N, float* d_feat_nchw, float* d_mlp_params, int32_t clear_after,
+                                   void* stream);
 
 /* BTSNet.forward on raw points (models_bts.py:266-338): xyz (n, P, 3) -> rgb (n, P, nv*3), invalid (n, P, max(nv,1)),
  * sigma (n, P).  only_density != 0 skips the colour taps: rgb may be NULL and invalid is (n, P, 1). */

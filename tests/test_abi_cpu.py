@@ -38,7 +38,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
         assert hasattr(lib, n), f"{n} declared in include/bts_render.h but not exported"
         assert n in _lib.SYMBOLS, f"{n} has no ctypes signature in _lib.SYMBOLS"
     assert set(_lib.SYMBOLS) == set(names)
-    assert lib.bts_abi_version() == _lib.ABI_VERSION == 5
+    assert lib.bts_abi_version() == _lib.ABI_VERSION == 6
 
 
 def test_ctypes_structs_match_the_c_layout():
@@ -55,6 +55,7 @@ int main(void) {
   printf("%zu %zu\n", offsetof(BtsRenderArgs, sigma_noise), offsetof(BtsFieldCfg, feat_shift));
   printf("%zu %zu %zu %zu\n", offsetof(BtsFieldCfg, enc_render_view), offsetof(BtsRenderArgs, jitter), offsetof(BtsRenderArgs, z_samp_out),
          offsetof(BtsRenderArgs, lindisp));
+  printf("%zu\n", offsetof(BtsRenderGrads, d_proj_tiles));
   return 0;
 }'''
     with tempfile.TemporaryDirectory() as d:
@@ -73,8 +74,10 @@ int main(void) {
     # ABI 3: the density noise; ABI 4: the feature map at its own scale -- both appended
     assert [int(x) for x in out[11:13]] == [_lib.BtsRenderArgs.sigma_noise.offset, _lib.BtsFieldCfg.feat_shift.offset]
     # ABI 5: the encoder-view hint and the in-kernel sample_coarse -- appended
-    assert [int(x) for x in out[13:]] == [_lib.BtsFieldCfg.enc_render_view.offset, _lib.BtsRenderArgs.jitter.offset,
-                                          _lib.BtsRenderArgs.z_samp_out.offset, _lib.BtsRenderArgs.lindisp.offset]
+    assert [int(x) for x in out[13:17]] == [_lib.BtsFieldCfg.enc_render_view.offset, _lib.BtsRenderArgs.jitter.offset,
+                                            _lib.BtsRenderArgs.z_samp_out.offset, _lib.BtsRenderArgs.lindisp.offset]
+    # ABI 6: the tile flags of the sparse map gradient -- appended
+    assert [int(x) for x in out[17:]] == [_lib.BtsRenderGrads.d_proj_tiles.offset]
 
 
 def test_host_only_entry_points(lib):
@@ -134,6 +137,12 @@ def test_errors_are_codes_with_messages_never_exceptions(lib):
     hint.enc_render_view = 1
     args = _lib.BtsRenderArgs(rays_per_sample=8, K=4, rays=1, rgb=1, depth=1)       # neither z_samp nor jitter
     assert lib.bts_render_fwd(C.byref(hint), C.byref(tens), C.byref(args), None) == -1 and b"jitter" in lib.bts_last_error()
+    # ABI 6: tiles of 64 texels of the map in memory; the tile backward wants its flag array
+    assert lib.bts_proj_tile_count(C.byref(native._spec_cfg(native.FieldSpec(C=64, d_hidden=64, n_blocks=0), n=1, H=192, W=640))) == 1920
+    assert lib.bts_proj_tile_count(C.byref(ok_size)) == (8 * 24 + 63) // 64 and lib.bts_proj_tile_count(C.byref(bad)) == (4 * 12 + 63) // 64
+    assert lib.bts_proj_tile_count(None) == 0
+    assert lib.bts_project_features_bwd_tiles(C.byref(ok_size), 16, 16, None, 16, 1, 16, 16, 1, None) == -1 and b"NULL" in lib.bts_last_error()
+    assert lib.bts_project_features_bwd_tiles(C.byref(cfg), 16, 16, 16, 16, 1, 16, 16, 1, None) == -2 and b"envelope" in lib.bts_last_error()
     with pytest.raises(bts.BtsNativeError):
         native.nchw_to_nhwc(torch.zeros(1, 4, 2, 2))                                # CPU tensor: no CPU path
     with pytest.raises(bts.BtsNativeError):

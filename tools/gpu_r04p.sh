@@ -1,0 +1,18 @@
+cd $GRAFT_REPO_ROOT
+O=gpurun_out/r04p
+mkdir -p $O
+timeout 900 python -m pytest tests/test_gpu_grad.py tests/test_gpu_scales.py tests/test_gpu_train_step.py tests/test_gpu_sparse_grad.py tests/test_gpu_loss.py tests/test_gpu_abi5.py -q --timeout 600 --tb=short -rf 2>&1 | tail -12 > $O/pytest.txt; tail -12 $O/pytest.txt
+for w in train kitti_raw re10k; do timeout 300 python bench.py --workload $w --steps 20 --warmup 3 --no-cpu-baseline 2>/dev/null | python -c "
+import json,sys; j=json.loads([l for l in sys.stdin if l.startswith('{')][0]); print('$w', round(j['ms_per_step'],3), round(j['roofline']['fwd_ms'],3), round(j['roofline']['bwd_ms'],3))" | tee -a $O/bench.txt; done
+timeout 300 python bench.py --workload re10k --samples 128 --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | python -c "
+import json,sys; j=json.loads([l for l in sys.stdin if l.startswith('{')][0]); print('re10k_k128', round(j['ms_per_step'],3), round(j['roofline']['fwd_ms'],3), round(j['roofline']['bwd_ms'],3))" | tee -a $O/bench.txt
+export TMPDIR=/tmp
+(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/trace_re10k -o trace -- python $GRAFT_REPO_ROOT/bench.py --workload re10k --steps 5 --warmup 2 --no-cpu-baseline > $GRAFT_REPO_ROOT/$O/trace_re10k.log 2>&1)
+python - <<PY
+import csv,glob
+for f in glob.glob("$O/trace_re10k/**/*kernel_stats.csv", recursive=True):
+    rows=list(csv.DictReader(open(f)))
+    for row in rows[:14]: print("re10k", f"{float(row['AverageNs'])/1e6:9.4f} ms x {row['Calls']:>4s} {row['Percentage']:>6s}%  {row['Name'][:90]}")
+PY
+for w in re10k kitti_raw; do python bench.py --workload $w --ops-profile --no-cpu-baseline 2> $O/ops_$w.txt >/dev/null; done
+find $O -type f ! -name "*stats.csv" ! -name "*.log" ! -name "*.txt" ! -name "*.json" ! -name "*.err" -delete
