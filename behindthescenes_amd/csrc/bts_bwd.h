@@ -30,6 +30,38 @@ struct BwdParams {
 constexpr int kFlushSlots = 8;
 constexpr int kFlushRows = kPeDim + 1;   // 40 encoding inputs incl. the bias row
 
+// A ray's wave-uniform inputs of the backward -- origin, direction (8 floats of `rays`), its upstream colour gradient (nv * 3 floats)
+// and depth gradient -- fetched ONE ITERATION AHEAD as one vector load: lane i < 8 holds float i of the ray, lanes 8 .. 8 + 3 NVMAX - 1 the
+// colour gradient (index clamped to the nv * 3 that exist), lane 48 the depth gradient.  As scalar loads at the top of the iteration they
+// were a full memory round trip with the wave idle (7 % of rowsb_kernel's iteration, profiles/r03v section 10); issued early as scalar
+// loads they would turn every LDS wait behind them into lgkmcnt(0).  The iteration's head moves the lanes into SGPRs (v_readlane).
+template <class Q>
+__device__ __forceinline__ float fetch_ray_record(Q q, long ray, int nv3, int lane) {
+  const float* a = q->f.rays + ray * 8 + (lane & 7);
+  const float* b = q->g_rgb ? q->g_rgb + ray * nv3 + min(max(lane - 8, 0), max(nv3 - 1, 0)) : a;
+  const float* c = q->g_depth ? q->g_depth + ray : a;
+  return *(lane < 8 ? a : (lane < 48 ? b : c));
+}
+template <int NV3>
+struct RayIn {
+  float o[3], d[3], g_rgb[NV3], g_bkgd, g_depth;
+};
+template <int NV3, class Q>
+__device__ __forceinline__ RayIn<NV3> unpack_ray_record(Q q, float rec, int nv3) {
+  RayIn<NV3> r;
+  r.o[0] = lane_value(rec, 0), r.o[1] = lane_value(rec, 1), r.o[2] = lane_value(rec, 2);
+  r.d[0] = lane_value(rec, 3), r.d[1] = lane_value(rec, 4), r.d[2] = lane_value(rec, 5);
+  const bool has = q->g_rgb != nullptr;
+  r.g_bkgd = 0.0f;
+#pragma unroll
+  for (int i = 0; i < NV3; ++i) {
+    r.g_rgb[i] = (has && i < nv3) ? lane_value(rec, 8 + i) : 0.0f;
+    r.g_bkgd -= r.g_rgb[i];
+  }
+  r.g_depth = q->g_depth ? lane_value(rec, 48) : 0.0f;
+  return r;
+}
+
 __device__ __forceinline__ void atomic_add_f32(float* p, float v) {
 
   __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -364,6 +364,14 @@ __global__ __launch_bounds__(256, 2) void rowsb_kernel(const BwdParams bp, const
     s_pre = at32(f->sigma_raw + row, r), t_pre = at32(f->trans + row, r);
   };
   if (g >= 0) fetch_state(&kernarg_view<BwdParams>()->f, g, kc_last);
+  // the rays' wave-uniform inputs one iteration ahead (bts_bwd.h: fetch_ray_record): `rec` the group's ray (PK: its fourth ray), `recm`
+  // (PK) the ray lanes 0-47 take in the next iteration
+  const int nv3 = p.nv * 3;
+  float rec = 0.0f, recm = 0.0f;
+  if (g >= 0) {
+    rec = fetch_ray_record(kernarg_view<BwdParams>(), PK ? (long)g * 4 + 3 : (long)g, nv3, lane);
+    if (PK) recm = fetch_ray_record(kernarg_view<BwdParams>(), (long)g * 4 + 2, nv3, lane);
+  }
 #ifdef BTS_TICKS
   unsigned long long t_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long t_last = __builtin_readcyclecounter();
@@ -380,32 +388,11 @@ __global__ __launch_bounds__(256, 2) void rowsb_kernel(const BwdParams bp, const
     while (ray0 >= sample_end) ++sample, sample_end += Bp;
     const Cam enc = load_cam(ih.w2c_enc + sample * 16, ih.K_enc + sample * 9);
     const float4* __restrict__ G = reinterpret_cast<const float4*>(ih.proj) + (long)sample * (H >> fs) * (W >> fs) * (HD / 4);
-    // a ray's scalars: origin, direction, upstream gradients -- one batch of scalar loads (index clamped, the entries beyond nv zeroed by
-    // selects: a condition per entry is a branch, a load and a wait per entry)
-    struct RayIn {
-      float o[3], d[3], g_rgb[NVMAX * 3], g_bkgd, g_depth;
-    };
-    auto load_ray = [&](long ray) -> RayIn {
-      RayIn r;
-      const cfp rp = as_const(ih.rays) + ray * 8;
-      r.o[0] = rp[0], r.o[1] = rp[1], r.o[2] = rp[2], r.d[0] = rp[3], r.d[1] = rp[4], r.d[2] = rp[5];
-      r.g_bkgd = 0.0f;
-#pragma unroll
-      for (int i = 0; i < NVMAX * 3; ++i) r.g_rgb[i] = 0.0f;
-      if (qb->g_rgb) {
-        const cfp gr = as_const(qb->g_rgb) + ray * (long)(nv * 3);
-#pragma unroll
-        for (int i = 0; i < NVMAX * 3; ++i) r.g_rgb[i] = gr[min(i, nv * 3 - 1)];
-      }
-#pragma unroll
-      for (int i = 0; i < NVMAX * 3; ++i) {
-        r.g_rgb[i] = i < nv * 3 ? r.g_rgb[i] : 0.0f;
-        r.g_bkgd -= r.g_rgb[i];
-      }
-      r.g_depth = qb->g_depth ? as_const(qb->g_depth)[ray] : 0.0f;
-      return r;
-    };
-    RayIn rin = load_ray(PK ? ray0 + 3 : ray0);   // PK: the fourth ray's, selected into lanes 48-63 of every iteration below
+    // the ray's scalars (PK: the fourth ray's, selected into lanes 48-63 of every iteration below), fetched during the previous group;
+    // the next group's go out now
+    const RayIn<NVMAX * 3> rin = unpack_ray_record<NVMAX * 3>(qb, rec, nv3);
+    const int g_nxg = group_of(idx + waves_per_xcd);
+    if (g_nxg >= 0) rec = fetch_ray_record(qb, PK ? (long)g_nxg * 4 + 3 : (long)g_nxg, nv3, lane);
     float S_carry = 0.0f;   // sum over the samples of the chunks behind this one of g_w w (PK: of the fourth ray's rows behind this one)
     RB_TICK(10)   // (part of 0) the ray's scalars are in
 
@@ -419,7 +406,9 @@ __global__ __launch_bounds__(256, 2) void rowsb_kernel(const BwdParams bp, const
       const float z = z_pre, z_nx = zn_pre, s_raw = s_pre, T = t_pre;
       float ox, oy, oz, dx, dy, dz, g_rgb[NVMAX * 3], g_bkgd, g_depth;
       if constexpr (PK) {
-        const RayIn rm = load_ray(ray0 + (kc >> 6));
+        const RayIn<NVMAX * 3> rm = unpack_ray_record<NVMAX * 3>(qb, recm, nv3);
+        const long r_nx = kc > 0 ? ray0 + (kc >> 6) - 1 : (g_nxg >= 0 ? (long)g_nxg * 4 + 2 : -1);
+        if (r_nx >= 0) recm = fetch_ray_record(qb, r_nx, nv3, lane);
         ox = mainl ? rm.o[0] : rin.o[0], oy = mainl ? rm.o[1] : rin.o[1], oz = mainl ? rm.o[2] : rin.o[2];
         dx = mainl ? rm.d[0] : rin.d[0], dy = mainl ? rm.d[1] : rin.d[1], dz = mainl ? rm.d[2] : rin.d[2];
 #pragma unroll

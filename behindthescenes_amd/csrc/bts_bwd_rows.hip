@@ -245,6 +245,8 @@ __global__ __launch_bounds__(256, 2) void rows_kernel(const BwdParams bp) {
     z_pre = p.z_samp[pk], zn_pre = p.z_samp[(long)g * K + min(kk + 1, K - 1)];
     s_pre = p.sigma_raw[pk], t_pre = p.trans[pk];
   }
+  const int nv3 = p.nv * 3;
+  float rec = g >= 0 ? fetch_ray_record(kernarg_view<BwdParams>(), (long)g, nv3, lane) : 0.0f;   // bts_bwd.h: the ray's scalars, one iteration ahead
 
   for (; g >= 0; idx += waves_per_xcd, g = group_of(idx)) {
     auto qb = kernarg_view<BwdParams>();   // this iteration's parameters, re-read where they are used (bts_common.h: kernarg_view)
@@ -254,12 +256,13 @@ __global__ __launch_bounds__(256, 2) void rows_kernel(const BwdParams bp) {
     while (g >= sample_end) ++sample, sample_end += Bp;
     const Cam enc = load_cam(qb->f.w2c_enc + sample * 16, qb->f.K_enc + sample * 9);
     const float4* __restrict__ G = reinterpret_cast<const float4*>(qb->f.proj) + (long)sample * (H >> fs) * (W >> fs) * (HD / 4);
-    const cfp rp = as_const(qb->f.rays) + ray * 8;
-    const float ox = rp[0], oy = rp[1], oz = rp[2], dx = rp[3], dy = rp[4], dz = rp[5];
+    const RayIn<NVMAX * 3> rin = unpack_ray_record<NVMAX * 3>(qb, rec, nv3);
+    const float ox = rin.o[0], oy = rin.o[1], oz = rin.o[2], dx = rin.d[0], dy = rin.d[1], dz = rin.d[2];
     const float z = z_pre, z_nx = zn_pre, s_raw = s_pre, T = t_pre;
-    {  // the next ray's per-sample state lands while this ray is evaluated
+    {  // the next ray's per-sample state (and its scalars) land while this ray is evaluated
       const int gn = group_of(idx + waves_per_xcd);
       if (gn >= 0) {
+        rec = fetch_ray_record(qb, (long)gn, nv3, lane);
         const long pk = (long)gn * K + kk;
         z_pre = qb->f.z_samp[pk], zn_pre = qb->f.z_samp[(long)gn * K + min(kk + 1, K - 1)];
         s_pre = qb->f.sigma_raw[pk], t_pre = qb->f.trans[pk];
@@ -274,22 +277,9 @@ __global__ __launch_bounds__(256, 2) void rows_kernel(const BwdParams bp) {
     // condition per entry is a branch, a load and a wait per entry) and the forward's per-sample colours: issued here, used behind the
     // geometry and the first gather blocks (read where they are needed, each is a full memory round trip with the wave idle)
     float g_rgb[NVMAX * 3];
-    float g_bkgd = 0.0f;
-    {
 #pragma unroll
-      for (int i = 0; i < NVMAX * 3; ++i) g_rgb[i] = 0.0f;
-      if (qb->g_rgb) {
-        const cfp gr = as_const(qb->g_rgb) + ray * (long)(nv * 3);
-#pragma unroll
-        for (int i = 0; i < NVMAX * 3; ++i) g_rgb[i] = gr[min(i, nv * 3 - 1)];
-      }
-#pragma unroll
-      for (int i = 0; i < NVMAX * 3; ++i) {
-        g_rgb[i] = i < nv * 3 ? g_rgb[i] : 0.0f;
-        g_bkgd -= g_rgb[i];
-      }
-    }
-    const float g_depth = qb->g_depth ? as_const(qb->g_depth)[ray] : 0.0f;
+    for (int i = 0; i < NVMAX * 3; ++i) g_rgb[i] = rin.g_rgb[i];
+    const float g_bkgd = rin.g_bkgd, g_depth = rin.g_depth;
     float cs_v[NVMAX * 3];
     const bool have_cs = qb->f.rgb_samps != nullptr;
 #pragma unroll

@@ -82,6 +82,11 @@ __device__ __forceinline__ const T __attribute__((address_space(4)))* kernarg_vi
   return (const T __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
 }
 
+// lane `i` of a register as a wave-uniform value (an SGPR)
+__device__ __forceinline__ float lane_value(float v, int i) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), i));
+}
+
 // Element `idx` (a 32-bit lane value) of an array whose base is WAVE-UNIFORM: the byte offset is formed in 32 bits, so the access is
 // the scalar-base form `global_load v, v_off32, s[base:base+1]` -- no 64-bit per-lane address (two VGPRs per access, computed ahead of
 // the load and, in the register-starved kernels, spilled: a reload from scratch waits with vmcnt(0) for every load in flight).

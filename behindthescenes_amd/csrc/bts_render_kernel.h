@@ -722,6 +722,14 @@ __global__ __launch_bounds__(256, 2) void render_kernel_p(const FwdParams p) {
     if (p.z_samp) z_pre = p.z_samp[row + kk], zn_pre = p.z_samp[row + min(kk + 1, K - 1)];
     else z_pre = p.jitter[row + kk];
   }
+  // one ray per iteration: the ray (origin, direction, near, far: 32 bytes, wave-uniform) of the NEXT iteration is fetched while this one
+  // is evaluated -- as a VECTOR load (all lanes the same address: one request), because a scalar load in flight turns every LDS wait
+  // behind it into lgkmcnt(0) (scalar loads return out of order), i.e. the round trip would stall the first weight read instead of the
+  // loop head.  Lane i (mod 8) holds float i of the record: one register, one 32-byte request; the loop head moves eight lanes into SGPRs.
+  float nrec = 0.0f;
+  if constexpr (ONE_RAY) {
+    if (g >= 0) nrec = p.rays[(long)g * 8 + (lane & 7)];
+  }
   const float step0 = 1.0f / (float)p.K;                       // nerf.py:107
   const float base0 = coarse_base(p.K, min(kl, p.K - 1));      // linspace(0, 1 - step, K)[k] of this lane's sample (first chunk)
 
@@ -740,10 +748,9 @@ __global__ __launch_bounds__(256, 2) void render_kernel_p(const FwdParams p) {
     const float4* __restrict__ G = reinterpret_cast<const float4*>(ih.proj) + (long)sample * (H >> fs) * (W >> fs) * (HD / 4);
     float ox, oy, oz, dx, dy, dz, near = 0.0f, far = 0.0f;
     const bool from_jitter = ih.z_samp == nullptr;   // wave-uniform
-    if constexpr (ONE_RAY) {  // wave-uniform ray: scalar loads
-      const cfp rp = as_const(ih.rays) + (long)g * 8;
-      ox = rp[0], oy = rp[1], oz = rp[2], dx = rp[3], dy = rp[4], dz = rp[5];
-      if (from_jitter) near = rp[6], far = rp[7];
+    if constexpr (ONE_RAY) {  // wave-uniform ray, fetched during the previous iteration (nr0 / nr1 above)
+      ox = lane_value(nrec, 0), oy = lane_value(nrec, 1), oz = lane_value(nrec, 2), dx = lane_value(nrec, 3), dy = lane_value(nrec, 4);
+      dz = lane_value(nrec, 5), near = lane_value(nrec, 6), far = lane_value(nrec, 7);
     } else {
       const float4 r0 = reinterpret_cast<const float4*>(ih.rays)[ray * 2];
       const float4 r1 = reinterpret_cast<const float4*>(ih.rays)[ray * 2 + 1];
@@ -761,6 +768,9 @@ __global__ __launch_bounds__(256, 2) void render_kernel_p(const FwdParams p) {
     };
     const int g_next = group_of(idx + waves_per_xcd);
     if (!pk48 && g_next >= 0) prefetch_z(g_next, 0);
+    if constexpr (ONE_RAY) {
+      if (g_next >= 0) nrec = ih.rays[(long)g_next * 8 + (lane & 7)];
+    }
 
     float T_carry = 1.0f, depth_part = 0.0f, w_part = 0.0f;
     float Tc_D = 1.0f;   // 48-lane mode: transmittance in front of the fourth ray's current row
