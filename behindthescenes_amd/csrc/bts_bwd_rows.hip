@@ -648,8 +648,21 @@ __global__ __launch_bounds__(64) void scatter_kernel(const ScatterMaskParams sp)
 
   const int k_lo = seg * sp.kseg, k_hi = min(K, k_lo + sp.kseg);   // this wave's steps: k_hi - 1 down to k_lo
   if (k_lo >= k_hi) return;
-  float z_n = zrow[k_hi - 1], gs_n = ray_ok ? gsrow[k_hi - 1] : 0.0f;
-  unsigned m_n = (!ROWS && ray_ok) ? mrow[k_hi - 1] : 0u;
+  // lane = ray: a step's depth, g_s and gate word sit K floats apart between neighbouring lanes -- every load instruction touches 64
+  // lines for 4 bytes each, the wave's 192 lines do not survive in L1 / L2 from one step to the next (2 048 waves walk theirs at the
+  // same time), and the pass fetched 1.3 GB for 50 MB of per-sample inputs (profiles/r03w_train).  With rows that start on 16-byte
+  // boundaries (K % 4 == 0) a lane therefore takes FOUR steps per load, one block ahead of its use.
+  const bool blk4 = (K & 3) == 0;
+  float4 zc = make_float4(0.0f, 0.0f, 0.0f, 0.0f), zq = zc, gc = zc, gq = zc;
+  uint4 mc = make_uint4(0u, 0u, 0u, 0u), mq = mc;
+  auto load_block = [&](int b) {   // steps 4 b .. 4 b + 3 of this lane's ray
+    zq = *reinterpret_cast<const float4*>(zrow + 4 * b);
+    gq = ray_ok ? *reinterpret_cast<const float4*>(gsrow + 4 * b) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if constexpr (!ROWS) mq = ray_ok ? *reinterpret_cast<const uint4*>(mrow + 4 * b) : make_uint4(0u, 0u, 0u, 0u);
+  };
+  if (blk4) load_block((k_hi - 1) >> 2);
+  float z_n = blk4 ? 0.0f : zrow[k_hi - 1], gs_n = (ray_ok && !blk4) ? gsrow[k_hi - 1] : 0.0f;
+  unsigned m_n = (!ROWS && ray_ok && !blk4) ? mrow[k_hi - 1] : 0u;
   constexpr int NROW = ROWS ? 32 : 1;
   float cur[NROW], nxt[NROW];
   if constexpr (ROWS) {
@@ -657,12 +670,24 @@ __global__ __launch_bounds__(64) void scatter_kernel(const ScatterMaskParams sp)
     for (int i = 0; i < 32; ++i) nxt[i] = i < half_pts ? urow[i * pstride + (long)(k_hi - 1) * HD] : 0.0f;
   }
   for (int k = k_hi - 1; k >= k_lo; --k) {
-    const float z = z_n, gs = gs_n;
-    const unsigned gate = m_n;
+    float z = z_n, gs = gs_n;
+    unsigned gate = m_n;
     {  // the next step's inputs
       const int kn = max(k - 1, k_lo);
-      z_n = zrow[kn], gs_n = ray_ok ? gsrow[kn] : 0.0f;
-      if constexpr (!ROWS) m_n = ray_ok ? mrow[kn] : 0u;
+      if (blk4) {
+        if ((k & 3) == 3 || k == k_hi - 1) {   // a new block starts: the one fetched a block ago becomes current, the next goes out
+          zc = zq, gc = gq, mc = mq;
+          const int bn = (k >> 2) - 1;
+          if (4 * bn + 3 >= k_lo) load_block(bn);
+        }
+        const int j = k & 3;   // uniform
+        z = j == 0 ? zc.x : j == 1 ? zc.y : j == 2 ? zc.z : zc.w;
+        gs = j == 0 ? gc.x : j == 1 ? gc.y : j == 2 ? gc.z : gc.w;
+        gate = j == 0 ? mc.x : j == 1 ? mc.y : j == 2 ? mc.z : mc.w;
+      } else {
+        z_n = zrow[kn], gs_n = ray_ok ? gsrow[kn] : 0.0f;
+        if constexpr (!ROWS) m_n = ray_ok ? mrow[kn] : 0u;
+      }
       if constexpr (ROWS) {
 #pragma unroll
         for (int i = 0; i < 32; ++i) cur[i] = nxt[i];
@@ -1235,9 +1260,12 @@ static int launch_rows(const BwdParams& bp, int n, int grid, hipStream_t s) {
   return BTS_OK;
 }
 
-// segments of the K steps per ray group: enough waves for two per SIMD (2048), at least 8 steps each (window set-up + final flush)
+// segments of the K steps per ray group: as many waves as the chip holds AT ONCE -- eight per CU, 20 KB of LDS each -- and not one more
+// (rounding up gave exp_re10k.yaml's 384 patches six segments = 2 304 waves on 2 048 places: a second round for the last 256, i.e. twice
+// the steps on the critical path; five segments = 1 920 waves finish in one), at least 8 steps each (window set-up + final flush)
+int device_cu_count();
 static void scatter_segments(ScatterMaskParams& sp, long units, int K) {
-  long want = (2048 + units - 1) / units;
+  long want = 8L * device_cu_count() / units;
   const long most = K >= 8 ? K / 8 : 1;
   if (want > most) want = most;
   if (want < 1) want = 1;

@@ -62,7 +62,7 @@ void render_geometry(FwdParams& p, int n) {
 
 // persistent grid: 2 work-groups (8 waves) per CU of the current device, multiple of 8 so that every XCD owns an equal contiguous
 // share of the rays
-int render_grid(const FwdParams& p) {
+int device_cu_count() {
   static thread_local int cus[16] = {0};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
@@ -70,7 +70,11 @@ int render_grid(const FwdParams& p) {
     hipDeviceProp_t prop;
     cus[dev] = hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   }
-  const long cap = 2L * cus[dev];
+  return cus[dev];
+}
+
+int render_grid(const FwdParams& p) {
+  const long cap = 2L * device_cu_count();
   const long want = (p.groups + 3) / 4;
   long g = want < cap ? want : cap;
   g = (g + 7) / 8 * 8;
