@@ -27,6 +27,14 @@ struct BwdParams {
 // ablated): 0.16 of dwpe_kernel's 0.33 ms and 0.09 of dwpe_rows_kernel's 0.18 ms were these atomics queueing at L2.  The work-groups
 // therefore add into one of kFlushSlots copies (work-group b -> slot b % kFlushSlots: 1/8 of the queue per address), and a 40 x HD
 // thread kernel (dwpe_reduce_kernel) folds the copies into d_mlp.
+// the status of the launches issued so far, read ONCE (hipGetLastError clears it): the HIP error string goes to bts_last_error()
+inline int launch_status() {
+  const hipError_t e = hipGetLastError();
+  if (e == hipSuccess) return BTS_OK;
+  set_error("%s: backward kernel launch failed (%ld)", hipGetErrorString(e), (long)e);
+  return BTS_E_LAUNCH;
+}
+
 constexpr int kFlushSlots = 8;
 constexpr int kFlushRows = kPeDim + 1;   // 40 encoding inputs incl. the bias row
 

@@ -853,7 +853,7 @@ static int launch_rowsb(const BwdParams& bp, const RowsbOut& ro, int grid, hipSt
       else if (bp.f.nv <= 2) go(rowsb_kernel<C, HD, NB, 2, true>);
       else if (bp.f.nv <= 4) go(rowsb_kernel<C, HD, NB, 4, true>);
       else go(rowsb_kernel<C, HD, NB, 8, true>);
-      return hipGetLastError() == hipSuccess ? BTS_OK : BTS_E_LAUNCH;
+      return launch_status();
     }
   }
   if (bp.f.lpr != 64) return BTS_E_UNSUPPORTED;
@@ -861,7 +861,7 @@ static int launch_rowsb(const BwdParams& bp, const RowsbOut& ro, int grid, hipSt
   else if (bp.f.nv <= 2) go(rowsb_kernel<C, HD, NB, 2>);
   else if (bp.f.nv <= 4) go(rowsb_kernel<C, HD, NB, 4>);
   else go(rowsb_kernel<C, HD, NB, 8>);
-  return hipGetLastError() == hipSuccess ? BTS_OK : BTS_E_LAUNCH;
+  return launch_status();
 }
 
 // bp.gs_ws: (n*Bp, K) floats; u0_ws: (n*Bp, K, HD) floats; p.groups / chunk_log2 / lpr set for one ray per wave iteration
@@ -878,7 +878,6 @@ int launch_bwd_blocks(const BwdParams& bp, float* u0_ws, int C, int HD, int NB, 
   else if (C == 32 && HD == 32 && NB == 0) rc = launch_rowsb<32, 32, 0>(bp, ro, grid, s);
   if (rc == BTS_OK && (bp.d_proj || bp.d_empty_proj)) rc = launch_scatter_rows(bp, u0_ws, HD, n, s);
   if (rc == BTS_OK && bp.d_mlp) rc = launch_dwpe_rows(bp.f, u0_ws, bp.d_mlp, bp.flush_ws, C, HD, NB, n, grid, s);
-  if (rc == BTS_E_LAUNCH) set_error("%s: backward kernel launch failed (%ld)", hipGetErrorString(hipGetLastError()), 0);
   return rc;
 }
 

@@ -1285,7 +1285,7 @@ int launch_scatter_rows(const BwdParams& bp, const float* u0_ws, int HD, int n, 
   if (HD == 64) scatter_kernel<64, true><<<(int)(units * sp.nseg), 64, 0, s>>>(sp);
   else if (HD == 32) scatter_kernel<32, true><<<(int)(units * sp.nseg), 64, 0, s>>>(sp);
   else return BTS_E_UNSUPPORTED;
-  return hipGetLastError() == hipSuccess ? BTS_OK : BTS_E_LAUNCH;
+  return launch_status();
 }
 
 int launch_dwpe_rows(const FwdParams& p, const float* u0_ws, float* d_mlp, float* flush_ws, int C, int HD, int NB, int n, int grid, hipStream_t s) {
@@ -1306,7 +1306,7 @@ int launch_dwpe_rows(const FwdParams& p, const float* u0_ws, float* d_mlp, float
     dwpe_reduce_kernel<32, 32><<<(kFlushRows * 32 + 255) / 256, 256, 0, s>>>(flush_ws, d_mlp);
   } else return BTS_E_UNSUPPORTED;
   (void)NB;
-  return hipGetLastError() == hipSuccess ? BTS_OK : BTS_E_LAUNCH;
+  return launch_status();
 }
 
 // bp.gs_ws: (n*Bp, K) floats, bp.mask_ws: (n*Bp, HD/32, K) dwords, bp.pmask_ws: (n*Bp, HD) x 64 bits; p.groups / chunk_log2 / lpr set for one ray per wave iteration

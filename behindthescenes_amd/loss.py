@@ -7,7 +7,7 @@ reference become one launch, one reduction and one device-to-host copy for the l
 alpha / surfaceness / depth-smoothness / ray-entropy, all off in the shipped configs) are a few elementwise torch expressions on
 top.  Same constructor keys, same call signature, same ``(loss, loss_dict)`` result as the reference."""
 import math
-from collections.abc import Mapping
+from collections.abc import MutableMapping
 
 import torch
 from torch.autograd import profiler
@@ -49,11 +49,14 @@ def _same_view(a, b):
                       and a._base is not None and a._base is b._base)
 
 
-class LazyScalars(Mapping):
+class LazyScalars(MutableMapping):
     """The loss dict of loss.py:219-229 ({name: python float}) without its synchronisation: the values are copied to pinned host memory
     asynchronously when the loss is computed and the host waits for that copy only when an entry is read (logging handlers read them
     every N iterations; a step whose dict nobody reads never stalls, and the backward is launched while the forward still runs).  A
-    read-only Mapping: ``d["loss"]``, ``d.items()``, ``dict(d)`` behave like the reference's dict."""
+    mutable Mapping: ``d["loss"]``, ``d.items()``, ``dict(d)``, ``d["x"] = 1.0``, ``d.update(...)`` behave like the reference's dict (the
+    first access of any kind waits for the copy); pickling / ``copy.deepcopy`` (torch.save of an engine's output) yield a plain dict.
+    It is NOT a ``dict`` subclass -- ``json.dumps`` walks a dict subclass' own storage behind its methods' back and would print the
+    unmaterialised (empty) one: ``json.dumps(dict(d))`` is the spelling."""
 
     def __init__(self, keys, values: torch.Tensor):
         self._keys, self._vals = list(keys), None
@@ -75,11 +78,20 @@ class LazyScalars(Mapping):
     def __getitem__(self, k):
         return self._dict()[k]
 
+    def __setitem__(self, k, v):
+        self._dict()[k] = v
+
+    def __delitem__(self, k):
+        del self._dict()[k]
+
     def __iter__(self):
-        return iter(self._keys)
+        return iter(self._keys if self._vals is None else self._vals)
 
     def __len__(self):
-        return len(self._keys)
+        return len(self._keys if self._vals is None else self._vals)
+
+    def __reduce__(self):
+        return (dict, (self._dict(),))
 
     def __repr__(self):
         return repr(self._dict())

@@ -193,7 +193,10 @@ int bts_field_query(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const floa
  * c: sigma := 1 where any view flags the point invalid (:219), running sum over the levels y = 0 .. Y-1 (:224), profile (n, columns)
  * = (number of levels whose running sum is <= threshold) / Y (:225; threshold 8 in the reference).  only_density != 0: only the
  * encoder view's frustum test counts as invalid (the LiDAR / 3D-bbox evaluators' query mode, evaluator_lidar.py:300-308).
- * sigma (n, Y * columns), when given, also receives the raw densities.  Y <= 64 (the reference uses 64); needs proj_nhwc.  ABI 3. */
+ * sigma (n, Y * columns), when given, also receives the raw densities.  Y <= 64 (the reference uses 64); needs proj_nhwc.  ABI 3.
+ * Rounding: the running sum is a wave-wide parallel scan, the reference's a sequential fp32 cumsum -- on a column whose running sum
+ * passes within ~2e-4 of the threshold the `<=` test can fall the other way and move that column's value by 1 / Y (the parity tests
+ * compare the columns that are decided by a wider margin, tests/_cases.py: decided_columns). */
 int bts_occupancy_profile(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const float* xyz, int32_t Y, int32_t columns, float threshold,
                           int32_t only_density, float* profile, float* sigma, void* stream);
 

@@ -103,13 +103,21 @@ def test_packed_parameter_vector_is_cached_until_a_parameter_changes():
     assert m2.__dict__["_packed_cache"] is None and torch.equal(m2.packed(), m.packed())
 
 
-def test_loss_dict_is_a_lazy_read_only_mapping():
+def test_loss_dict_is_a_lazy_mapping_that_behaves_like_the_reference_dict():
+    import copy
+    import json
+    import pickle
     from behindthescenes_amd.loss import LazyScalars
     d = LazyScalars(["loss", "loss_rgb_coarse"], torch.tensor([1.5, 0.25]))
-    assert d["loss"] == 1.5 and dict(d) == {"loss": 1.5, "loss_rgb_coarse": 0.25} and len(d) == 2 and list(d) == ["loss", "loss_rgb_coarse"]
+    assert len(d) == 2 and list(d) == ["loss", "loss_rgb_coarse"]                      # (no materialisation needed for these)
+    assert d["loss"] == 1.5 and dict(d) == {"loss": 1.5, "loss_rgb_coarse": 0.25}
     assert "loss" in d and "nope" not in d and isinstance(d["loss_rgb_coarse"], float)
-    with pytest.raises(TypeError):
-        d["loss"] = 2.0
+    d["lr"] = 1e-4                                                                     # engine handlers add entries (dict semantics)
+    d.update(loss=2.0)
+    assert d["loss"] == 2.0 and list(d.items())[-1] == ("lr", 1e-4) and len(d) == 3
+    for clone in (pickle.loads(pickle.dumps(d)), copy.deepcopy(d)):                    # torch.save of an engine's output
+        assert type(clone) is dict and clone == dict(d)
+    assert json.loads(json.dumps(dict(d)))["loss"] == 2.0
 
 
 def test_scale_maps_keep_their_size_only_for_power_of_two_ratios():
