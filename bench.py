@@ -428,8 +428,10 @@ def train_workload(args, world, rank, dev):
                          "kernel": "bts_render_fwd + bts_render_bwd, all launches of a step",
                          "kernel_ms": ms["fwd"] + ms["bwd"], "fwd_ms": ms["fwd"], "bwd_ms": ms["bwd"], "algorithmic_flop_per_step": flop,
                          "counters": counters,
-                         "note": f"algorithmic 3 x {flop_pt} FLOP / sample (SURVEY 8d) against the fp32 vector = fp32-input-MFMA peak; bwd_ms includes "
-                                 "the zero fill of dG.  Backward passes: DESIGN.md section 3"},
+                         "note": f"algorithmic 3 x {flop_pt} FLOP / sample (SURVEY 8d) against the fp32 vector = fp32-input-MFMA peak; bwd_ms = "
+                                 "bts_render_bwd's passes (no fill of dG: it is added into the kept (d_proj, tile flags) pair that "
+                                 "bts_project_features_bwd_tiles returns to zero, ABI 6" + (" -- off: --dense-proj-grad" if args.dense_proj_grad else "")
+                                 + ").  Backward passes: DESIGN.md section 3"},
         }
         if world == 1 and not args.no_cpu_baseline and args.encoder == "feature_map":
             out["cpu_baseline"] = train_cpu_baseline(cfg, net, scene, rank)
