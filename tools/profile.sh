@@ -10,7 +10,8 @@ set -u
 TAG=${1:-r02}
 MODE=${2:-fwd}
 REPO=$(pwd)
-OUT=$REPO/gpurun_out/prof_$TAG
+TOP=$REPO/gpurun_out/prof_$TAG                 # the summaries (traffic*.json) of every mode of a tag collect here ...
+OUT=$TOP/raw_${MODE}${3:+_k$3}                 # ... the raw CSVs of a mode in its own directory
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
@@ -76,9 +77,9 @@ if mode == "fwd" and "render_kernel_p" in summary:
     rays = 245760
     s["valu_insts_per_ray"] = s["counters"].get("SQ_INSTS_VALU", 0) / rays
     s["mfma_insts_per_ray"] = s["counters"].get("SQ_INSTS_MFMA", 0) / rays
-    json.dump(s, open("$OUT/traffic.json", "w"), indent=1)
+    json.dump(s, open("$TOP/traffic.json", "w"), indent=1)
 else:
     k = "${3:-}"
     ksfx = "_k" + k if mode == "bwd_re10k" and k and k != "48" else ""      # a pass at another K than the yaml's names it (bench.py matches on that)
-    json.dump(summary, open("$OUT/traffic_" + mode + ksfx + ".json", "w"), indent=1)
+    json.dump(summary, open("$TOP/traffic_" + mode + ksfx + ".json", "w"), indent=1)
 PY
