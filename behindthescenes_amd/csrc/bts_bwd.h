@@ -41,7 +41,7 @@ constexpr int kFlushRows = kPeDim + 1;   // 40 encoding inputs incl. the bias ro
 // A ray's wave-uniform inputs of the backward -- origin, direction (8 floats of `rays`), its upstream colour gradient (nv * 3 floats)
 // and depth gradient -- fetched ONE ITERATION AHEAD as one vector load: lane i < 8 holds float i of the ray, lanes 8 .. 8 + 3 NVMAX - 1 the
 // colour gradient (index clamped to the nv * 3 that exist), lane 48 the depth gradient.  As scalar loads at the top of the iteration they
-// were a full memory round trip with the wave idle (7 % of rowsb_kernel's iteration, profiles/r03v section 10); issued early as scalar
+// were a full memory round trip with the wave idle (7 % of rowsb_kernel's iteration, profiles/r03_experiments/r03v section 10); issued early as scalar
 // loads they would turn every LDS wait behind them into lgkmcnt(0).  The iteration's head moves the lanes into SGPRs (v_readlane).
 template <class Q>
 __device__ __forceinline__ float fetch_ray_record(Q q, long ray, int nv3, int lane) {

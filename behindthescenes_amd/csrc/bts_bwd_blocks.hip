@@ -382,7 +382,7 @@ __global__ __launch_bounds__(256, 2) void rowsb_kernel(const BwdParams bp, const
   for (; g >= 0; idx += waves_per_xcd, g = group_of(idx)) {
     auto qb = kernarg_view<BwdParams>();   // this iteration's parameters, re-read where they are used (bts_common.h: kernarg_view)
     asm volatile("" : "+s"(qb));
-    IterHead ih(qb);   // (batching these scalar loads -- IterHeadT<true> -- changes nothing here either: 0.640 vs 0.634 ms, profiles/r03s)
+    IterHead ih(qb);   // (batching these scalar loads -- IterHeadT<true> -- changes nothing here either: 0.640 vs 0.634 ms, profiles/r03_experiments/r03s)
     const int H = ih.H, W = ih.W, nv = ih.nv, fs = ih.fs;
     const long ray0 = PK ? (long)g * 4 : (long)g;   // the (first) ray of the group
     while (ray0 >= sample_end) ++sample, sample_end += Bp;

@@ -493,7 +493,7 @@ __device__ __forceinline__ void gl_fetch(const GatherLds& c, GRows& r) {
 // one step: block T (its rows requested from LDS one step ago) is blended (acc += w_tap * row, the order of gblend), block T + 3 goes
 // out into T's slot, the offsets of block T + 4 are fetched from the table, and the rows of block T + 1 are requested from LDS -- last,
 // when block T + 1 has had the whole step to land (two blocks may still be in flight behind it).  -DBTS_GL_FETCH_EARLY requests them
-// first instead (rounds 1 - 2 shipped that order; 3 % slower on the eval frame, profiles/r03k).
+// first instead (rounds 1 - 2 shipped that order; 3 % slower on the eval frame, profiles/r03_experiments/r03k).
 template <int HD, int T>
 __device__ __forceinline__ void gl_consume(f32x16 (&acc)[HD / 32][2], const GatherLds& c, GRows& r, const float4* G, const float (&w)[2][4],
                                            unsigned (&off_next)[4]) {
@@ -613,7 +613,7 @@ struct IterHeadT {
     w2c_enc = f->w2c_enc, K_enc = f->K_enc, proj = f->proj, rays = f->rays, z_samp = f->z_samp, jitter = f->jitter;
     K = f->K, H = f->H, W = f->W, nv = f->nv, fs = f->fs, code_mode = f->code_mode, inv_z = f->inv_z, learn_empty = f->learn_empty;
     inv_dmax = f->inv_dmax, inv_range = f->inv_range, d_min = f->d_min, range = f->range, freq_factor = f->freq_factor;
-    // A/B (profiles/r03q): with the pin the FORWARD is 1.5 % slower -- the second wave of the SIMD hides the scalar round trips, and
+    // A/B (profiles/r03_experiments/r03q): with the pin the FORWARD is 1.5 % slower -- the second wave of the SIMD hides the scalar round trips, and
     // the 22 more spilled SGPRs are VALU instructions in a VALU-bound loop.  Without it this struct is only a list of names: the
     // compiler sinks every load to its use.  The backward's pass A is the other way round (it waits, it does not issue): PIN = true.
     if constexpr (PIN)

@@ -1,6 +1,6 @@
 // Can the LDS write of a global_load_lds_dwordx4 (LDS-DMA) overtake a ds_read_b128 of the SAME wave that was issued BEFORE it and is
 // still waiting in the LDS queue?  This is the hazard behind the run-to-run differences of the gather ring's "late" order on the RE10K
-// shapes (bts_render_kernel.h: gl_issue, profiles/r03i - r03k): the program order  ds_read(slot) ... global_load_lds(slot)  is kept,
+// shapes (bts_render_kernel.h: gl_issue, profiles/r03_experiments/r03i - r03k): the program order  ds_read(slot) ... global_load_lds(slot)  is kept,
 // yet nothing makes the DMA wait for the read to RETURN -- lgkmcnt counts the read, vmcnt the DMA, and the two travel separately.
 //
 // One wave per work-group plays the ring: it fills a 4 KB slot with pattern A (ds_write, drained), then in ONE asm block
