@@ -131,3 +131,50 @@ def test_scale_maps_keep_their_size_only_for_power_of_two_ratios():
     assert net._scale_shift((8, 15), (16, 32)) is None and net._scale_shift((5, 10), (16, 32)) is None
     net_r = bts.BTSNet(dict(conf, native_scale_maps=False))
     assert net_r._scale_shift((8, 16), (16, 32)) is None and net_r._scale_shift((16, 32), (16, 32)) == 0
+
+
+@pytest.mark.parametrize("n_scales,with_fine,eas", [(1, True, 0.001), (4, True, 0.001), (4, False, 0.0), (2, True, 0.0)])
+def test_loss_algebra_as_one_matrix_equals_the_spelled_out_path(monkeypatch, n_scales, with_fine, eas):
+    """ReconstructionLoss._call_photometric_only (loss, logging dict and their gradient as ONE matrix applied to the per-scale sums of the
+    HIP pass) against the general path that spells the reference's algebra out (loss.py:219-293) -- on the CPU, with the HIP pass replaced
+    by a differentiable stand-in that returns (sum of rgb errors, sum of a smoothness term, invalid count)."""
+    from behindthescenes_amd import loss as L
+
+    class FakeSums:
+        @staticmethod
+        def apply(rgb, depth, weights, invalid, rgb_gt, ph, pw, policy, eas_on, invalid_wsum=None, invalid_any=None):
+            e = (rgb.reshape(rgb.shape[0], -1, 3) - rgb_gt[:, None, :]).abs().sum()
+            s = (depth ** 2).sum() * 0.01 if (eas_on and depth is not None) else rgb.sum() * 0.0
+            return torch.stack([e, s, (invalid_wsum > 0.9).all(-1).float().sum().detach()])
+
+    monkeypatch.setattr(L, "_PhotometricSums", FakeSums)
+    g = torch.Generator().manual_seed(n_scales)
+    n, pc, h, w, nv = 2, 3, 8, 8, 2
+
+    def data(req):
+        coarse = []
+        for s in range(n_scales):
+            gs = torch.Generator().manual_seed(100 + s)
+            c = dict(rgb=torch.rand(n, pc, h, w, nv, 3, generator=gs).requires_grad_(req), depth=(torch.rand(n, pc, h, w, generator=gs) * 10).requires_grad_(req),
+                     invalid_wsum=torch.rand(n, pc, h, w, nv, generator=gs) * 1.2, invalid_any=torch.zeros(n, pc, h, w, nv))
+            coarse.append(c)
+        fine = [dict(c) for c in coarse] if with_fine else [dict() for _ in coarse]   # trainer.py:247-248: fine = dict(coarse)
+        return dict(coarse=coarse, fine=fine, rgb_gt=torch.rand(n, pc, h, w, 3, generator=torch.Generator().manual_seed(7)))
+
+    crit = L.ReconstructionLoss({"criterion": "l1+ssim", "invalid_policy": "weight_guided", "lambda_edge_aware_smoothness": eas, "lambda_coarse": 0.7,
+                                 "lambda_fine": 1.3})
+    d1 = data(True)
+    loss1, parts1 = crit(d1)
+    loss1.backward()
+    monkeypatch.setattr(L.ReconstructionLoss, "_call_photometric_only", lambda self, data: None)     # force the general path
+    d2 = data(True)
+    loss2, parts2 = crit(d2)
+    loss2.backward()
+    assert abs(loss1.item() - loss2.item()) <= 1e-6 * max(1.0, abs(loss2.item()))
+    assert list(parts1) == list(parts2)
+    for k in parts2:
+        assert abs(parts1[k] - parts2[k]) <= 1e-6 * max(1.0, abs(parts2[k])), k
+    for a, b in zip(d1["coarse"], d2["coarse"]):
+        torch.testing.assert_close(a["rgb"].grad, b["rgb"].grad, rtol=1e-5, atol=1e-9)
+        if eas > 0:
+            torch.testing.assert_close(a["depth"].grad, b["depth"].grad, rtol=1e-5, atol=1e-9)
