@@ -64,6 +64,8 @@ SYMBOLS = {
     "bts_project_features_bwd": (C.c_int, [C.POINTER(BtsFieldCfg), _P, _P, _P, _I, _P, _P, _P]),
     "bts_proj_tile_count": (C.c_int64, [C.POINTER(BtsFieldCfg)]),
     "bts_project_features_bwd_tiles": (C.c_int, [C.POINTER(BtsFieldCfg), _P, _P, _P, _P, _I, _P, _P, _I, _P]),
+    "bts_mark_sampled_tiles": (C.c_int, [C.POINTER(BtsFieldCfg), _P, _P, C.POINTER(BtsRenderArgs), _P, _P]),
+    "bts_project_features_tiles": (C.c_int, [C.POINTER(BtsFieldCfg), _P, _P, _I, _P, _P, _P]),
     "bts_field_query": (C.c_int, [C.POINTER(BtsFieldCfg), C.POINTER(BtsFieldTensors), _P, _I, _I, _P, _P, _P, _P]),
     "bts_occupancy_profile": (C.c_int, [C.POINTER(BtsFieldCfg), C.POINTER(BtsFieldTensors), _P, _I, _I, C.c_float, _I, _P, _P, _P]),
     "bts_nchw_to_nhwc": (C.c_int, [_P, _P, _I, _I, _I, _I, _P]),

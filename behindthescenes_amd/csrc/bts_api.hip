@@ -22,7 +22,9 @@ int sample_coarse_launch(const float* rays, const float* u, long B, int K, int l
 int distance_to_z_launch(const float* depths, const float* invK, int N, int H, int W, float* out, hipStream_t s);
 int invert_small_launch(const float* src, float* dst, int N, int dim, hipStream_t s);
 
-int project_features_impl(int C, int HD, const float* feat, const float* mlp, int N, int HW, float* proj, hipStream_t s);
+int project_features_impl(int C, int HD, const float* feat, const float* mlp, int N, int HW, float* proj, const unsigned char* tiles, hipStream_t s);
+int mark_tiles_impl(const float* rays, const float* z_samp, const float* jitter, const float* w2c_enc, const float* K_enc, long B, int Bp, int K, int lindisp,
+                    int H, int W, int fs, unsigned char* tiles, hipStream_t s);
 int project_features_bwd_tiles_impl(int C, int HD, const float* feat, float* dproj, unsigned char* tiles, const float* mlp, int N, int HW, float* dfeat,
                                     float* d_mlp, int clear, hipStream_t s);
 int project_features_bwd_impl(int C, int HD, const float* feat, const float* dproj, const float* mlp, int N, int HW, float* dfeat,
@@ -157,8 +159,38 @@ int bts_project_features(const BtsFieldCfg* cfg, const float* feat_nchw, const f
     return BTS_E_UNSUPPORTED;
   }
   if (int rc = check_shift(cfg, "bts_project_features")) return rc;
-  int rc = project_features_impl(cfg->C, cfg->d_hidden, feat_nchw, mlp_params, N, (int)feat_texels(cfg), proj_nhwc, (hipStream_t)stream);
+  int rc = project_features_impl(cfg->C, cfg->d_hidden, feat_nchw, mlp_params, N, (int)feat_texels(cfg), proj_nhwc, nullptr, (hipStream_t)stream);
   if (rc) set_error("%s: kernel launch failed", "bts_project_features");
+  return rc;
+}
+
+int bts_project_features_tiles(const BtsFieldCfg* cfg, const float* feat_nchw, const float* mlp_params, int32_t N, const uint8_t* tiles, float* proj_nhwc,
+                               void* stream) {
+  if (!cfg || !feat_nchw || !mlp_params || !proj_nhwc || !tiles || N <= 0 || cfg->H <= 0 || cfg->W <= 0) {
+    set_error("%s: NULL pointer or non-positive size", "bts_project_features_tiles");
+    return BTS_E_INVALID;
+  }
+  if (!bts_supported(cfg)) {
+    set_error("%s: configuration outside the compiled envelope (C=%ld d_hidden=%ld n_blocks=%ld)", "bts_project_features_tiles", cfg->C, cfg->d_hidden,
+              cfg->n_blocks);
+    return BTS_E_UNSUPPORTED;
+  }
+  if (int rc = check_shift(cfg, "bts_project_features_tiles")) return rc;
+  int rc = project_features_impl(cfg->C, cfg->d_hidden, feat_nchw, mlp_params, N, (int)feat_texels(cfg), proj_nhwc, tiles, (hipStream_t)stream);
+  if (rc) set_error("%s: kernel launch failed", "bts_project_features_tiles");
+  return rc;
+}
+
+int bts_mark_sampled_tiles(const BtsFieldCfg* cfg, const float* K_enc, const float* w2c_enc, const BtsRenderArgs* a, uint8_t* tiles, void* stream) {
+  if (!cfg || !K_enc || !w2c_enc || !a || !tiles || !a->rays || (!a->z_samp && !a->jitter) || cfg->n <= 0 || cfg->H <= 0 || cfg->W <= 0 ||
+      a->rays_per_sample <= 0 || a->K <= 0) {
+    set_error("%s: NULL pointer, non-positive size, or neither z_samp nor jitter", "bts_mark_sampled_tiles");
+    return BTS_E_INVALID;
+  }
+  if (int rc = check_shift(cfg, "bts_mark_sampled_tiles")) return rc;
+  int rc = mark_tiles_impl(a->rays, a->z_samp, a->z_samp ? nullptr : a->jitter, w2c_enc, K_enc, (long)cfg->n * a->rays_per_sample, a->rays_per_sample, a->K,
+                           a->lindisp, cfg->H, cfg->W, cfg->feat_shift, tiles, (hipStream_t)stream);
+  if (rc) set_error("%s: kernel launch failed", "bts_mark_sampled_tiles");
   return rc;
 }
 

@@ -196,14 +196,30 @@ class BTSNet(nn.Module):
         ids_r, id_e = [int(i) for i in ids_render], int(ids_encoder[0])
         self._enc_view = ids_r.index(id_e) if id_e in ids_r else -1
 
-    def native_field(self, coarse=True) -> "native.FieldTensors":
+    def native_field(self, coarse=True, sampled=None) -> "native.FieldTensors":
         """Field state of the current scale in the C-ABI layouts.  The projected feature map G = F . w_in[:, :C]^T is built lazily
         per scale (one HIP pass that also does the NCHW -> channels-last hand-over) and cached until the next ``encode`` or until
         lin_in.weight changes.  Under autograd the projection is differentiable w.r.t. F and the MLP parameters.  ``coarse=False`` with
-        a separate fine MLP: the map projected with THAT MLP's lin_in."""
+        a separate fine MLP: the map projected with THAT MLP's lin_in.
+        ``sampled`` = (rays (n*Bp, 8), z_samp | None, jitter | None, lindisp): a ONE-SHOT field for the render of exactly these samples
+        -- only the 64-texel tiles of G their taps land in are projected (a training step's rays read 10-40 % of them), the rest of the
+        map is uninitialised memory; never cached, never handed to field queries."""
         s = self._scale
         fine = not coarse and self.mlp_fine is not None
         mlp, spec = (self.mlp_fine, self.spec_fine) if fine else (self.mlp_coarse, self.spec)
+        if sampled is not None:
+            rays, z_samp, jitter, lindisp = sampled
+            f = self._latents_ms[s]
+            f = f.reshape(f.shape[0], *f.shape[2:]).float()
+            sh = self._shift_ms[s]
+            tiles = native.mark_sampled_tiles(spec, f.shape[0], f.shape[-2] << sh, f.shape[-1] << sh, sh, self._K_enc, self._w2c_enc, rays, z_samp,
+                                              jitter, lindisp)
+            link = native.ProjLink()
+            proj = native.ProjectFunction.apply(f, mlp.packed(), spec, link, tiles)
+            ft = native.FieldTensors(spec, proj, self._K_enc, self._w2c_enc, self._imgs_nhwc4, self._K_r, self._w2c_r,
+                                     self.empty_feature if self.learn_empty else None, feat_shift=self._shift_ms[s], enc_view=self._enc_view)
+            ft.proj_link = link
+            return ft
         version = (mlp.lin_in.weight._version, torch.is_grad_enabled())
         hit = self._native.get((s, fine))
         if hit is None or hit[1] != version:

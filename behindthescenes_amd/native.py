@@ -231,16 +231,38 @@ def proj_storage_order(d_hidden: int) -> torch.Tensor:
     return ht * 32 + 8 * q + 4 * h + e
 
 
-def project_features(spec: FieldSpec, feat_nchw: torch.Tensor, mlp_params: torch.Tensor) -> torch.Tensor:
+def project_features(spec: FieldSpec, feat_nchw: torch.Tensor, mlp_params: torch.Tensor, tiles: Optional[torch.Tensor] = None) -> torch.Tensor:
     """F (N,C,H,W) -> G (N,H,W,Hd) = F . w_in[:, :C]^T with the channels in storage order (proj_storage_order)
-    (bts_project_features)."""
+    (bts_project_features).  With ``tiles`` (N, proj_tile_count) uint8 only the flagged 64-texel tiles are evaluated and the rest of G
+    is UNINITIALISED (bts_project_features_tiles): a map for the render whose samples ``mark_sampled_tiles`` flagged, nothing else."""
     N, Cc, H, W = feat_nchw.shape
     _req(feat_nchw, "feat_nchw", (N, spec.C, H, W)), _req(mlp_params, "mlp_params", (spec.mlp_param_count(),))
     out = torch.empty((N, H, W, spec.d_hidden), device=feat_nchw.device, dtype=torch.float32)
     cfg = _spec_cfg(spec, N, H, W)
-    _lib.check(_lib.load().bts_project_features(C.byref(cfg), _ptr(feat_nchw), _ptr(mlp_params), N, _ptr(out), _stream(out)),
-               "bts_project_features")
+    if tiles is not None:
+        if tiles.dtype != torch.uint8 or not tiles.is_contiguous() or tiles.numel() != N * proj_tile_count(spec, H, W) or tiles.device != out.device:
+            raise ValueError("tiles: expected a contiguous uint8 tensor of (N, proj_tile_count) on the map's device")
+        _lib.check(_lib.load().bts_project_features_tiles(C.byref(cfg), _ptr(feat_nchw), _ptr(mlp_params), N, _ptr(tiles), _ptr(out), _stream(out)),
+                   "bts_project_features_tiles")
+    else:
+        _lib.check(_lib.load().bts_project_features(C.byref(cfg), _ptr(feat_nchw), _ptr(mlp_params), N, _ptr(out), _stream(out)),
+                   "bts_project_features")
     return out
+
+
+def mark_sampled_tiles(spec: FieldSpec, n: int, H: int, W: int, feat_shift: int, K_enc, w2c_enc, rays, z_samp=None, jitter=None, lindisp=True):
+    """Flags (n, tiles per image of the (H >> s, W >> s) map) uint8 of the 64-texel tiles of the projected map that a render of
+    ``rays`` (n*Bp, 8) at the depths ``z_samp`` (n*Bp, K) -- or, as bts_render_fwd forms them, from ``jitter`` -- reads
+    (bts_mark_sampled_tiles: the render kernels' own routines, the same texels bit for bit)."""
+    src = z_samp if z_samp is not None else jitter
+    _req(rays, "rays", (src.shape[0], 8)), _req(src, "z_samp / jitter"), _req(K_enc, "K_enc", (n, 3, 3)), _req(w2c_enc, "w2c_enc", (n, 4, 4))
+    cfg = _spec_cfg(spec, n, H, W, feat_shift=feat_shift)
+    tiles = torch.zeros((n, proj_tile_count(spec, H >> feat_shift, W >> feat_shift)), device=rays.device, dtype=torch.uint8)
+    args = BtsRenderArgs(rays_per_sample=rays.shape[0] // n, K=src.shape[1], rays=rays.data_ptr(), z_samp=None if z_samp is None else z_samp.data_ptr(),
+                         jitter=None if z_samp is not None else jitter.data_ptr(), lindisp=int(bool(lindisp)), reserved_=0)
+    _lib.check(_lib.load().bts_mark_sampled_tiles(C.byref(cfg), _ptr(K_enc), _ptr(w2c_enc), C.byref(args), _ptr(tiles), _stream(rays)),
+               "bts_mark_sampled_tiles")
+    return tiles
 
 
 def project_features_bwd(spec: FieldSpec, feat_nchw, d_proj, mlp_params, need_feat=True, need_mlp=True, tiles=None, clear_after=False):
@@ -527,17 +549,17 @@ class ProjectFunction(torch.autograd.Function):
     """(F nchw, packed mlp params) -> G nhwc.  Backward: per-pixel GEMMs in bts_project_features_bwd (_tiles)."""
 
     @staticmethod
-    def forward(ctx, feat_nchw, mlp_params, spec, link=None):
+    def forward(ctx, feat_nchw, mlp_params, spec, link=None, tiles=None):
         feat_nchw = feat_nchw.contiguous()
         ctx.set_materialize_grads(False)
         ctx.spec, ctx.link = spec, link
         ctx.save_for_backward(feat_nchw, mlp_params)
-        return project_features(spec, feat_nchw, mlp_params.contiguous())
+        return project_features(spec, feat_nchw, mlp_params.contiguous(), tiles)
 
     @staticmethod
     def backward(ctx, g):
         if g is None:
-            return None, None, None, None
+            return None, None, None, None, None
         feat_nchw, mlp_params = ctx.saved_tensors
         need = ctx.needs_input_grad[:2]
         entry = ctx.link.entry if ctx.link is not None else None
@@ -546,12 +568,12 @@ class ProjectFunction(torch.autograd.Function):
             if g.data_ptr() == entry.buf.data_ptr() and entry.buf._version == entry.version and g.shape == entry.buf.shape:
                 d_feat, d_mlp = project_features_bwd(ctx.spec, feat_nchw, entry.buf, mlp_params, *need, tiles=entry.tiles, clear_after=True)
                 entry.busy = False
-                return d_feat, d_mlp, None, None
+                return d_feat, d_mlp, None, None, None
         d_feat, d_mlp = project_features_bwd(ctx.spec, feat_nchw, g.contiguous(), mlp_params, *need)
         if entry is not None:   # the kept pair was replaced or modified on its way here: dense on what arrived, and the pair starts over
             entry.buf.zero_(), entry.tiles.zero_()
             entry.busy = False
-        return d_feat, d_mlp, None, None
+        return d_feat, d_mlp, None, None, None
 
 
 class RenderFunction(torch.autograd.Function):

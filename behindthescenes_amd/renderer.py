@@ -46,6 +46,9 @@ class NeRFRenderer(torch.nn.Module):
         # SURVEY 8f.1 (not a reference key): in training mode return only what a training step consumes -- rgb, depth and the
         # per-ray reductions behindthescenes_amd.ReconstructionLoss builds its invalid-ray mask from -- see forward()
         self.lean_training_outputs = bool(lean_training_outputs)
+        # the lean training render also projects only the tiles of the feature map its samples read (BTSNet.native_field(sampled=...));
+        # an attribute, not a config key: switch it off for an A/B
+        self.sparse_projection = True
 
     # ---- sampling (nerf.py:103-208) ---------------------------------------------------------------------------------
     def sample_coarse(self, rays, u=None):
@@ -110,23 +113,24 @@ class NeRFRenderer(torch.nn.Module):
                                    sigma_noise)
 
     def _composite(self, model, rays, z_samp, coarse, sb, want_weights, want_alphas, want_rgb_samps, want_invalid, want_invalid_sums,
-                   sigma_noise=None, jitter=None, want_z=False):
+                   sigma_noise=None, jitter=None, want_z=False, sparse_proj=False):
         """z_samp None: ``sample_coarse`` runs INSIDE the render kernel from the jitter ``jitter`` (B, K) ~ U[0, 1) (BtsRenderArgs.jitter:
         the same routine, bit-identical depths, no z_samp round trip through HBM); entry 5 of the result is then the depth tensor only
         when ``want_z`` or when autograd needs it (else None)."""
         if not isinstance(model, BTSNet):
             raise native.BtsNativeError("composite() needs a behindthescenes_amd.BTSNet (the fused HIP kernel IS the field query)")
-        ft = model.native_field(coarse)
-        n = ft.n
-        if sb > 0 and sb != n:
-            raise native.BtsNativeError(f"super-batch {sb} does not match the encoded batch {n}")
-        if sb <= 0 and n != 1:
-            raise native.BtsNativeError("sb=0 (no super-batch) is only meaningful for an encoded batch of 1")
         rays = rays.float().contiguous()
         if z_samp is not None:
             z_samp, jitter = z_samp.float().contiguous(), None
         else:
             jitter = jitter.float().contiguous()
+        # sparse_proj (the lean training path): the projected map is built for THIS render's samples only (BTSNet.native_field)
+        ft = model.native_field(coarse, sampled=(rays, z_samp, jitter, bool(self.lindisp)) if sparse_proj else None)
+        n = ft.n
+        if sb > 0 and sb != n:
+            raise native.BtsNativeError(f"super-batch {sb} does not match the encoded batch {n}")
+        if sb <= 0 and n != 1:
+            raise native.BtsNativeError("sb=0 (no super-batch) is only meaningful for an encoded batch of 1")
         shape = (z_samp if z_samp is not None else jitter).shape
         mlp_params = model.mlp(coarse).packed()      # models_bts.py:293-307: mlp_coarse, or mlp_fine when the fine pass has its own
         empty = model.empty_feature if model.learn_empty else None
@@ -178,7 +182,8 @@ class NeRFRenderer(torch.nn.Module):
             # even when the (reference) trainer asks for them.  Opt-in (`lean_training_outputs`), training mode only.
             # (rgb_samps is still written, as the backward's saved state only: the stores are free in the latency-bound forward and
             # spare the backward one projection + four taps per view and sample; it is not returned)
-            comp = self._composite(model, rays, z_coarse, True, sb, False, False, True, False, True, jitter=jitter)
+            comp = self._composite(model, rays, z_coarse, True, sb, False, False, True, False, True, jitter=jitter,
+                                   sparse_proj=self.sparse_projection)
             nv = comp[7].shape[-1]
             return dict(coarse=dict(rgb=comp[1].reshape(sb, -1, comp[1].shape[-1]), depth=comp[2].reshape(sb, -1),
                                     invalid_wsum=comp[7].reshape(sb, -1, nv), invalid_any=comp[8].reshape(sb, -1, nv)))

@@ -56,6 +56,9 @@ def parse():
     ap.add_argument("--dense-proj-grad", action="store_true",
                     help="training workloads, A/B: the gradient of the projected map as a dense autograd tensor (zero fill + full read) instead of "
                          "the kept (d_proj, tile flags) pair (native.SPARSE_PROJ_GRAD)")
+    ap.add_argument("--dense-projection", action="store_true",
+                    help="training workloads, A/B: project the whole feature map per render instead of the tiles the render's samples read "
+                         "(NeRFRenderer.sparse_projection)")
     ap.add_argument("--tile-stats", action="store_true",
                     help="training workloads, diagnostic: how much of the projected map's gradient a step touches (texels, 16-texel segments, "
                          "64-texel tiles, 8 x 8 blocks); prints to stderr and exits")
@@ -238,6 +241,7 @@ def train_workload(args, world, rank, dev):
     net = net.to(dev).train()
     renderer = bts.NeRFRenderer.from_conf(dict(n_coarse=Kt, lindisp=True, hard_alpha_cap=cfg["hard_cap"],
                                                lean_training_outputs=not args.full_outputs)).to(dev).train()
+    renderer.sparse_projection = not args.dense_projection
     sampler = bts.PatchRaySampler(ray_batch_size=cfg["rays"], z_near=cfg["z"][0], z_far=cfg["z"][1], patch_size=8)
     images, projs, poses = scene["images"].to(dev), scene["projs"].to(dev), scene["poses"].to(dev)
     ids_loss, ids_render = cfg["ids_loss"], cfg["ids_render"]

@@ -179,6 +179,17 @@ int bts_project_features_bwd(const BtsFieldCfg* cfg, const float* feat_nchw, con
  * (d_proj, tiles) pair per map shape zero-fills it once and never again (the fill of a training step's d_proj is as large as the
  * gradient's whole HBM traffic otherwise: 503 MB at exp_kitti_360.yaml's batch). */
 int64_t bts_proj_tile_count(const BtsFieldCfg* cfg);
+/* ABI 6: the forward side of the same observation -- a render reads only the tiles its samples' taps land in.
+ * bts_mark_sampled_tiles: for every sample of every ray of `a` (rays, rays_per_sample, K, and z_samp or jitter + lindisp exactly as
+ * bts_render_fwd takes them; cfg->n, H, W, feat_shift; the encoder cameras) the flags (n, bts_proj_tile_count(cfg)) of the four tap
+ * texels' tiles are SET (caller zero-fills) -- computed with the render kernels' own depth / projection / tap routines, i.e. the same
+ * texels bit for bit.  bts_project_features_tiles then evaluates the flagged tiles of proj_nhwc only and leaves the rest of the buffer
+ * untouched (uninitialised memory stays uninitialised): such a map is good for bts_render_fwd / bts_render_bwd on THAT sample set and
+ * for nothing else (no field queries). */
+int bts_mark_sampled_tiles(const BtsFieldCfg* cfg, const float* K_enc, const float* w2c_enc, const BtsRenderArgs* a, uint8_t* tiles,
+                           void* stream);
+int bts_project_features_tiles(const BtsFieldCfg* cfg, const float* feat_nchw, const float* mlp_params, int32_t N, const uint8_t* tiles,
+                               float* proj_nhwc, void* stream);
 int bts_project_features_bwd_tiles(const BtsFieldCfg* cfg, const float* feat_nchw, float* d_proj_nhwc, uint8_t* tiles,
                                    const float* mlp_params, int32_t N, float* d_feat_nchw, float* d_mlp_params, int32_t clear_after,
                                    void* stream);

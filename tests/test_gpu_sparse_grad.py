@@ -181,3 +181,83 @@ def test_autograd_route_through_the_kept_pair(hip, model):
     close(kept, dense)
     assert gG is not None and gG.data_ptr() != e.buf.data_ptr() and gG.abs().max().item() > 0
     native.release_sparse_grads()
+
+
+@pytest.mark.parametrize("model", ["kitti", "re10k"])
+def test_sparse_forward_projection_covers_every_tap(hip, model):
+    """bts_mark_sampled_tiles + bts_project_features_tiles: the map built for one render's samples.  Every texel the render reads must
+    be computed -- shown the hard way: the unflagged part of the map is NaN, and the render (forward, from the jitter and from injected
+    depths, and backward) must equal the dense map's bit for bit."""
+    from behindthescenes_amd import native
+    scene, net, g, cfg, K = _scene_net(model, seed=23)
+    ft, params = net.native_field(), net.mlp_coarse.packed().detach()
+    rays = _patch_rays(scene, cfg, 64, 160, 6, g).reshape(-1, 8).cuda()
+    u = torch.rand(rays.shape[0], K, generator=g).cuda()
+    z = native.sample_coarse(rays, u, True)
+    feat = net.encoder.feats[0].detach()
+    feat = feat.reshape(feat.shape[0], *feat.shape[-3:]).contiguous()
+    kw = dict(hard_alpha_cap=model == "kitti", want_saved=True, want_rgb_samps=True, want_weights=True)
+    for mode in ("jitter", "z"):
+        tiles = native.mark_sampled_tiles(ft.spec, 2, 64, 160, 0, ft.K_enc, ft.w2c_enc, rays, z if mode == "z" else None, u if mode == "jitter" else None, True)
+        frac = tiles.float().mean().item()
+        assert 0.0 < frac < 0.9, frac
+        G = native.project_features(ft.spec, feat, params, tiles=tiles)
+        flagged = tiles.bool().repeat_interleave(64, dim=1)[:, :64 * 160].reshape(2, 64, 160)
+        assert torch.equal(G[flagged], ft.proj_nhwc.detach()[flagged])                 # the flagged tiles are the dense map's
+        G = torch.where(flagged.unsqueeze(-1), G, torch.full_like(G, float("nan")))      # everything else must never be read
+        sp = native.FieldTensors(ft.spec, G, ft.K_enc, ft.w2c_enc, ft.imgs_nhwc4, ft.K_r, ft.w2c_r, ft.empty_feature, enc_view=ft.enc_view)
+        a = native.render_fwd(ft, params, rays, z if mode == "z" else None, jitter=u if mode == "jitter" else None, **kw)
+        b = native.render_fwd(sp, params, rays, z if mode == "z" else None, jitter=u if mode == "jitter" else None, **kw)
+        for k_ in ("rgb", "depth", "weights", "sigma_raw", "trans", "rgb_samps"):
+            assert torch.equal(a[k_], b[k_]), (mode, k_)
+    g_rgb, g_depth = torch.randn(a["rgb"].shape, generator=g).cuda(), torch.randn(a["depth"].shape, generator=g).cuda()
+    bk = dict(hard_alpha_cap=model == "kitti", g_rgb=g_rgb, g_depth=g_depth, rgb_samps=a["rgb_samps"], need_empty=cfg.learn_empty)
+    ga = native.render_bwd(ft, params, rays, z, a["sigma_raw"], a["trans"], **bk)
+    gb = native.render_bwd(sp, params, rays, z, a["sigma_raw"], a["trans"], **bk)
+    for x, y in zip(ga, gb):
+        if x is not None:
+            assert torch.isfinite(y).all() and (x - y).abs().max().item() <= 2e-5 * x.abs().max().item()
+
+
+def test_lean_training_step_with_and_without_the_sparse_projection(hip):
+    """renderer(...) in training mode with lean outputs: the sparse projection (default) against the dense one -- same outputs bit for
+    bit, same gradients to summation order; multi-scale maps (feat_shift) included."""
+    import torch.nn.functional as F
+    from tests._hip_helpers import make_conf, load_mlp
+    n, v, H, W, C = 2, 3, 64, 160, 64
+    cfg = O.FieldConfig(learn_empty=True)
+    g = torch.Generator().manual_seed(31)
+    scene = O.synthetic_scene(n, v, H, W, C, seed=31, intrinsics=O.K_KITTI360, smooth=True)
+    conf = make_conf(cfg, C, 64, 0, H, W)
+    conf["encoder"].update(n_scales=3, pyramid=True, num_views=n)
+    net = hip.BTSNet(conf)
+    load_mlp(net, O.init_mlp(C + 39, 64, 0, gen=g))
+    with torch.no_grad():
+        for s, dst in enumerate(net.encoder.feats):
+            dst.copy_(F.avg_pool2d(torch.randn(n, C, H >> s, W >> s, generator=g), 3, 1, 1) * 2)
+        net.empty_feature.copy_(torch.randn(C, generator=g))
+    net = net.cuda().train()
+    renderer = hip.NeRFRenderer.from_conf(dict(n_coarse=64, lindisp=True, hard_alpha_cap=True, lean_training_outputs=True)).cuda().train()
+    rays = _patch_rays(scene, cfg, H, W, 5, g).cuda()
+    coef = torch.randn(n, rays.shape[1], 6, generator=g).cuda()
+    res = {}
+    for sparse in (True, False):
+        renderer.sparse_projection = sparse
+        net.zero_grad(set_to_none=True)
+        net.encode(scene["images"].cuda(), scene["projs"].cuda(), scene["poses"].cuda(), ids_encoder=[0], ids_render=[1, 2])
+        outs, total = [], 0.0
+        for scale in (0, 1, 2):
+            net.set_scale(scale)
+            torch.manual_seed(100 + scale)                                   # the same jitter in both runs
+            o = renderer.bind_parallel(net)(rays)["coarse"]
+            outs.append(o)
+            total = total + (o["rgb"] * coef).sum() + 0.05 * o["depth"].sum()
+        net.set_scale(0)
+        total.backward()
+        grads = [p.grad.clone() for p in (net.mlp_coarse.lin_in.weight, net.mlp_coarse.lin_out.weight, net.empty_feature, *net.encoder.feats)]
+        res[sparse] = (outs, grads)
+    for a, b in zip(res[True][0], res[False][0]):
+        for k_ in ("rgb", "depth", "invalid_wsum", "invalid_any"):
+            assert torch.equal(a[k_], b[k_]), k_
+    for a, b in zip(res[True][1], res[False][1]):
+        assert torch.isfinite(a).all() and (a - b).abs().max().item() <= 3e-5 * b.abs().max().item()
