@@ -415,20 +415,31 @@ int project_features_impl(int C, int HD, const float* feat, const float* mlp, in
 __global__ __launch_bounds__(256) void mark_tiles_kernel(const float* __restrict__ rays, const float* __restrict__ z_samp, const float* __restrict__ jitter,
                                                        const float* __restrict__ w2c_enc, const float* __restrict__ K_enc, long B, int Bp, int K,
                                                        int lindisp, int H, int W, int fs, int tiles_per_img, unsigned char* __restrict__ tiles) {
-  const long total = B * K;
+  // lane = sample, one ray per wave iteration (ray, camera: wave-uniform scalar loads), as the render kernels walk them
+  const int lane = threadIdx.x & 63;
+  const long wave = blockIdx.x * 4L + (threadIdx.x >> 6), n_waves = gridDim.x * 4L;
   const float step = 1.0f / (float)K;
-  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const long b = i / K;
-    const int k = (int)(i - b * K);
+  for (long b = wave; b < B; b += n_waves) {
     const int sample = (int)(b / Bp);
-    const float4 r0 = reinterpret_cast<const float4*>(rays)[b * 2], r1 = reinterpret_cast<const float4*>(rays)[b * 2 + 1];
-    const float z = z_samp ? z_samp[i] : coarse_depth(jitter[i], coarse_base(K, k), step, r1.z, r1.w, lindisp != 0);
-    const float px = r0.x + z * r0.w, py = r0.y + z * r1.x, pz = r0.z + z * r1.y;
+    const cfp rp = as_const(rays) + b * 8;
+    const float ox = rp[0], oy = rp[1], oz = rp[2], dx = rp[3], dy = rp[4], dz = rp[5], near = rp[6], far = rp[7];
     const Cam enc = load_cam(w2c_enc + sample * 16, K_enc + sample * 9);
-    const Proj pe = project<false>(enc, px, py, pz);
-    const Taps tp = make_taps(pe.x, pe.y, H, W, fs);
     unsigned char* t = tiles + (long)sample * tiles_per_img;
-    t[(unsigned)tp.o00 >> 6] = 1, t[(unsigned)tp.o01 >> 6] = 1, t[(unsigned)tp.o10 >> 6] = 1, t[(unsigned)tp.o11 >> 6] = 1;
+    for (int k = lane; k < K; k += 64) {
+      const float z = z_samp ? z_samp[b * K + k] : coarse_depth(jitter[b * K + k], coarse_base(K, k), step, near, far, lindisp != 0);
+      const float px = ox + z * dx, py = oy + z * dy, pz = oz + z * dz;
+      const Proj pe = project<false>(enc, px, py, pz);
+      const Taps tp = make_taps(pe.x, pe.y, H, W, fs);
+      // a sample's two taps of a row share their tile but for a tile border; neighbouring samples mostly share both: one store per
+      // distinct tile and lane run instead of four per sample
+      const unsigned ta = (unsigned)tp.o00 >> 6, tb = (unsigned)tp.o01 >> 6, tc = (unsigned)tp.o10 >> 6, td = (unsigned)tp.o11 >> 6;
+      const unsigned pa = (unsigned)__builtin_amdgcn_update_dpp((int)~0u, (int)ta, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
+      const unsigned pc = (unsigned)__builtin_amdgcn_update_dpp((int)~0u, (int)tc, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
+      if (ta != pa) t[ta] = 1;
+      if (tb != ta) t[tb] = 1;
+      if (tc != pc) t[tc] = 1;
+      if (td != tc) t[td] = 1;
+    }
   }
 }
 
@@ -436,7 +447,8 @@ int mark_tiles_impl(const float* rays, const float* z_samp, const float* jitter,
                     int H, int W, int fs, unsigned char* tiles, hipStream_t s) {
   const long total = B * K;
   const int tpi = (int)((((long)(H >> fs) * (W >> fs)) + 63) / 64);
-  const long want = (total + 255) / 256;
+  const long want = (B + 3) / 4;   // one ray per wave iteration
+  (void)total;
   mark_tiles_kernel<<<(int)(want < 8192 ? want : 8192), 256, 0, s>>>(rays, z_samp, jitter, w2c_enc, K_enc, B, Bp, K, lindisp, H, W, fs, tpi, tiles);
   return hipGetLastError() == hipSuccess ? BTS_OK : BTS_E_LAUNCH;
 }
