@@ -778,6 +778,8 @@ __global__ __launch_bounds__(256, 2) void render_kernel_p(const FwdParams p) {
 #pragma unroll
     for (int i = 0; i < NVMAX * 3; ++i) rgb_part[i] = 0.0f;
 
+    float *o_rgb = nullptr, *o_depth = nullptr;   // (read in the chunk loop with the other output pointers, used behind it as well)
+    int white_bkgd = 0;
     for (int kc = 0; kc < (pk48 ? 192 : K); kc += 64) {
       const int it = kc >> 6;
       const int k = pk48 ? lane_k(it) : kc + kl;
@@ -993,6 +995,16 @@ __global__ __launch_bounds__(256, 2) void render_kernel_p(const FwdParams p) {
       if (q->sigma_noise) sigma += q->sigma_noise[ray * K + min(k, K - 1)];   // nerf.py:279-280, the caller drew it
       BTS_TICK(2)
 
+      // ---------------- the iteration's ten output pointers in ONE batch of scalar loads (they are neighbours in the kernarg segment),
+      // issued here so that the round trip runs under the colour taps.  Read where they are used -- each inside its own `if (pointer)` --
+      // they were ten dependent load / wait / branch steps behind each other in the store section (profiles/r04t: 3.8 k of the training
+      // forward's 28 k cycles per iteration).
+      o_rgb = q->rgb, o_depth = q->depth, white_bkgd = q->white_bkgd;
+      float *o_weights = q->weights, *o_alphas = q->alphas, *o_invalid = q->invalid, *o_rgb_samps = q->rgb_samps;
+      float *o_sigma_raw = q->sigma_raw, *o_trans = q->trans, *o_iw = q->invalid_wsum, *o_ia = q->invalid_any;
+      asm volatile("" : "+s"(o_rgb), "+s"(o_depth), "+s"(o_weights), "+s"(o_alphas), "+s"(o_invalid), "+s"(o_rgb_samps), "+s"(o_sigma_raw), "+s"(o_trans),
+                   "+s"(o_iw), "+s"(o_ia));
+
       // ---------------- colours (models_bts.py:218-264): projection into each render view + 4-tap fetch of the rgb0-packed frame.
       // Issued here, after lin_out, rather than before the MFMA phase: the taps' registers are not live across the accumulators
       // (0 spilled VGPRs, 5 % faster).  Round 1 had this order fail parity for nv <= 2 -- that was the packed-FP32 operand-select
@@ -1056,21 +1068,35 @@ __global__ __launch_bounds__(256, 2) void render_kernel_p(const FwdParams p) {
       BTS_TICK(3)
       // ---------------- per-ray reductions for the loss' invalid-ray policies (loss.py:100-118), instead of weights + invalid in HBM
       if constexpr (EPI) {
+        // every view's sum and flag first (no branch between the scans), then ONE block of stores on the ray's last lane: view after
+        // view -- scan, ballot, lane branch, two pointer branches, two one-lane stores -- was 16 branches per iteration at nv = 4
+        float ws[NVMAX], any[NVMAX];
+        const unsigned long long seg = pk48 ? (mainl ? 0x0000FFFFFFFFFFFFull : 0xFFFF000000000000ull)
+                                            : (lpr == 64 ? ~0ull : (((1ull << lpr) - 1ull) << ((lane | (lpr - 1)) - (lpr - 1))));
 #pragma unroll
-        for (int j = 0; j < NVMAX; ++j)
-          if (j < nv) {
-            const float ws = seg_scan_add((valid && inv[j]) ? wgt : 0.0f, lpr, kl);       // the last lane of each ray has the sum
-            const unsigned long long hit = __ballot(valid && inv[j]);
-            if (pk48 ? (lane == 47 || lane == 63) : kl == lpr - 1) {
-              const long idx = ray * nv + j;
-              const unsigned long long seg = pk48 ? (mainl ? 0x0000FFFFFFFFFFFFull : 0xFFFF000000000000ull)
-                                                  : (lpr == 64 ? ~0ull : (((1ull << lpr) - 1ull) << (lane - (lpr - 1))));
-              const float any = (hit & seg) ? 1.0f : 0.0f;
-              const bool more = pk48 ? (!mainl && it > 0) : kc > 0;   // K > 64: chunk after chunk; 48-lane mode: the fourth ray's rows
-              if (q->invalid_wsum) q->invalid_wsum[idx] = (more ? q->invalid_wsum[idx] : 0.0f) + ws;
-              if (q->invalid_any) q->invalid_any[idx] = more ? fmaxf(q->invalid_any[idx], any) : any;
+        for (int j = 0; j < NVMAX; ++j) {
+          ws[j] = seg_scan_add((valid && inv[j]) ? wgt : 0.0f, lpr, kl);       // the last lane of each ray has the sum
+          const unsigned long long hit = __ballot(valid && inv[j]);
+          any[j] = (hit & seg) ? 1.0f : 0.0f;
+        }
+        if (pk48 ? (lane == 47 || lane == 63) : kl == lpr - 1) {
+          const bool more = pk48 ? (!mainl && it > 0) : kc > 0;   // K > 64: chunk after chunk; 48-lane mode: the fourth ray's rows
+          const long idx = ray * nv;
+          if (nv == NVMAX && NVMAX % 4 == 0 && !more) {   // the common case: whole rows, nothing to merge with
+#pragma unroll
+            for (int j4 = 0; j4 < NVMAX / 4; ++j4) {
+              if (o_iw) reinterpret_cast<float4*>(o_iw + idx)[j4] = make_float4(ws[4 * j4], ws[4 * j4 + 1], ws[4 * j4 + 2], ws[4 * j4 + 3]);
+              if (o_ia) reinterpret_cast<float4*>(o_ia + idx)[j4] = make_float4(any[4 * j4], any[4 * j4 + 1], any[4 * j4 + 2], any[4 * j4 + 3]);
             }
+          } else {
+#pragma unroll
+            for (int j = 0; j < NVMAX; ++j)
+              if (j < nv) {
+                if (o_iw) o_iw[idx + j] = (more ? o_iw[idx + j] : 0.0f) + ws[j];
+                if (o_ia) o_ia[idx + j] = more ? fmaxf(o_ia[idx + j], any[j]) : any[j];
+              }
           }
+        }
       }
       depth_part = depth_part + wgt * z;
       w_part = w_part + wgt;
@@ -1078,19 +1104,19 @@ __global__ __launch_bounds__(256, 2) void render_kernel_p(const FwdParams p) {
       for (int i = 0; i < NVMAX * 3; ++i) rgb_part[i] = rgb_part[i] + wgt * col[i];
       if (valid && !BTS_ABL(16)) {
         const long pk = ray * K + k;
-        if (q->weights) q->weights[pk] = wgt;
-        if (q->alphas) q->alphas[pk] = alpha;
-        if (q->sigma_raw) q->sigma_raw[pk] = s_raw;
-        if (q->trans) q->trans[pk] = T;
-        if (q->invalid) {
+        if (o_weights) o_weights[pk] = wgt;
+        if (o_alphas) o_alphas[pk] = alpha;
+        if (o_sigma_raw) o_sigma_raw[pk] = s_raw;
+        if (o_trans) o_trans[pk] = T;
+        if (o_invalid) {
 #pragma unroll
           for (int j = 0; j < NVMAX; ++j)
-            if (j < nv) q->invalid[pk * nv + j] = inv[j] ? 1.0f : 0.0f;
+            if (j < nv) o_invalid[pk * nv + j] = inv[j] ? 1.0f : 0.0f;
         }
-        if (q->rgb_samps) {
+        if (o_rgb_samps) {
           // a sample's nv * 3 colours are contiguous: with every view present they leave as 16- (or 8-) byte pieces -- as 4-byte stores
           // 48 bytes apart between lanes, every instruction touched 24 lines for 4 bytes each (12 of them per sample at nv = 4)
-          float* dst = q->rgb_samps + pk * (nv * 3);
+          float* dst = o_rgb_samps + pk * (nv * 3);
           if (nv == NVMAX && (NVMAX * 3) % 4 == 0) {
 #pragma unroll
             for (int i = 0; i < NVMAX * 3 / 4; ++i)
@@ -1113,10 +1139,10 @@ __global__ __launch_bounds__(256, 2) void render_kernel_p(const FwdParams p) {
 #pragma unroll
         for (int i = 0; i < NVMAX * 3; ++i) csum[i] = i < nv * 3 ? seg_scan_add(rgb_part[i], 48, kl) : 0.0f;
         if (lane == 47 || (lane == 63 && it == 2)) {
-          q->depth[ray] = dsum;
+          o_depth[ray] = dsum;
 #pragma unroll
           for (int i = 0; i < NVMAX * 3; ++i)
-            if (i < nv * 3) q->rgb[ray * nv * 3 + i] = q->white_bkgd ? (csum[i] + 1.0f) - wsum : csum[i];  // nerf.py:301-304
+            if (i < nv * 3) o_rgb[ray * nv * 3 + i] = white_bkgd ? (csum[i] + 1.0f) - wsum : csum[i];  // nerf.py:301-304
         }
       }
     }
@@ -1129,10 +1155,19 @@ __global__ __launch_bounds__(256, 2) void render_kernel_p(const FwdParams p) {
       for (int i = 0; i < NVMAX * 3; ++i)
         if (i < nv * 3) rgb_part[i] = seg_scan_add(rgb_part[i], lpr, kl);
       if (kl == lpr - 1) {
-        q->depth[ray] = depth_part;
+        o_depth[ray] = depth_part;
+        float out[NVMAX * 3];
 #pragma unroll
-        for (int i = 0; i < NVMAX * 3; ++i)
-          if (i < nv * 3) q->rgb[ray * nv * 3 + i] = q->white_bkgd ? (rgb_part[i] + 1.0f) - w_part : rgb_part[i];  // nerf.py:301-304
+        for (int i = 0; i < NVMAX * 3; ++i) out[i] = white_bkgd ? (rgb_part[i] + 1.0f) - w_part : rgb_part[i];  // nerf.py:301-304
+        if (nv == NVMAX && (NVMAX * 3) % 4 == 0) {   // one lane, whole row: 16-byte stores
+#pragma unroll
+          for (int i = 0; i < NVMAX * 3 / 4; ++i)
+            reinterpret_cast<float4*>(o_rgb + ray * (NVMAX * 3))[i] = make_float4(out[4 * i], out[4 * i + 1], out[4 * i + 2], out[4 * i + 3]);
+        } else {
+#pragma unroll
+          for (int i = 0; i < NVMAX * 3; ++i)
+            if (i < nv * 3) o_rgb[ray * nv * 3 + i] = out[i];
+        }
       }
     }
     BTS_TICK(5)
