@@ -143,6 +143,12 @@ def test_errors_are_codes_with_messages_never_exceptions(lib):
     assert lib.bts_proj_tile_count(None) == 0
     assert lib.bts_project_features_bwd_tiles(C.byref(ok_size), 16, 16, None, 16, 1, 16, 16, 1, None) == -1 and b"NULL" in lib.bts_last_error()
     assert lib.bts_project_features_bwd_tiles(C.byref(cfg), 16, 16, 16, 16, 1, 16, 16, 1, None) == -2 and b"envelope" in lib.bts_last_error()
+    assert lib.bts_project_features_tiles(C.byref(ok_size), 16, 16, 1, None, 16, None) == -1 and b"NULL" in lib.bts_last_error()
+    assert lib.bts_project_features_tiles(C.byref(cfg), 16, 16, 1, 16, 16, None) == -2 and b"envelope" in lib.bts_last_error()
+    margs = _lib.BtsRenderArgs(rays_per_sample=8, K=4, rays=1)                      # neither z_samp nor jitter
+    assert lib.bts_mark_sampled_tiles(C.byref(ok_size), 16, 16, C.byref(margs), 16, None) == -1 and b"jitter" in lib.bts_last_error()
+    assert lib.bts_mark_sampled_tiles(C.byref(bad), 16, 16, C.byref(_lib.BtsRenderArgs(rays_per_sample=8, K=4, rays=1, z_samp=1)), 16, None) == -1
+    assert b"feat_shift" in lib.bts_last_error()
     with pytest.raises(bts.BtsNativeError):
         native.nchw_to_nhwc(torch.zeros(1, 4, 2, 2))                                # CPU tensor: no CPU path
     with pytest.raises(bts.BtsNativeError):
