@@ -19,8 +19,25 @@ struct BwdParams {
   uint2* pmask_ws;        //                    (n*Bp, HD) the same gates per channel, one bit per sample of the ray
   unsigned char* tiles;   // (n, tiles_per_img) dirty flags of d_proj's 64-texel tiles (BtsRenderGrads.d_proj_tiles), or null
   int tiles_per_img;
+#ifdef BTS_TICKS
+  unsigned long long* ticks;   // diagnostic build: [waves][16] cycles per section (rows_kernel: tools/bwd_ticks.py; scatter_kernel behind them)
+#endif
   float* flush_ws;        // kFlushSlots x (40 x HD) floats, zeroed by the launcher: pass C's dW_pe partial sums (dwpe_flush below)
 };
+
+// diagnostic build (-DBTS_TICKS, behindthescenes_amd/variants): s_memtime at the section borders of a kernel's iteration.  Reading the counter
+// drains lgkmcnt, so the sections are somewhat longer than in the product; their shares are what the numbers are for.
+#ifdef BTS_TICKS
+#define BW_TICK(i)                                                   \
+  {                                                                  \
+    const unsigned long long t_now = __builtin_readcyclecounter();   \
+    t_acc[i] += t_now - t_last;                                      \
+    t_last = t_now;                                                  \
+  }
+constexpr long kTicksScatterOffset = 4096L * 16;   // scatter_kernel's records start behind 4096 wave records of rows_kernel
+#else
+#define BW_TICK(i)
+#endif
 
 // Pass C ends with every work-group adding its 40 x HD partial sums of dW_pe / db_in into the SAME 40 x HD addresses of d_mlp: ~500-770
 // float atomics per address, issued by work-groups that all finish within microseconds of each other.  Measured (profiles/r04j, flush

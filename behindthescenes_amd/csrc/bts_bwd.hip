@@ -764,6 +764,10 @@ int render_bwd_impl(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const BtsR
   bp.g_rgb = g->g_rgb, bp.g_depth = g->g_depth, bp.g_weights = g->g_weights, bp.g_alphas = g->g_alphas;
   bp.d_proj = g->d_proj_nhwc, bp.d_mlp = g->d_mlp_params, bp.d_empty_proj = g->d_empty_proj;
   bp.gh_ws = nullptr, bp.gs_ws = nullptr, bp.mask_ws = nullptr, bp.pmask_ws = nullptr, bp.flush_ws = nullptr;
+#ifdef BTS_TICKS
+  bp.ticks = nullptr;
+  if (const char* e = getenv("BTS_DBG_PTR")) bp.ticks = (unsigned long long*)strtoull(e, nullptr, 0);   // diagnostic build only
+#endif
   bp.tiles = bp.d_proj ? g->d_proj_tiles : nullptr;
   bp.tiles_per_img = (int)((((long)(cfg->H >> cfg->feat_shift) * (cfg->W >> cfg->feat_shift)) + 63) / 64);
 #ifdef BTS_PROBE

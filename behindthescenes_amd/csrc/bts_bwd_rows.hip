@@ -247,6 +247,15 @@ __global__ __launch_bounds__(256, 2) void rows_kernel(const BwdParams bp) {
   }
   const int nv3 = p.nv * 3;
   float rec = g >= 0 ? fetch_ray_record(kernarg_view<BwdParams>(), (long)g, nv3, lane) : 0.0f;   // bts_bwd.h: the ray's scalars, one iteration ahead
+#ifdef BTS_TICKS
+  // sections: 0 head (ray record, camera, per-sample loads issued, geometry, taps, tile broadcast, first gather blocks out)
+  //           1 upstream weight gradient + compositing gradient (waits for the per-sample loads)   2 forward pipeline (gather, encoding, lin_in)
+  //           3 gate masks + dw_out
+  unsigned long long t_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long t_last = __builtin_readcyclecounter();
+  const unsigned long long t_begin = t_last;
+  unsigned n_iter = 0;
+#endif
 
   for (; g >= 0; idx += waves_per_xcd, g = group_of(idx)) {
     auto qb = kernarg_view<BwdParams>();   // this iteration's parameters, re-read where they are used (bts_common.h: kernarg_view)
@@ -339,6 +348,7 @@ __global__ __launch_bounds__(256, 2) void rows_kernel(const BwdParams bp) {
 #endif
 #endif
 
+    BW_TICK(0)
     // ---------------- upstream gradient of this sample's weight: g_w = g_depth z + sum_j g_rgb_j . c_kj (+ g_weights_k)
     float g_w = qb->g_depth ? g_depth * z : 0.0f;
     {
@@ -389,6 +399,7 @@ __global__ __launch_bounds__(256, 2) void rows_kernel(const BwdParams bp) {
       if (valid) qb->gs_ws[pk] = g_s;
     }
     db_acc += g_s;
+    BW_TICK(1)
     unsigned* __restrict__ mrow = qb->mask_ws + ray * (long)(HT * K);
     uint2* __restrict__ prow = qb->pmask_ws + ray * (long)HD;
 
@@ -449,6 +460,7 @@ __global__ __launch_bounds__(256, 2) void rows_kernel(const BwdParams bp) {
         }
     }
 
+    BW_TICK(2)
     // ---------------- gate masks; dw_out += relu(h) g_s (2^S removed through g_s)
     float gs_t[2];
     {
@@ -461,7 +473,19 @@ __global__ __launch_bounds__(256, 2) void rows_kernel(const BwdParams bp) {
 #else
     gates_and_dwout<HD>(acc, gs_t, mrow, prow, K, lane, dw_acc);
 #endif
+    BW_TICK(3)
+#ifdef BTS_TICKS
+    ++n_iter;
+#endif
   }
+#ifdef BTS_TICKS
+  if (bp.ticks && lane == 0 && (long)blockIdx.x * 4 + wave < 4096) {
+    unsigned long long* d = bp.ticks + ((long)blockIdx.x * 4 + wave) * 16;
+#pragma unroll
+    for (int i = 0; i < 13; ++i) d[i] = t_acc[i];
+    d[14] = n_iter, d[15] = __builtin_readcyclecounter() - t_begin;
+  }
+#endif
 
   // ---------------- dw_out, db_out: wave registers -> work-group LDS -> one atomic per parameter
   if (bp.d_mlp) {
@@ -509,6 +533,9 @@ struct ScatterMaskParams {
   int tiles_per_img;         // tile that receives a contribution is set to 1
   int groups_per_sample;
   int w_out_off;             // offset of w_out in the packed parameter vector
+#ifdef BTS_TICKS
+  unsigned long long* ticks; // diagnostic build: [waves][16] cycles per section of a step (tools/bwd_ticks.py)
+#endif
   int nseg, kseg;            // the K steps of a ray group are cut into nseg segments of kseg steps, one wave each (own window, own flush):
                              // a batch of few patches (RE10K: 384, KITTI-Raw: 256) otherwise leaves most of the 1024 SIMDs idle
 };
@@ -669,6 +696,15 @@ __global__ __launch_bounds__(64) void scatter_kernel(const ScatterMaskParams sp)
 #pragma unroll
     for (int i = 0; i < 32; ++i) nxt[i] = i < half_pts ? urow[i * pstride + (long)(k_hi - 1) * HD] : 0.0f;
   }
+#ifdef BTS_TICKS
+  // sections: 0 step inputs + geometry + taps   1 footprint (four wave minima), window move + flushes   2 slots, conflict test, table
+  //           3 read-modify-write rounds (+ the direct-atomics fallback)   12 set-up in front of the first step   13 final flush
+  unsigned long long t_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long t_last = __builtin_readcyclecounter();
+  const unsigned long long t_begin = clock64();
+  unsigned n_iter = 0;
+  BW_TICK(12)
+#endif
   for (int k = k_hi - 1; k >= k_lo; --k) {
     float z = z_n, gs = gs_n;
     unsigned gate = m_n;
@@ -705,6 +741,7 @@ __global__ __launch_bounds__(64) void scatter_kernel(const ScatterMaskParams sp)
     if (y1 == y0) tp.w00 += tp.w10, tp.w01 += tp.w11, tp.w10 = tp.w11 = 0.0f;
     const bool use_empty = (p.learn_empty != 0) & pe.invalid;
     if constexpr (!ROWS) tp.w00 *= gs, tp.w01 *= gs, tp.w10 *= gs, tp.w11 *= gs;   // ROWS: g_s is part of the rows
+    BW_TICK(0)
     bool fits = false;
     if (scatter) {
       const int mnx = wave_min_i(x0), mxx = -wave_min_i(-x1), mny = wave_min_i(y0), mxy = -wave_min_i(-y1);
@@ -718,6 +755,7 @@ __global__ __launch_bounds__(64) void scatter_kernel(const ScatterMaskParams sp)
         wx = nwx, wy = nwy;
       }
     }
+    BW_TICK(1)
     // window slots of the four taps.  A clamped tap (x1 == x0 or y1 == y0 at the far border: weight exactly 0) would alias its
     // neighbour's slot inside one round; it goes to the scratch row.  An empty-feature point sends g_s to its half's EMPTY row.
     const int rya = (int)((unsigned)y0 % CH) * CW, ryb = (int)((unsigned)y1 % CH) * CW;
@@ -756,6 +794,7 @@ __global__ __launch_bounds__(64) void scatter_kernel(const ScatterMaskParams sp)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    BW_TICK(2)
     if (amask == 0) {
       // one straight block: the table reads of later pairs may run ahead of the window's read-modify-write rounds
 #ifdef BTS_ABL_S1   // timing ablation: no read-modify-write rounds
@@ -805,8 +844,21 @@ __global__ __launch_bounds__(64) void scatter_kernel(const ScatterMaskParams sp)
         }
       }
     }
+    BW_TICK(3)
+#ifdef BTS_TICKS
+    ++n_iter;
+#endif
   }
   if (scatter) flush(0, 0, true);
+#ifdef BTS_TICKS
+  BW_TICK(13)
+  if (sp.ticks && lane == 0 && blockIdx.x < 4096) {
+    unsigned long long* d = sp.ticks + kTicksScatterOffset + (long)blockIdx.x * 16;
+#pragma unroll
+    for (int i = 0; i < 14; ++i) d[i] = t_acc[i];
+    d[14] = n_iter, d[15] = clock64() - t_begin;
+  }
+#endif
   if (sp.d_empty_proj && h == 0) {
     const float v = cache[EMPTY * 32 + c] + cache[(EMPTY + 1) * 32 + c];
     if (v != 0.0f) atomic_add_f32(sp.d_empty_proj + proj_hidden_of_storage(chg), v);
@@ -1236,6 +1288,9 @@ static int launch_rows(const BwdParams& bp, int n, int grid, hipStream_t s) {
     ScatterMaskParams sp;
     sp.f = p, sp.mask_ws = bp.mask_ws, sp.u0_ws = nullptr, sp.gs_ws = bp.gs_ws, sp.d_proj = bp.d_proj, sp.d_empty_proj = bp.d_empty_proj;
     sp.tiles = bp.tiles, sp.tiles_per_img = bp.tiles_per_img;
+#ifdef BTS_TICKS
+    sp.ticks = bp.ticks;
+#endif
     sp.groups_per_sample = (p.Bp + 63) / 64, sp.w_out_off = ml.w_out();
     const long units = (long)n * sp.groups_per_sample * (HD / 32);
     scatter_segments(sp, units, p.K);
@@ -1266,6 +1321,13 @@ static int launch_rows(const BwdParams& bp, int n, int grid, hipStream_t s) {
 int device_cu_count();
 static void scatter_segments(ScatterMaskParams& sp, long units, int K) {
   long want = 8L * device_cu_count() / units;
+  // ... unless the patches alone (nearly) fill the chip: then FOUR segments each, i.e. several rounds of short waves.  A wave's time
+  // depends on its patch (pairs that share window slots, footprints that outgrow the window, many window moves): at exp_kitti_360.yaml's
+  // 2 048 patch halves the slowest wave lived 1.8 x the average one and the launch lasted as long as it did (tools/bwd_ticks.py,
+  // profiles/r04zz/bwd_ticks.txt); with 8 192 waves of 16 steps the places are refilled as waves finish and a slow patch holds one for a
+  // quarter of the time (0.955 -> 0.909 ms of backward per step, profiles/r04zz/scatter_oversub.txt; two segments: 0.934).  Between one
+  // and two rounds is the bad zone (above).
+  if (want < 2) want = 4;
   const long most = K >= 8 ? K / 8 : 1;
   if (want > most) want = most;
   if (want < 1) want = 1;
@@ -1279,6 +1341,9 @@ int launch_scatter_rows(const BwdParams& bp, const float* u0_ws, int HD, int n, 
   ScatterMaskParams sp;
   sp.f = p, sp.mask_ws = nullptr, sp.u0_ws = u0_ws, sp.gs_ws = bp.gs_ws, sp.d_proj = bp.d_proj, sp.d_empty_proj = bp.d_empty_proj;
   sp.tiles = bp.tiles, sp.tiles_per_img = bp.tiles_per_img;
+#ifdef BTS_TICKS
+  sp.ticks = bp.ticks;
+#endif
   sp.groups_per_sample = (p.Bp + 63) / 64, sp.w_out_off = 0;
   const long units = (long)n * sp.groups_per_sample * (HD / 32);
   scatter_segments(sp, units, p.K);
