@@ -7,9 +7,14 @@ import os
 import threading
 
 PKG = os.path.dirname(os.path.abspath(__file__))
-# BTS_RENDER_LIB lets the profiling tools load the instrumented probe build (libbts_probe.so); the product always loads libbts_render.so
-LIB_PATH = os.environ.get("BTS_RENDER_LIB") or os.path.join(PKG, "libbts_render.so")
-ABI_VERSION = 6
+# The product always loads libbts_render.so from the package directory.  The profiling / A-B tools load another build of the same sources
+# (the instrumented probe build, an older revision's kernels) through BTS_RENDER_LIB -- honoured ONLY together with
+# BTS_ALLOW_LIB_OVERRIDE=1 and announced on stderr, so that a stale variable in somebody's shell cannot silently swap the library.
+_OVERRIDE = os.environ.get("BTS_RENDER_LIB") if os.environ.get("BTS_ALLOW_LIB_OVERRIDE") == "1" else None
+LIB_PATH = _OVERRIDE or os.path.join(PKG, "libbts_render.so")
+ABI_VERSION = 7
+BTS_MAX_SCALES = 4
+BTS_MAX_LOSS_VIEWS = 16
 
 BTS_MAX_VIEWS = 8
 ERRORS = {-1: "BTS_E_INVALID", -2: "BTS_E_UNSUPPORTED", -3: "BTS_E_LAUNCH", -4: "BTS_E_WORKSPACE"}
@@ -48,6 +53,27 @@ class BtsLossArgs(C.Structure):
                [("scale_rgb", C.c_float), ("scale_eas", C.c_float)] + [(k, C.c_void_p) for k in ("invalid_wsum", "invalid_any")]
 
 
+class BtsTrainScale(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("feat_nchw", "jitter", "rgb", "depth", "invalid_wsum", "invalid_any", "proj_nhwc", "sampled_tiles",
+                                          "z_samp", "sigma_raw", "trans", "rgb_samps", "loss_parts", "g_rgb", "g_depth", "gs_rgb", "gs_depth",
+                                          "d_proj_nhwc", "d_proj_tiles", "d_feat_nchw")] + \
+               [("feat_shift", C.c_int32), ("reserved_", C.c_int32)]
+
+
+class BtsTrainStep(C.Structure):
+    _fields_ = [("cfg", BtsFieldCfg), ("v", C.c_int32), ("id_encoder", C.c_int32), ("ids_render", C.c_int32 * BTS_MAX_VIEWS),
+                ("n_loss", C.c_int32), ("ids_loss", C.c_int32 * BTS_MAX_LOSS_VIEWS)] + \
+               [(k, C.c_int32) for k in ("P", "ph", "pw", "K", "lindisp", "hard_alpha_cap", "invalid_policy", "edge_aware_smoothness", "n_scales",
+                                         "reserved_")] + \
+               [(k, C.c_float) for k in ("z_near", "z_far", "img_scale", "img_shift")] + \
+               [("loss_matrix", C.c_float * (9 * 3 * BTS_MAX_SCALES))] + \
+               [(k, C.c_void_p) for k in ("images", "Ks", "poses_c2w", "patch_v", "patch_y", "patch_x", "mlp_params", "empty_feature", "rays", "rgb_gt",
+                                          "loss_vals", "cams", "imgs_nhwc4", "bwd_workspace")] + \
+               [("bwd_workspace_bytes", C.c_size_t)] + \
+               [(k, C.c_void_p) for k in ("d_empty_proj", "d_mlp_params", "d_empty_feature")] + \
+               [("scale", BtsTrainScale * BTS_MAX_SCALES)]
+
+
 # every symbol include/bts_render.h declares: name -> (restype, argtypes)
 _P = C.c_void_p
 _I = C.c_int32
@@ -77,6 +103,8 @@ SYMBOLS = {
     "bts_sample_coarse": (C.c_int, [_P, _P, C.c_int64, _I, _I, _P, _P]),
     "bts_distance_to_z": (C.c_int, [_P, _P, _I, _I, _I, _P, _P]),
     "bts_invert_small": (C.c_int, [_P, _P, _I, _I, _P]),
+    "bts_train_step_fwd": (C.c_int, [C.POINTER(BtsTrainStep), _P]),
+    "bts_train_step_bwd": (C.c_int, [C.POINTER(BtsTrainStep), _P, _P]),
 }
 
 _lock = threading.Lock()
@@ -95,6 +123,10 @@ def load():
             raise BtsNativeError(
                 f"{LIB_PATH} not found: the HIP renderer has not been built. Run `python -m behindthescenes_amd.build` "
                 "(needs hipcc, no GPU). There is no fallback path.")
+        if _OVERRIDE:
+            import sys
+            print(f"behindthescenes_amd: loading {LIB_PATH} instead of the package's libbts_render.so (BTS_RENDER_LIB + BTS_ALLOW_LIB_OVERRIDE=1)",
+                  file=sys.stderr)
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             try:
@@ -104,7 +136,7 @@ def load():
             fn.restype, fn.argtypes = res, args
         # (A/B tools load an older revision's kernels through BTS_RENDER_LIB: the structs only ever grew at their ends, so a library
         # of an older ABI reads the prefix it knows -- opt-in, tools only)
-        if lib.bts_abi_version() != ABI_VERSION and not (os.environ.get("BTS_RENDER_LIB") and os.environ.get("BTS_ALLOW_OLDER_ABI") == "1"
+        if lib.bts_abi_version() != ABI_VERSION and not (_OVERRIDE and os.environ.get("BTS_ALLOW_OLDER_ABI") == "1"
                                                          and lib.bts_abi_version() < ABI_VERSION):
             raise BtsNativeError(f"ABI mismatch: library {lib.bts_abi_version()} vs binding {ABI_VERSION}; rebuild")
         _lib = lib

@@ -18,7 +18,7 @@ LIB = os.path.join(PKG, "libbts_render.so")
 VARIANTS = os.path.join(PKG, "variants")
 # objects, saved assembly and the digest stamp live outside the repo (they are large and must not travel to the GPU box)
 OBJ = os.path.join(os.environ.get("BTS_OBJ_DIR", "/tmp"), "bts_render_obj")
-SOURCES = ["bts_fwd.hip", "bts_fwd_proj.hip", "bts_fwd_epi.hip", "bts_query.hip", "bts_bwd.hip", "bts_bwd_rows.hip", "bts_bwd_blocks.hip", "bts_prep.hip", "bts_aux.hip", "bts_loss.hip", "bts_api.hip"]
+SOURCES = ["bts_fwd.hip", "bts_fwd_proj.hip", "bts_fwd_epi.hip", "bts_query.hip", "bts_bwd.hip", "bts_bwd_rows.hip", "bts_bwd_blocks.hip", "bts_prep.hip", "bts_aux.hip", "bts_loss.hip", "bts_train.hip", "bts_api.hip"]
 # -fno-slp-vectorize: hipcc's SLP vectoriser builds v_pk_*_f32 with op_sel:[x,1], which MI355X evaluates wrongly in lanes 48-63 next
 # to a wide MFMA (tools/check_pk_opsel.py, tools/ubench/pk_opsel_lanes.hip); explicit float2 code keeps the packed FMAs that matter
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-fno-gpu-rdc",
@@ -43,11 +43,13 @@ def hipcc():
 
 
 def build_library(force: bool = False, verbose: bool = False, probe: bool = False, tag: str = "", extra_flags=()) -> str:
-    """probe=True builds libbts_probe.so: the same sources with -DBTS_PROBE (section-ablation hooks for tools/ablate_probe.py;
+    """probe=True builds variants/libbts_probe.so: the same sources with -DBTS_PROBE (section-ablation hooks for tools/ablate_probe.py;
     never loaded by the product path).  tag="x" builds behindthescenes_amd/variants/libbts_x.so with `extra_flags` appended (or
     replacing -O3 when an -O level is given): differently scheduled builds of the same sources for the second-schedule parity
     tests and for hazard bisection; loaded only through BTS_RENDER_LIB."""
-    lib = LIB.replace("libbts_render", "libbts_probe") if probe else LIB
+    lib = os.path.join(VARIANTS, "libbts_probe.so") if probe else LIB      # (never in the package directory: the product has ONE library)
+    if probe:
+        os.makedirs(VARIANTS, exist_ok=True)
     obj_dir = OBJ + ("_probe" if probe else "")
     extra = list(extra_flags) + [f for f in os.environ.get("BTS_EXTRA_FLAGS", "").split() if f]
     flags = FLAGS + (["-DBTS_PROBE"] if probe else [])

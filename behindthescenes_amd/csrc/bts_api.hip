@@ -213,7 +213,13 @@ int bts_project_features_bwd(const BtsFieldCfg* cfg, const float* feat_nchw, con
 }
 
 int64_t bts_proj_tile_count(const BtsFieldCfg* cfg) {
-  if (!cfg || cfg->H <= 0 || cfg->W <= 0 || cfg->feat_shift < 0 || cfg->feat_shift > 3) return 0;
+  // the same bound every entry point that takes the flags checks (check_shift: 0 .. 6, H and W multiples of 2^feat_shift); an invalid
+  // configuration answers -1 with a message, never 0 -- a caller that sized its flag array with 0 would hand the kernels no flags at all
+  if (!cfg || cfg->H <= 0 || cfg->W <= 0) {
+    set_error("%s: NULL cfg or non-positive size", "bts_proj_tile_count");
+    return -1;
+  }
+  if (check_shift(cfg, "bts_proj_tile_count")) return -1;
   return (feat_texels(cfg) + 63) / 64;
 }
 

@@ -50,11 +50,18 @@ int transpose_launch(const float* src, float* dst, int N, int C, int H, int W, b
   return hipGetLastError() == hipSuccess ? BTS_OK : BTS_E_LAUNCH;
 }
 
-// (N, 3, H, W) -> (N, H, W, 4) rgb0, x*scale + shift  (encode's images * .5 + .5, models_bts.py:82)
+// (N, 3, H, W) -> (N, H, W, 4) rgb0, x*scale + shift  (encode's images * .5 + .5, models_bts.py:82).  With a frame table (nv > 0) the
+// source is (n, v, 3, H, W) and output frame (smp, j) reads input frame (smp, ids[j]): BTSNet.encode's `images[:, ids_render]` without
+// the copy (bts_train_step_fwd)
+struct FrameIds {
+  int nv, v, ids[BTS_MAX_VIEWS];
+};
 __global__ __launch_bounds__(256) void pack_rgb_kernel(const float* __restrict__ src, float4* __restrict__ dst, long HW, long total,
-                                                       float scale, float shift) {
+                                                       float scale, float shift, const FrameIds f) {
   for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const long n = i / HW, p = i - n * HW;
+    long n = i / HW;
+    const long p = i - n * HW;
+    if (f.nv > 0) n = (n / f.nv) * f.v + f.ids[n % f.nv];
     const float* s = src + n * 3 * HW + p;
     float4 o;
     o.x = s[0] * scale + shift;
@@ -68,10 +75,23 @@ __global__ __launch_bounds__(256) void pack_rgb_kernel(const float* __restrict__
 int pack_rgb_launch(const float* src, float* dst, int N, int H, int W, float scale, float shift, hipStream_t s) {
   const long HW = (long)H * W, total = HW * N;
   const int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
-  pack_rgb_kernel<<<grid, 256, 0, s>>>(src, reinterpret_cast<float4*>(dst), HW, total, scale, shift);
+  FrameIds f;
+  f.nv = 0, f.v = 0;
+  pack_rgb_kernel<<<grid, 256, 0, s>>>(src, reinterpret_cast<float4*>(dst), HW, total, scale, shift, f);
   return hipGetLastError() == hipSuccess ? BTS_OK : BTS_E_LAUNCH;
 }
 
+// frames (n, v, 3, H, W) -> (n, nv, H, W, 4): frame ids[j] of every batch element
+int pack_rgb_views_launch(const float* src, float* dst, int n, int v, int nv, const int* ids, int H, int W, float scale, float shift, hipStream_t s) {
+  const long HW = (long)H * W, total = HW * n * nv;
+  if (total == 0) return BTS_OK;
+  const int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+  FrameIds f;
+  f.nv = nv, f.v = v;
+  for (int j = 0; j < BTS_MAX_VIEWS; ++j) f.ids[j] = j < nv ? ids[j] : 0;
+  pack_rgb_kernel<<<grid, 256, 0, s>>>(src, reinterpret_cast<float4*>(dst), HW, total, scale, shift, f);
+  return hipGetLastError() == hipSuccess ? BTS_OK : BTS_E_LAUNCH;
+}
 
 // the ray of pixel (x, y) of a view: [c2w translation, R @ unproj(pixel), near, far]  (util.py:113-149, 244-273)
 __device__ __forceinline__ void ray_of_pixel(const float* __restrict__ P, const float* __restrict__ Kp, int H, int W, int x, int y,
@@ -122,11 +142,17 @@ int gen_rays_launch(const float* poses, const float* projs, int V, int H, int W,
 // patch_rays: PatchRaySampler.sample on device (ray_sampler.py:125-162).  Per sample P patches (view, y0, x0) of ph x pw pixels:
 // the rays of exactly those pixels (never the (n, v, H, W, 8) ray volume the reference builds and then slices) and, when frames are
 // given, their ground-truth colours gathered from the NCHW frames.  Output order = the reference's: patch-major, then row, then column.
+// With a view table (m.n > 0) the patch's view index names an entry of it (the reference samples from images[:, ids_loss]); the colours
+// leave as x * gt_scale + gt_shift (mul, then add: the trainer's images * .5 + .5 applied to the gathered pixels only).
+struct ViewTable {
+  int n, ids[BTS_MAX_LOSS_VIEWS];
+};
 __global__ __launch_bounds__(256) void patch_rays_kernel(const float* __restrict__ poses, const float* __restrict__ projs,
                                                          const float* __restrict__ images, const int* __restrict__ pv,
                                                          const int* __restrict__ py, const int* __restrict__ px, int n, int v, int c, int H,
                                                          int W, int P, int ph, int pw, float z_near, float z_far, int norm_dir,
-                                                         float4* __restrict__ rays, float* __restrict__ gt) {
+                                                         float4* __restrict__ rays, float* __restrict__ gt, const ViewTable m, float gt_scale,
+                                                         float gt_shift) {
   const int per = P * ph * pw;
   const long total = (long)n * per;
   for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
@@ -135,7 +161,8 @@ __global__ __launch_bounds__(256) void patch_rays_kernel(const float* __restrict
     const int patch = rem / (ph * pw);
     rem -= patch * ph * pw;
     const int dy = rem / pw, dx = rem - dy * pw;
-    const int view = pv[smp * P + patch];
+    int view = pv[smp * P + patch];
+    if (m.n > 0) view = m.ids[min(max(view, 0), m.n - 1)];
     const int y = py[smp * P + patch] + dy, x = px[smp * P + patch] + dx;
     float4 a, b;
     ray_of_pixel(poses + ((long)smp * v + view) * 16, projs + ((long)smp * v + view) * 9, H, W, x, y, z_near, z_far, norm_dir, a, b);
@@ -143,19 +170,28 @@ __global__ __launch_bounds__(256) void patch_rays_kernel(const float* __restrict
     rays[2 * i + 1] = b;
     if (gt) {
       const float* img = images + (((long)smp * v + view) * c) * H * W + (long)y * W + x;
-      for (int ch = 0; ch < c; ++ch) gt[i * c + ch] = img[(long)ch * H * W];
+      for (int ch = 0; ch < c; ++ch) gt[i * c + ch] = img[(long)ch * H * W] * gt_scale + gt_shift;
     }
   }
 }
 
-int patch_rays_launch(const float* poses, const float* projs, const float* images, const int* pv, const int* py, const int* px, int n, int v,
-                      int c, int H, int W, int P, int ph, int pw, float zn, float zf, int norm_dir, float* rays, float* gt, hipStream_t s) {
+int patch_rays_views_launch(const float* poses, const float* projs, const float* images, const int* pv, const int* py, const int* px, int n, int v,
+                            int c, int H, int W, int P, int ph, int pw, float zn, float zf, int norm_dir, float* rays, float* gt, int n_ids,
+                            const int* ids, float gt_scale, float gt_shift, hipStream_t s) {
   const long total = (long)n * P * ph * pw;
   if (total == 0) return BTS_OK;
   const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  ViewTable m;
+  m.n = n_ids;
+  for (int j = 0; j < BTS_MAX_LOSS_VIEWS; ++j) m.ids[j] = j < n_ids ? ids[j] : 0;
   patch_rays_kernel<<<grid, 256, 0, s>>>(poses, projs, images, pv, py, px, n, v, c, H, W, P, ph, pw, zn, zf, norm_dir,
-                                         reinterpret_cast<float4*>(rays), images ? gt : nullptr);
+                                         reinterpret_cast<float4*>(rays), images ? gt : nullptr, m, gt_scale, gt_shift);
   return hipGetLastError() == hipSuccess ? BTS_OK : BTS_E_LAUNCH;
+}
+
+int patch_rays_launch(const float* poses, const float* projs, const float* images, const int* pv, const int* py, const int* px, int n, int v,
+                      int c, int H, int W, int P, int ph, int pw, float zn, float zf, int norm_dir, float* rays, float* gt, hipStream_t s) {
+  return patch_rays_views_launch(poses, projs, images, pv, py, px, n, v, c, H, W, P, ph, pw, zn, zf, norm_dir, rays, gt, 0, nullptr, 1.0f, 0.0f, s);
 }
 
 // sample_coarse: s = linspace(0, 1-1/K, K)[k] + u/K ; z = near(1-s) + far s   or   1/((1/near)(1-s) + (1/far) s)
@@ -215,14 +251,12 @@ int distance_to_z_launch(const float* depths, const float* invK, int N, int H, i
 // fp32 -- within 1 ulp of any correctly working fp32 LU, and no hipSOLVER call / host synchronisation on the render path.
 // ----------------------------------------------------------------------------------------------------------------
 template <int D>
-__global__ __launch_bounds__(64) void invert_small_kernel(const float* __restrict__ src, float* __restrict__ dst, int N) {
-  const int i = blockIdx.x * 64 + threadIdx.x;
-  if (i >= N) return;
+__device__ __forceinline__ void invert_small_dev(const float* __restrict__ src, float* __restrict__ dst) {
   double a[D][2 * D];
 #pragma unroll
   for (int r = 0; r < D; ++r)
 #pragma unroll
-    for (int c = 0; c < D; ++c) a[r][c] = (double)src[(long)i * D * D + r * D + c], a[r][D + c] = r == c ? 1.0 : 0.0;
+    for (int c = 0; c < D; ++c) a[r][c] = (double)src[r * D + c], a[r][D + c] = r == c ? 1.0 : 0.0;
 #pragma unroll
   for (int col = 0; col < D; ++col) {
     int piv = col;
@@ -253,7 +287,47 @@ __global__ __launch_bounds__(64) void invert_small_kernel(const float* __restric
 #pragma unroll
   for (int r = 0; r < D; ++r)
 #pragma unroll
-    for (int c = 0; c < D; ++c) dst[(long)i * D * D + r * D + c] = (float)a[r][D + c];
+    for (int c = 0; c < D; ++c) dst[r * D + c] = (float)a[r][D + c];
+}
+
+template <int D>
+__global__ __launch_bounds__(64) void invert_small_kernel(const float* __restrict__ src, float* __restrict__ dst, int N) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= N) return;
+  invert_small_dev<D>(src + (long)i * D * D, dst + (long)i * D * D);
+}
+
+// The camera part of BTSNet.encode (models_bts.py:71-97, 120-136) for a training step: world -> camera of the encoder frame and of the
+// nv render frames (the inverse above on exactly those poses) and their intrinsics, gathered into the contiguous blocks the render
+// kernels read: cams = [K_enc (n, 9) | w2c_enc (n, 16) | K_r (n, nv, 9) | w2c_r (n, nv, 16)].  One thread per (batch element, frame).
+struct CamIds {
+  int nv, v, id_enc, ids[BTS_MAX_VIEWS];
+};
+__global__ __launch_bounds__(64) void camera_prep_kernel(const float* __restrict__ Ks, const float* __restrict__ poses, int n, const CamIds f,
+                                                        float* __restrict__ cams) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= n * (1 + f.nv)) return;
+  const int smp = i / (1 + f.nv), j = i - smp * (1 + f.nv);
+  const int frame = j == 0 ? f.id_enc : f.ids[j - 1];
+  float* K_enc = cams;
+  float* w2c_enc = K_enc + (long)n * 9;
+  float* K_r = w2c_enc + (long)n * 16;
+  float* w2c_r = K_r + (long)n * f.nv * 9;
+  float* Kd = j == 0 ? K_enc + smp * 9 : K_r + ((long)smp * f.nv + (j - 1)) * 9;
+  float* Pd = j == 0 ? w2c_enc + smp * 16 : w2c_r + ((long)smp * f.nv + (j - 1)) * 16;
+  const float* Ksrc = Ks + ((long)smp * f.v + frame) * 9;
+#pragma unroll
+  for (int e = 0; e < 9; ++e) Kd[e] = Ksrc[e];
+  invert_small_dev<4>(poses + ((long)smp * f.v + frame) * 16, Pd);
+}
+
+int camera_prep_launch(const float* Ks, const float* poses, int n, int v, int id_enc, int nv, const int* ids, float* cams, hipStream_t s) {
+  CamIds f;
+  f.nv = nv, f.v = v, f.id_enc = id_enc;
+  for (int j = 0; j < BTS_MAX_VIEWS; ++j) f.ids[j] = j < nv ? ids[j] : 0;
+  const int total = n * (1 + nv);
+  camera_prep_kernel<<<(total + 63) / 64, 64, 0, s>>>(Ks, poses, n, f, cams);
+  return hipGetLastError() == hipSuccess ? BTS_OK : BTS_E_LAUNCH;
 }
 
 int invert_small_launch(const float* src, float* dst, int N, int dim, hipStream_t s) {

@@ -1,0 +1,327 @@
+// bts_train_step_fwd / bts_train_step_bwd (ABI 7): a training step's share of the renderer enqueued from ONE call per direction.
+//
+// Nothing here computes anything new: the forward is camera hand-over -> rgb0 packing of the render frames -> patch rays, then per
+// scale tile flags -> projection of the flagged tiles -> the fused render kernel (lean outputs + the backward's saved state) -> the
+// photometric loss pass, and one reduction of the per-patch sums; the backward is, per scale, the three render passes and the tile
+// projection backward.  The kernels, their launch geometry and their arguments are those of the entry-by-entry path
+// (bts_render_fwd, bts_photometric_loss, ...: the *_impl functions those entry points call) -- what goes away is the HOST work
+// between them: ~20 ctypes calls, ~40 allocator round trips, the autograd nodes and ~25 small torch kernels per exp_kitti_raw.yaml
+// step, which took longer to issue (1.1 ms) than the GPU needed to run the step's kernels (0.5 ms).
+// Reference: BTSWrapper.forward (models/bts/trainer.py:208-259) + the criterion call of utils/base_trainer.py:287-297.
+#include "bts_common.h"
+
+#include <cstring>
+
+namespace bts {
+
+void set_error(const char* fmt, const char* a = "", long b = 0, long c = 0, long d = 0);
+bool shape_supported(int C, int HD, int NB);
+
+int camera_prep_launch(const float* Ks, const float* poses, int n, int v, int id_enc, int nv, const int* ids, float* cams, hipStream_t s);
+int pack_rgb_views_launch(const float* src, float* dst, int n, int v, int nv, const int* ids, int H, int W, float scale, float shift, hipStream_t s);
+int patch_rays_views_launch(const float* poses, const float* projs, const float* images, const int* pv, const int* py, const int* px, int n, int v,
+                            int c, int H, int W, int P, int ph, int pw, float zn, float zf, int norm_dir, float* rays, float* gt, int n_ids,
+                            const int* ids, float gt_scale, float gt_shift, hipStream_t s);
+int photometric_loss_impl(const BtsLossArgs* a, hipStream_t s);
+int project_features_impl(int C, int HD, const float* feat, const float* mlp, int N, int HW, float* proj, const unsigned char* tiles, hipStream_t s);
+int mark_tiles_impl(const float* rays, const float* z_samp, const float* jitter, const float* w2c_enc, const float* K_enc, long B, int Bp, int K, int lindisp,
+                    int H, int W, int fs, unsigned char* tiles, hipStream_t s);
+int project_features_bwd_tiles_impl(int C, int HD, const float* feat, float* dproj, unsigned char* tiles, const float* mlp, int N, int HW, float* dfeat,
+                                    float* d_mlp, int clear, hipStream_t s);
+int render_fwd_impl(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const BtsRenderArgs* a, hipStream_t s);
+size_t render_bwd_workspace_impl(const BtsFieldCfg* cfg, const BtsRenderArgs* a);
+int render_bwd_impl(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const BtsRenderArgs* a, const BtsRenderGrads* g, void* ws, size_t ws_bytes,
+                    hipStream_t s);
+
+// ---- loss_vals = loss_matrix . [per-scale sums of the loss pass' per-patch parts]: one work-group, lanes stride the patches
+struct FinishParams {
+  const float* parts[BTS_MAX_SCALES];   // (n_patches, 4) each
+  int n_scales, n_patches;
+  float M[9 * 3 * BTS_MAX_SCALES];
+  float* out;   // (9)
+};
+__global__ __launch_bounds__(256) void loss_finish_kernel(const FinishParams p) {
+  __shared__ float red[4][3 * BTS_MAX_SCALES];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float acc[3 * BTS_MAX_SCALES];
+#pragma unroll
+  for (int i = 0; i < 3 * BTS_MAX_SCALES; ++i) acc[i] = 0.0f;
+#pragma unroll
+  for (int s = 0; s < BTS_MAX_SCALES; ++s) {
+    if (s >= p.n_scales) break;
+    const float4* q = reinterpret_cast<const float4*>(p.parts[s]);
+    for (int i = threadIdx.x; i < p.n_patches; i += 256) {
+      const float4 v = q[i];
+      acc[3 * s] += v.x, acc[3 * s + 1] += v.y, acc[3 * s + 2] += v.z;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 3 * BTS_MAX_SCALES; ++i) {
+    float v = acc[i];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    if (lane == 0) red[wave][i] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 9) {
+    const int cols = 3 * p.n_scales;
+    float o = 0.0f;
+    for (int c = 0; c < cols; ++c) o += p.M[threadIdx.x * cols + c] * (((red[0][c] + red[1][c]) + red[2][c]) + red[3][c]);
+    p.out[threadIdx.x] = o;
+  }
+}
+
+// ---- gs = g * (coefficient of the scale's sum in the loss * upstream gradient): what autograd does with the loss pass' gradients on the
+// entry-by-entry path (`g_rgb * g[0]`, g = loss_matrix[8] * upstream: the same two roundings)
+struct ScaleGradParams {
+  const float* g_rgb[BTS_MAX_SCALES];
+  const float* g_depth[BTS_MAX_SCALES];
+  float* gs_rgb[BTS_MAX_SCALES];
+  float* gs_depth[BTS_MAX_SCALES];
+  float c_rgb[BTS_MAX_SCALES], c_eas[BTS_MAX_SCALES];
+  const float* g_loss;   // device scalar or null (1)
+  int n_scales;
+  long n_rgb, n_depth;   // elements per scale
+};
+__global__ __launch_bounds__(256) void scale_grads_kernel(const ScaleGradParams p) {
+  const float up = p.g_loss ? *p.g_loss : 1.0f;
+  const int s = blockIdx.y;
+  const float a = p.c_rgb[s] * up, b = p.c_eas[s] * up;
+  const float* gr = p.g_rgb[s];
+  const float* gd = p.g_depth[s];
+  float* orr = p.gs_rgb[s];
+  float* od = p.gs_depth[s];
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < p.n_rgb; i += (long)gridDim.x * 256) orr[i] = gr[i] * a;
+  if (gd && od)
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < p.n_depth; i += (long)gridDim.x * 256) od[i] = gd[i] * b;
+}
+
+// ---- learn_empty: the render backward leaves the gradient of the PROJECTED empty feature e_p = w_in[:, :C] . e in d_empty_proj (Hd);
+// chain rule on parameter-sized tensors: d e[c] = sum_h w_in[h, c] d e_p[h],  d w_in[h, c] += d e_p[h] e[c]
+__global__ __launch_bounds__(256) void empty_grad_kernel(const float* __restrict__ mlp, const float* __restrict__ empty, const float* __restrict__ d_eproj,
+                                                       int C, int HD, int d_in, float* __restrict__ d_mlp, float* __restrict__ d_empty) {
+  for (int i = threadIdx.x; i < HD * C; i += 256) {
+    const int h = i / C, c = i - h * C;
+    if (d_mlp) d_mlp[h * d_in + c] += d_eproj[h] * empty[c];
+  }
+  if (d_empty)
+    for (int c = threadIdx.x; c < C; c += 256) {
+      float a = 0.0f;
+      for (int h = 0; h < HD; ++h) a += mlp[h * d_in + c] * d_eproj[h];
+      d_empty[c] = a;
+    }
+}
+
+static long map_texels(const BtsTrainStep* st, int s) { return (long)(st->cfg.H >> st->scale[s].feat_shift) * (st->cfg.W >> st->scale[s].feat_shift); }
+
+static int check_step(const BtsTrainStep* st, const char* who, bool bwd) {
+  if (!st) {
+    set_error("%s: NULL step", who);
+    return BTS_E_INVALID;
+  }
+  const BtsFieldCfg& c = st->cfg;
+  if (c.n <= 0 || c.H <= 0 || c.W <= 0 || st->v <= 0 || st->P <= 0 || st->ph <= 0 || st->pw <= 0 || st->K <= 0 || st->ph * st->pw > 64 ||
+      st->ph > c.H || st->pw > c.W) {
+    set_error("%s: non-positive size, or a patch of more than 64 pixels / larger than the frame (n=%ld, P=%ld, K=%ld)", who, c.n, st->P, st->K);
+    return BTS_E_INVALID;
+  }
+  if (!shape_supported(c.C, c.d_hidden, c.n_blocks) || c.num_freqs != kNumFreqs || c.nv < 1 || c.nv > BTS_MAX_VIEWS) {
+    set_error("%s: configuration outside the compiled envelope (C=%ld d_hidden=%ld n_blocks=%ld; needs num_freqs=6, 1 <= nv <= 8)", who, c.C, c.d_hidden,
+              c.n_blocks);
+    return BTS_E_UNSUPPORTED;
+  }
+  if (st->n_scales < 1 || st->n_scales > BTS_MAX_SCALES || st->n_loss < 1 || st->n_loss > BTS_MAX_LOSS_VIEWS) {
+    set_error("%s: n_scales=%ld must be 1..4 and n_loss=%ld 1..16", who, st->n_scales, st->n_loss);
+    return BTS_E_INVALID;
+  }
+  if (st->invalid_policy < 0 || st->invalid_policy > 2 || (c.code_mode != 0 && c.code_mode != 1) || c.enc_render_view < -1 || c.enc_render_view >= c.nv) {
+    set_error("%s: invalid_policy=%ld / code_mode=%ld / enc_render_view=%ld out of range", who, st->invalid_policy, c.code_mode, c.enc_render_view);
+    return BTS_E_INVALID;
+  }
+  bool ids_ok = st->id_encoder >= 0 && st->id_encoder < st->v;
+  for (int j = 0; j < c.nv; ++j) ids_ok = ids_ok && st->ids_render[j] >= 0 && st->ids_render[j] < st->v;
+  for (int j = 0; j < st->n_loss; ++j) ids_ok = ids_ok && st->ids_loss[j] >= 0 && st->ids_loss[j] < st->v;
+  if (!ids_ok) {
+    set_error("%s: a frame id outside [0, v=%ld)", who, st->v);
+    return BTS_E_INVALID;
+  }
+  if (!st->images || !st->Ks || !st->poses_c2w || !st->patch_v || !st->patch_y || !st->patch_x || !st->mlp_params || !st->rays || !st->rgb_gt ||
+      !st->loss_vals || !st->cams || !st->imgs_nhwc4 || (c.learn_empty && !st->empty_feature)) {
+    set_error("%s: NULL input / output / scratch pointer", who);
+    return BTS_E_INVALID;
+  }
+  for (int s = 0; s < st->n_scales; ++s) {
+    const BtsTrainScale& q = st->scale[s];
+    const int fs = q.feat_shift;
+    if (fs < 0 || fs > 6 || (c.H & ((1 << fs) - 1)) || (c.W & ((1 << fs) - 1))) {
+      set_error("%s: scale %ld: feat_shift=%ld needs 0..6 and H, W multiples of 2^feat_shift", who, s, fs);
+      return BTS_E_INVALID;
+    }
+    if (!q.feat_nchw || !q.jitter || !q.rgb || !q.depth || !q.invalid_wsum || !q.invalid_any || !q.proj_nhwc || !q.sampled_tiles || !q.z_samp ||
+        !q.sigma_raw || !q.trans || !q.rgb_samps || !q.loss_parts || !q.g_rgb || !q.g_depth) {
+      set_error("%s: scale %ld: NULL pointer", who, s);
+      return BTS_E_INVALID;
+    }
+    if (bwd && (!q.gs_rgb || !q.gs_depth || !q.d_proj_nhwc || !q.d_proj_tiles)) {
+      set_error("%s: scale %ld: NULL backward pointer (gs_rgb, gs_depth, d_proj_nhwc, d_proj_tiles)", who, s);
+      return BTS_E_INVALID;
+    }
+  }
+  return BTS_OK;
+}
+
+// the per-scale views of the step as the single-call entry points take them
+struct ScaleView {
+  BtsFieldCfg cfg;
+  BtsFieldTensors t;
+  BtsRenderArgs a;
+};
+static ScaleView scale_view(const BtsTrainStep* st, int s) {
+  ScaleView v;
+  memset(&v, 0, sizeof(v));
+  const BtsTrainScale& q = st->scale[s];
+  const int n = st->cfg.n, nv = st->cfg.nv;
+  v.cfg = st->cfg;
+  v.cfg.feat_shift = q.feat_shift;
+  float* K_enc = st->cams;
+  float* w2c_enc = K_enc + (long)n * 9;
+  float* K_r = w2c_enc + (long)n * 16;
+  float* w2c_r = K_r + (long)n * nv * 9;
+  v.t.proj_nhwc = q.proj_nhwc, v.t.K_enc = K_enc, v.t.w2c_enc = w2c_enc, v.t.imgs_nhwc4 = st->imgs_nhwc4, v.t.K_r = K_r, v.t.w2c_r = w2c_r;
+  v.t.empty_feature = st->cfg.learn_empty ? st->empty_feature : nullptr, v.t.mlp_params = st->mlp_params;
+  v.a.rays_per_sample = st->P * st->ph * st->pw, v.a.K = st->K, v.a.hard_alpha_cap = st->hard_alpha_cap, v.a.white_bkgd = 0;
+  v.a.rays = st->rays, v.a.lindisp = st->lindisp;
+  return v;
+}
+
+int train_step_fwd_impl(const BtsTrainStep* st, hipStream_t stream) {
+  const BtsFieldCfg& c = st->cfg;
+  const int n = c.n, nv = c.nv, Bp = st->P * st->ph * st->pw;
+  int rc = camera_prep_launch(st->Ks, st->poses_c2w, n, st->v, st->id_encoder, nv, st->ids_render, st->cams, stream);
+  if (!rc) rc = pack_rgb_views_launch(st->images, st->imgs_nhwc4, n, st->v, nv, st->ids_render, c.H, c.W, st->img_scale, st->img_shift, stream);
+  if (!rc)
+    rc = patch_rays_views_launch(st->poses_c2w, st->Ks, st->images, st->patch_v, st->patch_y, st->patch_x, n, st->v, 3, c.H, c.W, st->P, st->ph, st->pw,
+                                 st->z_near, st->z_far, 1, st->rays, st->rgb_gt, st->n_loss, st->ids_loss, st->img_scale, st->img_shift, stream);
+  if (rc) {
+    set_error("%s: a hand-over kernel launch failed", "bts_train_step_fwd");
+    return rc;
+  }
+  FinishParams fin;
+  memset(&fin, 0, sizeof(fin));
+  for (int s = 0; s < st->n_scales; ++s) {
+    const BtsTrainScale& q = st->scale[s];
+    ScaleView v = scale_view(st, s);
+    const long texels = map_texels(st, s);
+    const long tiles = (texels + 63) / 64;
+    if (hipMemsetAsync(q.sampled_tiles, 0, (size_t)(n * tiles), stream) != hipSuccess) return BTS_E_LAUNCH;
+    rc = mark_tiles_impl(st->rays, nullptr, q.jitter, v.t.w2c_enc, v.t.K_enc, (long)n * Bp, Bp, st->K, st->lindisp, c.H, c.W, q.feat_shift, q.sampled_tiles,
+                         stream);
+    if (!rc) rc = project_features_impl(c.C, c.d_hidden, q.feat_nchw, st->mlp_params, n, (int)texels, q.proj_nhwc, q.sampled_tiles, stream);
+    if (rc) {
+      set_error("%s: projection launch failed at scale %ld", "bts_train_step_fwd", s);
+      return rc;
+    }
+    v.a.jitter = q.jitter, v.a.z_samp_out = q.z_samp;
+    v.a.rgb = q.rgb, v.a.depth = q.depth, v.a.rgb_samps = q.rgb_samps, v.a.sigma_raw = q.sigma_raw, v.a.trans = q.trans;
+    v.a.invalid_wsum = q.invalid_wsum, v.a.invalid_any = q.invalid_any;
+    rc = render_fwd_impl(&v.cfg, &v.t, &v.a, stream);
+    if (rc) return rc;
+    BtsLossArgs la;
+    memset(&la, 0, sizeof(la));
+    la.rgb = q.rgb, la.depth = st->edge_aware_smoothness ? q.depth : nullptr, la.rgb_gt = st->rgb_gt, la.parts = q.loss_parts;
+    la.g_rgb = q.g_rgb, la.g_depth = st->edge_aware_smoothness ? q.g_depth : nullptr;
+    la.n_patches = n * st->P, la.patch_h = st->ph, la.patch_w = st->pw, la.nv = nv, la.K = 0;
+    la.invalid_policy = st->invalid_policy, la.edge_aware_smoothness = st->edge_aware_smoothness, la.scale_rgb = 1.0f, la.scale_eas = 1.0f;
+    // the invalid-ray mask of EVERY scale's term comes from scale 0's render (loss.py:100-118 reads data["coarse"][0])
+    la.invalid_wsum = st->invalid_policy == 2 ? st->scale[0].invalid_wsum : nullptr;
+    la.invalid_any = st->invalid_policy == 1 ? st->scale[0].invalid_any : nullptr;
+    rc = photometric_loss_impl(&la, stream);
+    if (rc) return rc;
+    fin.parts[s] = q.loss_parts;
+  }
+  fin.n_scales = st->n_scales, fin.n_patches = n * st->P, fin.out = st->loss_vals;
+  memcpy(fin.M, st->loss_matrix, sizeof(float) * 9 * 3 * st->n_scales);
+  loss_finish_kernel<<<1, 256, 0, stream>>>(fin);
+  if (hipGetLastError() != hipSuccess) {
+    set_error("%s: loss reduction launch failed", "bts_train_step_fwd");
+    return BTS_E_LAUNCH;
+  }
+  return BTS_OK;
+}
+
+int train_step_bwd_impl(const BtsTrainStep* st, const float* g_loss, hipStream_t stream) {
+  const BtsFieldCfg& c = st->cfg;
+  const int n = c.n, nv = c.nv, Bp = st->P * st->ph * st->pw;
+  const int cols = 3 * st->n_scales;
+  const long n_params = MlpLayout{c.C + 3 + 6 * c.num_freqs, c.d_hidden, c.n_blocks}.total();
+  ScaleGradParams sg;
+  memset(&sg, 0, sizeof(sg));
+  for (int s = 0; s < st->n_scales; ++s) {
+    const BtsTrainScale& q = st->scale[s];
+    sg.g_rgb[s] = q.g_rgb, sg.g_depth[s] = st->edge_aware_smoothness ? q.g_depth : nullptr, sg.gs_rgb[s] = q.gs_rgb, sg.gs_depth[s] = q.gs_depth;
+    sg.c_rgb[s] = st->loss_matrix[8 * cols + 3 * s], sg.c_eas[s] = st->loss_matrix[8 * cols + 3 * s + 1];
+  }
+  sg.g_loss = g_loss, sg.n_scales = st->n_scales, sg.n_rgb = (long)n * Bp * nv * 3, sg.n_depth = (long)n * Bp;
+  const long want = (sg.n_rgb + 255) / 256;
+  scale_grads_kernel<<<dim3((unsigned)(want < 1024 ? want : 1024), (unsigned)st->n_scales), 256, 0, stream>>>(sg);
+  if (st->d_mlp_params && hipMemsetAsync(st->d_mlp_params, 0, sizeof(float) * (size_t)n_params, stream) != hipSuccess) return BTS_E_LAUNCH;
+  const bool want_empty = c.learn_empty && st->d_empty_proj && (st->d_mlp_params || st->d_empty_feature);
+  if (want_empty && hipMemsetAsync(st->d_empty_proj, 0, sizeof(float) * (size_t)c.d_hidden, stream) != hipSuccess) return BTS_E_LAUNCH;
+  if (hipGetLastError() != hipSuccess) {
+    set_error("%s: gradient scaling launch failed", "bts_train_step_bwd");
+    return BTS_E_LAUNCH;
+  }
+  for (int s = 0; s < st->n_scales; ++s) {
+    const BtsTrainScale& q = st->scale[s];
+    ScaleView v = scale_view(st, s);
+    v.a.z_samp = q.z_samp, v.a.sigma_raw = q.sigma_raw, v.a.trans = q.trans, v.a.rgb_samps = q.rgb_samps;
+    BtsRenderGrads g;
+    memset(&g, 0, sizeof(g));
+    g.g_rgb = q.gs_rgb, g.g_depth = st->edge_aware_smoothness ? q.gs_depth : nullptr;
+    const bool need_map = q.d_feat_nchw != nullptr || st->d_mlp_params != nullptr;
+    g.d_proj_nhwc = need_map ? q.d_proj_nhwc : nullptr, g.d_proj_tiles = need_map ? q.d_proj_tiles : nullptr;
+    g.d_mlp_params = st->d_mlp_params, g.d_empty_proj = want_empty ? st->d_empty_proj : nullptr;
+    const size_t need = render_bwd_workspace_impl(&v.cfg, &v.a);
+    if (need > st->bwd_workspace_bytes || (need && !st->bwd_workspace)) {
+      set_error("%s: bwd_workspace too small (%ld bytes needed)", "bts_train_step_bwd", (long)need);
+      return BTS_E_WORKSPACE;
+    }
+    int rc = render_bwd_impl(&v.cfg, &v.t, &v.a, &g, st->bwd_workspace, st->bwd_workspace_bytes, stream);
+    if (rc) return rc;
+    if (need_map) {
+      rc = project_features_bwd_tiles_impl(c.C, c.d_hidden, q.feat_nchw, q.d_proj_nhwc, q.d_proj_tiles, st->mlp_params, n, (int)map_texels(st, s),
+                                           q.d_feat_nchw, st->d_mlp_params, 1, stream);
+      if (rc) {
+        set_error("%s: projection backward launch failed at scale %ld", "bts_train_step_bwd", s);
+        return rc;
+      }
+    }
+  }
+  if (want_empty) {
+    empty_grad_kernel<<<1, 256, 0, stream>>>(st->mlp_params, st->empty_feature, st->d_empty_proj, c.C, c.d_hidden, c.C + 3 + 6 * c.num_freqs, st->d_mlp_params,
+                                             st->d_empty_feature);
+    if (hipGetLastError() != hipSuccess) {
+      set_error("%s: empty-feature gradient launch failed", "bts_train_step_bwd");
+      return BTS_E_LAUNCH;
+    }
+  }
+  return BTS_OK;
+}
+
+}  // namespace bts
+
+using namespace bts;
+
+extern "C" {
+
+int bts_train_step_fwd(const BtsTrainStep* st, void* stream) {
+  if (int rc = check_step(st, "bts_train_step_fwd", false)) return rc;
+  return train_step_fwd_impl(st, (hipStream_t)stream);
+}
+
+int bts_train_step_bwd(const BtsTrainStep* st, const float* g_loss, void* stream) {
+  if (int rc = check_step(st, "bts_train_step_bwd", true)) return rc;
+  return train_step_bwd_impl(st, g_loss, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -119,7 +119,7 @@ class ReconstructionLoss:
         self.alpha_reg_fraction = config.get("alpha_reg_fraction", 1 / 8)
         if self.alpha_reg_reduction not in ("ray", "slice"):
             raise ValueError(f"Unknown reduction for alpha regularization: {self.alpha_reg_reduction}")
-        self._lin = {}    # (scales, rays per scale, fine present, device) -> the (9 x 3 S) matrix of _call_photometric_only
+        self._lin = {}    # (scales, rays per scale, fine present, lambdas[, device]) -> the (9 x 3 S) matrix of loss_matrix()
         if self.criterion_str != "l1+ssim" or use_automasking or self.median_thresholding or self.invalid_policy == "weight_guided_diverse":
             raise NotImplementedError("the fused HIP loss covers criterion 'l1+ssim' with invalid_policy strict / weight_guided / none, "
                                       "without automasking / median thresholding (every shipped config); got "
@@ -176,7 +176,16 @@ class ReconstructionLoss:
         eas_on = self.lambda_edge_aware_smoothness > 0
         sums, Bs = zip(*(self._sums(c, coarse_0, data["rgb_gt"], eas_on) for c in data["coarse"]))
         st = torch.stack(sums).reshape(-1)                      # (3 S): rgb, eas, invalid count per scale
-        key = (S, Bs, tuple(has_fine), st.device)
+        M = self.loss_matrix(S, Bs, tuple(has_fine), st.device)
+        loss = torch.dot(M[8], st)
+        return loss, LazyScalars(self._KEYS, torch.mv(M, st.detach()))
+
+    def loss_matrix(self, S, Bs, has_fine, device=None):
+        """The (9 x 3 S) matrix that takes the per-scale sums [rgb term, smoothness term, invalid rays] of the HIP loss pass to the logging
+        dict (rows in ``_KEYS`` order; row 8 = the loss).  Cached per (layout, lambdas): the reference reads ``self.lambda_*`` on every
+        call, so a schedule that changes one of them gets a new matrix."""
+        eas_on = self.lambda_edge_aware_smoothness > 0
+        key = (S, tuple(Bs), tuple(has_fine), float(self.lambda_coarse), float(self.lambda_fine), float(self.lambda_edge_aware_smoothness))
         M = self._lin.get(key)
         if M is None:
             M = torch.zeros(9, 3 * S, dtype=torch.float64)
@@ -188,9 +197,14 @@ class ReconstructionLoss:
                 M[8, 3 * s] = lam / Bs[s] / S
                 M[8, 3 * s + 1] = (self.lambda_edge_aware_smoothness / 2 ** s if eas_on else 0) / Bs[s] / S
             M[7, 2] = 1.0 / Bs[0]
-            M = self._lin[key] = M.float().to(st.device)
-        loss = torch.dot(M[8], st)
-        return loss, LazyScalars(self._KEYS, torch.mv(M, st.detach()))
+            M = self._lin[key] = M.float()
+        if device is not None and device.type != "cpu":
+            dkey = key + (device,)
+            Md = self._lin.get(dkey)
+            if Md is None:
+                Md = self._lin[dkey] = M.to(device)
+            return Md
+        return M
 
     def __call__(self, data):
         with profiler.record_function("loss_computation"):       # loss.py:84

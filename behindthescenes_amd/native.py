@@ -6,6 +6,8 @@ from dataclasses import dataclass
 from typing import Optional
 
 import ctypes as C
+import weakref
+
 import torch
 
 from . import _lib
@@ -289,7 +291,10 @@ def project_features_bwd(spec: FieldSpec, feat_nchw, d_proj, mlp_params, need_fe
 def proj_tile_count(spec: FieldSpec, H: int, W: int) -> int:
     """Tiles (64 consecutive texels) per image of an (H, W) projected map (bts_proj_tile_count)."""
     cfg = _spec_cfg(spec, 1, H, W)
-    return int(_lib.load().bts_proj_tile_count(C.byref(cfg)))
+    n = int(_lib.load().bts_proj_tile_count(C.byref(cfg)))
+    if n < 0:
+        raise BtsNativeError(f"bts_proj_tile_count: {_lib.load().bts_last_error().decode(errors='replace')}")
+    return n
 
 
 class FieldTensors:
@@ -326,6 +331,10 @@ class FieldTensors:
         self.imgs_nhwc4, self.K_r, self.w2c_r = imgs_nhwc4, K_r, w2c_r
         self.empty_feature = empty_feature
         self.proj_link = None   # ProjLink when proj_nhwc came out of ProjectFunction (field.py): see SPARSE_PROJ_GRAD
+        # (rays data_ptr, z / jitter data_ptr, rows) of the ONE sample set a sparsely projected map is valid for (BTSNet.native_field(
+        # sampled=...): only the tiles those samples read were projected, the rest of proj_nhwc is uninitialised memory), else None.
+        # field_query / occupancy_profile reject a partial map, render_fwd / render_bwd check the sample set.
+        self.partial = None
 
     def cfg(self, nv=None) -> BtsFieldCfg:
         return _spec_cfg(self.spec, self.n, self.H, self.W, self.nv if nv is None else nv, self.feat_shift, self.enc_view)
@@ -385,6 +394,7 @@ def render_fwd(ft: FieldTensors, mlp_params: torch.Tensor, rays: torch.Tensor, z
     _req(rays, "rays", (B, 8)), _req(mlp_params.detach(), "mlp_params", (ft.spec.mlp_param_count(),))
     if B % ft.n != 0:
         raise BtsNativeError(f"{B} rays do not split evenly over n={ft.n} samples")
+    _check_partial(ft, rays, z_samp if z_samp is not None else jitter)
     dev, nv = rays.device, ft.nv
 
     def new(*shape):
@@ -402,6 +412,17 @@ def render_fwd(ft: FieldTensors, mlp_params: torch.Tensor, rays: torch.Tensor, z
     if z_samp is not None:
         outs["z_samp"] = z_samp
     return outs
+
+
+def _check_partial(ft: "FieldTensors", rays, samples, what="render"):
+    """A map projected for one sample set (FieldTensors.partial) serves that set and nothing else."""
+    if ft.partial is None:
+        return
+    if samples is None or rays is None:
+        raise BtsNativeError(f"{what}: this field's projected map holds only the tiles ONE render's samples read (native_field(sampled=...)); "
+                             "field queries need the full map: call net.native_field() without `sampled`")
+    if (rays.data_ptr(), rays.shape[0]) != ft.partial[:2]:
+        raise BtsNativeError(f"{what}: the projected map of this field was built for another ray set (sparse projection, native_field(sampled=...))")
 
 
 def render_bwd(ft: FieldTensors, mlp_params, rays, z_samp, sigma_raw, trans, *, hard_alpha_cap, g_rgb=None, g_depth=None,
@@ -469,6 +490,7 @@ def field_query(ft: FieldTensors, mlp_params: torch.Tensor, xyz: torch.Tensor, o
     """xyz (n, P, 3) -> rgb (n,P,nv*3) | None, invalid (n,P,nv or 1), sigma (n,P,1)  (bts_field_query)."""
     n, P, _ = xyz.shape
     _req(xyz, "xyz", (ft.n, P, 3))
+    _check_partial(ft, None, None, "field_query")
     dev = xyz.device
     nv = 0 if only_density else ft.nv
     rgb = torch.empty((n, P, nv * 3), device=dev, dtype=torch.float32) if nv else None
@@ -490,6 +512,7 @@ def occupancy_profile(ft: FieldTensors, mlp_params: torch.Tensor, xyz: torch.Ten
     _req(xyz, "xyz", (ft.n, P, 3))
     if levels <= 0 or P % levels:
         raise BtsNativeError(f"{P} points are not {levels} whole levels")
+    _check_partial(ft, None, None, "occupancy_profile")
     cols = P // levels
     profile = torch.empty((n, cols), device=xyz.device, dtype=torch.float32)
     sigma = torch.empty((n, P), device=xyz.device, dtype=torch.float32) if want_sigma else None
@@ -497,6 +520,16 @@ def occupancy_profile(ft: FieldTensors, mlp_params: torch.Tensor, xyz: torch.Ten
     _lib.check(_lib.load().bts_occupancy_profile(C.byref(cfg), C.byref(tens), _ptr(xyz), levels, cols, float(threshold), int(only_density),
                                                  _ptr(profile), _ptr(sigma), _stream(xyz)), "bts_occupancy_profile")
     return (profile, sigma) if want_sigma else profile
+
+
+def train_step_fwd(st, stream):
+    """bts_train_step_fwd on a filled ``_lib.BtsTrainStep`` (behindthescenes_amd.train_step builds it)."""
+    _lib.check(_lib.load().bts_train_step_fwd(C.byref(st), stream), "bts_train_step_fwd")
+
+
+def train_step_bwd(st, g_loss, stream):
+    """bts_train_step_bwd: ``g_loss`` a 0-dim float32 device tensor (the upstream gradient of the loss) or None (= 1)."""
+    _lib.check(_lib.load().bts_train_step_bwd(C.byref(st), None if g_loss is None else C.c_void_p(g_loss.data_ptr()), stream), "bts_train_step_bwd")
 
 
 # --------------------------------------------------------------------------------------------------------------
@@ -514,14 +547,23 @@ SPARSE_PROJ_GRAD = True
 
 class ProjLink:
     """Ties a map made by ProjectFunction to the RenderFunction calls that read it (FieldTensors.proj_link)."""
-    __slots__ = ("renders", "entry")
+    __slots__ = ("renders", "entry", "__weakref__")
 
     def __init__(self):
         self.renders, self.entry = 0, None
 
 
 class _SparseGrad:
-    __slots__ = ("buf", "tiles", "busy", "version")
+    __slots__ = ("buf", "tiles", "busy", "version", "owner")
+
+
+def _reclaim_stale(entry):
+    """A busy pair whose map is gone -- the projection's backward never ran for it (torch.autograd.grad(loss, [G]), `inputs=` without the
+    encoder, an interrupted backward): the ProjLink it was lent to died with its graph.  The pair is zeroed and free again; without this
+    every later step would silently take the dense path and the map-sized buffer would stay pinned half written."""
+    if entry.busy and (entry.owner is None or entry.owner() is None or entry.owner().entry is not entry):
+        entry.buf.zero_(), entry.tiles.zero_()
+        entry.busy = False
 
 
 _SPARSE = {}
@@ -535,7 +577,7 @@ def _sparse_grad(ft: "FieldTensors"):
         e = _SparseGrad()
         e.buf = torch.zeros(g.shape, device=g.device, dtype=torch.float32)
         e.tiles = torch.zeros((g.shape[0], proj_tile_count(ft.spec, g.shape[1], g.shape[2])), device=g.device, dtype=torch.uint8)
-        e.busy = False
+        e.busy, e.owner = False, None
         _SPARSE[key] = e
     return e
 
@@ -623,17 +665,27 @@ class RenderFunction(torch.autograd.Function):
 
         ft = ctx.ft
         need_proj, need_mlp, need_empty = ctx.needs_input_grad[:3]
-        pg, link, G = None, ctx.link, ft.proj_nhwc
+        pg, link, G, entry = None, ctx.link, ft.proj_nhwc, None
         if (need_proj and SPARSE_PROJ_GRAD and link is not None and link.renders == 1 and link.entry is None and not G.retains_grad
                 and not G._backward_hooks):
             entry = _sparse_grad(ft)
+            _reclaim_stale(entry)
             if not entry.busy:
                 entry.busy, entry.version, link.entry = True, entry.buf._version, entry
+                entry.owner = weakref.ref(link)
                 pg = (entry.buf, entry.tiles)
-        d_proj, d_mlp, d_eproj = render_bwd(ft, mlp_params, rays, z_samp, sigma_raw, trans, hard_alpha_cap=ctx.hard_alpha_cap,
-                                            g_rgb=prep(g_rgb), g_depth=prep(g_depth), g_weights=prep(g_weights, ctx.has[0]), white_bkgd=ctx.white_bkgd, rgb_samps=rgb_samps,
-                                            g_alphas=prep(g_alphas, ctx.has[1]), need_proj=need_proj, need_mlp=need_mlp,
-                                            need_empty=need_empty or (need_mlp and ft.spec.learn_empty), sigma_noise=ctx.sigma_noise, proj_grad=pg)
+            else:
+                entry = None
+        try:
+            d_proj, d_mlp, d_eproj = render_bwd(ft, mlp_params, rays, z_samp, sigma_raw, trans, hard_alpha_cap=ctx.hard_alpha_cap,
+                                                g_rgb=prep(g_rgb), g_depth=prep(g_depth), g_weights=prep(g_weights, ctx.has[0]), white_bkgd=ctx.white_bkgd,
+                                                rgb_samps=rgb_samps, g_alphas=prep(g_alphas, ctx.has[1]), need_proj=need_proj, need_mlp=need_mlp,
+                                                need_empty=need_empty or (need_mlp and ft.spec.learn_empty), sigma_noise=ctx.sigma_noise, proj_grad=pg)
+        except Exception:
+            if pg is not None:      # a failed launch may have left the kept pair half written: it starts over, and the link forgets it
+                entry.buf.zero_(), entry.tiles.zero_()
+                entry.busy, link.entry = False, None
+            raise
         d_empty = None
         if d_eproj is not None:
             # the projected empty feature is w_in[:, :C] @ empty_feature (a 64x64 GEMV): chain rule on parameter-sized tensors

@@ -14,10 +14,15 @@ no collective on the data path); value = total rays of all ranks / max-over-rank
 Prints ONE JSON line (rank 0).  Next to the headline it carries `others` (N = 1: BASELINE configs[2], [3], [4], [4] at K = 128 and the
 occupancy profile, each = `bench.py --workload X --steps 10 --warmup 3` in a child process) and, under torch.distributed.run, `ddp_train`
 (KITTI-Raw shapes with the Monodepth2 encoder through DistributedDataParallel: the path's one collective, with `allreduce_ms`);
-`--no-others` skips both.  `roofline` is for the dominant kernel (bts::render_kernel_p = bts_render_fwd), timed live with HIP
-events on the launch stream inside the timed region; `roofline.traffic` is the HBM byte count of the committed rocprofv3 PMC passes
-of the same workload (profiles/<round>/traffic.json, written by tools/profile.sh), null when absent; `cpu_baseline` times the CPU
-oracle port on a bounded sample of the same workload.
+`--no-others` skips both.  `roofline` is for the dominant kernel (bts::render_kernel_p = bts_render_fwd) TOGETHER WITH bts::project_kernel
+(the feature half of lin_in, hoisted out of the render kernel by the declared projected-feature shortcut), both timed live with HIP
+events on the launch stream inside the timed region: `achieved` / `frac` = the FLOP those two kernels EXECUTE / their summed time -- a
+true fraction of the fp32 vector peak; the algorithmic figure of SURVEY 8d (13 312 FLOP / sample, what a kernel without the shortcut
+would have to execute) is reported beside it as `algorithmic_tflops` / `frac_algorithmic` and may exceed 1.  Training lines: `kernel_ms`
+= EVERY library call of the step (event pairs around each C-ABI entry point), `gpu_busy_frac` = kernel_ms / ms_per_step, `frac` = the
+algorithmic 3 x forward FLOP / kernel_ms.  `roofline.traffic` is the HBM byte count of the committed rocprofv3 PMC passes of the same
+workload (profiles/<round>/traffic.json, written by tools/profile.sh), null when absent; `cpu_baseline` times the CPU oracle port on a
+bounded sample of the same workload.
 """
 import argparse
 import json
@@ -33,6 +38,10 @@ sys.path.insert(0, ROOT)
 
 FLOP_PER_POINT = 2 * (103 * 64 + 64)          # 13 312 FLOP per field query (KITTI MLP), the ALGORITHMIC figure
 EXEC_FLOP_PER_POINT = 2 * (40 * 64 + 64) + 2 * 4 * 64   # what the kernel executes: 40 PE / bias rows x 64 on the matrix pipe + lin_out + the 4-tap blend of G
+PROJECT_FLOP_PER_TEXEL = 2 * 64 * 64          # bts::project_kernel: G = F . w_in[:, :C]^T, once per texel of the map instead of once per sample
+# wave64 VALU issue on one SIMD-32 of gfx950, measured (tools/ubench/valu_issue.hip -> profiles/r05*/valu_issue*.txt): ns per wave-instruction
+# per SIMD at TWO resident waves (what the render kernels run at), wall-clock, for an FMA-like and a MUL-like instruction mix
+VALU_NS_PER_INST_2WAVES = {"fma_like": 1.88, "mul_like": 1.14}
 PEAK_FP32_MATRIX_TFLOPS = 157.3               # MI355X_MICROARCH.md: fp32 vector / fp32-input MFMA peak (256 CU x 256 FLOP/clk x 2.4 GHz)
 DTYPE = "f32 (lin_in as 3-term f16 split products on the f16 MFMA, f32 accumulate; everything else f32)"
 H, W, K, C, HD, V = 192, 640, 64, 64, 64, 2
@@ -53,6 +62,13 @@ def parse():
                     help="training workloads: feature_map (default) = learnable stand-in for the CNN output (the renderer's share of the step); "
                          "monodepth2 = the shipped Monodepth2 (ResNet of the yaml, random weights): whole step incl. the CNN")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--entries", action="store_true",
+                    help="training workloads, A/B: the entry-by-entry sequence of the reference's trainer (encode, sample, render, reconstruct, loss: "
+                         "~20 library calls + torch glue per step) instead of FusedTrainStep's two calls (bts_train_step_fwd / _bwd, ABI 7)")
+    ap.add_argument("--shard", choices=("frames", "rays"), default="frames",
+                    help="eval workload under torch.distributed.run: frames (default) = every rank renders its own frame, no collective; rays = ONE "
+                         "frame, its rays split over the ranks (parallel.render_sharded) and the per-ray outputs all-gathered inside the timed "
+                         "region (SURVEY 8e's second axis; the reference's dead DataParallel hook, nerf.py:454-456)")
     ap.add_argument("--dense-proj-grad", action="store_true",
                     help="training workloads, A/B: the gradient of the projected map as a dense autograd tensor (zero fill + full read) instead of "
                          "the kept (d_proj, tile flags) pair (native.SPARSE_PROJ_GRAD)")
@@ -76,6 +92,49 @@ def parse():
     ap.add_argument("--cpu-child", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-rows", type=int, default=24, help="image rows of view 0 rendered by the CPU oracle sample")
     return ap.parse_args()
+
+
+class KernelTimer:
+    """HIP event pairs (on the launch stream) around the C-ABI entry points of behindthescenes_amd.native: every bts:: kernel of a step
+    lies inside exactly one pair (nested entry points -- distance_to_z -> invert_small -- count once, at the outermost).  What the pairs
+    do NOT contain: torch's own kernels (the jitter draw, torch.cat of the parameters, DDP) and host gaps between entry points."""
+    ENTRIES = ("nchw_to_nhwc", "nhwc_to_nchw", "pack_rgb", "gen_rays", "patch_rays", "photometric_loss", "sample_coarse", "invert_small",
+               "distance_to_z", "project_features", "mark_sampled_tiles", "project_features_bwd", "render_fwd", "render_bwd", "field_query",
+               "occupancy_profile", "train_step_fwd", "train_step_bwd")
+
+    def __init__(self):
+        from behindthescenes_amd import native
+        self.native, self.orig, self.ev, self.depth = native, {}, {k: [] for k in self.ENTRIES}, 0
+
+    def _wrap(self, name, fn):
+        def f(*a, **kw):
+            if self.depth:
+                return fn(*a, **kw)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            self.depth += 1
+            try:
+                e0.record()
+                out = fn(*a, **kw)
+                e1.record()
+            finally:
+                self.depth -= 1
+            self.ev[name].append((e0, e1))
+            return out
+        return f
+
+    def install(self):
+        for k in self.ENTRIES:
+            self.orig[k] = getattr(self.native, k)
+            setattr(self.native, k, self._wrap(k, self.orig[k]))
+
+    def remove(self):
+        for k, fn in self.orig.items():
+            setattr(self.native, k, fn)
+        self.orig = {}
+
+    def ms_per_step(self, steps):
+        """{entry point: ms per step}, only the ones that ran (call after a synchronize)"""
+        return {k: sum(a.elapsed_time(b) for a, b in v) / max(steps, 1) for k, v in self.ev.items() if v}
 
 
 def cpu_baseline(scene, net, rows, device="cpu", learn_empty=True, threads=None):
@@ -245,47 +304,23 @@ def train_workload(args, world, rank, dev):
     sampler = bts.PatchRaySampler(ray_batch_size=cfg["rays"], z_near=cfg["z"][0], z_far=cfg["z"][1], patch_size=8)
     images, projs, poses = scene["images"].to(dev), scene["projs"].to(dev), scene["poses"].to(dev)
     ids_loss, ids_render = cfg["ids_loss"], cfg["ids_render"]
-    kern = {"fwd": [], "bwd": []}
-    orig_fwd, orig_bwd = native.render_fwd, native.render_bwd
-
-    def timed(fn, key):
-        def f(*a, **kw):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            out = fn(*a, **kw)
-            e1.record()
-            kern[key].append((e0, e1))
-            return out
-        return f
-
     wrapped = renderer.bind_parallel(net).train()
     crit = bts.ReconstructionLoss({"criterion": "l1+ssim", "invalid_policy": "weight_guided", "lambda_edge_aware_smoothness": 0.001})
-    lo, hi = ids_loss[0], ids_loss[-1] + 1
+    fused = bts.FusedTrainStep(wrapped, sampler, crit, multiscale=n_scales > 1, fused=not args.entries and not args.full_outputs)
 
     class Task(torch.nn.Module):
-        """trainer.py:208-259 after the CNN, as ONE module so that DistributedDataParallel wraps it exactly as idist.auto_model wraps
+        """trainer.py:208-259 after the data loader, as ONE module so that DistributedDataParallel wraps it exactly as idist.auto_model wraps
         the reference's BTSWrapper (trainer.py:418): the gradient all-reduce of its parameters (MLP + feature maps here; + the CNN in
-        a real run) is DDP's bucketed RCCL all-reduce, overlapped with the backward."""
+        a real run) is DDP's bucketed RCCL all-reduce, overlapped with the backward.  The body is behindthescenes_amd.FusedTrainStep:
+        encoder, then bts_train_step_fwd (hand-over, patch rays, per scale: flagged-tile projection, render, photometric loss) -- or,
+        with --entries, the same kernels entry by entry as the reference's trainer spells them."""
 
         def __init__(self):
             super().__init__()
-            self.wrapped = wrapped
+            self.step = fused
 
         def forward(self, images, projs, poses):
-            images_ip = images * .5 + .5
-            net.encode(images, projs, poses, ids_encoder=[0], ids_render=ids_render, images_alt=images_ip)
-            all_rays, all_rgb_gt = sampler.sample(images_ip[:, lo:hi], poses[:, lo:hi], projs[:, lo:hi])       # ids_loss are consecutive frames
-            data = dict(coarse=[], fine=[])
-            for scale in (net.encoder.scales if n_scales > 1 else [0]):     # trainer.py:220-242 ("multiscale") / :243-259
-                net.set_scale(scale)
-                rd = self.wrapped(all_rays, want_weights=True, want_alphas=True, want_rgb_samps=True)
-                rd["fine"] = dict(rd["coarse"])
-                rd["rgb_gt"], rd["rays"] = all_rgb_gt, all_rays
-                rd = sampler.reconstruct(rd)
-                data["coarse"].append(rd["coarse"]), data["fine"].append(rd["fine"])
-                data["rgb_gt"] = rd["rgb_gt"]
-            net.set_scale(0)
-            return crit(data)[0]
+            return self.step(images, projs, poses, ids_encoder=[0], ids_render=ids_render, ids_loss=ids_loss)[0]
 
     task = Task()
     if args.encoder == "feature_map":
@@ -350,7 +385,8 @@ def train_workload(args, world, rank, dev):
         for (name, where), (cnt, us) in sorted(by.items(), key=lambda kv: -kv[1][1]):
             print(f"{name:28s} {cnt / 3:6.1f} {us / 3:9.1f}  {where}", file=sys.stderr)
         return
-    native.render_fwd, native.render_bwd = timed(orig_fwd, "fwd"), timed(orig_bwd, "bwd")
+    timer = KernelTimer()
+    timer.install()
     torch.cuda.synchronize()
     if torch.distributed.is_initialized():
         torch.distributed.barrier()
@@ -364,7 +400,7 @@ def train_workload(args, world, rank, dev):
         torch.distributed.barrier()
         torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    native.render_fwd, native.render_bwd = orig_fwd, orig_bwd
+    timer.remove()
     if torch.distributed.is_initialized():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -385,12 +421,16 @@ def train_workload(args, world, rank, dev):
                          note="device time of the RCCL kernels per step (torch.profiler, two steps after the timed region); at world 1 the "
                               "collective is a local copy -- the number says the path ran, not what xGMI costs")
     n_rays = n * cfg["rays"]
-    # per STEP: the four scales of re10k are four launches each
-    ms = {k: sum(a.elapsed_time(b) for a, b in v) / max(args.steps, 1) for k, v in kern.items()}
+    # per STEP and entry point: the four scales of re10k are four calls each on the entry-by-entry path
+    ms = timer.ms_per_step(args.steps)
     if rank == 0:
         flop_pt = 2 * ((Cc + 39) * Hd + Nb * 2 * Hd * Hd + Hd)     # 13 312 (KITTI MLP) / 8 704 (RE10K MLP) per field query
         flop = 3 * n_rays * Kt * flop_pt * n_scales                # training = 3x forward (dX + dW); every scale renders all rays
-        achieved = flop / ((ms["fwd"] + ms["bwd"]) * 1e-3) / 1e12
+        kernel_ms = sum(ms.values())                               # EVERY library call of the step
+        fwd_ms = sum(v for k, v in ms.items() if k in ("render_fwd", "train_step_fwd"))
+        bwd_ms = sum(v for k, v in ms.items() if k in ("render_bwd", "train_step_bwd"))
+        step_ms = elapsed * 1e3 / args.steps
+        achieved = flop / (kernel_ms * 1e-3) / 1e12
         # HBM bytes and issue counters of every training kernel from the committed rocprofv3 PMC passes (tools/profile.sh <tag> <workload>)
         traffic, counters = None, {}
         pdir = os.path.join(ROOT, "profiles")
@@ -429,13 +469,19 @@ def train_workload(args, world, rank, dev):
                        "parallelism": f"batch x{world}", "peak_hbm_bytes": torch.cuda.max_memory_allocated()},
             "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_MATRIX_TFLOPS, "traffic": traffic,
-                         "kernel": "bts_render_fwd + bts_render_bwd, all launches of a step",
-                         "kernel_ms": ms["fwd"] + ms["bwd"], "fwd_ms": ms["fwd"], "bwd_ms": ms["bwd"], "algorithmic_flop_per_step": flop,
+                         "kernel": ("bts_train_step_fwd + bts_train_step_bwd: every bts:: kernel of the step (hand-over, patch rays, tile flags, "
+                                    "projection, render, loss, the backward's passes, projection backward)" if fused.last_path == "fused" else
+                                    "every library call of the step, entry by entry: " + ", ".join(sorted(ms))),
+                         "kernel_ms": kernel_ms, "fwd_ms": fwd_ms, "bwd_ms": bwd_ms, "entry_ms": {k: round(v, 4) for k, v in sorted(ms.items())},
+                         "gpu_busy_frac": kernel_ms / step_ms, "frac_step": flop / (step_ms * 1e-3) / 1e12 / PEAK_FP32_MATRIX_TFLOPS,
+                         "algorithmic_flop_per_step": flop, "path": fused.last_path,
                          "counters": counters,
-                         "note": f"algorithmic 3 x {flop_pt} FLOP / sample (SURVEY 8d) against the fp32 vector = fp32-input-MFMA peak; bwd_ms = "
-                                 "bts_render_bwd's passes (no fill of dG: it is added into the kept (d_proj, tile flags) pair that "
-                                 "bts_project_features_bwd_tiles returns to zero, ABI 6" + (" -- off: --dense-proj-grad" if args.dense_proj_grad else "")
-                                 + ").  Backward passes: DESIGN.md section 3"},
+                         "note": f"`achieved` / `frac` = the algorithmic 3 x {flop_pt} FLOP / sample (SURVEY 8d) over kernel_ms = the summed "
+                                 "HIP-event time of EVERY library call of a step (nothing that carries priced FLOPs is left out: the feature "
+                                 "half of lin_in and its two gradients live in the projection kernels); frac_step = the same over the whole "
+                                 "step; gpu_busy_frac = kernel_ms / ms_per_step (the rest: torch's jitter draw / parameter packing / autograd, "
+                                 "host gaps).  fwd_ms / bwd_ms = the two render phases (the whole phase on the fused path).  Backward passes: "
+                                 "DESIGN.md section 3"},
         }
         if world == 1 and not args.no_cpu_baseline and args.encoder == "feature_map":
             out["cpu_baseline"] = train_cpu_baseline(cfg, net, scene, rank)
@@ -596,25 +642,23 @@ def main():
     n_rays = V * H * W
 
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    kernel_events = []
-
-    # time the dominant kernel alone: wrap the C-ABI forward launch with events on the launch stream
-    from behindthescenes_amd import native
-    orig_render_fwd = native.render_fwd
-
-    def timed_render_fwd(*a, **kw):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        out = orig_render_fwd(*a, **kw)
-        e1.record()
-        kernel_events.append((e0, e1))
-        return out
+    from behindthescenes_amd import native, parallel
+    timer = KernelTimer()       # event pairs around every C-ABI entry point of the step (render_fwd = the dominant kernel)
+    shard_rays = launched and args.shard == "rays"
+    if shard_rays:
+        # SURVEY 8e, second axis: ONE frame (the same scene on every rank), its rays split over the ranks, per-ray outputs all-gathered
+        scene = S.synthetic_scene(1, V, H, W, C, seed=1000, intrinsics=S.K_KITTIRAW)
+        S.set_feature_map(net, scene["feat"].to(dev))
+        images, projs, poses = scene["images"].to(dev), scene["projs"].to(dev), scene["poses"].to(dev)
 
     def step():
         with torch.no_grad():
             net.encode(images, projs, poses, ids_encoder=[0], ids_render=[0])
             all_rays, all_rgb_gt = sampler.sample(images * .5 + .5, poses, projs)
-            rd = wrapped(all_rays, want_weights=True, want_alphas=True)
+            if shard_rays:    # every rank holds the field; rank r renders rays [r B / N, (r + 1) B / N) and gathers depth / rgb / weights / alphas
+                rd = parallel.render_sharded(wrapped, all_rays, rank, world, want_weights=True, want_alphas=True)
+            else:
+                rd = wrapped(all_rays, want_weights=True, want_alphas=True)
             rd["fine"] = dict(rd["coarse"])
             rd["rgb_gt"] = all_rgb_gt
             rd = sampler.reconstruct(rd)
@@ -623,7 +667,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    native.render_fwd = timed_render_fwd
+    timer.install()
     torch.cuda.synchronize()
     if launched:
         torch.distributed.barrier()
@@ -638,13 +682,15 @@ def main():
         torch.distributed.barrier()
         torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    native.render_fwd = orig_render_fwd
+    timer.remove()
     if launched:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = t.item()
 
-    kernel_ms = sum(a.elapsed_time(b) for a, b in kernel_events) / max(len(kernel_events), 1)
+    entry_ms = timer.ms_per_step(args.steps)
+    kernel_ms = entry_ms.get("render_fwd", float("nan"))          # bts::render_kernel_p alone
+    project_ms = entry_ms.get("project_features", 0.0)            # bts::project_kernel: the feature half of lin_in, once per texel
     # counters of the same kernel on the same workload from the committed rocprofv3 PMC passes (tools/profile.sh -> profiles/<tag>/)
     traffic, counters = None, {}
     prof = sorted(d for d in os.listdir(os.path.join(ROOT, "profiles")) if os.path.exists(os.path.join(ROOT, "profiles", d, "traffic.json"))) \
@@ -658,28 +704,46 @@ def main():
                               "doubled per MI355X_MICROARCH.md; valu_busy = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES, wait_frac = SQ_WAIT_ANY / SQ_WAVE_CYCLES, "
                               "mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles)")
     step_ms = elapsed * 1e3 / args.steps
-    value = world * n_rays * args.steps / elapsed
+    value = (1 if shard_rays else world) * n_rays * args.steps / elapsed
     if rank == 0:
-        flop_per_launch = n_rays * K * FLOP_PER_POINT
-        exec_flop = n_rays * K * EXEC_FLOP_PER_POINT
-        achieved = flop_per_launch / (kernel_ms * 1e-3) / 1e12
+        rays_launch = n_rays // world if shard_rays else n_rays            # rays one launch of the render kernel processes on this rank
+        flop_per_launch = rays_launch * K * FLOP_PER_POINT                  # algorithmic
+        exec_flop = rays_launch * K * EXEC_FLOP_PER_POINT + H * W * PROJECT_FLOP_PER_TEXEL      # what render_kernel_p + project_kernel execute
+        exec_ms = kernel_ms + project_ms
+        achieved = exec_flop / (exec_ms * 1e-3) / 1e12
+        algorithmic = flop_per_launch / (kernel_ms * 1e-3) / 1e12
+        # how much of the kernel's time the SIMDs need just to ISSUE its VALU instructions: wave-instructions per SIMD x the measured issue
+        # time per instruction at two resident waves (tools/ubench/valu_issue.hip), over the kernel time
+        valu_issue = None
+        if counters.get("valu_insts_per_ray"):
+            per_simd = counters["valu_insts_per_ray"] * rays_launch / 1024
+            valu_issue = {k: per_simd * ns * 1e-6 / kernel_ms for k, ns in VALU_NS_PER_INST_2WAVES.items()}
         out = {
             "metric": "rendered rays/sec (192x640x64 samples)", "value": value, "unit": "rays/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": step_ms, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
             "config": {"workload": "KITTI eval_depth.yaml forward, bs=1/GPU, 192x640, 2 views x 122880 rays, 64 samples/ray, nv=1, "
                                    "learn_empty=True (the yaml's effective default), want_weights+alphas, renderer only (feature-map "
-                                   "encoder stand-in)",
-                       "rays_per_step_per_gpu": n_rays, "samples_per_ray": K, "parallelism": f"frames x{world}"},
+                                   "encoder stand-in)" + (": ONE frame, its rays sharded over the ranks + all-gather of the per-ray outputs" if shard_rays else ""),
+                       "rays_per_step_per_gpu": rays_launch, "samples_per_ray": K, "parallelism": f"rays x{world} of one frame" if shard_rays else f"frames x{world}",
+                       **({"all_gather_bytes_per_step": n_rays * (3 + 1 + 3 * K) * 4,
+                           "all_gather": "rgb, depth, weights, alphas, invalid of all rays on every rank (what the un-sharded call returns)"} if shard_rays else {})},
             "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_MATRIX_TFLOPS, "traffic": traffic,
-                         "kernel": "bts::render_kernel_p<64,64,0,1,true,true>", "kernel_ms": kernel_ms,
-                         "algorithmic_flop_per_launch": flop_per_launch, "executed_flop_per_launch": exec_flop,
-                         "frac_executed": exec_flop / (kernel_ms * 1e-3) / 1e12 / PEAK_FP32_MATRIX_TFLOPS, "counters": counters,
-                         "note": "bound: VALU issue + latency at 2 waves / SIMD (not the matrix pipe, not HBM).  `achieved` / `frac` price the "
-                                 "ALGORITHMIC 13 312 FLOP / sample (SURVEY 8d) against the fp32 vector = fp32-input-MFMA peak; the kernel "
-                                 "EXECUTES 5 760 FLOP / sample thanks to the declared projected-feature shortcut (DESIGN.md section 3), "
-                                 "`frac_executed` prices that; the 39 lin_in rows run as 3 f16 MFMAs each (f16 pipe peak 2.5 PF: <1 % used)"},
+                         "kernel": "bts::render_kernel_p<64,64,0,1,true,true> + bts::project_kernel<64,64>", "kernel_ms": kernel_ms, "project_ms": project_ms,
+                         "executed_flop_per_launch": exec_flop, "algorithmic_flop_per_launch": flop_per_launch,
+                         "algorithmic_tflops": algorithmic, "frac_algorithmic": algorithmic / PEAK_FP32_MATRIX_TFLOPS,
+                         "valu_issue_frac": valu_issue, "entry_ms": {k: round(v, 4) for k, v in sorted(entry_ms.items())},
+                         "gpu_busy_frac": sum(entry_ms.values()) / step_ms, "counters": counters,
+                         "note": "bound: VALU issue + latency at 2 waves / SIMD (not the matrix pipe, not HBM).  `achieved` / `frac` = the FLOP the "
+                                 "render kernel (5 760 / sample: 40 encoding + bias rows x 64 on the matrix pipe, lin_out, the 4-tap blend of G) "
+                                 "and bts::project_kernel (2 x 64 x 64 / texel: the feature half of lin_in, hoisted out of the sample loop by "
+                                 "the declared projected-feature shortcut, DESIGN.md section 3) EXECUTE, over their summed event time, against "
+                                 "the fp32 vector = fp32-input-MFMA peak: a true fraction.  `algorithmic_tflops` / `frac_algorithmic` price "
+                                 "SURVEY 8d's 13 312 FLOP / sample over the render kernel's time: what a kernel without the shortcut would have "
+                                 "to sustain; above 1 by construction.  `valu_issue_frac` = VALU wave-instructions per SIMD (PMC) x the measured "
+                                 "issue time per instruction at two waves per SIMD (tools/ubench/valu_issue.hip; FMA-like / MUL-like mix) / "
+                                 "kernel time.  The 39 lin_in rows run as 3 f16 MFMAs each (f16 pipe peak 2.5 PF: < 1 % used)"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, net, args.cpu_rows)
@@ -703,7 +767,7 @@ def _condense(rec):
     r = rec["roofline"]
     keep = {"metric": rec["metric"], "value": rec["value"], "unit": rec["unit"], "steps": rec["steps"], "warmup": rec["warmup"],
             "ms_per_step": rec["ms_per_step"], "workload": rec["config"]["workload"],
-            "roofline": {k: r[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms", "fwd_ms", "bwd_ms") if k in r}}
+            "roofline": {k: r[k] for k in ("bound", "achieved", "peak", "unit", "frac", "frac_step", "gpu_busy_frac", "traffic", "kernel", "kernel_ms", "fwd_ms", "bwd_ms", "entry_ms", "path") if k in r}}
     if "allreduce" in rec:
         keep["allreduce"] = rec["allreduce"]
     return keep

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define BTS_ABI_VERSION 6
+#define BTS_ABI_VERSION 7
 
 enum {
   BTS_OK = 0,
@@ -178,6 +178,8 @@ int bts_project_features_bwd(const BtsFieldCfg* cfg, const float* feat_nchw, con
  * clear_after != 0 the call also writes zeros over the flagged tiles of d_proj_nhwc and resets their flags: a caller that keeps one
  * (d_proj, tiles) pair per map shape zero-fills it once and never again (the fill of a training step's d_proj is as large as the
  * gradient's whole HBM traffic otherwise: 503 MB at exp_kitti_360.yaml's batch). */
+/* tiles per image of cfg's map ((H >> feat_shift) * (W >> feat_shift) texels, 64 per tile, rounded up); -1 for an invalid cfg (feat_shift
+ * outside 0 .. 6, H or W not a multiple of 2^feat_shift, non-positive sizes) */
 int64_t bts_proj_tile_count(const BtsFieldCfg* cfg);
 /* ABI 6: the forward side of the same observation -- a render reads only the tiles its samples' taps land in.
  * bts_mark_sampled_tiles: for every sample of every ray of `a` (rays, rays_per_sample, K, and z_samp or jitter + lindisp exactly as
@@ -269,6 +271,115 @@ int bts_distance_to_z(const float* depths, const float* inv_K, int32_t N, int32_
  * BTSNet.encode (models/bts/model/models_bts.py:71) and on the intrinsics in distance_to_z (utils/projection_operations.py:9):
  * fp64 Gauss-Jordan with partial pivoting rounded to fp32, enqueued on the stream (no solver library, no host sync). */
 int bts_invert_small(const float* src, float* dst, int32_t N, int32_t dim, void* stream);
+
+
+/* ---------------------------------------------------------------------------------------------------------------------------------
+ * ABI 7: a training step's share of the renderer as TWO calls.
+ *
+ * The reference's training forward (BTSWrapper.forward, models/bts/trainer.py:208-259, and the criterion call of
+ * utils/base_trainer.py:287-297) is, after the CNN: encode's hand-over (models_bts.py:65-136), PatchRaySampler.sample
+ * (ray_sampler.py:125-162), one render per scale (trainer.py:220-259 -> nerf.py:315-375), reconstruct (views only) and
+ * ReconstructionLoss.__call__ (loss.py:83-293); autograd then walks the same chain backwards.  Entry by entry that is ~20 calls into
+ * this library per step with allocator, autograd and ctypes work around each -- at exp_kitti_raw.yaml's shapes the HOST then takes
+ * longer to issue the step (1.1 ms) than the GPU to run it (0.5 ms).  bts_train_step_fwd enqueues the whole forward chain, and
+ * bts_train_step_bwd the whole backward chain, from one call each: the same kernels in the same order with the same arguments as the
+ * entry-by-entry path (bit-identical forward results; the backward's float atomics make its summation order run-to-run variable
+ * either way).  Every buffer is the caller's: nothing is allocated, nothing synchronises, the struct is only read.
+ *
+ * Frames: images (n, v, 3, H, W) in [-1, 1] as the data loader delivers them; x * img_scale + img_shift (0.5, 0.5: models_bts.py:82,
+ * trainer.py's image processor) happens where a frame is read.  id_encoder / ids_render / ids_loss index the v frames of a batch
+ * element (trainer.py:118-190 draws them per step); the patches' view index patch_v indexes ids_loss (the reference samples from
+ * images_ip[:, ids_loss]).
+ * Per scale s (trainer.py:220-242 "multiscale": encoder.scales; otherwise one scale): the decoder's map at ITS size (feat_shift, ABI
+ * 4), this render's jitter, and the loss term on this scale's rgb / depth with scale 0's invalid-ray reductions (loss.py:100-118).
+ * loss_matrix (9 x 3 n_scales, row-major): the logging dict of loss.py:219-229 and the loss itself are LINEAR in the per-scale sums
+ * [rgb term, smoothness term, invalid rays] the loss pass returns; row 8 is the loss (its entries 3 s and 3 s + 1 are also the
+ * coefficients d loss / d sums the backward applies), rows 0-7 the dict's other entries, in the order loss_rgb_coarse, loss_rgb_fine,
+ * loss_ray_entropy, loss_depth_reg, loss_alpha_reg, loss_eas, loss_depth_smoothness, loss_invalid_ratio.
+ * --------------------------------------------------------------------------------------------------------------------------------- */
+#define BTS_MAX_SCALES 4
+#define BTS_MAX_LOSS_VIEWS 16
+
+typedef struct BtsTrainScale {
+  /* inputs */
+  const float* feat_nchw;    /* (n, C, H >> feat_shift, W >> feat_shift) the decoder's map of this scale */
+  const float* jitter;       /* (n*Bp, K) in [0, 1): this render's stratified jitter (the caller's torch.rand draw, nerf.py:112) */
+  /* outputs of the forward */
+  float* rgb;                /* (n*Bp, nv*3) */
+  float* depth;              /* (n*Bp) */
+  float* invalid_wsum;       /* (n*Bp, nv)  } BtsRenderArgs.invalid_wsum / invalid_any (ABI 2) */
+  float* invalid_any;        /* (n*Bp, nv)  } */
+  /* state the forward leaves for the backward (contents need no initialisation) */
+  float* proj_nhwc;          /* (n, H >> s, W >> s, Hd): valid in the tiles flagged in sampled_tiles only (ABI 6) */
+  uint8_t* sampled_tiles;    /* (n, tiles of the scale's map) */
+  float* z_samp;             /* (n*Bp, K) */
+  float* sigma_raw;          /* (n*Bp, K) */
+  float* trans;              /* (n*Bp, K) */
+  float* rgb_samps;          /* (n*Bp, K, nv*3) */
+  float* loss_parts;         /* (n*P, 4) per-patch sums of the loss pass */
+  float* g_rgb;              /* (n*Bp, nv*3) d (sum of the rgb term) / d rgb            } written by the forward's loss pass */
+  float* g_depth;            /* (n*Bp)       d (sum of the smoothness term) / d depth   } */
+  float* gs_rgb;             /* the two above times (loss_matrix[8][3 s], [3 s + 1]) * upstream gradient: backward scratch */
+  float* gs_depth;
+  /* backward */
+  float* d_proj_nhwc;        /* (n, H >> s, W >> s, Hd) ALL ZERO on entry, all zero again on return (the kept pair of ABI 6) */
+  uint8_t* d_proj_tiles;     /* (n, tiles)              ALL ZERO on entry, all zero again on return */
+  float* d_feat_nchw;        /* (n, C, H >> s, W >> s) gradient of feat_nchw, WRITTEN by the backward, or NULL */
+  int32_t feat_shift;
+  int32_t reserved_;
+} BtsTrainScale;
+
+typedef struct BtsTrainStep {
+  BtsFieldCfg cfg;           /* n, H, W (frame size), C, d_hidden, ..., nv = number of render views; feat_shift is per scale (ignored
+                              * here); enc_render_view as in ABI 5 (-1 is always correct) */
+  int32_t v;                 /* frames per batch element */
+  int32_t id_encoder;        /* ids_encoder[0] */
+  int32_t ids_render[BTS_MAX_VIEWS];
+  int32_t n_loss;            /* number of loss frames, <= BTS_MAX_LOSS_VIEWS */
+  int32_t ids_loss[BTS_MAX_LOSS_VIEWS];
+  int32_t P, ph, pw;         /* patches per batch element, patch size: Bp = P * ph * pw rays per batch element, ph * pw <= 64 */
+  int32_t K;                 /* samples per ray */
+  int32_t lindisp, hard_alpha_cap;          /* nerf.py:117, :285-286 */
+  int32_t invalid_policy;    /* 0 none, 1 strict, 2 weight_guided (BtsLossArgs) */
+  int32_t edge_aware_smoothness;
+  int32_t n_scales;          /* 1 .. BTS_MAX_SCALES */
+  int32_t reserved_;
+  float z_near, z_far;       /* the ray sampler's (ray_sampler.py:108-123) */
+  float img_scale, img_shift;
+  float loss_matrix[9 * 3 * BTS_MAX_SCALES];   /* (9, 3 n_scales) row-major, see above */
+  /* inputs */
+  const float* images;       /* (n, v, 3, H, W) */
+  const float* Ks;           /* (n, v, 3, 3) normalised intrinsics */
+  const float* poses_c2w;    /* (n, v, 4, 4) */
+  const int32_t* patch_v;    /* (n, P) index into ids_loss  } the caller's draws (the reference uses the CPU RNG, */
+  const int32_t* patch_y;    /* (n, P) top row              }  ray_sampler.py:141-143)                            */
+  const int32_t* patch_x;    /* (n, P) left column          } */
+  const float* mlp_params;   /* packed (see the top of this file) */
+  const float* empty_feature;/* (C) or NULL (learn_empty) */
+  /* outputs of the forward */
+  float* rays;               /* (n*Bp, 8) */
+  float* rgb_gt;             /* (n*Bp, 3) colours of the patch pixels in [0, 1] */
+  float* loss_vals;          /* (9) loss_matrix . sums: [8] = the loss */
+  /* scratch (caller-owned, contents need no initialisation) */
+  float* cams;               /* n * (9 + 16 + nv * (9 + 16)) floats: K_enc (n, 9), w2c_enc (n, 16), K_r (n, nv, 9), w2c_r (n, nv, 16) */
+  float* imgs_nhwc4;         /* (n, nv, H, W, 4) */
+  void* bwd_workspace;       /* max over the scales of bts_render_bwd_workspace */
+  size_t bwd_workspace_bytes;
+  float* d_empty_proj;       /* (Hd) or NULL */
+  /* outputs of the backward */
+  float* d_mlp_params;       /* packed like mlp_params, WRITTEN (zero-filled inside, then accumulated over the scales), or NULL */
+  float* d_empty_feature;    /* (C) WRITTEN, or NULL */
+  BtsTrainScale scale[BTS_MAX_SCALES];
+} BtsTrainStep;
+
+/* Forward: cameras (bts_invert_small on the encoder / render poses), bts_pack_rgb of the render frames, bts_patch_rays, then per scale
+ * bts_mark_sampled_tiles + bts_project_features_tiles + bts_render_fwd (lean outputs: rgb, depth, the invalid-ray reductions and the
+ * backward's saved state) + bts_photometric_loss, and one reduction of the per-patch sums into loss_vals. */
+int bts_train_step_fwd(const BtsTrainStep* st, void* stream);
+/* Backward of the above for the SAME struct contents: g_loss = device pointer to the upstream gradient of loss_vals[8] (a scalar), or
+ * NULL for 1.  Per scale bts_render_bwd (adding into the kept (d_proj, tiles) pair) + bts_project_features_bwd_tiles (clear_after);
+ * d_mlp_params / d_empty_feature collect every scale's contribution. */
+int bts_train_step_bwd(const BtsTrainStep* st, const float* g_loss, void* stream);
 
 #ifdef __cplusplus
 }

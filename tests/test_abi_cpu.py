@@ -38,7 +38,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
         assert hasattr(lib, n), f"{n} declared in include/bts_render.h but not exported"
         assert n in _lib.SYMBOLS, f"{n} has no ctypes signature in _lib.SYMBOLS"
     assert set(_lib.SYMBOLS) == set(names)
-    assert lib.bts_abi_version() == _lib.ABI_VERSION == 6
+    assert lib.bts_abi_version() == _lib.ABI_VERSION == 7
 
 
 def test_ctypes_structs_match_the_c_layout():
@@ -56,6 +56,9 @@ int main(void) {
   printf("%zu %zu %zu %zu\n", offsetof(BtsFieldCfg, enc_render_view), offsetof(BtsRenderArgs, jitter), offsetof(BtsRenderArgs, z_samp_out),
          offsetof(BtsRenderArgs, lindisp));
   printf("%zu\n", offsetof(BtsRenderGrads, d_proj_tiles));
+  printf("%zu %zu %zu %zu\n", sizeof(BtsTrainScale), sizeof(BtsTrainStep), offsetof(BtsTrainScale, feat_shift), offsetof(BtsTrainScale, d_feat_nchw));
+  printf("%zu %zu %zu %zu %zu %zu\n", offsetof(BtsTrainStep, ids_loss), offsetof(BtsTrainStep, loss_matrix), offsetof(BtsTrainStep, images),
+         offsetof(BtsTrainStep, bwd_workspace_bytes), offsetof(BtsTrainStep, d_empty_feature), offsetof(BtsTrainStep, scale));
   return 0;
 }'''
     with tempfile.TemporaryDirectory() as d:
@@ -77,7 +80,13 @@ int main(void) {
     assert [int(x) for x in out[13:17]] == [_lib.BtsFieldCfg.enc_render_view.offset, _lib.BtsRenderArgs.jitter.offset,
                                             _lib.BtsRenderArgs.z_samp_out.offset, _lib.BtsRenderArgs.lindisp.offset]
     # ABI 6: the tile flags of the sparse map gradient -- appended
-    assert [int(x) for x in out[17:]] == [_lib.BtsRenderGrads.d_proj_tiles.offset]
+    assert [int(x) for x in out[17:18]] == [_lib.BtsRenderGrads.d_proj_tiles.offset]
+    # ABI 7: the two-call training step
+    assert [int(x) for x in out[18:22]] == [C.sizeof(_lib.BtsTrainScale), C.sizeof(_lib.BtsTrainStep), _lib.BtsTrainScale.feat_shift.offset,
+                                            _lib.BtsTrainScale.d_feat_nchw.offset]
+    T = _lib.BtsTrainStep
+    assert [int(x) for x in out[22:]] == [T.ids_loss.offset, T.loss_matrix.offset, T.images.offset, T.bwd_workspace_bytes.offset,
+                                          T.d_empty_feature.offset, T.scale.offset]
 
 
 def test_host_only_entry_points(lib):
@@ -139,8 +148,28 @@ def test_errors_are_codes_with_messages_never_exceptions(lib):
     assert lib.bts_render_fwd(C.byref(hint), C.byref(tens), C.byref(args), None) == -1 and b"jitter" in lib.bts_last_error()
     # ABI 6: tiles of 64 texels of the map in memory; the tile backward wants its flag array
     assert lib.bts_proj_tile_count(C.byref(native._spec_cfg(native.FieldSpec(C=64, d_hidden=64, n_blocks=0), n=1, H=192, W=640))) == 1920
-    assert lib.bts_proj_tile_count(C.byref(ok_size)) == (8 * 24 + 63) // 64 and lib.bts_proj_tile_count(C.byref(bad)) == (4 * 12 + 63) // 64
-    assert lib.bts_proj_tile_count(None) == 0
+    assert lib.bts_proj_tile_count(C.byref(ok_size)) == (8 * 24 + 63) // 64
+    # an invalid cfg (H, W not multiples of 2^feat_shift; a shift beyond 6) answers -1 with a message -- never 0: a caller sizing its flag
+    # array with that would hand the kernels no flags; shifts 4 .. 6 are as valid here as in every entry point that takes the flags
+    assert lib.bts_proj_tile_count(C.byref(bad)) == -1 and b"feat_shift" in lib.bts_last_error()
+    deep = native._spec_cfg(native.FieldSpec(C=64, d_hidden=64, n_blocks=0), n=1, H=192, W=640, feat_shift=5)
+    assert lib.bts_proj_tile_count(C.byref(deep)) == (6 * 20 + 63) // 64
+    deep.feat_shift = 7
+    assert lib.bts_proj_tile_count(C.byref(deep)) == -1
+    assert lib.bts_proj_tile_count(None) == -1
+    # ABI 7: the two-call training step validates the whole struct before anything is enqueued
+    assert lib.bts_train_step_fwd(None, None) == -1 and b"NULL" in lib.bts_last_error()
+    st = _lib.BtsTrainStep()
+    st.cfg = native._spec_cfg(native.FieldSpec(C=64, d_hidden=64, n_blocks=0), n=2, H=48, W=160, nv=2)
+    st.v, st.P, st.ph, st.pw, st.K, st.n_scales, st.n_loss = 4, 4, 8, 8, 64, 1, 2
+    st.ids_render[0], st.ids_render[1], st.ids_loss[1] = 2, 3, 1
+    assert lib.bts_train_step_fwd(C.byref(st), None) == -1 and b"NULL input" in lib.bts_last_error()
+    st.ids_render[1] = 9
+    assert lib.bts_train_step_bwd(C.byref(st), None, None) == -1 and b"frame id" in lib.bts_last_error()
+    st.ids_render[1], st.pw = 3, 16
+    assert lib.bts_train_step_fwd(C.byref(st), None) == -1 and b"64 pixels" in lib.bts_last_error()
+    st.pw, st.cfg.C = 8, 48
+    assert lib.bts_train_step_fwd(C.byref(st), None) == -2 and b"envelope" in lib.bts_last_error()
     assert lib.bts_project_features_bwd_tiles(C.byref(ok_size), 16, 16, None, 16, 1, 16, 16, 1, None) == -1 and b"NULL" in lib.bts_last_error()
     assert lib.bts_project_features_bwd_tiles(C.byref(cfg), 16, 16, 16, 16, 1, 16, 16, 1, None) == -2 and b"envelope" in lib.bts_last_error()
     assert lib.bts_project_features_tiles(C.byref(ok_size), 16, 16, 1, None, 16, None) == -1 and b"NULL" in lib.bts_last_error()
@@ -268,7 +297,7 @@ def test_drop_in_emits_the_reference_profiler_ranges():
 
 def test_the_product_library_reads_no_environment_variables():
     """A/B switches (BTS_RENDER_V1, BTS_BWD_V1, BTS_ABLATE, BTS_DBG_PTR ...) exist only in the probe and diagnostic builds: the shipped
-    library does not even import getenv.  (The loader's BTS_RENDER_LIB is Python-side and documented in README.md.)"""
+    library does not even import getenv.  (The loader's BTS_RENDER_LIB is Python-side, honoured only with BTS_ALLOW_LIB_OVERRIDE=1 and documented in README.md.)"""
     import shutil
     nm = shutil.which("nm") or "/opt/rocm/lib/llvm/bin/llvm-nm"
     lib = os.path.join(ROOT, "behindthescenes_amd", "libbts_render.so")

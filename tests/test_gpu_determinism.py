@@ -96,7 +96,7 @@ def _variant(tag):
 def test_parity_holds_on_a_second_schedule(tag):
     """The reference goldens, the fp64 arbiter, the ragged / training shapes and the gradient goldens against a differently scheduled
     build of the same sources (its own process: the library is chosen at load time through BTS_RENDER_LIB)."""
-    env = dict(os.environ, BTS_RENDER_LIB=_variant(tag))
+    env = dict(os.environ, BTS_RENDER_LIB=_variant(tag), BTS_ALLOW_LIB_OVERRIDE="1")
     sel = "(golden or test_fp64_arbiter or ragged_and_training or single_ray) and not real_training"
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-k", sel, "-p", "no:cacheprovider",
                         os.path.join(ROOT, "tests", "test_gpu_parity.py"), os.path.join(ROOT, "tests", "test_gpu_grad.py")],
@@ -131,7 +131,7 @@ torch.save(out, sys.argv[1])
         env = dict(os.environ)
         env.pop("BTS_RENDER_LIB", None)
         if lib:
-            env["BTS_RENDER_LIB"] = lib
+            env["BTS_RENDER_LIB"], env["BTS_ALLOW_LIB_OVERRIDE"] = lib, "1"
         r = subprocess.run([sys.executable, "-c", code, str(f)], env=env, capture_output=True, text=True, cwd=ROOT)
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(torch.load(f))

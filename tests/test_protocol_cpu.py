@@ -178,3 +178,34 @@ def test_loss_algebra_as_one_matrix_equals_the_spelled_out_path(monkeypatch, n_s
         torch.testing.assert_close(a["rgb"].grad, b["rgb"].grad, rtol=1e-5, atol=1e-9)
         if eas > 0:
             torch.testing.assert_close(a["depth"].grad, b["depth"].grad, rtol=1e-5, atol=1e-9)
+
+
+def test_fused_train_step_says_why_a_configuration_takes_the_entry_by_entry_path():
+    """behindthescenes_amd.FusedTrainStep (ABI 7: the training step in two library calls) covers the shipped training configurations and
+    names the condition that sends any other one through the reference's call sequence; host logic only (no kernel runs here).  The
+    loss matrix it hands the library is the criterion's own (rows = the logging dict, row 8 = the loss) and follows the lambdas."""
+    import behindthescenes_amd as bts
+    from behindthescenes_amd import synthetic as S
+    net = bts.BTSNet(S.field_conf(64, 64, 0, 48, 160)).train()
+    renderer = bts.NeRFRenderer.from_conf(dict(n_coarse=64, lindisp=True, hard_alpha_cap=True, lean_training_outputs=True)).train()
+    sampler = bts.PatchRaySampler(ray_batch_size=256, z_near=3.0, z_far=80.0, patch_size=8)
+    crit = bts.ReconstructionLoss({"criterion": "l1+ssim", "invalid_policy": "weight_guided", "lambda_edge_aware_smoothness": 0.001})
+    step = bts.FusedTrainStep(renderer.bind_parallel(net).train(), sampler, crit)
+    ok = dict(ids_encoder=[0], ids_render=[2, 3], ids_loss=[0, 1])
+    assert step.why_not(None, **ok) is None
+    assert "float32" in step.why_not(torch.zeros(1, 4, 3, 48, 160), **ok)                       # CPU frames: the library has no CPU path
+    assert "encoder view" in step.why_not(None, ids_encoder=[0, 1], ids_render=[2], ids_loss=[3])
+    assert "render" in step.why_not(None, ids_encoder=[0], ids_render=list(range(9)), ids_loss=[0])
+    renderer.eval()
+    assert "training mode" in step.why_not(None, **ok)
+    renderer.train()
+    renderer.noise_std = 0.5
+    assert "noise" in step.why_not(None, **ok)
+    renderer.noise_std = 0.0
+    crit.lambda_entropy = 0.01
+    assert "regulariser" in step.why_not(None, **ok)
+    crit.lambda_entropy = 0
+    M = crit.loss_matrix(2, (512, 512), (True, True))
+    assert M.shape == (9, 6) and abs(M[8, 0].item() - 2.0 / 512 / 2) < 1e-12 and abs(M[8, 4].item() - 0.001 / 2 / 512 / 2) < 1e-12
+    crit.lambda_edge_aware_smoothness = 0.01          # a schedule that changes a lambda gets a new matrix (the reference reads it per call)
+    assert abs(crit.loss_matrix(2, (512, 512), (True, True))[8, 1].item() - 0.01 / 512 / 2) < 1e-12

@@ -38,7 +38,7 @@ if __name__ == "__main__":
     outs = []
     for i, lib in enumerate(libs):
         f = f"/tmp/variant_diff_{i}.pt"
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", f] + cases, env=dict(os.environ, BTS_RENDER_LIB=os.path.abspath(lib)),
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", f] + cases, env=dict(os.environ, BTS_RENDER_LIB=os.path.abspath(lib), BTS_ALLOW_LIB_OVERRIDE="1"),
                            capture_output=True, text=True)
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(torch.load(f))

@@ -1,11 +1,12 @@
 """Section-ablation timing of the fused forward (probe build, -DBTS_PROBE) on the BASELINE configs[1] workload.
-    BTS_RENDER_LIB=behindthescenes_amd/libbts_probe.so python tools/ablate_probe.py [rounds]
+    BTS_ALLOW_LIB_OVERRIDE=1 BTS_RENDER_LIB=behindthescenes_amd/variants/libbts_probe.so python tools/ablate_probe.py [rounds]
 Bits: 1 = no G gather/blend, 2 = no sincos, 4 = no MFMA, 8 = no colour taps, 16 = no per-sample stores, 32 = no lin_out.
 Marginal cost of a section = t(0) - t(bit); results are NOT valid renders."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("BTS_RENDER_LIB", os.path.join(ROOT, "behindthescenes_amd", "libbts_probe.so"))
+os.environ.setdefault("BTS_RENDER_LIB", os.path.join(ROOT, "behindthescenes_amd", "variants", "libbts_probe.so"))
+os.environ.setdefault("BTS_ALLOW_LIB_OVERRIDE", "1")
 import torch
 import behindthescenes_amd as bts
 from behindthescenes_amd import native

@@ -8,7 +8,7 @@ res = {a: [] for a in names}
 for _ in range(int(os.environ.get("LIB_AB_PASSES", "2"))):
     for a in names:
         lib = os.path.join(ROOT, "behindthescenes_amd", "libbts_render.so" if a == "default" else f"variants/libbts_{a}.so")
-        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bwd_probe.py"), "7", shape, K], env=dict(os.environ, BTS_RENDER_LIB=lib),
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bwd_probe.py"), "7", shape, K], env=dict(os.environ, BTS_RENDER_LIB=lib, BTS_ALLOW_LIB_OVERRIDE="1"),
                            capture_output=True, text=True)
         m = re.findall(r"colours from the forward: median ([0-9.]+) ms", r.stdout)
         if r.returncode or not m:

@@ -1,6 +1,6 @@
 """Where do the waves of the gate-bit backward (rows_kernel = pass A, scatter_kernel = pass B) spend their cycles?  Needs the diagnostic build
     python -m behindthescenes_amd.build --tag ticks -DBTS_TICKS
-    BTS_RENDER_LIB=behindthescenes_amd/variants/libbts_ticks.so python tools/bwd_ticks.py [kitti360 | kitti_raw]
+    BTS_ALLOW_LIB_OVERRIDE=1 BTS_RENDER_LIB=behindthescenes_amd/variants/libbts_ticks.so python tools/bwd_ticks.py [kitti360 | kitti_raw]
 rows_kernel, cycles per ray iteration: 0 head (ray record, camera, per-sample loads issued, geometry, taps, tile broadcast, first gather blocks
 out)   1 upstream weight gradient + compositing gradient (waits for the per-sample loads)   2 forward pipeline (gather, encoding, lin_in)
 3 gate masks + dw_out.

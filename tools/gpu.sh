@@ -7,6 +7,8 @@
 #   smoke                   __graft_entry__.smoke()
 #   bench[:<args>]          bench.py <args> -> bench[_<args>].json (+ .err)      (args with , for spaces, e.g. bench:--workload,train)
 #   trace:<name>:<args>     rocprofv3 --kernel-trace --stats of bench.py <args> -> <name>_kernel_stats.csv (+ the bts:: lines on stdout)
+#   steptrace:<name>:<marker>:<args>   rocprofv3 --kernel-trace of bench.py <args>; per-kernel table of the last 3 steps (delimited by the
+#                           once-per-step kernel <marker>) -> <name>_steps.txt
 #   ubench:<name>           tools/ubench/<name> -> <name>.txt
 #   prof:<mode>[:K]         tools/profile.sh <tag> <mode> [K]   (PMC passes; summaries under gpurun_out/prof_<tag>/)
 #   py:<script>[:<args>]    python tools/<script>.py <args> -> <script>[_<args>].txt
@@ -34,6 +36,13 @@ for STEP in "$@"; do
       F=$(find $O/trace_$NAME -name "*kernel_stats.csv" | head -1)
       [ -n "$F" ] && cp $F $O/${NAME}_kernel_stats.csv && python tools/trace_table.py $O/${NAME}_kernel_stats.csv ${TRACE_STEPS:-1} 45
       rm -rf $O/trace_$NAME ;;
+    steptrace)
+      # steptrace:<name>:<marker kernel>:<bench args>   steady-state kernel table of the LAST 3 steps (tools/trace_steps.py)
+      NAME=${REST%%:*}; R2=${REST#*:}; MARK=${R2%%:*}; ARGS=${R2#*:}; ARGS=${ARGS//,/ }
+      (cd /tmp && timeout 1200 rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$O/strace_$NAME -o trace -- python $GRAFT_REPO_ROOT/bench.py $ARGS > $GRAFT_REPO_ROOT/$O/strace_$NAME.log 2>&1)
+      F=$(find $O/strace_$NAME -name "*kernel_trace.csv" | head -1)
+      [ -n "$F" ] && python tools/trace_steps.py $F $MARK 3 > $O/${NAME}_steps.txt 2>&1; head -60 $O/${NAME}_steps.txt
+      rm -rf $O/strace_$NAME ;;
     ubench) timeout 600 tools/ubench/$REST > $O/$REST.txt 2>&1; cat $O/$REST.txt ;;
     prof) MODE=${REST%%:*}; KK=${REST#*:}; [ "$KK" = "$REST" ] && KK=""; timeout 1200 bash tools/profile.sh $TAG $MODE $KK 2>&1 | tail -20 ;;
     py)

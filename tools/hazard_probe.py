@@ -68,7 +68,7 @@ def main():
     for tag, lib in libs.items():
         out = os.path.join(tmp, f"hazard_{tag}")
         os.makedirs(out, exist_ok=True)
-        env = dict(os.environ, BTS_RENDER_LIB=lib)
+        env = dict(os.environ, BTS_RENDER_LIB=lib, BTS_ALLOW_LIB_OVERRIDE="1")
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", lib, out], env=env, capture_output=True, text=True)
         if r.returncode != 0:
             report[tag] = dict(error=r.stderr[-2000:])

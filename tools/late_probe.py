@@ -1,7 +1,7 @@
 """Which samples change between launches of a (not shipped) gather-order build?  Renders the RE10K determinism case `runs` times with the
 library named by BTS_RENDER_LIB and compares the per-sample pre-softplus densities (independent per sample: a corrupted gather block shows
 up as exactly the samples it fed) with the first launch.
-    BTS_RENDER_LIB=.../variants/libbts_fetchlate.so python tools/late_probe.py [runs] [case]"""
+    BTS_ALLOW_LIB_OVERRIDE=1 BTS_RENDER_LIB=.../variants/libbts_fetchlate.so python tools/late_probe.py [runs] [case]"""
 import os, sys, collections
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

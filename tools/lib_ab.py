@@ -49,7 +49,7 @@ def main():
             name, *modes = a.split(":")
             lib = os.path.join(ROOT, "behindthescenes_amd", "libbts_render.so" if name == "default" else f"variants/libbts_{name}.so")
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", "15"] + (["--learn-empty"] if le else []) + ["--modes=" + ",".join(modes)],
-                               env=dict(os.environ, BTS_RENDER_LIB=lib, BTS_ALLOW_OLDER_ABI="1"), capture_output=True, text=True)
+                               env=dict(os.environ, BTS_RENDER_LIB=lib, BTS_ALLOW_LIB_OVERRIDE="1", BTS_ALLOW_OLDER_ABI="1"), capture_output=True, text=True)
             if r.returncode:
                 print(a, "FAILED", r.stderr[-500:])
                 continue

@@ -1,6 +1,6 @@
 """Where does a wave of rowsb_kernel (pass A of the row backward) spend its cycles?  Needs the diagnostic build
     python -m behindthescenes_amd.build --tag ticks -DBTS_TICKS
-    BTS_RENDER_LIB=behindthescenes_amd/variants/libbts_ticks.so python tools/rowsb_ticks.py [K]
+    BTS_ALLOW_LIB_OVERRIDE=1 BTS_RENDER_LIB=behindthescenes_amd/variants/libbts_ticks.so python tools/rowsb_ticks.py [K]
 Sections (cycles per ray-chunk iteration, averaged over the waves):
  0 top: loads issued, geometry, taps, table, first blocks out   1 compositing gradient   2 forward pipeline (gather, encoding, lin_in)
  3 block forward   4 dw_out   5 v, vn = mn.W1^T v   6 dW1 tiles   7 t2 = W0^T vn   8 dW0 tiles + v update   9 u0 row stores issued

@@ -6,7 +6,8 @@ Sections (s_memtime deltas accumulated per wave, averaged over waves, per ray it
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("BTS_RENDER_LIB", os.path.join(ROOT, "behindthescenes_amd", "libbts_probe.so"))
+os.environ.setdefault("BTS_RENDER_LIB", os.path.join(ROOT, "behindthescenes_amd", "variants", "libbts_probe.so"))
+os.environ.setdefault("BTS_ALLOW_LIB_OVERRIDE", "1")
 import torch
 import behindthescenes_amd as bts
 from behindthescenes_amd import native

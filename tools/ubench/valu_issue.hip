@@ -6,9 +6,12 @@
 // One work-group per CU (96 KB of LDS keeps a second one out), 256 * W threads = W waves per SIMD (W = 1 .. 4; waves of a work-group go
 // round-robin over the four SIMDs).  Every wave runs ITERS iterations of a block of 64 instructions of one kind on 16 independent
 // register chains (so a chain's next instruction is 16 issue slots behind its producer: no dependency stall), bracketed by s_memtime.
-// Printed per kind and W: cycles per wave-instruction as ONE wave sees them (its own cadence), and cycles per instruction per SIMD
-// (= wave cycles / instructions / W: the pipe's throughput).  If the pipe needs 2 cycles per instruction, the second column bottoms out
-// at 2 once W >= 2; if it needs 4, it stays at 4.
+// Every wave also records the SIMD it ran on (HW_ID) and the constant 100 MHz counter (s_memrealtime).  Printed per kind and W: cycles per
+// wave-instruction as ONE wave sees them (its own cadence); cycles per instruction per SIMD measured PER SIMD as (last wave's end - first
+// wave's start) / instructions issued on that SIMD -- the pipe's throughput whatever the placement of the waves; the waves-per-SIMD
+// histogram (is the placement what the launch intended?); the shader clock (s_memtime ticks per s_memrealtime tick x 100 MHz) and the
+// wall-clock ns per instruction per SIMD.  If the pipe needs 2 cycles per instruction, the throughput column bottoms out near 2 once
+// W >= 2; if it needs 4, it stays at 4.  (Version 1 of this file divided the mean wave time by W and is kept in profiles/r05a.)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
@@ -26,9 +29,23 @@ __device__ __forceinline__ uint64_t memtime() {
   asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
   return t;
 }
+__device__ __forceinline__ uint64_t realtime() {
+  uint64_t t;
+  asm volatile("s_memrealtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  return t;
+}
+__device__ __forceinline__ unsigned hw_id() {
+  unsigned v;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(v));
+  return v;
+}
+struct WaveRec {
+  uint64_t t0, t1, r0, r1;
+  unsigned hw, pad;
+};
 
 template <int KIND>
-__global__ __launch_bounds__(1024) void k(float* out, uint64_t* cycles, int iters, float seed) {
+__global__ __launch_bounds__(1024) void k(float* out, WaveRec* recs, int iters, float seed) {
   extern __shared__ float pad[];
   const int lane = threadIdx.x & 63;
   float v[16];
@@ -39,6 +56,7 @@ __global__ __launch_bounds__(1024) void k(float* out, uint64_t* cycles, int iter
   const f32x2 cc = {c, c};
   if (threadIdx.x == 0) pad[0] = seed;   // keeps the LDS allocation alive
   __syncthreads();
+  const uint64_t r0 = realtime();
   const uint64_t t0 = memtime();
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
@@ -66,36 +84,72 @@ __global__ __launch_bounds__(1024) void k(float* out, uint64_t* cycles, int iter
     }
   }
   const uint64_t t1 = memtime();
+  const uint64_t r1 = realtime();
   float s = 0;
 #pragma unroll
   for (int i = 0; i < 16; ++i) s += v[i] + p[i][0] + p[i][1];
   out[blockIdx.x * blockDim.x + threadIdx.x] = s;
-  if (lane == 0) cycles[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = t1 - t0;
+  if (lane == 0) {
+    WaveRec r;
+    r.t0 = t0, r.t1 = t1, r.r0 = r0, r.r1 = r1, r.hw = hw_id(), r.pad = 0;
+    recs[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = r;
+  }
 }
 
+struct Result {
+  double wave_cpi, simd_cpi, ms, ghz, ns_per_inst;
+  int hist[9];
+};
+
 template <int KIND>
-void run(float* out, uint64_t* cyc_d, int n_cu, double* wave_cpi, double* simd_cpi, double* ms_out, int W) {
+Result run(float* out, WaveRec* rec_d, int n_cu, int W) {
   const int iters = 4000, threads = 256 * W, n_waves = n_cu * 4 * W;
   const size_t lds = 96 * 1024;
   hipFuncSetAttribute((const void*)k<KIND>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipEvent_t e0, e1;
   hipEventCreate(&e0), hipEventCreate(&e1);
-  k<KIND><<<n_cu, threads, lds>>>(out, cyc_d, 16, 1.0f);
+  k<KIND><<<n_cu, threads, lds>>>(out, rec_d, 16, 1.0f);
   hipDeviceSynchronize();
   hipEventRecord(e0);
-  k<KIND><<<n_cu, threads, lds>>>(out, cyc_d, iters, 1.0f);
+  k<KIND><<<n_cu, threads, lds>>>(out, rec_d, iters, 1.0f);
   hipEventRecord(e1);
   hipEventSynchronize(e1);
   float ms;
   hipEventElapsedTime(&ms, e0, e1);
-  static uint64_t host[256 * 16];
-  hipMemcpy(host, cyc_d, n_waves * sizeof(uint64_t), hipMemcpyDeviceToHost);
-  double sum = 0;
-  for (int i = 0; i < n_waves; ++i) sum += (double)host[i];
+  static WaveRec host[256 * 16];
+  hipMemcpy(host, rec_d, n_waves * sizeof(WaveRec), hipMemcpyDeviceToHost);
   const double insts = (double)iters * 64;
-  *wave_cpi = sum / n_waves / insts;
-  *simd_cpi = *wave_cpi / W;
-  *ms_out = ms;
+  Result r;
+  memset(&r, 0, sizeof(r));
+  double wave_sum = 0, simd_sum = 0, clk_sum = 0;
+  int n_simd = 0;
+  for (int b = 0; b < n_cu; ++b) {
+    // the waves of work-group b (= CU b: one work-group fits a CU) by SIMD
+    for (int simd = 0; simd < 4; ++simd) {
+      uint64_t first = ~0ull, lastt = 0;
+      int cnt = 0;
+      for (int w = 0; w < 4 * W; ++w) {
+        const WaveRec& q = host[b * 4 * W + w];
+        if ((int)((q.hw >> 4) & 3) != simd) continue;
+        ++cnt;
+        if (q.t0 < first) first = q.t0;
+        if (q.t1 > lastt) lastt = q.t1;
+      }
+      r.hist[cnt < 8 ? cnt : 8]++;
+      if (cnt) simd_sum += (double)(lastt - first) / (cnt * insts), ++n_simd;
+    }
+    for (int w = 0; w < 4 * W; ++w) {
+      const WaveRec& q = host[b * 4 * W + w];
+      wave_sum += (double)(q.t1 - q.t0);
+      clk_sum += (double)(q.t1 - q.t0) / (double)(q.r1 - q.r0);
+    }
+  }
+  r.wave_cpi = wave_sum / n_waves / insts;
+  r.simd_cpi = simd_sum / n_simd;
+  r.ms = ms;
+  r.ghz = clk_sum / n_waves * 0.1;       // s_memrealtime: 100 MHz
+  r.ns_per_inst = r.simd_cpi / r.ghz;
+  return r;
 }
 
 int main() {
@@ -103,22 +157,27 @@ int main() {
   hipGetDeviceProperties(&prop, 0);
   const int n_cu = prop.multiProcessorCount;
   float* out;
-  uint64_t* cyc;
+  WaveRec* rec;
   hipMalloc(&out, (size_t)n_cu * 1024 * 4);
-  hipMalloc(&cyc, (size_t)n_cu * 16 * 8);
-  printf("# %s, %d CUs, clock %d MHz (s_memtime ticks; the wall-clock column says what a tick is)\n", prop.gcnArchName, n_cu, prop.clockRate / 1000);
-  printf("# one work-group of 256*W threads per CU = W waves per SIMD; 4000 x 64 instructions per wave on 16 independent chains\n");
-  printf("%-34s %2s %12s %12s %10s %14s\n", "instruction", "W", "cyc/inst/wave", "cyc/inst/SIMD", "ms", "ticks per ns");
+  hipMalloc(&rec, (size_t)n_cu * 16 * sizeof(WaveRec));
+  printf("# %s, %d CUs, nominal clock %d MHz\n", prop.gcnArchName, n_cu, prop.clockRate / 1000);
+  printf("# one work-group of 256*W threads per CU = W waves per SIMD intended; 4000 x 64 instructions per wave on 16 independent chains\n");
+  printf("# cyc/inst/wave: one wave's own cadence.  cyc/inst/SIMD: per SIMD (last end - first start) / instructions issued there, mean over the SIMDs.\n");
+  printf("# waves/SIMD histogram: number of SIMDs that hosted 0,1,2,... waves.  GHz: s_memtime ticks per s_memrealtime tick x 100 MHz.\n");
+  printf("%-34s %2s %13s %13s %8s %8s %12s  %s\n", "instruction", "W", "cyc/inst/wave", "cyc/inst/SIMD", "GHz", "ms", "ns/inst/SIMD", "waves/SIMD histogram");
   for (int kind = 0; kind < N_KINDS; ++kind)
     for (int W = 1; W <= 4; ++W) {
-      double w, s, ms;
+      Result r;
       switch (kind) {
-#define CASE(K_) case K_: run<K_>(out, cyc, n_cu, &w, &s, &ms, W); break;
+#define CASE(K_) case K_: r = run<K_>(out, rec, n_cu, W); break;
         CASE(FMA) CASE(MUL) CASE(PKFMA) CASE(PKMUL) CASE(EXP) CASE(RCP) CASE(DPP_SHR) CASE(DPP_BCAST) CASE(CNDMASK) CASE(CVT_PK_F16) CASE(FMA_DEP)
         CASE(MIX_FMA_EXP)
 #undef CASE
       }
-      printf("%-34s %2d %12.2f %12.2f %10.3f %14.3f\n", kNames[kind], W, w, s, ms, w * 4000 * 64 / (ms * 1e6));
+      printf("%-34s %2d %13.2f %13.2f %8.3f %8.3f %12.3f  ", kNames[kind], W, r.wave_cpi, r.simd_cpi, r.ghz, r.ms, r.ns_per_inst);
+      for (int i = 0; i <= 8; ++i)
+        if (r.hist[i]) printf("%d:%d ", i, r.hist[i]);
+      printf("\n");
     }
   return 0;
 }
