@@ -1,7 +1,7 @@
 """behindthescenes_amd -- MI355X-native density-field renderer behind the reference's (Brummi/BehindTheScenes) Python
 interfaces.  The computation lives in libbts_render.so (hand-written HIP for gfx950); see include/bts_render.h."""
 from ._lib import BtsNativeError  # noqa: F401
-from . import parallel  # noqa: F401
+from . import parallel, torch_modes  # noqa: F401
 from .backbone import FeatureMapEncoder, make_backbone, register_backbone  # noqa: F401
 from .code import PositionalEncoding  # noqa: F401
 from .field import BTSNet  # noqa: F401

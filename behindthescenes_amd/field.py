@@ -53,15 +53,18 @@ class BTSNet(nn.Module):
         self.flip_augmentation = conf.get("flip_augmentation", False)
         self.return_sample_depth = conf.get("return_sample_depth", False)
         self.sample_color = conf.get("sample_color", True)
-        if not self.sample_color or self.return_sample_depth:
-            raise NotImplementedError("sample_color=False / return_sample_depth are not used by any shipped config")
+        if self.return_sample_depth:
+            raise NotImplementedError("return_sample_depth is not used by any shipped config")
 
         d_in = self.encoder.latent_size + self.code_xyz.d_out
-        self._d_in, self._d_out = d_in, 1
-        self.mlp_coarse = make_mlp(conf["mlp_coarse"], d_in, d_out=1)
+        # models_bts.py:41-42: colours predicted by the MLP (sample_color=False) make it four outputs wide; no shipped config does that,
+        # and the fused kernels know the one-output density MLP only: that mode runs as a PyTorch composition (torch_modes.py)
+        self._d_in, self._d_out = d_in, (1 if self.sample_color else 4)
+        self.mlp_coarse = make_mlp(conf["mlp_coarse"], d_in, d_out=self._d_out)
         # models_bts.py:45, 293-307: a separate MLP for the fine pass (`coarse=False`); every shipped config says `type: empty` and the
         # coarse MLP serves both.  Here it is one more packed parameter vector (and its own projected map G) through the same kernels.
-        self.mlp_fine = make_mlp(conf["mlp_fine"], d_in, d_out=1, allow_empty=True)
+        self.mlp_fine = make_mlp(conf["mlp_fine"], d_in, d_out=self._d_out, allow_empty=True)
+        self._combined = False        # set by encode(): several encoder views merged per point (combine_ids, the waymo mode)
         if self.learn_empty:
             self.empty_feature = nn.Parameter(torch.randn((self.encoder.latent_size,), requires_grad=True))
         self._scale = 0
@@ -84,6 +87,13 @@ class BTSNet(nn.Module):
             dataclasses.replace(self.spec, d_hidden=self.mlp_fine.d_hidden, n_blocks=self.mlp_fine.n_blocks)
         if not self.code_xyz.include_input:
             raise NotImplementedError("include_input=False is not used by any shipped config")
+
+    @property
+    def torch_mode(self):
+        """True when the field is served by the PyTorch compositions of torch_modes.py instead of the fused HIP kernels: the two modes
+        no shipped config uses -- MLP-predicted colours (`sample_color: false`) and merged encoder views
+        (`encode(..., combine_ids=...)` or more than one encoder view)."""
+        return (not self.sample_color) or self._combined
 
     def mlp(self, coarse=True):
         """models_bts.py:293-307: the MLP of the coarse pass, or of the fine pass when a separate one was configured."""
@@ -135,23 +145,24 @@ class BTSNet(nn.Module):
 
     def encode(self, images, Ks, poses_c2w, ids_encoder=None, ids_render=None, images_alt=None, combine_ids=None):
         """images (n,v,3,H,W) in [-1,1]; Ks (n,v,3,3) normalised intrinsics; poses_c2w (n,v,4,4)  (models_bts.py:65-136)."""
-        if combine_ids is not None:
-            raise NotImplementedError("combine_ids (waymo multi-encoder-view mode) is not part of the HIP render path")
         # a new step: a new autograd graph for the packed parameter vector -- and the one point where edits packed() cannot see
         # (`p.data.copy_()`, an EMA swap: no version bump) are picked up, so also without autograd
         self.mlp_coarse.invalidate_packed()
         if self.mlp_fine is not None:
             self.mlp_fine.invalidate_packed()
-        poses_w2c = native.invert_small(poses_c2w)
         if ids_encoder is None:
             ids_encoder = list(range(images.shape[1]))
+        self._combined = combine_ids is not None or len(ids_encoder) != 1
+        # (the PyTorch-composed modes also run where torch runs; everything else is HIP and says so loudly on a CPU tensor)
+        poses_w2c = torch.inverse(poses_c2w) if (self.torch_mode and not poses_c2w.is_cuda) else native.invert_small(poses_c2w)
         images_encoder, Ks_encoder, poses_w2c_encoder = _take(images, ids_encoder), _take(Ks, ids_encoder), _take(poses_w2c, ids_encoder)
         colours = images_alt if images_alt is not None else None
         if ids_render is None:
             ids_render = list(range(images.shape[1]))
         n, nv_enc, c, h, w = images_encoder.shape
-        if nv_enc != 1:
-            raise NotImplementedError("the HIP render path takes exactly one encoder view (ids_encoder=[0] in every shipped mode)")
+        if self.torch_mode:
+            return self._encode_torch_mode(images, Ks, poses_w2c, images_encoder, Ks_encoder, poses_w2c_encoder, ids_encoder, ids_render, colours,
+                                           combine_ids)
 
         do_flip = bool(self.flip_augmentation and self.training and (torch.rand(1) > .5).item())
         if do_flip:
@@ -196,6 +207,35 @@ class BTSNet(nn.Module):
         ids_r, id_e = [int(i) for i in ids_render], int(ids_encoder[0])
         self._enc_view = ids_r.index(id_e) if id_e in ids_r else -1
 
+    def _encode_torch_mode(self, images, Ks, poses_w2c, images_encoder, Ks_encoder, poses_w2c_encoder, ids_encoder, ids_render, colours, combine_ids):
+        """encode() for the PyTorch-composed modes (models_bts.py:93-136): every encoder view's maps at scale 0's size, the view groups."""
+        from . import torch_modes
+        torch_modes.warn_once("combine_ids / several encoder views" if self._combined else "sample_color=False")
+        n, nv_enc, c, h, w = images_encoder.shape
+        enc_groups = ren_groups = None
+        if combine_ids is not None:
+            groups = [list(g) for g in combine_ids]
+            grouped = set(sum(groups, []))
+            groups += [[i] for i in range(images.shape[1]) if i not in grouped]
+            pos_e = {int(f): i for i, f in enumerate(ids_encoder)}
+            pos_r = {int(f): i for i, f in enumerate(ids_render)}
+            enc_groups = [g for g in ([pos_e[i] for i in grp if i in pos_e] for grp in groups) if g]
+            ren_groups = [g for g in ([pos_r[i] for i in grp if i in pos_r] for grp in groups) if g]
+        do_flip = bool(self.flip_augmentation and self.training and (torch.rand(1) > .5).item())
+        enc_in = torch.flip(images_encoder, dims=(-1,)) if do_flip else images_encoder
+        latents = self.encoder(enc_in.reshape(n * nv_enc, c, h, w))
+        if do_flip:
+            latents = [torch.flip(il, dims=(-1,)) for il in latents]
+        h_, w_ = latents[0].shape[-2:]
+        self._grid_f_features = [F.interpolate(il, (h_, w_)).view(n, nv_enc, -1, h_, w_) for il in latents]
+        self._has_latents, self._grid_size = True, (h_, w_)
+        self._latents_ms, self._shift_ms = None, None
+        self.grid_f_Ks, self.grid_f_poses_w2c, self.grid_f_combine = Ks_encoder, poses_w2c_encoder, enc_groups
+        src = _take(colours if colours is not None else images, ids_render)
+        self._grid_c_src, self._grid_c_raw = src, colours is None
+        self.grid_c_Ks, self.grid_c_poses_w2c, self.grid_c_combine = _take(Ks, ids_render), _take(poses_w2c, ids_render), ren_groups
+        self._native = {}
+
     def native_field(self, coarse=True, sampled=None) -> "native.FieldTensors":
         """Field state of the current scale in the C-ABI layouts.  The projected feature map G = F . w_in[:, :C]^T is built lazily
         per scale (one HIP pass that also does the NCHW -> channels-last hand-over) and cached until the next ``encode`` or until
@@ -204,6 +244,9 @@ class BTSNet(nn.Module):
         ``sampled`` = (rays (n*Bp, 8), z_samp | None, jitter | None, lindisp): a ONE-SHOT field for the render of exactly these samples
         -- only the 64-texel tiles of G their taps land in are projected (a training step's rays read 10-40 % of them), the rest of the
         map is uninitialised memory; never cached, never handed to field queries."""
+        if self.torch_mode:
+            raise native.BtsNativeError("this field runs as a PyTorch composition (sample_color=False / merged encoder views, torch_modes.py): "
+                                        "it has no state in the fused kernels' layouts")
         s = self._scale
         fine = not coarse and self.mlp_fine is not None
         mlp, spec = (self.mlp_fine, self.spec_fine) if fine else (self.mlp_coarse, self.spec)
@@ -219,6 +262,7 @@ class BTSNet(nn.Module):
             ft = native.FieldTensors(spec, proj, self._K_enc, self._w2c_enc, self._imgs_nhwc4, self._K_r, self._w2c_r,
                                      self.empty_feature if self.learn_empty else None, feat_shift=self._shift_ms[s], enc_view=self._enc_view)
             ft.proj_link = link
+            ft.partial = (rays.data_ptr(), rays.shape[0])     # valid for THIS sample set only (native.FieldTensors.partial)
             return ft
         version = (mlp.lin_in.weight._version, torch.is_grad_enabled())
         hit = self._native.get((s, fine))
@@ -237,6 +281,10 @@ class BTSNet(nn.Module):
         """xyz (n, P, 3) world points -> rgb (n,P,nv*3), invalid (n,P,nv) float, sigma (n,P,1)  (models_bts.py:266-338).
         Forward-only (the reference's callers of this entry point -- occupancy profiles, LiDAR / 3D-bbox evaluators -- run it
         under no_grad); training goes through the renderer's composite, which is differentiable."""
+        if self.torch_mode:
+            from . import torch_modes
+            with profiler.record_function("model_inference"):
+                return torch_modes.field_forward(self, xyz, coarse=coarse, only_density=only_density)
         ft = self.native_field(coarse)
         with torch.no_grad(), profiler.record_function("model_inference"):   # models_bts.py:275
             rgb, invalid, sigma = native.field_query(ft, self.mlp(coarse).packed().detach(), xyz.detach().float().contiguous(),

@@ -124,6 +124,16 @@ class NeRFRenderer(torch.nn.Module):
             z_samp, jitter = z_samp.float().contiguous(), None
         else:
             jitter = jitter.float().contiguous()
+        if model.torch_mode:
+            # MLP-predicted colours / merged encoder views run as a PyTorch composition (torch_modes.py) -- the field
+            # query AND the compositing around it, differentiable through autograd; no shipped configuration comes here
+            from . import torch_modes
+            if z_samp is None:
+                z_samp = native.sample_coarse(rays, jitter, self.lindisp) if rays.is_cuda else torch_modes.sample_coarse(rays, jitter, self.lindisp)
+            comp = torch_modes.composite(self, model, rays, z_samp, coarse=coarse, sb=sb)
+            if want_invalid_sums:
+                raise native.BtsNativeError("lean_training_outputs is a feature of the fused kernels; switch it off for the PyTorch-composed modes")
+            return comp
         # sparse_proj (the lean training path): the projected map is built for THIS render's samples only (BTSNet.native_field)
         ft = model.native_field(coarse, sampled=(rays, z_samp, jitter, bool(self.lindisp)) if sparse_proj else None)
         n = ft.n
@@ -175,7 +185,7 @@ class NeRFRenderer(torch.nn.Module):
             ns = prop_weights.shape[-1]
             z_coarse = self.sample_coarse_from_dist(rays, prop_weights.reshape(-1, ns), prop_z.reshape(-1, ns))
             z_coarse, _ = torch.sort(z_coarse, dim=-1)
-        if self.lean_training_outputs and self.training and not self.using_fine and torch.is_grad_enabled():
+        if self.lean_training_outputs and self.training and not self.using_fine and torch.is_grad_enabled() and not getattr(model, "torch_mode", False):
             # in a training step nothing downstream of the renderer reads the per-sample tensors except the loss'
             # invalid-ray mask, and that only through sum_k weights * invalid / any_k invalid per view -- the render kernel's
             # epilogue emits exactly those (8 B per ray and view), and weights / alphas / invalid are neither written nor returned

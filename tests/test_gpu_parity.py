@@ -596,3 +596,60 @@ def test_errors_are_loud(hip):
         renderer.composite(torch.nn.Linear(3, 3), c.rays.reshape(-1, 8).cuda(), c.z_samp.cuda(), sb=1)
     with pytest.raises(native.BtsNativeError):
         native.check_supported(native.FieldSpec(C=48, d_hidden=64, n_blocks=0))
+
+
+@pytest.mark.parametrize("learn_empty", [False, True])
+def test_raw_rows_worst_case_vs_fp64(hip, learn_empty):
+    """lin_in's three RAW inputs -- the projected x, y and the depth code -- ride the f16 matrix pipe as two round-to-nearest halves
+    (hi + lo: |v - hi - lo| <= 2^-24 |v|, the bound stated next to BtsFieldCfg in include/bts_render.h), like the 36 trig rows, but
+    unlike those they are not bounded by 1: a point beside or behind the encoder camera projects to |x|, |y| in the hundreds (the
+    perspective divide clamps z at 1e-3, models_bts.py:150-155), and with learn_empty=False its features and density still enter the
+    composite.  Adversarial query points: |x|, |y| log-uniform in [1, 2000] with both signs, inside the frustum too, the depth code at
+    both ends of [-1, 1] and clamped; HIP vs the fp32 oracle (= what the reference computes), both against an fp64 evaluation, under
+    the rule of test_fp64_arbiter (HIP may not miss fp64 by more than 1.5 x what the fp32 oracle misses it by)."""
+    from tests._hip_helpers import build_net
+    cfg = O.FieldConfig(learn_empty=learn_empty)
+    g = torch.Generator().manual_seed(77 + int(learn_empty))
+    H, W, P = 96, 320, 60000
+    scene = O.synthetic_scene(1, 2, H, W, 64, seed=77, intrinsics=O.K_KITTIRAW, smooth=True)
+    mlp = O.init_mlp(103, 64, 0, gen=g)
+    Kmat = scene["projs"][0, 0]
+    fx, fy, cx, cy = Kmat[0, 0].item(), Kmat[1, 1].item(), Kmat[0, 2].item(), Kmat[1, 2].item()
+    mag = lambda: 10 ** (torch.rand(P, generator=g) * 3.3) * (torch.randint(0, 2, (P,), generator=g) * 2 - 1).float()
+    xn, yn = mag(), mag()
+    inside = torch.rand(P, generator=g) < 0.25                       # a quarter inside the frustum (|x|, |y| < 1): the ordinary case
+    xn = torch.where(inside, torch.rand(P, generator=g) * 2 - 1, xn)
+    yn = torch.where(inside, torch.rand(P, generator=g) * 2 - 1, yn)
+    zc = torch.tensor([3.0, 80.0, 0.5, 10.0, 1e-3, 2e-4])[torch.randint(0, 6, (P,), generator=g)]       # code +1, -1, beyond, mid, clamped
+    zeff = zc.clamp_min(1e-3)
+    # view 0 is the encoder camera at the identity pose: camera coordinates are world coordinates
+    pts = torch.stack(((xn - cx) * zeff / fx, (yn - cy) * zeff / fy, zc), dim=-1).view(1, P, 3).contiguous()
+    empty = torch.randn(64, generator=g) if learn_empty else None
+    st = O.make_state(scene, [1], cfg, empty)
+    dd = lambda t: None if t is None else t.double()
+    with torch.no_grad():
+        _, inv32, s32 = O.field_forward(pts, st, mlp, cfg)
+        st64 = O.FieldState(dd(st.feat), dd(st.K_enc), dd(st.w2c_enc), dd(st.imgs), dd(st.K_r), dd(st.w2c_r), dd(st.empty_feature))
+        mlp64 = O.MlpParams(dd(mlp.w_in), dd(mlp.b_in), [], dd(mlp.w_out), dd(mlp.b_out))
+        torch.set_default_dtype(torch.float64)
+        try:
+            _, inv64, s64 = O.field_forward(dd(pts), st64, mlp64, cfg)
+        finally:
+            torch.set_default_dtype(torch.float32)
+        net = build_net(cfg, mlp, scene, [1], empty_feature=empty)
+        _, inv_h, s_h = net(pts.cuda())
+    # the sweep is what it claims to be
+    xy32, *_ = O.project(pts, st.w2c_enc.unsqueeze(1), st.K_enc.unsqueeze(1))
+    big = xy32[0, 0].abs().amax(-1)
+    assert (big > 1000).sum() > 500 and (big > 100).sum() > 5000 and (big < 1).sum() > 5000
+    # compare where the three evaluations agree on the frustum flags (a point within rounding of the border may flip: with learn_empty
+    # it then swaps its whole feature vector)
+    same = (inv_h.cpu() == inv32).all(-1) & (inv64.float() == inv32).all(-1)
+    assert same.float().mean().item() > 0.999
+    for lo, hi_ in ((0.0, 1.0), (1.0, 100.0), (100.0, 3000.0)):
+        m = (same & (big >= lo) & (big < hi_)).reshape(-1)
+        e_ref = (s32.double() - s64).abs().reshape(-1)[m]
+        e_hip = (s_h.cpu().double() - s64).abs().reshape(-1)[m]
+        assert m.sum() > 1000
+        assert e_hip.max().item() <= 1.5 * e_ref.max().item() + 1e-7, (lo, hi_, e_hip.max().item(), e_ref.max().item())
+        assert e_hip.square().mean().sqrt().item() <= 1.5 * e_ref.square().mean().sqrt().item() + 1e-9, (lo, hi_)

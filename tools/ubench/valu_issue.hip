@@ -19,10 +19,15 @@
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-enum Kind { FMA = 0, MUL, PKFMA, PKMUL, EXP, RCP, DPP_SHR, DPP_BCAST, CNDMASK, CVT_PK_F16, FMA_DEP, MIX_FMA_EXP, N_KINDS };
+enum Kind { FMA = 0, MUL, PKFMA, PKMUL, EXP, RCP, DPP_SHR, DPP_BCAST, CNDMASK, CVT_PK_F16, FMA_DEP, MIX_FMA_EXP,
+            ADD, FMAC, MUL_E64, FMA3, CNDMASK_SET, CNDMASK_E64, MAX, MOV, LSHL, CVT_F16, MED3, FMA_MIX, MUL_2W, N_KINDS };
 static const char* kNames[N_KINDS] = {"v_fma_f32", "v_mul_f32", "v_pk_fma_f32", "v_pk_mul_f32", "v_exp_f32", "v_rcp_f32",
                                       "v_add_f32 dpp row_shr:1", "v_add_f32 dpp row_bcast:15", "v_cndmask_b32", "v_cvt_pk_f16_f32",
-                                      "v_fma_f32 (ONE dependent chain)", "3 v_fma_f32 : 1 v_exp_f32"};
+                                      "v_fma_f32 (ONE dependent chain)", "3 v_fma_f32 : 1 v_exp_f32",
+                                      "v_add_f32 (e32)", "v_fmac_f32 (e32)", "v_mul_f32_e64 (VOP3 encoding)", "v_fma_f32, 3 distinct sources",
+                                      "v_cndmask_b32 e32, vcc written first", "v_cndmask_b32_e64, SGPR-pair mask", "v_max_f32 (e32)",
+                                      "v_mov_b32 (e32)", "v_lshlrev_b32 (e32)", "v_cvt_f16_f32 (e32)", "v_med3_f32 (VOP3)",
+                                      "v_fma_mix_f32 (VOP3P)", "v_mul_f32 e32, 2 distinct sources"};
 
 __device__ __forceinline__ uint64_t memtime() {
   uint64_t t;
@@ -56,6 +61,8 @@ __global__ __launch_bounds__(1024) void k(float* out, WaveRec* recs, int iters, 
   const f32x2 cc = {c, c};
   if (threadIdx.x == 0) pad[0] = seed;   // keeps the LDS allocation alive
   __syncthreads();
+  unsigned long long mask = 0x5555aaaa3333ccccull ^ (unsigned long long)iters;
+  if constexpr (KIND == CNDMASK_SET) asm volatile("v_cmp_gt_f32 vcc, %0, %1" ::"v"(v[0]), "v"(c) : "vcc");
   const uint64_t r0 = realtime();
   const uint64_t t0 = memtime();
   for (int it = 0; it < iters; ++it) {
@@ -74,6 +81,19 @@ __global__ __launch_bounds__(1024) void k(float* out, WaveRec* recs, int iters, 
         if constexpr (KIND == CNDMASK) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(v[j]) : "v"(c));
         if constexpr (KIND == CVT_PK_F16) asm volatile("v_cvt_pk_f16_f32 %0, %0, %1" : "+v"(v[j]) : "v"(c));
         if constexpr (KIND == FMA_DEP) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(v[0]) : "v"(c));
+        if constexpr (KIND == ADD) asm volatile("v_add_f32 %0, %0, %1" : "+v"(v[j]) : "v"(c));
+        if constexpr (KIND == FMAC) asm volatile("v_fmac_f32 %0, %1, %1" : "+v"(v[j]) : "v"(c));
+        if constexpr (KIND == MUL_E64) asm volatile("v_mul_f32_e64 %0, %0, %1" : "+v"(v[j]) : "v"(c));
+        if constexpr (KIND == FMA3) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v[j]) : "v"(c), "v"(v[(j + 5) & 15]));
+        if constexpr (KIND == CNDMASK_SET) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(v[j]) : "v"(c));
+        if constexpr (KIND == CNDMASK_E64) asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(v[j]) : "v"(c), "s"(mask));
+        if constexpr (KIND == MAX) asm volatile("v_max_f32 %0, %0, %1" : "+v"(v[j]) : "v"(c));
+        if constexpr (KIND == MOV) asm volatile("v_mov_b32 %0, %1" : "+v"(v[j]) : "v"(c));
+        if constexpr (KIND == LSHL) asm volatile("v_lshlrev_b32 %0, 1, %0" : "+v"(v[j]));
+        if constexpr (KIND == CVT_F16) asm volatile("v_cvt_f16_f32 %0, %0" : "+v"(v[j]));
+        if constexpr (KIND == MED3) asm volatile("v_med3_f32 %0, %0, %1, %1" : "+v"(v[j]) : "v"(c));
+        if constexpr (KIND == FMA_MIX) asm volatile("v_fma_mix_f32 %0, %0, %1, %1" : "+v"(v[j]) : "v"(c));
+        if constexpr (KIND == MUL_2W) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(v[j]) : "v"(v[(j + 5) & 15]));
         if constexpr (KIND == MIX_FMA_EXP) {
           if ((j & 3) == 3)
             asm volatile("v_exp_f32 %0, %0" : "+v"(v[j]));
@@ -166,12 +186,14 @@ int main() {
   printf("# waves/SIMD histogram: number of SIMDs that hosted 0,1,2,... waves.  GHz: s_memtime ticks per s_memrealtime tick x 100 MHz.\n");
   printf("%-34s %2s %13s %13s %8s %8s %12s  %s\n", "instruction", "W", "cyc/inst/wave", "cyc/inst/SIMD", "GHz", "ms", "ns/inst/SIMD", "waves/SIMD histogram");
   for (int kind = 0; kind < N_KINDS; ++kind)
-    for (int W = 1; W <= 4; ++W) {
+    for (int W = 1; W <= 4; W += (kind > MIX_FMA_EXP ? 1 : 1)) {
+      if (kind > MIX_FMA_EXP && W == 3) continue;
       Result r;
       switch (kind) {
 #define CASE(K_) case K_: r = run<K_>(out, rec, n_cu, W); break;
         CASE(FMA) CASE(MUL) CASE(PKFMA) CASE(PKMUL) CASE(EXP) CASE(RCP) CASE(DPP_SHR) CASE(DPP_BCAST) CASE(CNDMASK) CASE(CVT_PK_F16) CASE(FMA_DEP)
-        CASE(MIX_FMA_EXP)
+        CASE(MIX_FMA_EXP) CASE(ADD) CASE(FMAC) CASE(MUL_E64) CASE(FMA3) CASE(CNDMASK_SET) CASE(CNDMASK_E64) CASE(MAX) CASE(MOV) CASE(LSHL) CASE(CVT_F16)
+        CASE(MED3) CASE(FMA_MIX) CASE(MUL_2W)
 #undef CASE
       }
       printf("%-34s %2d %13.2f %13.2f %8.3f %8.3f %12.3f  ", kNames[kind], W, r.wave_cpi, r.simd_cpi, r.ghz, r.ms, r.ns_per_inst);
