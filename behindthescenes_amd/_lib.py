@@ -74,6 +74,11 @@ class BtsTrainStep(C.Structure):
                [("scale", BtsTrainScale * BTS_MAX_SCALES)]
 
 
+class BtsConv3x3(C.Structure):
+    _fields_ = [(k, C.c_int32) for k in ("N", "H", "W", "C", "up2", "elu", "out_nchw", "reserved_")] + \
+               [(k, C.c_void_p) for k in ("x", "weight", "bias", "y")]
+
+
 # every symbol include/bts_render.h declares: name -> (restype, argtypes)
 _P = C.c_void_p
 _I = C.c_int32
@@ -105,6 +110,9 @@ SYMBOLS = {
     "bts_invert_small": (C.c_int, [_P, _P, _I, _I, _P]),
     "bts_train_step_fwd": (C.c_int, [C.POINTER(BtsTrainStep), _P]),
     "bts_train_step_bwd": (C.c_int, [C.POINTER(BtsTrainStep), _P, _P]),
+    "bts_conv3x3_fwd": (C.c_int, [C.POINTER(BtsConv3x3), _P]),
+    "bts_conv3x3_bwd_workspace": (C.c_size_t, [C.POINTER(BtsConv3x3)]),
+    "bts_conv3x3_bwd": (C.c_int, [C.POINTER(BtsConv3x3), _P, _P, C.c_size_t, _P, _P, _P, _P]),
 }
 
 _lock = threading.Lock()

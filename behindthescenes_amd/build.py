@@ -18,7 +18,7 @@ LIB = os.path.join(PKG, "libbts_render.so")
 VARIANTS = os.path.join(PKG, "variants")
 # objects, saved assembly and the digest stamp live outside the repo (they are large and must not travel to the GPU box)
 OBJ = os.path.join(os.environ.get("BTS_OBJ_DIR", "/tmp"), "bts_render_obj")
-SOURCES = ["bts_fwd.hip", "bts_fwd_proj.hip", "bts_fwd_epi.hip", "bts_query.hip", "bts_bwd.hip", "bts_bwd_rows.hip", "bts_bwd_blocks.hip", "bts_prep.hip", "bts_aux.hip", "bts_loss.hip", "bts_train.hip", "bts_api.hip"]
+SOURCES = ["bts_fwd.hip", "bts_fwd_proj.hip", "bts_fwd_epi.hip", "bts_query.hip", "bts_bwd.hip", "bts_bwd_rows.hip", "bts_bwd_blocks.hip", "bts_prep.hip", "bts_aux.hip", "bts_loss.hip", "bts_train.hip", "bts_conv.hip", "bts_api.hip"]
 # -fno-slp-vectorize: hipcc's SLP vectoriser builds v_pk_*_f32 with op_sel:[x,1], which MI355X evaluates wrongly in lanes 48-63 next
 # to a wide MFMA (tools/check_pk_opsel.py, tools/ubench/pk_opsel_lanes.hip); explicit float2 code keeps the packed FMAs that matter
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-fno-gpu-rdc",

@@ -1,0 +1,480 @@
+// bts_conv.hip -- the Monodepth2 decoder's tail as hand-written CDNA4 kernels.
+//
+// With d_out = 64 the decoder's widths are clamped to >= 64 (models/common/backbones/monodepth2.py:189-206), so the layers that produce
+// the renderer's scale-0 feature map are   upconv(0,0): ConvBlock 64 -> 64 @ H/2   ->  nearest x2  ->  upconv(0,1): ConvBlock 64 -> 64
+// @ H  ->  dispconv(0): Conv3x3 64 -> 64 @ H   (monodepth2.py:211-239; ConvBlock = Conv3x3 + ELU, Conv3x3 = ReflectionPad2d(1) +
+// 3 x 3 convolution, models/common/model/layers.py:11-40).  Through MIOpen the three cost 23.1 ms of a 47.5 ms exp_kitti_360.yaml
+// step (profiles/r05c/md2_tail_probe.txt) -- and only 4.1 ms per full-size layer of that are the convolution kernels themselves
+// (fp32 implicit GEMMs at 100-120 TFLOP/s: forward 1.18, data gradient 1.52, weight gradient 1.45 ms); the other 6 ms are the padded
+// copy the reflection makes, layout changes around the channels-last kernels, ELU and its backward, the x2 upsampling and its backward
+// as separate passes over 0.5 GB tensors.
+//
+// One operator, three kernels, nothing materialised in between:
+//   y = [ELU]( conv3x3( reflect_pad1( [nearest x2]( x ) ), W ) + b ),   x (N, Hs, Ws, C) channels-last, y channels-last or NCHW
+//   conv_kernel<FWD>    : implicit GEMM over the 9 taps; the reflection and the x2 upsampling are index arithmetic on the source pixel
+//   conv_kernel<DGRAD>  : the exact adjoint -- for an input pixel p the (output pixel q, tap t) pairs with reflect(q + t) = p: three
+//                         per axis, a fourth for the two lines next to a border (the reflected line folds back onto them); with
+//                         the x2 upsampling the wave accumulates the 2 x 2 children of a source pixel before it stores
+//   wgrad_kernel        : dW[t] = sum_pixels x[reflect(p + t)] (x) dy[p], contraction over the pixels as the MFMA's k axis
+// All three run on v_mfma_f32_32x32x2_f32 with exact fp32 products (the products of a convolution have no bounded range to build an
+// f16 / bf16 split on without a scaling pass, and the fp32-input MFMA's 157 TFLOP/s are what MIOpen's kernels run against too): the
+// win is the traffic and the launches that disappear, not a faster matrix pipe.  Weights (9 x 64 x 64 x 4 B = 144 KB) are staged ONCE
+// per persistent work-group into LDS in the order the MFMA's k-steps read them; the activations of a tile come straight from HBM / L2
+// as 16-byte pieces per lane (the k order of an MFMA is free: k-step (q, j) pairs channel 8 q + j of lane half 0 with channel
+// 8 q + 4 + j of half 1, so a lane's float4 feeds four MFMAs).
+#include "bts_common.h"
+
+#include <cstring>
+
+namespace bts {
+
+void set_error(const char* fmt, const char* a = "", long b = 0, long c = 0, long d = 0);
+int device_cu_count();
+int transpose_launch(const float* src, float* dst, int N, int C, int H, int W, bool to_nhwc, hipStream_t s);
+
+constexpr int kTapFloats = 64 * 64;          // one tap's weights
+constexpr int kConvLds = 9 * kTapFloats;     // floats: 147 456 bytes
+
+struct ConvParams {
+  const float* x;     // source (N, Hs, Ws, 64) channels-last: the layer's input (FWD, WGRAD) or the output gradient dy' (DGRAD)
+  const float* w;     // (64, 64, 3, 3) torch layout [co][ci][ty][tx]
+  const float* bias;  // (64) or null (FWD)
+  float* y;           // FWD: output (N, H, W, 64) or (N, 64, H, W); DGRAD: dx (N, Hs, Ws, 64)
+  int N, H, W;        // the convolution's domain (output size of the layer = size of its padded-and-upsampled input)
+  int up2;            // the layer's input is (N, H/2, W/2, 64), read through a nearest x2 upsampling
+  int elu;            // FWD: ELU(alpha = 1) on the output
+  int out_nchw;       // FWD: y is (N, 64, H, W)
+  int tiles_per_row;  // tiles of 64 pixels along a row
+  long n_tiles;       // N * rows * tiles_per_row (DGRAD with up2: rows = H / 2, a tile = 64 pixels of TWO adjacent rows)
+};
+
+__device__ __forceinline__ int reflect(int i, int L) { return i < 0 ? -i : (i >= L ? 2 * L - 2 - i : i); }
+
+// weights -> LDS: slot (((tap * 8 + q) * 2 + h) * 64 + col) * 4 + j holds Wk[tap][k = 8 q + 4 h + j][col];
+//   FWD / WGRAD-free form: k = ci, col = co  (y[co] += W[co][ci] x[ci]);  DGRAD: k = co, col = ci (dx[ci] += W[co][ci] dy[co])
+template <bool TRANSPOSED>
+__device__ __forceinline__ void stage_conv_weights(float* lds, const float* __restrict__ w) {
+  for (int i = threadIdx.x; i < kConvLds; i += blockDim.x) {
+    const int j = i & 3, col = (i >> 2) & 63, h = (i >> 8) & 1, q = (i >> 9) & 7, tap = i >> 12;
+    const int k = 8 * q + 4 * h + j;
+    const int co = TRANSPOSED ? k : col, ci = TRANSPOSED ? col : k;
+    lds[i] = w[(co * 64 + ci) * 9 + tap];
+  }
+}
+
+// one pass of a tile: acc[pt][ct] += X-fragment (64 pixels x 64 k) . Wk[tap] (64 k x 64 cols); `src` = per-lane element offsets of the
+// two pixel tiles' source pixels (+ 4 h already applied), `ok` = per-lane validity (a masked lane contributes zeros)
+template <bool OUT_NCHW>
+__device__ __forceinline__ void conv_pass(f32x16 (&acc)[2][2], const float* lds, const float* __restrict__ base, const unsigned (&src)[2], const bool (&ok)[2],
+                                          int tap, int h, int col) {
+  float4 xa[2][8];
+#pragma unroll
+  for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+    for (int q = 0; q < 8; ++q) xa[pt][q] = ok[pt] ? *reinterpret_cast<const float4*>(base + src[pt] + 8 * q) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  __builtin_amdgcn_sched_barrier(0);   // all sixteen loads in flight before the first MFMA (the scheduler otherwise sinks each to its use)
+  const float* wt = lds + tap * kTapFloats + h * 256 + col * 4;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const float4 w0 = *reinterpret_cast<const float4*>(wt + q * 512);
+    const float4 w1 = *reinterpret_cast<const float4*>(wt + q * 512 + 128);
+    const float wv[2][4] = {{w0.x, w0.y, w0.z, w0.w}, {w1.x, w1.y, w1.z, w1.w}};
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt) {
+      const float xv[4] = {xa[pt][q].x, xa[pt][q].y, xa[pt][q].z, xa[pt][q].w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) acc[pt][ct] = OUT_NCHW ? mfma(wv[ct][j], xv[j], acc[pt][ct]) : mfma(xv[j], wv[ct][j], acc[pt][ct]);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// forward: one wave = 64 consecutive pixels of an output row x all 64 output channels; 9 passes (taps)
+// ---------------------------------------------------------------------------------------------------------------------------------
+template <bool OUT_NCHW>
+__global__ __launch_bounds__(512) void conv_fwd_kernel(const ConvParams p) {
+  extern __shared__ float lds[];
+  stage_conv_weights<false>(lds, p.w);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, col = lane & 31;
+  const int Hs = p.up2 ? p.H >> 1 : p.H, Ws = p.up2 ? p.W >> 1 : p.W;
+  const long rows = (long)p.H * p.tiles_per_row;
+  for (long tile = (long)blockIdx.x * 8 + wave; tile < p.n_tiles; tile += (long)gridDim.x * 8) {
+    const int img = (int)(tile / rows);
+    const int rem = (int)(tile - (long)img * rows);
+    const int y = rem / p.tiles_per_row, x0 = (rem - y * p.tiles_per_row) * 64;
+    const float* base = p.x + (long)img * Hs * Ws * 64;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        // the accumulators are born from the bias: D[pixel][co] (channels across the lanes) or D[co][pixel] (channels in the registers)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[pt][ct][r] = !p.bias ? 0.0f : (OUT_NCHW ? p.bias[ct * 32 + mfma_row(r, h)] : p.bias[ct * 32 + col]);
+      }
+    const int xl[2] = {min(x0 + col, p.W - 1), min(x0 + 32 + col, p.W - 1)};   // (lanes beyond a ragged row end repeat its last pixel; not stored)
+#pragma unroll
+    for (int ty = 0; ty < 3; ++ty) {
+      int sy = reflect(y + ty - 1, p.H);
+      if (p.up2) sy >>= 1;
+#pragma unroll
+      for (int tx = 0; tx < 3; ++tx) {
+        unsigned src[2];
+        const bool ok[2] = {true, true};
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt) {
+          int sx = reflect(xl[pt] + tx - 1, p.W);
+          if (p.up2) sx >>= 1;
+          src[pt] = (unsigned)((sy * Ws + sx) * 64 + 4 * h);
+        }
+        conv_pass<OUT_NCHW>(acc, lds, base, src, ok, ty * 3 + tx, h, col);
+      }
+    }
+    // epilogue: ELU, store.  NHWC: row r of the tile = pixel, the 32 lanes of a half = 32 consecutive channels (128-byte pieces);
+    // NCHW: row r = channel, the lanes = 32 consecutive pixels of that channel's row
+    float* out = p.y + (long)img * p.H * p.W * 64;
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = acc[pt][ct][r];
+          if (p.elu) v = v > 0.0f ? v : expm1f(v);
+          if (OUT_NCHW) {
+            const int x = x0 + pt * 32 + col;
+            if (x < p.W) out[(unsigned)(((ct * 32 + mfma_row(r, h)) * p.H + y) * p.W + x)] = v;
+          } else {
+            const int x = x0 + pt * 32 + mfma_row(r, h);
+            if (x < p.W) out[(unsigned)((y * p.W + x) * 64 + ct * 32 + col)] = v;
+          }
+        }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// data gradient: dx[p] = sum over the (q, t) with reflect(q + t) = p of W[t]^T dy[q].  Per axis (length L, coordinate c): q = c - t for
+// t = -1, 0, +1 where that lies inside, plus (q = 0, t = -1) for c == 1 and (q = L - 1, t = +1) for c == L - 2 -- the padded lines -1
+// and L are copies of lines 1 and L - 2, so what the convolution read there flows back onto those.  Rows are wave-uniform (a tile is one
+// row); along the row the two extra pairs concern ONE lane each and run as passes of their own in the tiles that hold x = 1 / x = W - 2.
+// With the x2 upsampling in front of the layer a tile is 64 pixels of rows 2 ys and 2 ys + 1: both rows accumulate into the same
+// registers, horizontal neighbours are summed in registers (rows 2 m, 2 m + 1 of the MFMA tile sit in one lane), and the wave stores the
+// gradient of 32 source pixels.
+// ---------------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void conv_dgrad_kernel(const ConvParams p) {
+  extern __shared__ float lds[];
+  stage_conv_weights<true>(lds, p.w);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, col = lane & 31;
+  const int out_rows = p.up2 ? p.H >> 1 : p.H;
+  const long rows = (long)out_rows * p.tiles_per_row;
+  for (long tile = (long)blockIdx.x * 8 + wave; tile < p.n_tiles; tile += (long)gridDim.x * 8) {
+    const int img = (int)(tile / rows);
+    const int rem = (int)(tile - (long)img * rows);
+    const int yt = rem / p.tiles_per_row, x0 = (rem - yt * p.tiles_per_row) * 64;
+    const float* base = p.x + (long)img * p.H * p.W * 64;   // dy' (N, H, W, 64)
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) acc[pt][ct] = zero_acc();
+    const int xq[2] = {x0 + col, x0 + 32 + col};
+    for (int sub = 0; sub < (p.up2 ? 2 : 1); ++sub) {
+      const int y = p.up2 ? 2 * yt + sub : yt;
+      for (int ry = 0; ry < 5; ++ry) {     // 0..2: t_y = ry - 1, q_y = y - t_y; 3: (q_y = 0, t_y = -1) for y == 1; 4: (q_y = H - 1, t_y = +1) for y == H - 2
+        int ty, qy;
+        if (ry < 3) ty = ry - 1, qy = y - ty;
+        else if (ry == 3) ty = -1, qy = (y == 1) ? 0 : -1;
+        else ty = 1, qy = (y == p.H - 2) ? p.H - 1 : -1;
+        if (qy < 0 || qy >= p.H) continue;
+        for (int rx = 0; rx < 5; ++rx) {
+          int tx;
+          unsigned src[2];
+          bool ok[2];
+          if (rx < 3) {
+            tx = rx - 1;
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt) {
+              const int qx = xq[pt] - tx;
+              ok[pt] = qx >= 0 && qx < p.W && xq[pt] < p.W;
+              src[pt] = (unsigned)((qy * p.W + min(max(qx, 0), p.W - 1)) * 64 + 4 * h);
+            }
+          } else {
+            const int xs = rx == 3 ? 1 : p.W - 2, qx = rx == 3 ? 0 : p.W - 1;
+            tx = rx == 3 ? -1 : 1;
+            if (xs < x0 || xs >= x0 + 64) continue;   // wave-uniform: this tile does not hold the column next to the border
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt) ok[pt] = xq[pt] == xs, src[pt] = (unsigned)((qy * p.W + qx) * 64 + 4 * h);
+          }
+          conv_pass<false>(acc, lds, base, src, ok, (ty + 1) * 3 + (tx + 1), h, col);
+        }
+      }
+    }
+    if (p.up2) {
+      const int Ws = p.W >> 1;
+      float* out = p.y + ((long)img * out_rows + yt) * Ws * 64;
+#pragma unroll
+      for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+          for (int r = 0; r < 16; r += 2) {   // tile rows mfma_row(r, h), mfma_row(r, h) + 1: the two children of one source pixel along x
+            const int x = x0 + pt * 32 + mfma_row(r, h);
+            if (x < p.W) out[(unsigned)((x >> 1) * 64 + ct * 32 + col)] = acc[pt][ct][r] + acc[pt][ct][r + 1];
+          }
+    } else {
+      float* out = p.y + ((long)img * p.H + yt) * p.W * 64;
+#pragma unroll
+      for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int x = x0 + pt * 32 + mfma_row(r, h);
+            if (x < p.W) out[(unsigned)(x * 64 + ct * 32 + col)] = acc[pt][ct][r];
+          }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// weight gradient: dW[co][ci][t] = sum over all pixels p of dy'[p][co] x[reflect(p + t)][ci];  db[co] = sum_p dy'[p][co].
+// D[co][ci] = A[co][k = pixel] . B[k = pixel][ci]: both operands are 128-byte row pieces of the channels-last tensors (a lane half = 32
+// consecutive channels of one pixel; the two halves = the two pixels of a k-step).  A work-group = 8 waves = 2 pixel streams x the 4
+// (co half, ci half) quadrants; a wave keeps its quadrant of all 9 taps in registers (9 accumulator tiles) over the whole launch and
+// writes it once: partial sums per (work-group, stream) into the workspace, a second small kernel adds them up -- no atomics, the same
+// bits on every run.
+// ---------------------------------------------------------------------------------------------------------------------------------
+struct WgradParams {
+  const float* x;     // layer input (N, Hs, Ws, 64)
+  const float* dy;    // dy' (N, H, W, 64)
+  float* part;        // (gridDim.x * 2, 9 * 64 * 64 + 64) partial sums: [tap][co][ci], then db
+  int N, H, W, up2, tiles_per_row;
+  long n_tiles;
+};
+constexpr int kWgradPart = 9 * kTapFloats + 64;
+
+__global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgradParams p) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, col = lane & 31;
+  const int quad = wave & 3, stream = wave >> 2, ct = quad >> 1, cit = quad & 1;
+  const int Hs = p.up2 ? p.H >> 1 : p.H, Ws = p.up2 ? p.W >> 1 : p.W;
+  const long rows = (long)p.H * p.tiles_per_row;
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) acc[t] = zero_acc();
+  float db = 0.0f;
+  for (long tile = (long)blockIdx.x * 2 + stream; tile < p.n_tiles; tile += (long)gridDim.x * 2) {
+    const int img = (int)(tile / rows);
+    const int rem = (int)(tile - (long)img * rows);
+    const int y = rem / p.tiles_per_row, x0 = (rem - y * p.tiles_per_row) * 64;
+    const float* xb = p.x + (long)img * Hs * Ws * 64 + cit * 32 + col;
+    const float* dyb = p.dy + ((long)img * p.H + y) * p.W * 64 + ct * 32 + col;
+    int sy[3];
+#pragma unroll
+    for (int ty = 0; ty < 3; ++ty) {
+      sy[ty] = reflect(y + ty - 1, p.H);
+      if (p.up2) sy[ty] >>= 1;
+    }
+    for (int s = 0; s < 32; s += 4) {     // four k-steps (eight pixels) per round: 40 loads in flight
+      float a[4], b[4][9];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int x = x0 + 2 * (s + u) + h;
+        const bool in = x < p.W;
+        const int xc = min(x, p.W - 1);
+        a[u] = in ? dyb[(unsigned)(xc * 64)] : 0.0f;    // (a pixel beyond a ragged row end contributes nothing)
+#pragma unroll
+        for (int tx = 0; tx < 3; ++tx) {
+          int sx = reflect(xc + tx - 1, p.W);
+          if (p.up2) sx >>= 1;
+#pragma unroll
+          for (int ty = 0; ty < 3; ++ty) b[u][ty * 3 + tx] = xb[(unsigned)((sy[ty] * Ws + sx) * 64)];
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        db += a[u];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[t] = mfma(a[u], b[u][t], acc[t]);
+      }
+    }
+  }
+  float* part = p.part + ((long)blockIdx.x * 2 + stream) * kWgradPart;
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) part[(unsigned)(t * kTapFloats + (ct * 32 + mfma_row(r, h)) * 64 + cit * 32 + col)] = acc[t][r];
+  if (cit == 0) {
+    db += __shfl_xor(db, 32, 64);     // the two pixels of every k-step
+    if (h == 0) part[9 * kTapFloats + ct * 32 + col] = db;
+  }
+}
+
+// dW (64, 64, 3, 3) [co][ci][t] and db (64) = sums of the partials; written (not accumulated)
+__global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __restrict__ part, int n_part, float* __restrict__ d_w, float* __restrict__ d_b) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= kWgradPart) return;
+  float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+  int k = 0;
+  for (; k + 4 <= n_part; k += 4) {
+    s0 += part[(long)k * kWgradPart + i], s1 += part[(long)(k + 1) * kWgradPart + i];
+    s2 += part[(long)(k + 2) * kWgradPart + i], s3 += part[(long)(k + 3) * kWgradPart + i];
+  }
+  for (; k < n_part; ++k) s0 += part[(long)k * kWgradPart + i];
+  const float s = (s0 + s1) + (s2 + s3);
+  if (i < 9 * kTapFloats) {
+    const int t = i / kTapFloats, co = (i % kTapFloats) / 64, ci = i % 64;
+    if (d_w) d_w[(co * 64 + ci) * 9 + t] = s;
+  } else if (d_b) {
+    d_b[i - 9 * kTapFloats] = s;
+  }
+}
+
+// dy' = dy * elu'(y) from the layer's OUTPUT y (ELU, alpha = 1: elu' = 1 for y > 0, y + 1 otherwise -- torch's backward of the in-place
+// ELU of ConvBlock, layers.py:22-31); dy may be channels-last or NCHW (`dy_nchw`: the gradient of an NCHW output), dy' is channels-last
+__global__ __launch_bounds__(256) void elu_bwd_kernel(const float4* __restrict__ dy, const float4* __restrict__ y, float4* __restrict__ out, long n4) {
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const float4 g = dy[i], v = y[i];
+    float4 o;
+    o.x = g.x * (v.x > 0.0f ? 1.0f : v.x + 1.0f), o.y = g.y * (v.y > 0.0f ? 1.0f : v.y + 1.0f);
+    o.z = g.z * (v.z > 0.0f ? 1.0f : v.z + 1.0f), o.w = g.w * (v.w > 0.0f ? 1.0f : v.w + 1.0f);
+    out[i] = o;
+  }
+}
+
+static int conv_grid() { return device_cu_count(); }   // one persistent work-group of 8 waves per CU (the weights fill its LDS)
+
+static bool conv_ok(const BtsConv3x3* c, const char* who) {
+  if (!c || !c->x || !c->weight || c->N <= 0 || c->H < 4 || c->W < 4 || c->C != 64 || (c->up2 && ((c->H | c->W) & 1))) {
+    set_error("%s: NULL pointer, C != 64, a frame below 4 x 4, or an odd size with up2 (N=%ld H=%ld W=%ld)", who, c ? c->N : 0, c ? c->H : 0, c ? c->W : 0);
+    return false;
+  }
+  if ((long)c->H * c->W * 64 > 0x7FFFFFFFL) {
+    set_error("%s: tensor too large for 32-bit offsets inside an image (H=%ld W=%ld)", who, c->H, c->W);
+    return false;
+  }
+  return true;
+}
+
+int conv3x3_fwd_impl(const BtsConv3x3* c, hipStream_t s) {
+  ConvParams p;
+  memset(&p, 0, sizeof(p));
+  p.x = c->x, p.w = c->weight, p.bias = c->bias, p.y = c->y;
+  p.N = c->N, p.H = c->H, p.W = c->W, p.up2 = c->up2, p.elu = c->elu, p.out_nchw = c->out_nchw;
+  p.tiles_per_row = (c->W + 63) / 64;
+  p.n_tiles = (long)c->N * c->H * p.tiles_per_row;
+  const long want = (p.n_tiles + 7) / 8;
+  const int grid = (int)(want < conv_grid() ? want : conv_grid());
+  const size_t lds = sizeof(float) * kConvLds;
+  if (c->out_nchw) {
+    static thread_local bool attr = false;
+    if (!attr) (void)hipFuncSetAttribute((const void*)conv_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), attr = true;
+    conv_fwd_kernel<true><<<grid, 512, lds, s>>>(p);
+  } else {
+    static thread_local bool attr = false;
+    if (!attr) (void)hipFuncSetAttribute((const void*)conv_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), attr = true;
+    conv_fwd_kernel<false><<<grid, 512, lds, s>>>(p);
+  }
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: convolution forward launch failed (%ld)", hipGetErrorString(e), (long)e);
+    return BTS_E_LAUNCH;
+  }
+  return BTS_OK;
+}
+
+size_t conv3x3_bwd_workspace_impl(const BtsConv3x3* c) {
+  const size_t dyp = sizeof(float) * (size_t)c->N * c->H * c->W * 64;            // dy' channels-last
+  const size_t part = sizeof(float) * (size_t)conv_grid() * 2 * kWgradPart;     // weight-gradient partial sums
+  return ((dyp + 255) & ~(size_t)255) + part;
+}
+
+int conv3x3_bwd_impl(const BtsConv3x3* c, const float* g_y, void* workspace, size_t ws_bytes, float* d_x, float* d_weight, float* d_bias, hipStream_t s) {
+  if (ws_bytes < conv3x3_bwd_workspace_impl(c) || !workspace) {
+    set_error("%s: workspace too small (%ld bytes needed)", "bts_conv3x3_bwd", (long)conv3x3_bwd_workspace_impl(c));
+    return BTS_E_WORKSPACE;
+  }
+  float* dyp = static_cast<float*>(workspace);
+  const size_t dyp_bytes = (sizeof(float) * (size_t)c->N * c->H * c->W * 64 + 255) & ~(size_t)255;
+  float* part = reinterpret_cast<float*>(static_cast<char*>(workspace) + dyp_bytes);
+  const long n = (long)c->N * c->H * c->W * 64;
+  const float* dy = g_y;
+  if (c->out_nchw) {          // the gradient of an NCHW output (the renderer's d_feat) -> channels-last
+    if (c->elu) {
+      set_error("%s: ELU with an NCHW output is not a layer of the decoder", "bts_conv3x3_bwd");
+      return BTS_E_UNSUPPORTED;
+    }
+    if (int rc = transpose_launch(g_y, dyp, c->N, 64, c->H, c->W, true, s)) return rc;
+    dy = dyp;
+  } else if (c->elu) {
+    const long n4 = n / 4;
+    const long want = (n4 + 255) / 256;
+    elu_bwd_kernel<<<(int)(want < 4096 ? want : 4096), 256, 0, s>>>(reinterpret_cast<const float4*>(g_y), reinterpret_cast<const float4*>(c->y),
+                                                                   reinterpret_cast<float4*>(dyp), n4);
+    dy = dyp;
+  }
+  const int tpr = (c->W + 63) / 64;
+  const size_t lds = sizeof(float) * kConvLds;
+  if (d_x) {
+    ConvParams p;
+    memset(&p, 0, sizeof(p));
+    p.x = dy, p.w = c->weight, p.y = d_x, p.N = c->N, p.H = c->H, p.W = c->W, p.up2 = c->up2, p.tiles_per_row = tpr;
+    p.n_tiles = (long)c->N * (c->up2 ? c->H / 2 : c->H) * tpr;
+    const long want = (p.n_tiles + 7) / 8;
+    static thread_local bool attr = false;
+    if (!attr) (void)hipFuncSetAttribute((const void*)conv_dgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), attr = true;
+    conv_dgrad_kernel<<<(int)(want < conv_grid() ? want : conv_grid()), 512, lds, s>>>(p);
+  }
+  if (d_weight || d_bias) {
+    WgradParams q;
+    memset(&q, 0, sizeof(q));
+    q.x = c->x, q.dy = dy, q.part = part, q.N = c->N, q.H = c->H, q.W = c->W, q.up2 = c->up2, q.tiles_per_row = tpr;
+    q.n_tiles = (long)c->N * c->H * tpr;
+    const long want = (q.n_tiles + 1) / 2;
+    const int grid = (int)(want < conv_grid() ? want : conv_grid());
+    conv_wgrad_kernel<<<grid, 512, 0, s>>>(q);
+    conv_wgrad_reduce_kernel<<<(kWgradPart + 255) / 256, 256, 0, s>>>(part, grid * 2, d_weight, d_bias);
+  }
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: convolution backward launch failed (%ld)", hipGetErrorString(e), (long)e);
+    return BTS_E_LAUNCH;
+  }
+  return BTS_OK;
+}
+
+}  // namespace bts
+
+using namespace bts;
+
+extern "C" {
+
+int bts_conv3x3_fwd(const BtsConv3x3* c, void* stream) {
+  if (!conv_ok(c, "bts_conv3x3_fwd")) return BTS_E_INVALID;
+  if (!c->y) {
+    set_error("%s: NULL output", "bts_conv3x3_fwd");
+    return BTS_E_INVALID;
+  }
+  return conv3x3_fwd_impl(c, (hipStream_t)stream);
+}
+
+size_t bts_conv3x3_bwd_workspace(const BtsConv3x3* c) {
+  if (!c || c->N <= 0 || c->H <= 0 || c->W <= 0) return 0;
+  return conv3x3_bwd_workspace_impl(c);
+}
+
+int bts_conv3x3_bwd(const BtsConv3x3* c, const float* g_y, void* workspace, size_t workspace_bytes, float* d_x, float* d_weight, float* d_bias,
+                    void* stream) {
+  if (!conv_ok(c, "bts_conv3x3_bwd")) return BTS_E_INVALID;
+  if (!g_y || (c->elu && !c->y)) {
+    set_error("%s: NULL output gradient, or an ELU layer without its output y", "bts_conv3x3_bwd");
+    return BTS_E_INVALID;
+  }
+  return conv3x3_bwd_impl(c, g_y, workspace, workspace_bytes, d_x, d_weight, d_bias, (hipStream_t)stream);
+}
+
+}  // extern "C"

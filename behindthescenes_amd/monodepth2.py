@@ -169,10 +169,33 @@ class Decoder(nn.Module):
         self.decoder_keys = keys
         self.decoder = nn.ModuleList(convs)
 
+    # the layers that PRODUCE the renderer's scale-0 feature map -- upconv(0,0), the x2 upsampling,
+    # upconv(0,1), dispconv(0) -- run as bts_conv3x3_fwd / _bwd (csrc/bts_conv.hip: reflection, upsampling and ELU are index arithmetic
+    # and an epilogue of one kernel per layer instead of padded copies, layout changes and element-wise passes around a library
+    # convolution: 23 ms of a 47.5 ms exp_kitti_360.yaml step through MIOpen, profiles/r05c/md2_tail_probe.txt) whenever the three are
+    # 64 -> 64 (d_out = 64: every KITTI configuration) on a GPU; `fused_tail = False` keeps the module path for an A/B.
+    fused_tail = True
+
+    def tail_is_fused(self, x):
+        return (self.fused_tail and x.is_cuda and x.dtype == torch.float32 and 0 in self.scales and self.num_ch_dec[0] == 64
+                and self.num_ch_dec[1] == 64 and self.d_out == 64)
+
+    def _conv(self, key, x_nhwc, up2=False, elu=False, out_nchw=False):
+        from . import native
+        m = self.decoder[self.decoder_keys[key]]
+        conv = m.conv.conv if isinstance(m, ConvBlock) else m.conv
+        return native.Conv3x3Function.apply(x_nhwc, conv.weight, conv.bias, up2, elu, out_nchw)
+
     def trunk(self, input_features):
         """The activations feeding the per-scale output convolutions: {scale: (N, num_ch_dec[scale], h, w)}."""
         feats, x = {}, input_features[-1]
         for i in range(4, -1, -1):
+            if i == 0 and self.tail_is_fused(x):
+                # x (N, 64, H/2, W/2) in channels_last memory IS (N, H/2, W/2, 64): upconv(0,0), then x2 + upconv(0,1) in one kernel
+                y = self._conv(("upconv", 0, 0), x.permute(0, 2, 3, 1), elu=True)
+                y = self._conv(("upconv", 0, 1), y, up2=True, elu=True)
+                feats[0] = y.permute(0, 3, 1, 2)        # (N, 64, H, W) view over channels-last memory, like MIOpen's output
+                break
             x = self.decoder[self.decoder_keys[("upconv", i, 0)]](x)
             x = [F.interpolate(x, scale_factor=(2, 2), mode="nearest")]
             if self.use_skips and i > 0:
@@ -220,7 +243,10 @@ class Monodepth2(nn.Module):
     def forward(self, x):
         """images (B, 3, H, W) in [-1, 1] -> [features (B, d_out, H / 2^s, W / 2^s) for s in scales]  (monodepth2.py:279-291)."""
         feats = self._trunk(x)
-        return [self.decoder.decoder[self.decoder.decoder_keys[("dispconv", s)]](feats[s]) for s in self.scales]
+        dec = self.decoder
+        # scale 0's output convolution writes true NCHW: what bts_project_features takes, no layout pass in between (SURVEY 8 row f4)
+        return [dec._conv(("dispconv", 0), feats[0].permute(0, 2, 3, 1), out_nchw=True) if (s == 0 and dec.tail_is_fused(feats[0])) else
+                dec.decoder[dec.decoder_keys[("dispconv", s)]](feats[s]) for s in self.scales]
 
     @classmethod
     def from_conf(cls, conf, **kw):

@@ -522,6 +522,69 @@ def occupancy_profile(ft: FieldTensors, mlp_params: torch.Tensor, xyz: torch.Ten
     return (profile, sigma) if want_sigma else profile
 
 
+# --------------------------------------------------------------------------------------------------------------
+# the Monodepth2 decoder's tail: reflect-pad 3x3 convolution [+ nearest x2 in front] [+ ELU], channels-last
+# --------------------------------------------------------------------------------------------------------------
+def _conv_struct(x, weight, bias, y, N, H, W, up2, elu, out_nchw):
+    return _lib.BtsConv3x3(N=N, H=H, W=W, C=x.shape[-1], up2=int(up2), elu=int(elu), out_nchw=int(out_nchw), reserved_=0, x=x.data_ptr(),
+                           weight=weight.data_ptr(), bias=None if bias is None else bias.data_ptr(), y=None if y is None else y.data_ptr())
+
+
+def conv3x3_fwd(x, weight, bias, up2=False, elu=False, out_nchw=False):
+    """x (N, Hs, Ws, C) channels-last, weight (C, C, 3, 3), bias (C) | None -> y (N, H, W, C), or (N, C, H, W) with ``out_nchw``; H, W = 2 Hs,
+    2 Ws with ``up2`` (bts_conv3x3_fwd: reflection pad 1 + 3 x 3 convolution, the x2 nearest upsampling in front and the ELU behind fused)."""
+    _req(x, "x"), _req(weight, "weight", (x.shape[-1], x.shape[-1], 3, 3))
+    if bias is not None:
+        _req(bias, "bias", (x.shape[-1],))
+    N, Hs, Ws, Cc = x.shape
+    H, W = (2 * Hs, 2 * Ws) if up2 else (Hs, Ws)
+    y = torch.empty((N, Cc, H, W) if out_nchw else (N, H, W, Cc), device=x.device, dtype=torch.float32)
+    c = _conv_struct(x, weight, bias, y, N, H, W, up2, elu, out_nchw)
+    _lib.check(_lib.load().bts_conv3x3_fwd(C.byref(c), _stream(x)), "bts_conv3x3_fwd")
+    return y
+
+
+def conv3x3_bwd(x, weight, y, g_y, up2=False, elu=False, out_nchw=False, need=(True, True, True)):
+    """-> (d_x | None, d_weight | None, d_bias | None) of conv3x3_fwd (bts_conv3x3_bwd); ``y`` = the forward's output (read for elu')."""
+    _req(x, "x"), _req(weight, "weight"), _req(g_y, "g_y", tuple(y.shape))
+    N, Hs, Ws, Cc = x.shape
+    H, W = (2 * Hs, 2 * Ws) if up2 else (Hs, Ws)
+    d_x = torch.empty_like(x) if need[0] else None
+    d_w = torch.empty_like(weight) if need[1] else None
+    d_b = torch.empty(Cc, device=x.device, dtype=torch.float32) if need[2] else None
+    c = _conv_struct(x, weight, None, y, N, H, W, up2, elu, out_nchw)
+    lib = _lib.load()
+    ws_bytes = int(lib.bts_conv3x3_bwd_workspace(C.byref(c)))
+    ws = torch.empty(ws_bytes // 4 + 4, device=x.device, dtype=torch.float32)     # (map-sized: goes back to the caching allocator)
+    _lib.check(lib.bts_conv3x3_bwd(C.byref(c), _ptr(g_y), _ptr(ws), ws_bytes, _ptr(d_x), _ptr(d_w), _ptr(d_b), _stream(x)), "bts_conv3x3_bwd")
+    return d_x, d_w, d_b
+
+
+class Conv3x3Function(torch.autograd.Function):
+    """layers.py:11-40 (Conv3x3 / ConvBlock) [+ the decoder's nearest x2, monodepth2.py:225] as one differentiable op on channels-last
+    tensors: (x (N, Hs, Ws, C), weight, bias | None, up2, elu, out_nchw) -> y."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, up2, elu, out_nchw):
+        x, weight = x.contiguous(), weight.contiguous()
+        y = conv3x3_fwd(x, weight, None if bias is None else bias.contiguous(), up2, elu, out_nchw)
+        ctx.flags = (bool(up2), bool(elu), bool(out_nchw), bias is not None)
+        ctx.save_for_backward(x, weight, y if elu else x.new_empty(0))
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight, y = ctx.saved_tensors
+        up2, elu, out_nchw, has_bias = ctx.flags
+        if not elu:      # (a plain convolution's backward does not read its output: only the shape matters)
+            N, Hs, Ws, Cc = x.shape
+            H, W = (2 * Hs, 2 * Ws) if up2 else (Hs, Ws)
+            y = g
+        need = (ctx.needs_input_grad[0], ctx.needs_input_grad[1], has_bias and ctx.needs_input_grad[2])
+        d_x, d_w, d_b = conv3x3_bwd(x, weight, y, g.contiguous(), up2, elu, out_nchw, need)
+        return d_x, d_w, d_b, None, None, None
+
+
 def train_step_fwd(st, stream):
     """bts_train_step_fwd on a filled ``_lib.BtsTrainStep`` (behindthescenes_amd.train_step builds it)."""
     _lib.check(_lib.load().bts_train_step_fwd(C.byref(st), stream), "bts_train_step_fwd")

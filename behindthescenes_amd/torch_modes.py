@@ -52,7 +52,10 @@ def _merge_groups(values, outside, groups, singles_twice):
             if not singles_twice:
                 continue
         o, v = outside[:, g], values[:, g]
-        pick = torch.min(o, dim=1, keepdim=True)[1]
+        # the reference's `torch.min(invalid, dim=1)[1]`: on ties the CPU kernel returns the FIRST member (what the fixtures pin), the GPU
+        # kernel whichever its reduction tree meets -- made explicit here so that every device gives the reference's CPU answer
+        order = torch.arange(len(g), device=o.device, dtype=torch.int32).view(1, -1, 1, 1)
+        pick = (o.to(torch.int32) * len(g) + order).argmin(dim=1, keepdim=True)
         flags.append(torch.gather(o, 1, pick))
         vals.append(torch.gather(v, 1, pick.expand(-1, -1, -1, v.shape[-1])))
     return torch.cat(vals, dim=1), torch.cat(flags, dim=1)

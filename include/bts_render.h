@@ -381,6 +381,39 @@ int bts_train_step_fwd(const BtsTrainStep* st, void* stream);
  * d_mlp_params / d_empty_feature collect every scale's contribution. */
 int bts_train_step_bwd(const BtsTrainStep* st, const float* g_loss, void* stream);
 
+
+/* ---------------------------------------------------------------------------------------------------------------------------------
+ * ABI 7: the Monodepth2 decoder's last convolutions, the layers that PRODUCE the renderer's scale-0
+ * feature map.  One operator:
+ *     y = [ELU]( conv3x3( reflect_pad1( [nearest x2]( x ) ), weight ) + bias )
+ * = Conv3x3 / ConvBlock of models/common/model/layers.py:11-40 (ReflectionPad2d(1) + 3 x 3 convolution [+ ELU, alpha 1]) with the
+ * decoder's nearest x2 upsampling (monodepth2.py:225) folded into the read of x.  With d_out = 64 the tail is (monodepth2.py:189-239)
+ *     upconv(0,0): {elu}            on (N, H/2, W/2, 64)   ->  upconv(0,1): {up2, elu}  ->  dispconv(0): {out_nchw}   at (N, H, W, 64)
+ * and its last output, NCHW, is exactly what bts_project_features / bts_train_step_fwd take as feat_nchw.  Tensors are channels-last
+ * (N, H, W, C) fp32 -- the memory of a torch tensor in channels_last format -- except an NCHW output when out_nchw is set.  C = 64.
+ * fp32 throughout (v_mfma_f32_32x32x2_f32: exact products, fp32 accumulation; the summation order differs from a library convolution's).
+ * --------------------------------------------------------------------------------------------------------------------------------- */
+typedef struct BtsConv3x3 {
+  int32_t N, H, W;       /* OUTPUT size; the input is (N, H, W, C), or (N, H / 2, W / 2, C) with up2 (H, W even) */
+  int32_t C;             /* input = output channels: 64 */
+  int32_t up2;           /* 1: read x through a nearest x2 upsampling */
+  int32_t elu;           /* 1: ELU on the output (ConvBlock) */
+  int32_t out_nchw;      /* 1: y is (N, C, H, W); not together with elu */
+  int32_t reserved_;
+  const float* x;        /* input, channels-last */
+  const float* weight;   /* (C, C, 3, 3) = nn.Conv2d.weight */
+  const float* bias;     /* (C) or NULL */
+  float* y;              /* output (written by bts_conv3x3_fwd; READ by bts_conv3x3_bwd of an ELU layer: elu' comes from the output) */
+} BtsConv3x3;
+
+int bts_conv3x3_fwd(const BtsConv3x3* c, void* stream);
+/* Backward for the same struct: g_y = gradient of y in y's layout.  d_x (layout of x), d_weight (C, C, 3, 3), d_bias (C) are WRITTEN (not
+ * accumulated); any of them may be NULL.  workspace: bts_conv3x3_bwd_workspace(c) bytes (g_y times elu' as a channels-last tensor + the
+ * weight gradient's partial sums); contents need no initialisation.  Deterministic: no atomics anywhere. */
+size_t bts_conv3x3_bwd_workspace(const BtsConv3x3* c);
+int bts_conv3x3_bwd(const BtsConv3x3* c, const float* g_y, void* workspace, size_t workspace_bytes, float* d_x, float* d_weight, float* d_bias,
+                    void* stream);
+
 #ifdef __cplusplus
 }
 #endif

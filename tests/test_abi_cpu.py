@@ -59,6 +59,7 @@ int main(void) {
   printf("%zu %zu %zu %zu\n", sizeof(BtsTrainScale), sizeof(BtsTrainStep), offsetof(BtsTrainScale, feat_shift), offsetof(BtsTrainScale, d_feat_nchw));
   printf("%zu %zu %zu %zu %zu %zu\n", offsetof(BtsTrainStep, ids_loss), offsetof(BtsTrainStep, loss_matrix), offsetof(BtsTrainStep, images),
          offsetof(BtsTrainStep, bwd_workspace_bytes), offsetof(BtsTrainStep, d_empty_feature), offsetof(BtsTrainStep, scale));
+  printf("%zu %zu %zu\n", sizeof(BtsConv3x3), offsetof(BtsConv3x3, x), offsetof(BtsConv3x3, y));
   return 0;
 }'''
     with tempfile.TemporaryDirectory() as d:
@@ -85,8 +86,9 @@ int main(void) {
     assert [int(x) for x in out[18:22]] == [C.sizeof(_lib.BtsTrainScale), C.sizeof(_lib.BtsTrainStep), _lib.BtsTrainScale.feat_shift.offset,
                                             _lib.BtsTrainScale.d_feat_nchw.offset]
     T = _lib.BtsTrainStep
-    assert [int(x) for x in out[22:]] == [T.ids_loss.offset, T.loss_matrix.offset, T.images.offset, T.bwd_workspace_bytes.offset,
-                                          T.d_empty_feature.offset, T.scale.offset]
+    assert [int(x) for x in out[22:28]] == [T.ids_loss.offset, T.loss_matrix.offset, T.images.offset, T.bwd_workspace_bytes.offset,
+                                            T.d_empty_feature.offset, T.scale.offset]
+    assert [int(x) for x in out[28:]] == [C.sizeof(_lib.BtsConv3x3), _lib.BtsConv3x3.x.offset, _lib.BtsConv3x3.y.offset]
 
 
 def test_host_only_entry_points(lib):
@@ -170,6 +172,14 @@ def test_errors_are_codes_with_messages_never_exceptions(lib):
     assert lib.bts_train_step_fwd(C.byref(st), None) == -1 and b"64 pixels" in lib.bts_last_error()
     st.pw, st.cfg.C = 8, 48
     assert lib.bts_train_step_fwd(C.byref(st), None) == -2 and b"envelope" in lib.bts_last_error()
+    # ABI 7: the decoder-tail convolution
+    cv = _lib.BtsConv3x3(N=1, H=8, W=8, C=32, x=16, weight=16, y=16)
+    assert lib.bts_conv3x3_fwd(C.byref(cv), None) == -1 and b"C != 64" in lib.bts_last_error()
+    cv.C, cv.up2, cv.H = 64, 1, 7
+    assert lib.bts_conv3x3_fwd(C.byref(cv), None) == -1
+    cv.up2, cv.H = 0, 8
+    assert lib.bts_conv3x3_bwd(C.byref(cv), 16, None, 0, 16, 16, 16, None) == -4 and b"workspace" in lib.bts_last_error()
+    assert lib.bts_conv3x3_bwd_workspace(C.byref(cv)) >= 8 * 8 * 64 * 4 + 2 * (9 * 4096 + 64) * 4
     assert lib.bts_project_features_bwd_tiles(C.byref(ok_size), 16, 16, None, 16, 1, 16, 16, 1, None) == -1 and b"NULL" in lib.bts_last_error()
     assert lib.bts_project_features_bwd_tiles(C.byref(cfg), 16, 16, 16, 16, 1, 16, 16, 1, None) == -2 and b"envelope" in lib.bts_last_error()
     assert lib.bts_project_features_tiles(C.byref(ok_size), 16, 16, 1, None, 16, None) == -1 and b"NULL" in lib.bts_last_error()

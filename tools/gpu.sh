@@ -23,7 +23,7 @@ for STEP in "$@"; do
   echo "=== $STEP"
   case $KIND in
     pytest)
-      if [ -n "$REST" ]; then timeout 1500 python -m pytest tests -m gpu -q --timeout 900 -rf -k "${REST//,/ }" 2>&1 | tail -30 > $O/pytest_k.txt; tail -8 $O/pytest_k.txt
+      if [ -n "$REST" ]; then timeout 1500 python -m pytest tests -m gpu -q --timeout 900 -rf --tb=short -k "${REST//,/ }" > $O/pytest_k.txt 2>&1; grep -E "^(E  |FAILED|ERROR|tests/.*(Error|assert))|passed|failed" $O/pytest_k.txt | cut -c1-240 | head -70
       else timeout 1700 python -m pytest tests -m gpu -q --timeout 900 --durations=8 -rf 2>&1 | tail -40 > $O/pytest_gpu.txt; tail -14 $O/pytest_gpu.txt; fi ;;
     smoke) timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | tee $O/smoke.txt ;;
     bench)
