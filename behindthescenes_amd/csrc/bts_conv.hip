@@ -278,29 +278,44 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgradParams p) {
       sy[ty] = reflect(y + ty - 1, p.H);
       if (p.up2) sy[ty] >>= 1;
     }
-    for (int s = 0; s < 32; s += 4) {     // four k-steps (eight pixels) per round: 40 loads in flight
-      float a[4], b[4][9];
+    // rounds of two k-steps (four pixels: 20 loads); round r + 1's loads are issued BEFORE round r's MFMAs, into the other buffer, so the
+    // 18 x 64 cycles of matrix work of a round run under the next round's memory latency
+    float a[2][2], b[2][2][9];
+    auto load_round = [&](int buf, int s) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < 2; ++u) {
         const int x = x0 + 2 * (s + u) + h;
         const bool in = x < p.W;
         const int xc = min(x, p.W - 1);
-        a[u] = in ? dyb[(unsigned)(xc * 64)] : 0.0f;    // (a pixel beyond a ragged row end contributes nothing)
+        a[buf][u] = in ? dyb[(unsigned)(xc * 64)] : 0.0f;    // (a pixel beyond a ragged row end contributes nothing)
 #pragma unroll
         for (int tx = 0; tx < 3; ++tx) {
           int sx = reflect(xc + tx - 1, p.W);
           if (p.up2) sx >>= 1;
 #pragma unroll
-          for (int ty = 0; ty < 3; ++ty) b[u][ty * 3 + tx] = xb[(unsigned)((sy[ty] * Ws + sx) * 64)];
+          for (int ty = 0; ty < 3; ++ty) b[buf][u][ty * 3 + tx] = xb[(unsigned)((sy[ty] * Ws + sx) * 64)];
         }
       }
-      __builtin_amdgcn_sched_barrier(0);
+    };
+    auto mfma_round = [&](int buf) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        db += a[u];
+      for (int u = 0; u < 2; ++u) {
+        db += a[buf][u];
 #pragma unroll
-        for (int t = 0; t < 9; ++t) acc[t] = mfma(a[u], b[u][t], acc[t]);
+        for (int t = 0; t < 9; ++t) acc[t] = mfma(a[buf][u], b[buf][u][t], acc[t]);
       }
+    };
+    load_round(0, 0);
+#pragma unroll 1
+    for (int s = 0; s < 32; s += 4) {
+      load_round(1, s + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_round(0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (s + 4 < 32) load_round(0, s + 4);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_round(1);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
   float* part = p.part + ((long)blockIdx.x * 2 + stream) * kWgradPart;
