@@ -64,7 +64,7 @@ class BtsTrainStep(C.Structure):
     _fields_ = [("cfg", BtsFieldCfg), ("v", C.c_int32), ("id_encoder", C.c_int32), ("ids_render", C.c_int32 * BTS_MAX_VIEWS),
                 ("n_loss", C.c_int32), ("ids_loss", C.c_int32 * BTS_MAX_LOSS_VIEWS)] + \
                [(k, C.c_int32) for k in ("P", "ph", "pw", "K", "lindisp", "hard_alpha_cap", "invalid_policy", "edge_aware_smoothness", "n_scales",
-                                         "reserved_")] + \
+                                         "concurrent_scales")] + \
                [(k, C.c_float) for k in ("z_near", "z_far", "img_scale", "img_shift")] + \
                [("loss_matrix", C.c_float * (9 * 3 * BTS_MAX_SCALES))] + \
                [(k, C.c_void_p) for k in ("images", "Ks", "poses_c2w", "patch_v", "patch_y", "patch_x", "mlp_params", "empty_feature", "rays", "rgb_gt",

@@ -112,6 +112,35 @@ __global__ __launch_bounds__(256) void empty_grad_kernel(const float* __restrict
     }
 }
 
+// ---- independent scales on independent queues.  A "multiscale" step (trainer.py:220-242; exp_re10k.yaml) renders the same rays against four
+// maps: four chains of small kernels (flag, project, render, loss | rows, scatter, dW_pe, reduce, projection backward) that share nothing
+// but read-only inputs and the atomically accumulated parameter gradient.  One after the other on one queue every kernel pays its own
+// ramp-up and tail (a persistent grid's last waves run alone) and ~45 launch gaps per step; on side queues the chains fill each other's
+// tails.  The queues and their fork / join events are created once per host thread and device (handles only, no device memory) and
+// are ordered INSIDE the caller's stream: the first kernel of a side chain waits for an event recorded on the caller's stream, the
+// caller's stream waits for every chain's last kernel before the call's last kernel -- to the caller the call is still one stream-ordered
+// unit (and capturable in a hipGraph as a fork / join).
+struct SideQueues {
+  hipStream_t q[BTS_MAX_SCALES - 1];
+  hipEvent_t fork, first, join[BTS_MAX_SCALES - 1];
+  bool ok;
+};
+static SideQueues* side_queues() {
+  static thread_local SideQueues* per_dev[16] = {nullptr};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  if (!per_dev[dev]) {
+    SideQueues* sq = new SideQueues;
+    sq->ok = hipEventCreateWithFlags(&sq->fork, hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&sq->first, hipEventDisableTiming) == hipSuccess;
+    for (int i = 0; i < BTS_MAX_SCALES - 1; ++i)
+      sq->ok = sq->ok && hipStreamCreateWithFlags(&sq->q[i], hipStreamNonBlocking) == hipSuccess &&
+               hipEventCreateWithFlags(&sq->join[i], hipEventDisableTiming) == hipSuccess;
+    per_dev[dev] = sq;
+  }
+  return per_dev[dev]->ok ? per_dev[dev] : nullptr;
+}
+
 static long map_texels(const BtsTrainStep* st, int s) { return (long)(st->cfg.H >> st->scale[s].feat_shift) * (st->cfg.W >> st->scale[s].feat_shift); }
 
 static int check_step(const BtsTrainStep* st, const char* who, bool bwd) {
@@ -194,7 +223,8 @@ static ScaleView scale_view(const BtsTrainStep* st, int s) {
   return v;
 }
 
-int train_step_fwd_impl(const BtsTrainStep* st, hipStream_t stream) {
+int train_step_fwd_impl(const BtsTrainStep* st, hipStream_t main_stream) {
+  hipStream_t stream = main_stream;
   const BtsFieldCfg& c = st->cfg;
   const int n = c.n, nv = c.nv, Bp = st->P * st->ph * st->pw;
   int rc = camera_prep_launch(st->Ks, st->poses_c2w, n, st->v, st->id_encoder, nv, st->ids_render, st->cams, stream);
@@ -208,7 +238,14 @@ int train_step_fwd_impl(const BtsTrainStep* st, hipStream_t stream) {
   }
   FinishParams fin;
   memset(&fin, 0, sizeof(fin));
+  SideQueues* sq = (st->concurrent_scales && st->n_scales > 1) ? side_queues() : nullptr;
+  if (sq) {
+    if (hipEventRecord(sq->fork, main_stream) != hipSuccess) return BTS_E_LAUNCH;
+    for (int s = 1; s < st->n_scales; ++s)
+      if (hipStreamWaitEvent(sq->q[s - 1], sq->fork, 0) != hipSuccess) return BTS_E_LAUNCH;
+  }
   for (int s = 0; s < st->n_scales; ++s) {
+    hipStream_t stream = (sq && s > 0) ? sq->q[s - 1] : main_stream;
     const BtsTrainScale& q = st->scale[s];
     ScaleView v = scale_view(st, s);
     const long texels = map_texels(st, s);
@@ -226,19 +263,25 @@ int train_step_fwd_impl(const BtsTrainStep* st, hipStream_t stream) {
     v.a.invalid_wsum = q.invalid_wsum, v.a.invalid_any = q.invalid_any;
     rc = render_fwd_impl(&v.cfg, &v.t, &v.a, stream);
     if (rc) return rc;
+    // the invalid-ray mask of EVERY scale's term comes from scale 0's render (loss.py:100-118 reads data["coarse"][0]): the side chains'
+    // loss passes wait for it
+    if (sq && s == 0 && hipEventRecord(sq->first, main_stream) != hipSuccess) return BTS_E_LAUNCH;
+    if (sq && s > 0 && st->invalid_policy != 0 && hipStreamWaitEvent(stream, sq->first, 0) != hipSuccess) return BTS_E_LAUNCH;
     BtsLossArgs la;
     memset(&la, 0, sizeof(la));
     la.rgb = q.rgb, la.depth = st->edge_aware_smoothness ? q.depth : nullptr, la.rgb_gt = st->rgb_gt, la.parts = q.loss_parts;
     la.g_rgb = q.g_rgb, la.g_depth = st->edge_aware_smoothness ? q.g_depth : nullptr;
     la.n_patches = n * st->P, la.patch_h = st->ph, la.patch_w = st->pw, la.nv = nv, la.K = 0;
     la.invalid_policy = st->invalid_policy, la.edge_aware_smoothness = st->edge_aware_smoothness, la.scale_rgb = 1.0f, la.scale_eas = 1.0f;
-    // the invalid-ray mask of EVERY scale's term comes from scale 0's render (loss.py:100-118 reads data["coarse"][0])
     la.invalid_wsum = st->invalid_policy == 2 ? st->scale[0].invalid_wsum : nullptr;
     la.invalid_any = st->invalid_policy == 1 ? st->scale[0].invalid_any : nullptr;
     rc = photometric_loss_impl(&la, stream);
     if (rc) return rc;
     fin.parts[s] = q.loss_parts;
+    if (sq && s > 0 && (hipEventRecord(sq->join[s - 1], stream) != hipSuccess || hipStreamWaitEvent(main_stream, sq->join[s - 1], 0) != hipSuccess))
+      return BTS_E_LAUNCH;
   }
+  stream = main_stream;
   fin.n_scales = st->n_scales, fin.n_patches = n * st->P, fin.out = st->loss_vals;
   memcpy(fin.M, st->loss_matrix, sizeof(float) * 9 * 3 * st->n_scales);
   loss_finish_kernel<<<1, 256, 0, stream>>>(fin);
@@ -249,7 +292,8 @@ int train_step_fwd_impl(const BtsTrainStep* st, hipStream_t stream) {
   return BTS_OK;
 }
 
-int train_step_bwd_impl(const BtsTrainStep* st, const float* g_loss, hipStream_t stream) {
+int train_step_bwd_impl(const BtsTrainStep* st, const float* g_loss, hipStream_t main_stream) {
+  hipStream_t stream = main_stream;
   const BtsFieldCfg& c = st->cfg;
   const int n = c.n, nv = c.nv, Bp = st->P * st->ph * st->pw;
   const int cols = 3 * st->n_scales;
@@ -271,7 +315,20 @@ int train_step_bwd_impl(const BtsTrainStep* st, const float* g_loss, hipStream_t
     set_error("%s: gradient scaling launch failed", "bts_train_step_bwd");
     return BTS_E_LAUNCH;
   }
+  // one workspace slice per scale when the scales run side by side (the passes of a scale hand each other its contents)
+  size_t ws_each = 0;
+  {
+    ScaleView v0 = scale_view(st, 0);
+    ws_each = (render_bwd_workspace_impl(&v0.cfg, &v0.a) + 255) & ~(size_t)255;
+  }
+  SideQueues* sq = (st->concurrent_scales && st->n_scales > 1 && st->bwd_workspace_bytes >= ws_each * (size_t)st->n_scales) ? side_queues() : nullptr;
+  if (sq) {
+    if (hipEventRecord(sq->fork, main_stream) != hipSuccess) return BTS_E_LAUNCH;
+    for (int s = 1; s < st->n_scales; ++s)
+      if (hipStreamWaitEvent(sq->q[s - 1], sq->fork, 0) != hipSuccess) return BTS_E_LAUNCH;
+  }
   for (int s = 0; s < st->n_scales; ++s) {
+    stream = (sq && s > 0) ? sq->q[s - 1] : main_stream;
     const BtsTrainScale& q = st->scale[s];
     ScaleView v = scale_view(st, s);
     v.a.z_samp = q.z_samp, v.a.sigma_raw = q.sigma_raw, v.a.trans = q.trans, v.a.rgb_samps = q.rgb_samps;
@@ -282,11 +339,13 @@ int train_step_bwd_impl(const BtsTrainStep* st, const float* g_loss, hipStream_t
     g.d_proj_nhwc = need_map ? q.d_proj_nhwc : nullptr, g.d_proj_tiles = need_map ? q.d_proj_tiles : nullptr;
     g.d_mlp_params = st->d_mlp_params, g.d_empty_proj = want_empty ? st->d_empty_proj : nullptr;
     const size_t need = render_bwd_workspace_impl(&v.cfg, &v.a);
-    if (need > st->bwd_workspace_bytes || (need && !st->bwd_workspace)) {
+    void* ws = sq ? static_cast<void*>(static_cast<char*>(st->bwd_workspace) + ws_each * (size_t)s) : st->bwd_workspace;
+    const size_t ws_bytes = sq ? ws_each : st->bwd_workspace_bytes;
+    if (need > ws_bytes || (need && !st->bwd_workspace)) {
       set_error("%s: bwd_workspace too small (%ld bytes needed)", "bts_train_step_bwd", (long)need);
       return BTS_E_WORKSPACE;
     }
-    int rc = render_bwd_impl(&v.cfg, &v.t, &v.a, &g, st->bwd_workspace, st->bwd_workspace_bytes, stream);
+    int rc = render_bwd_impl(&v.cfg, &v.t, &v.a, &g, ws, ws_bytes, stream);
     if (rc) return rc;
     if (need_map) {
       rc = project_features_bwd_tiles_impl(c.C, c.d_hidden, q.feat_nchw, q.d_proj_nhwc, q.d_proj_tiles, st->mlp_params, n, (int)map_texels(st, s),
@@ -296,7 +355,10 @@ int train_step_bwd_impl(const BtsTrainStep* st, const float* g_loss, hipStream_t
         return rc;
       }
     }
+    if (sq && s > 0 && (hipEventRecord(sq->join[s - 1], stream) != hipSuccess || hipStreamWaitEvent(main_stream, sq->join[s - 1], 0) != hipSuccess))
+      return BTS_E_LAUNCH;
   }
+  stream = main_stream;
   if (want_empty) {
     empty_grad_kernel<<<1, 256, 0, stream>>>(st->mlp_params, st->empty_feature, st->d_empty_proj, c.C, c.d_hidden, c.C + 3 + 6 * c.num_freqs, st->d_mlp_params,
                                              st->d_empty_feature);

@@ -163,11 +163,16 @@ class FusedTrainStep(torch.nn.Module):
     ``coarse`` / ``fine`` (aliases, trainer.py:247-248) per scale with ``rgb (n, P, ph, pw, nv, 3)``, ``depth (n, P, ph, pw)`` and the
     invalid-ray reductions, ``rgb_gt``, ``rays`` -- detached: the loss is already formed (and is what carries the graph)."""
 
-    def __init__(self, wrapped, sampler, criterion, multiscale=False, fused=True):
+    def __init__(self, wrapped, sampler, criterion, multiscale=False, fused=True, concurrent_scales=False):
         super().__init__()
         self.wrapped = wrapped
         self.sampler, self.criterion = sampler, criterion
         self.multiscale, self.fused = bool(multiscale), bool(fused)
+        # a multiscale step's per-scale kernel chains on side queues of the library, forked from / joined into the current stream inside
+        # the two calls (BtsTrainStep.concurrent_scales).  Measured and NOT the default: every kernel of a chain is a persistent grid
+        # that fills the chip, so the queues take turns instead of overlapping -- exp_re10k.yaml 2.635 ms serial vs 2.655 ms side by
+        # side, K = 128 5.32 vs 5.37 (profiles/r05i)
+        self.concurrent_scales = bool(concurrent_scales)
         self.last_path = None        # "fused" | "entries: <reason>" of the most recent call
 
     # ---- which path ------------------------------------------------------------------------------------------------
@@ -283,7 +288,8 @@ class FusedTrainStep(torch.nn.Module):
         def make():
             args = _lib.BtsRenderArgs(rays_per_sample=Bp, K=K)
             ws = int(_lib.load().bts_render_bwd_workspace(C.byref(cfg), C.byref(args)))
-            return _Arena(key, dev, n, nv, H, W, spec.d_hidden, Bp, K, P, shifts, spec, ws)
+            # one slice per scale: with `concurrent_scales` the scales' backward chains run side by side (BtsTrainStep.concurrent_scales)
+            return _Arena(key, dev, n, nv, H, W, spec.d_hidden, Bp, K, P, shifts, spec, ((ws + 255) // 256 * 256) * len(shifts))
         arena = _arena(key, make)
         per_scale = _r64(B * nv * 3) + _r64(B) + 2 * _r64(B * nv)
         out = torch.empty(_r64(B * 8) + _r64(B * 3) + 64 + S * per_scale, device=dev, dtype=torch.float32)
@@ -309,6 +315,7 @@ class FusedTrainStep(torch.nn.Module):
         st.invalid_policy = native.INVALID_POLICIES[crit.invalid_policy]
         st.edge_aware_smoothness = int(crit.lambda_edge_aware_smoothness > 0)
         st.n_scales = S
+        st.concurrent_scales = int(self.concurrent_scales and S > 1)
         st.z_near, st.z_far, st.img_scale, st.img_shift = float(smp.z_near), float(smp.z_far), 0.5, 0.5
         M = crit.loss_matrix(S, (B,) * S, (True,) * S)            # trainer.py:247-248: fine = dict(coarse) on every scale
         for i, x in enumerate(M.reshape(-1).tolist()):

@@ -65,6 +65,9 @@ def parse():
     ap.add_argument("--entries", action="store_true",
                     help="training workloads, A/B: the entry-by-entry sequence of the reference's trainer (encode, sample, render, reconstruct, loss: "
                          "~20 library calls + torch glue per step) instead of FusedTrainStep's two calls (bts_train_step_fwd / _bwd, ABI 7)")
+    ap.add_argument("--concurrent-scales", action="store_true",
+                    help="re10k workload, A/B: the four scales' kernel chains side by side on queues of the library (BtsTrainStep.concurrent_scales) "
+                         "instead of one after the other on the caller's stream; measured slower by 1 %, profiles/r05i")
     ap.add_argument("--shard", choices=("frames", "rays"), default="frames",
                     help="eval workload under torch.distributed.run: frames (default) = every rank renders its own frame, no collective; rays = ONE "
                          "frame, its rays split over the ranks (parallel.render_sharded) and the per-ray outputs all-gathered inside the timed "
@@ -306,7 +309,8 @@ def train_workload(args, world, rank, dev):
     ids_loss, ids_render = cfg["ids_loss"], cfg["ids_render"]
     wrapped = renderer.bind_parallel(net).train()
     crit = bts.ReconstructionLoss({"criterion": "l1+ssim", "invalid_policy": "weight_guided", "lambda_edge_aware_smoothness": 0.001})
-    fused = bts.FusedTrainStep(wrapped, sampler, crit, multiscale=n_scales > 1, fused=not args.entries and not args.full_outputs)
+    fused = bts.FusedTrainStep(wrapped, sampler, crit, multiscale=n_scales > 1, fused=not args.entries and not args.full_outputs,
+                               concurrent_scales=args.concurrent_scales)
 
     class Task(torch.nn.Module):
         """trainer.py:208-259 after the data loader, as ONE module so that DistributedDataParallel wraps it exactly as idist.auto_model wraps

@@ -343,7 +343,11 @@ typedef struct BtsTrainStep {
   int32_t invalid_policy;    /* 0 none, 1 strict, 2 weight_guided (BtsLossArgs) */
   int32_t edge_aware_smoothness;
   int32_t n_scales;          /* 1 .. BTS_MAX_SCALES */
-  int32_t reserved_;
+  /* 1: the scales' chains of kernels run side by side on queues of the library's own, forked from and joined back into the caller's
+   * stream inside the call (the scales share nothing but read-only inputs and the atomically accumulated d_mlp_params); the backward then
+   * needs bwd_workspace_bytes >= n_scales * (bts_render_bwd_workspace rounded up to 256), else it runs them one after the other.  0:
+   * everything on the caller's stream, in order.  Results are the same either way (the backward's float atomics are unordered anyway). */
+  int32_t concurrent_scales;
   float z_near, z_far;       /* the ray sampler's (ray_sampler.py:108-123) */
   float img_scale, img_shift;
   float loss_matrix[9 * 3 * BTS_MAX_SCALES];   /* (9, 3 n_scales) row-major, see above */

@@ -83,6 +83,23 @@ def test_fused_step_equals_the_entry_by_entry_step(shape):
         assert err <= 2e-5, (shape, k, err)
 
 
+def test_concurrent_scales_equal_serial_scales():
+    """BtsTrainStep.concurrent_scales: the four scales' chains of an exp_re10k.yaml step on side queues of the library against the same
+    chains one after the other -- identical forward bits, gradients to the order of the float atomics."""
+    cfg = SHAPES["re10k"]
+    step, net, inputs = _setup(cfg)
+    step.concurrent_scales = False
+    l_s, d_s, data_s, g_s = _run(step, net, inputs, cfg, fused=True)
+    step.concurrent_scales = True
+    for _ in range(3):      # (several rounds: an ordering bug between the queues would show up as a changing result)
+        l_c, d_c, data_c, g_c = _run(step, net, inputs, cfg, fused=True)
+        assert torch.equal(l_s, l_c) and all(d_s[k] == d_c[k] for k in d_s)
+        for a, b in zip(data_s["coarse"], data_c["coarse"]):
+            assert all(torch.equal(a[k], b[k]) for k in ("rgb", "depth", "invalid_wsum", "invalid_any"))
+        for k in g_s:
+            assert (g_s[k] - g_c[k]).abs().max().item() <= 2e-5 * g_s[k].abs().max().item(), k
+
+
 def test_fused_step_with_the_learned_empty_feature_and_an_upstream_factor():
     """learn_empty (models_bts.py:176-182): the empty feature's gradient and its share of lin_in's come out of the second call; an upstream
     gradient other than 1 (a scaled loss) reaches every gradient."""
