@@ -36,7 +36,7 @@ int occupancy_profile_impl(const BtsFieldCfg* cfg, const BtsFieldTensors* t, con
                            int only_density, float* profile, float* sigma, hipStream_t s);
 size_t render_bwd_workspace_impl(const BtsFieldCfg* cfg, const BtsRenderArgs* a);
 int render_bwd_impl(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const BtsRenderArgs* a, const BtsRenderGrads* g, void* ws,
-                    size_t ws_bytes, hipStream_t s);
+                    size_t ws_bytes, hipStream_t s, bool flush_clean = false);
 }  // namespace bts
 
 using namespace bts;

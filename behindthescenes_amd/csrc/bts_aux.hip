@@ -56,9 +56,9 @@ int transpose_launch(const float* src, float* dst, int N, int C, int H, int W, b
 struct FrameIds {
   int nv, v, ids[BTS_MAX_VIEWS];
 };
-__global__ __launch_bounds__(256) void pack_rgb_kernel(const float* __restrict__ src, float4* __restrict__ dst, long HW, long total,
-                                                       float scale, float shift, const FrameIds f) {
-  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+__device__ __forceinline__ void pack_rgb_body(const float* __restrict__ src, float4* __restrict__ dst, long HW, long total, float scale, float shift,
+                                              const FrameIds& f, long block, long n_blocks) {
+  for (long i = block * 256L + threadIdx.x; i < total; i += n_blocks * 256) {
     long n = i / HW;
     const long p = i - n * HW;
     if (f.nv > 0) n = (n / f.nv) * f.v + f.ids[n % f.nv];
@@ -70,6 +70,10 @@ __global__ __launch_bounds__(256) void pack_rgb_kernel(const float* __restrict__
     o.w = 0.0f;
     dst[i] = o;
   }
+}
+__global__ __launch_bounds__(256) void pack_rgb_kernel(const float* __restrict__ src, float4* __restrict__ dst, long HW, long total,
+                                                       float scale, float shift, const FrameIds f) {
+  pack_rgb_body(src, dst, HW, total, scale, shift, f, blockIdx.x, gridDim.x);
 }
 
 int pack_rgb_launch(const float* src, float* dst, int N, int H, int W, float scale, float shift, hipStream_t s) {
@@ -147,15 +151,13 @@ int gen_rays_launch(const float* poses, const float* projs, int V, int H, int W,
 struct ViewTable {
   int n, ids[BTS_MAX_LOSS_VIEWS];
 };
-__global__ __launch_bounds__(256) void patch_rays_kernel(const float* __restrict__ poses, const float* __restrict__ projs,
-                                                         const float* __restrict__ images, const int* __restrict__ pv,
-                                                         const int* __restrict__ py, const int* __restrict__ px, int n, int v, int c, int H,
-                                                         int W, int P, int ph, int pw, float z_near, float z_far, int norm_dir,
-                                                         float4* __restrict__ rays, float* __restrict__ gt, const ViewTable m, float gt_scale,
-                                                         float gt_shift) {
+__device__ __forceinline__ void patch_rays_body(const float* __restrict__ poses, const float* __restrict__ projs, const float* __restrict__ images,
+                                                const int* __restrict__ pv, const int* __restrict__ py, const int* __restrict__ px, int n, int v, int c, int H,
+                                                int W, int P, int ph, int pw, float z_near, float z_far, int norm_dir, float4* __restrict__ rays,
+                                                float* __restrict__ gt, const ViewTable& m, float gt_scale, float gt_shift, long block, long n_blocks) {
   const int per = P * ph * pw;
   const long total = (long)n * per;
-  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+  for (long i = block * 256L + threadIdx.x; i < total; i += n_blocks * 256) {
     const int smp = (int)(i / per);
     int rem = (int)(i - (long)smp * per);
     const int patch = rem / (ph * pw);
@@ -173,6 +175,14 @@ __global__ __launch_bounds__(256) void patch_rays_kernel(const float* __restrict
       for (int ch = 0; ch < c; ++ch) gt[i * c + ch] = img[(long)ch * H * W] * gt_scale + gt_shift;
     }
   }
+}
+__global__ __launch_bounds__(256) void patch_rays_kernel(const float* __restrict__ poses, const float* __restrict__ projs,
+                                                         const float* __restrict__ images, const int* __restrict__ pv,
+                                                         const int* __restrict__ py, const int* __restrict__ px, int n, int v, int c, int H,
+                                                         int W, int P, int ph, int pw, float z_near, float z_far, int norm_dir,
+                                                         float4* __restrict__ rays, float* __restrict__ gt, const ViewTable m, float gt_scale,
+                                                         float gt_shift) {
+  patch_rays_body(poses, projs, images, pv, py, px, n, v, c, H, W, P, ph, pw, z_near, z_far, norm_dir, rays, gt, m, gt_scale, gt_shift, blockIdx.x, gridDim.x);
 }
 
 int patch_rays_views_launch(const float* poses, const float* projs, const float* images, const int* pv, const int* py, const int* px, int n, int v,
@@ -303,9 +313,8 @@ __global__ __launch_bounds__(64) void invert_small_kernel(const float* __restric
 struct CamIds {
   int nv, v, id_enc, ids[BTS_MAX_VIEWS];
 };
-__global__ __launch_bounds__(64) void camera_prep_kernel(const float* __restrict__ Ks, const float* __restrict__ poses, int n, const CamIds f,
-                                                        float* __restrict__ cams) {
-  const int i = blockIdx.x * 64 + threadIdx.x;
+__device__ __forceinline__ void camera_prep_body(const float* __restrict__ Ks, const float* __restrict__ poses, int n, const CamIds& f,
+                                                 float* __restrict__ cams, int i) {
   if (i >= n * (1 + f.nv)) return;
   const int smp = i / (1 + f.nv), j = i - smp * (1 + f.nv);
   const int frame = j == 0 ? f.id_enc : f.ids[j - 1];
@@ -319,6 +328,84 @@ __global__ __launch_bounds__(64) void camera_prep_kernel(const float* __restrict
 #pragma unroll
   for (int e = 0; e < 9; ++e) Kd[e] = Ksrc[e];
   invert_small_dev<4>(poses + ((long)smp * f.v + frame) * 16, Pd);
+}
+__global__ __launch_bounds__(64) void camera_prep_kernel(const float* __restrict__ Ks, const float* __restrict__ poses, int n, const CamIds f,
+                                                        float* __restrict__ cams) {
+  camera_prep_body(Ks, poses, n, f, cams, blockIdx.x * 64 + threadIdx.x);
+}
+
+// ---- the hand-over of a training step in ONE launch (bts_train_step_fwd): cameras, rgb0 packing of the render frames, patch rays + colours
+// and the zero fill of every scale's tile flags are independent of each other; as four launches on one queue each paid its own dispatch
+// gap on an otherwise idle GPU (the step after them is 0.2 ms at exp_kitti_raw.yaml's shapes).  Work-group ranges take the roles.
+struct HandoverParams {
+  const float* Ks;
+  const float* poses;
+  const float* images;
+  const int *pv, *py, *px;
+  float* cams;
+  float4* imgs;
+  float4* rays;
+  float* gt;
+  unsigned char* zero[BTS_MAX_SCALES];
+  long zero_bytes[BTS_MAX_SCALES];
+  CamIds cam;
+  FrameIds frames;
+  ViewTable loss;
+  int n, v, H, W, P, ph, pw, n_zero;
+  float z_near, z_far, scale, shift;
+  int b_cam, b_pack, b_patch, b_zero;    // work-groups per role, in this order
+};
+__global__ __launch_bounds__(256) void handover_kernel(const HandoverParams p) {
+  int b = blockIdx.x;
+  if (b < p.b_cam) {
+    camera_prep_body(p.Ks, p.poses, p.n, p.cam, p.cams, b * 256 + threadIdx.x);
+    return;
+  }
+  b -= p.b_cam;
+  if (b < p.b_pack) {
+    const long HW = (long)p.H * p.W;
+    pack_rgb_body(p.images, p.imgs, HW, HW * p.n * p.frames.nv, p.scale, p.shift, p.frames, b, p.b_pack);
+    return;
+  }
+  b -= p.b_pack;
+  if (b < p.b_patch) {
+    patch_rays_body(p.poses, p.Ks, p.images, p.pv, p.py, p.px, p.n, p.v, 3, p.H, p.W, p.P, p.ph, p.pw, p.z_near, p.z_far, 1, p.rays, p.gt, p.loss, p.scale,
+                    p.shift, b, p.b_patch);
+    return;
+  }
+  b -= p.b_patch;
+  for (int r = 0; r < p.n_zero; ++r) {       // (flag arrays are multiples of 4 bytes only by accident: bytes at the ragged end)
+    unsigned* w = reinterpret_cast<unsigned*>(p.zero[r]);
+    const long words = p.zero_bytes[r] >> 2;
+    for (long i = b * 256L + threadIdx.x; i < words; i += (long)p.b_zero * 256) w[i] = 0u;
+    if (b == 0 && threadIdx.x < (p.zero_bytes[r] & 3)) p.zero[r][(words << 2) + threadIdx.x] = 0;
+  }
+}
+
+int handover_launch(const float* Ks, const float* poses, const float* images, const int* pv, const int* py, const int* px, int n, int v, int id_enc, int nv,
+                    const int* ids_render, int n_loss, const int* ids_loss, int H, int W, int P, int ph, int pw, float z_near, float z_far, float scale,
+                    float shift, float* cams, float* imgs, float* rays, float* gt, int n_zero, unsigned char* const* zero, const long* zero_bytes,
+                    hipStream_t s) {
+  HandoverParams p;
+  p.Ks = Ks, p.poses = poses, p.images = images, p.pv = pv, p.py = py, p.px = px, p.cams = cams;
+  p.imgs = reinterpret_cast<float4*>(imgs), p.rays = reinterpret_cast<float4*>(rays), p.gt = gt;
+  p.cam.nv = nv, p.cam.v = v, p.cam.id_enc = id_enc, p.frames.nv = nv, p.frames.v = v, p.loss.n = n_loss;
+  for (int j = 0; j < BTS_MAX_VIEWS; ++j) p.cam.ids[j] = p.frames.ids[j] = j < nv ? ids_render[j] : 0;
+  for (int j = 0; j < BTS_MAX_LOSS_VIEWS; ++j) p.loss.ids[j] = j < n_loss ? ids_loss[j] : 0;
+  p.n = n, p.v = v, p.H = H, p.W = W, p.P = P, p.ph = ph, p.pw = pw, p.n_zero = n_zero;
+  long zmax = 0;
+  for (int r = 0; r < BTS_MAX_SCALES; ++r) {
+    p.zero[r] = r < n_zero ? zero[r] : nullptr, p.zero_bytes[r] = r < n_zero ? zero_bytes[r] : 0;
+    if (p.zero_bytes[r] > zmax) zmax = p.zero_bytes[r];
+  }
+  p.z_near = z_near, p.z_far = z_far, p.scale = scale, p.shift = shift;
+  const long px_total = (long)n * nv * H * W, ray_total = (long)n * P * ph * pw;
+  p.b_cam = (n * (1 + nv) + 255) / 256;
+  p.b_pack = (int)((px_total + 255) / 256 < 2048 ? (px_total + 255) / 256 : 2048);
+  p.b_patch = (int)((ray_total + 255) / 256 < 1024 ? (ray_total + 255) / 256 : 1024);
+  p.b_zero = n_zero ? (int)((zmax / 4 + 255) / 256 < 64 ? (zmax / 4 + 255) / 256 + 1 : 64) : 0;
+  handover_kernel<<<p.b_cam + p.b_pack + p.b_patch + p.b_zero, 256, 0, s>>>(p);
+  return hipGetLastError() == hipSuccess ? BTS_OK : BTS_E_LAUNCH;
 }
 
 int camera_prep_launch(const float* Ks, const float* poses, int n, int v, int id_enc, int nv, const int* ids, float* cams, hipStream_t s) {

@@ -23,6 +23,7 @@ struct BwdParams {
   unsigned long long* ticks;   // diagnostic build: [waves][16] cycles per section (rows_kernel: tools/bwd_ticks.py; scatter_kernel behind them)
 #endif
   float* flush_ws;        // kFlushSlots x (40 x HD) floats, zeroed by the launcher: pass C's dW_pe partial sums (dwpe_flush below)
+  bool flush_clean;       // the caller already zeroed flush_ws on this stream (bts_train_step_bwd: one prep launch does every scale's)
 };
 
 // diagnostic build (-DBTS_TICKS, behindthescenes_amd/variants): s_memtime at the section borders of a kernel's iteration.  Reading the counter

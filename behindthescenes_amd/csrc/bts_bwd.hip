@@ -752,9 +752,17 @@ static int launch_scatter(const BwdParams& bp, int n, hipStream_t s) {
 }
 #endif
 
+// where pass C's slot copies sit inside a workspace (the tail of either layout), for a caller that zeroes them itself
+void render_bwd_flush_region(const BtsFieldCfg* cfg, const BtsRenderArgs* a, void* workspace, float** ptr, size_t* bytes) {
+  const size_t total = render_bwd_workspace_impl(cfg, a);
+  *bytes = flush_bytes(cfg);
+  *ptr = reinterpret_cast<float*>(static_cast<char*>(workspace) + (total - *bytes));
+}
+
 int render_bwd_impl(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const BtsRenderArgs* a, const BtsRenderGrads* g, void* workspace,
-                    size_t, hipStream_t s) {
+                    size_t, hipStream_t s, bool flush_clean) {
   BwdParams bp;
+  bp.flush_clean = flush_clean;
   bp.f = make_params(cfg, t);
   bp.f.rays = a->rays, bp.f.z_samp = a->z_samp;
   bp.f.Bp = a->rays_per_sample, bp.f.K = a->K, bp.f.hard_cap = a->hard_alpha_cap, bp.f.white_bkgd = a->white_bkgd;

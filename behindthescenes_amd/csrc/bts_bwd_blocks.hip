@@ -838,7 +838,8 @@ __global__ __launch_bounds__(256, 2) void rowsb_kernel(const BwdParams bp, const
 // launch
 // ---------------------------------------------------------------------------------------------------------------
 int launch_scatter_rows(const BwdParams& bp, const float* u0_ws, int HD, int n, hipStream_t s);
-int launch_dwpe_rows(const FwdParams& p, const float* u0_ws, float* d_mlp, float* flush_ws, int C, int HD, int NB, int n, int grid, hipStream_t s);
+int launch_dwpe_rows(const FwdParams& p, const float* u0_ws, float* d_mlp, float* flush_ws, int C, int HD, int NB, int n, int grid, hipStream_t s,
+                     bool flush_clean);
 
 template <int C, int HD, int NB>
 static int launch_rowsb(const BwdParams& bp, const RowsbOut& ro, int grid, hipStream_t s) {
@@ -877,7 +878,7 @@ int launch_bwd_blocks(const BwdParams& bp, float* u0_ws, int C, int HD, int NB, 
   else if (C == 32 && HD == 32 && NB == 1) rc = launch_rowsb<32, 32, 1>(bp, ro, grid, s);
   else if (C == 32 && HD == 32 && NB == 0) rc = launch_rowsb<32, 32, 0>(bp, ro, grid, s);
   if (rc == BTS_OK && (bp.d_proj || bp.d_empty_proj)) rc = launch_scatter_rows(bp, u0_ws, HD, n, s);
-  if (rc == BTS_OK && bp.d_mlp) rc = launch_dwpe_rows(bp.f, u0_ws, bp.d_mlp, bp.flush_ws, C, HD, NB, n, grid, s);
+  if (rc == BTS_OK && bp.d_mlp) rc = launch_dwpe_rows(bp.f, u0_ws, bp.d_mlp, bp.flush_ws, C, HD, NB, n, grid, s, bp.flush_clean);
   return rc;
 }
 

@@ -1074,13 +1074,16 @@ __global__ __launch_bounds__(256, 2) void dwpe_kernel(const DwpeParams dp) {
 // slots [kFlushSlots][kin][stored channel] -> d_mlp (w_in's encoding columns and b_in: at the start of the packed parameters whatever
 // the number of blocks)
 template <int C, int HD>
-__global__ __launch_bounds__(256) void dwpe_reduce_kernel(const float* __restrict__ slots, float* __restrict__ d_mlp) {
+__global__ __launch_bounds__(256) void dwpe_reduce_kernel(float* __restrict__ slots, float* __restrict__ d_mlp) {
   constexpr int D_IN = C + kPeDim;
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= kFlushRows * HD) return;
   float v = 0.0f;
 #pragma unroll
-  for (int s = 0; s < kFlushSlots; ++s) v += slots[s * (kFlushRows * HD) + i];
+  for (int s = 0; s < kFlushSlots; ++s) {
+    v += slots[s * (kFlushRows * HD) + i];
+    slots[s * (kFlushRows * HD) + i] = 0.0f;    // the slot copies leave as they must be found: a step's next scale needs no fill of its own
+  }
   const int kin = i / HD, hid = proj_hidden_of_storage(i % HD);
   const int src = kernel_to_ref_input<C>(kin + C);
   if (v != 0.0f) atomic_add_f32(d_mlp + (src >= 0 ? hid * D_IN + src : HD * D_IN + hid), v);
@@ -1303,7 +1306,7 @@ static int launch_rows(const BwdParams& bp, int n, int grid, hipStream_t s) {
     const long wgs = (dp.rays + 3) / 4;
     auto kern = dwpe_kernel<C, HD>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, DwpeLds::TOTAL);
-    (void)hipMemsetAsync(bp.flush_ws, 0, sizeof(float) * kFlushSlots * kFlushRows * HD, s);
+    if (!bp.flush_clean) (void)hipMemsetAsync(bp.flush_ws, 0, sizeof(float) * kFlushSlots * kFlushRows * HD, s);
     kern<<<(int)(wgs < grid ? wgs : grid), 256, DwpeLds::TOTAL, s>>>(dp);   // grid = 2 work-groups per CU
     dwpe_reduce_kernel<C, HD><<<(kFlushRows * HD + 255) / 256, 256, 0, s>>>(bp.flush_ws, bp.d_mlp);
     e = hipGetLastError();
@@ -1353,7 +1356,8 @@ int launch_scatter_rows(const BwdParams& bp, const float* u0_ws, int HD, int n, 
   return launch_status();
 }
 
-int launch_dwpe_rows(const FwdParams& p, const float* u0_ws, float* d_mlp, float* flush_ws, int C, int HD, int NB, int n, int grid, hipStream_t s) {
+int launch_dwpe_rows(const FwdParams& p, const float* u0_ws, float* d_mlp, float* flush_ws, int C, int HD, int NB, int n, int grid, hipStream_t s,
+                     bool flush_clean) {
   DwpeRowsParams dp;
   dp.f = p, dp.u0_ws = u0_ws, dp.d_mlp = d_mlp, dp.slots = flush_ws, dp.rays = (long)n * p.Bp;
   if ((long)p.Bp * p.K > 0x7FFFFF00L) return BTS_E_UNSUPPORTED;
@@ -1362,7 +1366,7 @@ int launch_dwpe_rows(const FwdParams& p, const float* u0_ws, float* d_mlp, float
   const long wgs = (units + 3) / 4;
   const long cap = HD == 32 ? (long)grid / 2 * 3 : grid;   // grid = 2 work-groups per CU; this kernel fits 3 at d_hidden 32
   const int g = (int)(wgs < cap ? wgs : cap);
-  (void)hipMemsetAsync(flush_ws, 0, sizeof(float) * kFlushSlots * kFlushRows * HD, s);
+  if (!flush_clean) (void)hipMemsetAsync(flush_ws, 0, sizeof(float) * kFlushSlots * kFlushRows * HD, s);
   if (C == 64 && HD == 64) {
     dwpe_rows_kernel<64, 64><<<g, 256, 0, s>>>(dp);
     dwpe_reduce_kernel<64, 64><<<(kFlushRows * 64 + 255) / 256, 256, 0, s>>>(flush_ws, d_mlp);

@@ -31,6 +31,11 @@ int project_features_bwd_tiles_impl(int C, int HD, const float* feat, float* dpr
 int render_fwd_impl(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const BtsRenderArgs* a, hipStream_t s);
 size_t render_bwd_workspace_impl(const BtsFieldCfg* cfg, const BtsRenderArgs* a);
 int render_bwd_impl(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const BtsRenderArgs* a, const BtsRenderGrads* g, void* ws, size_t ws_bytes,
+                    hipStream_t s, bool flush_clean);
+void render_bwd_flush_region(const BtsFieldCfg* cfg, const BtsRenderArgs* a, void* workspace, float** ptr, size_t* bytes);
+int handover_launch(const float* Ks, const float* poses, const float* images, const int* pv, const int* py, const int* px, int n, int v, int id_enc, int nv,
+                    const int* ids_render, int n_loss, const int* ids_loss, int H, int W, int P, int ph, int pw, float z_near, float z_far, float scale,
+                    float shift, float* cams, float* imgs, float* rays, float* gt, int n_zero, unsigned char* const* zero, const long* zero_bytes,
                     hipStream_t s);
 
 // ---- loss_vals = loss_matrix . [per-scale sums of the loss pass' per-patch parts]: one work-group, lanes stride the patches
@@ -82,6 +87,10 @@ struct ScaleGradParams {
   const float* g_loss;   // device scalar or null (1)
   int n_scales;
   long n_rgb, n_depth;   // elements per scale
+  // regions the backward accumulates into: the packed parameter gradient, the projected empty feature's, pass C's slot copies (float counts)
+  float* zero[2 + BTS_MAX_SCALES];
+  long zero_n[2 + BTS_MAX_SCALES];
+  int n_zero;
 };
 __global__ __launch_bounds__(256) void scale_grads_kernel(const ScaleGradParams p) {
   const float up = p.g_loss ? *p.g_loss : 1.0f;
@@ -94,6 +103,9 @@ __global__ __launch_bounds__(256) void scale_grads_kernel(const ScaleGradParams 
   for (long i = blockIdx.x * 256L + threadIdx.x; i < p.n_rgb; i += (long)gridDim.x * 256) orr[i] = gr[i] * a;
   if (gd && od)
     for (long i = blockIdx.x * 256L + threadIdx.x; i < p.n_depth; i += (long)gridDim.x * 256) od[i] = gd[i] * b;
+  if (s == 0)      // (one launch instead of a fill per region: each was a dispatch gap of its own on the queue)
+    for (int r = 0; r < p.n_zero; ++r)
+      for (long i = blockIdx.x * 256L + threadIdx.x; i < p.zero_n[r]; i += (long)gridDim.x * 256) p.zero[r][i] = 0.0f;
 }
 
 // ---- learn_empty: the render backward leaves the gradient of the PROJECTED empty feature e_p = w_in[:, :C] . e in d_empty_proj (Hd);
@@ -227,13 +239,14 @@ int train_step_fwd_impl(const BtsTrainStep* st, hipStream_t main_stream) {
   hipStream_t stream = main_stream;
   const BtsFieldCfg& c = st->cfg;
   const int n = c.n, nv = c.nv, Bp = st->P * st->ph * st->pw;
-  int rc = camera_prep_launch(st->Ks, st->poses_c2w, n, st->v, st->id_encoder, nv, st->ids_render, st->cams, stream);
-  if (!rc) rc = pack_rgb_views_launch(st->images, st->imgs_nhwc4, n, st->v, nv, st->ids_render, c.H, c.W, st->img_scale, st->img_shift, stream);
-  if (!rc)
-    rc = patch_rays_views_launch(st->poses_c2w, st->Ks, st->images, st->patch_v, st->patch_y, st->patch_x, n, st->v, 3, c.H, c.W, st->P, st->ph, st->pw,
-                                 st->z_near, st->z_far, 1, st->rays, st->rgb_gt, st->n_loss, st->ids_loss, st->img_scale, st->img_shift, stream);
+  unsigned char* zero[BTS_MAX_SCALES];
+  long zero_bytes[BTS_MAX_SCALES];
+  for (int s = 0; s < st->n_scales; ++s) zero[s] = st->scale[s].sampled_tiles, zero_bytes[s] = (long)n * ((map_texels(st, s) + 63) / 64);
+  int rc = handover_launch(st->Ks, st->poses_c2w, st->images, st->patch_v, st->patch_y, st->patch_x, n, st->v, st->id_encoder, nv, st->ids_render, st->n_loss,
+                           st->ids_loss, c.H, c.W, st->P, st->ph, st->pw, st->z_near, st->z_far, st->img_scale, st->img_shift, st->cams, st->imgs_nhwc4,
+                           st->rays, st->rgb_gt, st->n_scales, zero, zero_bytes, stream);
   if (rc) {
-    set_error("%s: a hand-over kernel launch failed", "bts_train_step_fwd");
+    set_error("%s: the hand-over kernel launch failed", "bts_train_step_fwd");
     return rc;
   }
   FinishParams fin;
@@ -249,8 +262,6 @@ int train_step_fwd_impl(const BtsTrainStep* st, hipStream_t main_stream) {
     const BtsTrainScale& q = st->scale[s];
     ScaleView v = scale_view(st, s);
     const long texels = map_texels(st, s);
-    const long tiles = (texels + 63) / 64;
-    if (hipMemsetAsync(q.sampled_tiles, 0, (size_t)(n * tiles), stream) != hipSuccess) return BTS_E_LAUNCH;
     rc = mark_tiles_impl(st->rays, nullptr, q.jitter, v.t.w2c_enc, v.t.K_enc, (long)n * Bp, Bp, st->K, st->lindisp, c.H, c.W, q.feat_shift, q.sampled_tiles,
                          stream);
     if (!rc) rc = project_features_impl(c.C, c.d_hidden, q.feat_nchw, st->mlp_params, n, (int)texels, q.proj_nhwc, q.sampled_tiles, stream);
@@ -306,22 +317,30 @@ int train_step_bwd_impl(const BtsTrainStep* st, const float* g_loss, hipStream_t
     sg.c_rgb[s] = st->loss_matrix[8 * cols + 3 * s], sg.c_eas[s] = st->loss_matrix[8 * cols + 3 * s + 1];
   }
   sg.g_loss = g_loss, sg.n_scales = st->n_scales, sg.n_rgb = (long)n * Bp * nv * 3, sg.n_depth = (long)n * Bp;
+  // one workspace slice per scale when the scales run side by side (the passes of a scale hand each other its contents)
+  size_t ws_each = 0;
+  ScaleView v0 = scale_view(st, 0);
+  ws_each = (render_bwd_workspace_impl(&v0.cfg, &v0.a) + 255) & ~(size_t)255;
+  if (ws_each > st->bwd_workspace_bytes || (ws_each && !st->bwd_workspace)) {
+    set_error("%s: bwd_workspace too small (%ld bytes needed)", "bts_train_step_bwd", (long)ws_each);
+    return BTS_E_WORKSPACE;
+  }
+  SideQueues* sq = (st->concurrent_scales && st->n_scales > 1 && st->bwd_workspace_bytes >= ws_each * (size_t)st->n_scales) ? side_queues() : nullptr;
+  const bool want_empty = c.learn_empty && st->d_empty_proj && (st->d_mlp_params || st->d_empty_feature);
+  if (st->d_mlp_params) sg.zero[sg.n_zero] = st->d_mlp_params, sg.zero_n[sg.n_zero++] = n_params;
+  if (want_empty) sg.zero[sg.n_zero] = st->d_empty_proj, sg.zero_n[sg.n_zero++] = c.d_hidden;
+  for (int s = 0; s < (sq ? st->n_scales : 1); ++s) {     // pass C's slot copies: the reduce kernel leaves them zero again, one fill serves every scale
+    float* fp;
+    size_t fb;
+    render_bwd_flush_region(&v0.cfg, &v0.a, static_cast<char*>(st->bwd_workspace) + ws_each * (size_t)s, &fp, &fb);
+    sg.zero[sg.n_zero] = fp, sg.zero_n[sg.n_zero++] = (long)(fb / sizeof(float));
+  }
   const long want = (sg.n_rgb + 255) / 256;
   scale_grads_kernel<<<dim3((unsigned)(want < 1024 ? want : 1024), (unsigned)st->n_scales), 256, 0, stream>>>(sg);
-  if (st->d_mlp_params && hipMemsetAsync(st->d_mlp_params, 0, sizeof(float) * (size_t)n_params, stream) != hipSuccess) return BTS_E_LAUNCH;
-  const bool want_empty = c.learn_empty && st->d_empty_proj && (st->d_mlp_params || st->d_empty_feature);
-  if (want_empty && hipMemsetAsync(st->d_empty_proj, 0, sizeof(float) * (size_t)c.d_hidden, stream) != hipSuccess) return BTS_E_LAUNCH;
   if (hipGetLastError() != hipSuccess) {
     set_error("%s: gradient scaling launch failed", "bts_train_step_bwd");
     return BTS_E_LAUNCH;
   }
-  // one workspace slice per scale when the scales run side by side (the passes of a scale hand each other its contents)
-  size_t ws_each = 0;
-  {
-    ScaleView v0 = scale_view(st, 0);
-    ws_each = (render_bwd_workspace_impl(&v0.cfg, &v0.a) + 255) & ~(size_t)255;
-  }
-  SideQueues* sq = (st->concurrent_scales && st->n_scales > 1 && st->bwd_workspace_bytes >= ws_each * (size_t)st->n_scales) ? side_queues() : nullptr;
   if (sq) {
     if (hipEventRecord(sq->fork, main_stream) != hipSuccess) return BTS_E_LAUNCH;
     for (int s = 1; s < st->n_scales; ++s)
@@ -345,7 +364,7 @@ int train_step_bwd_impl(const BtsTrainStep* st, const float* g_loss, hipStream_t
       set_error("%s: bwd_workspace too small (%ld bytes needed)", "bts_train_step_bwd", (long)need);
       return BTS_E_WORKSPACE;
     }
-    int rc = render_bwd_impl(&v.cfg, &v.t, &v.a, &g, ws, ws_bytes, stream);
+    int rc = render_bwd_impl(&v.cfg, &v.t, &v.a, &g, ws, ws_bytes, stream, true);
     if (rc) return rc;
     if (need_map) {
       rc = project_features_bwd_tiles_impl(c.C, c.d_hidden, q.feat_nchw, q.d_proj_nhwc, q.d_proj_tiles, st->mlp_params, n, (int)map_texels(st, s),
