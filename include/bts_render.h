@@ -43,7 +43,20 @@ enum {
 };
 
 /* Scalar configuration of the field: BTSNet.__init__ (models/bts/model/models_bts.py:18-54),
- * PositionalEncoding (models/common/model/code.py:11-28), ResnetFC shape (models/common/model/resnetfc.py:65-130). */
+ * PositionalEncoding (models/common/model/code.py:11-28), ResnetFC shape (models/common/model/resnetfc.py:65-130).
+ *
+ * Precision of lin_in's inputs (resnetfc.py:147, models_bts.py:150-171).  The 36 trigonometric inputs AND the three raw ones -- the
+ * projected x, y and the depth code -- enter the f16 matrix pipe as two round-to-nearest halves each: v = hi + lo + r with
+ * |r| <= 2^-22 |v| in the worst case (each half rounds to 11 significand bits; 2^-23 |v| typical), the weights likewise after an exact
+ * power-of-two scaling; the products hi.hi + lo.hi + hi.lo are exact in the fp32 accumulator, the dropped lo.lo term is <= 2^-22 |w v|.
+ * That is up to four fp32 rounding units (2^-24) per product.  For the sines (|v| <= 1) it vanishes in the accumulation's own rounding.
+ * x and y are NOT bounded by 1: a point beside or behind the encoder camera projects to |x|, |y| of hundreds (the perspective divide
+ * clamps z at 1e-3), and the split then costs up to 2^-22 |x| ABSOLUTE per product.  It stays invisible next to what the reference's own
+ * fp32 arithmetic does there: the twelve encoding inputs sin(f x [+ pi/2]), f = 1.5 .. 48, are evaluated on fp32 arguments whose rounding
+ * alone is 2^-24 f |x| -- 12 to 48 times the split's error on the raw row, through weights of the same size.  Beyond |x|, |y| = 2083
+ * (encoding arguments past the fast sines' range) a wave takes the exact fp32 routine.  Pinned by
+ * tests/test_gpu_parity.py::test_raw_rows_worst_case_vs_fp64: |x|, |y| log-uniform up to 2000, the code at both ends of [-1, 1] and
+ * clamped, learn_empty on and off -- never further from an fp64 evaluation than 1.5 x the fp32 reference's own distance. */
 typedef struct BtsFieldCfg {
   int32_t n;           /* batch ("super-batch") size */
   int32_t H, W;        /* feature-map and colour-frame size */
