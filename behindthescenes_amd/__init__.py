@@ -10,7 +10,7 @@ from .mlp import ResnetBlockFC, ResnetFC, make_mlp  # noqa: F401
 from .projection import distance_to_z  # noqa: F401
 from .ray_sampler import ImageRaySampler, PatchRaySampler, RandomRaySampler, gen_rays  # noqa: F401
 from .renderer import NeRFRenderer, _RenderWrapper  # noqa: F401
-from .train_step import FusedTrainStep  # noqa: F401
+from .train_step import FusedEvalFrame, FusedTrainStep  # noqa: F401
 
 __all__ = ["BTSNet", "NeRFRenderer", "PositionalEncoding", "ResnetFC", "ResnetBlockFC", "make_mlp", "make_backbone",
-           "ImageRaySampler", "PatchRaySampler", "RandomRaySampler", "gen_rays", "distance_to_z", "ReconstructionLoss", "FusedTrainStep", "BtsNativeError"]
+           "ImageRaySampler", "PatchRaySampler", "RandomRaySampler", "gen_rays", "distance_to_z", "ReconstructionLoss", "FusedTrainStep", "FusedEvalFrame", "BtsNativeError"]

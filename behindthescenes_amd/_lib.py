@@ -74,6 +74,14 @@ class BtsTrainStep(C.Structure):
                [("scale", BtsTrainScale * BTS_MAX_SCALES)]
 
 
+class BtsEvalFrame(C.Structure):
+    _fields_ = [("cfg", BtsFieldCfg), ("v", C.c_int32), ("id_encoder", C.c_int32), ("ids_render", C.c_int32 * BTS_MAX_VIEWS)] + \
+               [(k, C.c_int32) for k in ("K", "lindisp", "hard_alpha_cap", "norm_dir")] + \
+               [(k, C.c_float) for k in ("z_near", "z_far", "img_scale", "img_shift")] + \
+               [(k, C.c_void_p) for k in ("images", "Ks", "poses_c2w", "feat_nchw", "mlp_params", "empty_feature", "jitter", "cams", "imgs_nhwc4",
+                                          "proj_nhwc", "inv_K", "rays", "rgb", "depth", "depth_z", "weights", "alphas", "invalid")]
+
+
 class BtsConv3x3(C.Structure):
     _fields_ = [(k, C.c_int32) for k in ("N", "H", "W", "C", "up2", "elu", "out_nchw", "reserved_")] + \
                [(k, C.c_void_p) for k in ("x", "weight", "bias", "y")]
@@ -110,6 +118,7 @@ SYMBOLS = {
     "bts_invert_small": (C.c_int, [_P, _P, _I, _I, _P]),
     "bts_train_step_fwd": (C.c_int, [C.POINTER(BtsTrainStep), _P]),
     "bts_train_step_bwd": (C.c_int, [C.POINTER(BtsTrainStep), _P, _P]),
+    "bts_eval_frame": (C.c_int, [C.POINTER(BtsEvalFrame), _P]),
     "bts_conv3x3_fwd": (C.c_int, [C.POINTER(BtsConv3x3), _P]),
     "bts_conv3x3_bwd_workspace": (C.c_size_t, [C.POINTER(BtsConv3x3)]),
     "bts_conv3x3_bwd": (C.c_int, [C.POINTER(BtsConv3x3), _P, _P, C.c_size_t, _P, _P, _P, _P]),

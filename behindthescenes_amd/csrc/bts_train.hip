@@ -389,11 +389,88 @@ int train_step_bwd_impl(const BtsTrainStep* st, const float* g_loss, hipStream_t
   return BTS_OK;
 }
 
+int gen_rays_launch(const float* poses, const float* projs, int V, int H, int W, float zn, float zf, int norm_dir, float* rays, hipStream_t s);
+int distance_to_z_launch(const float* depths, const float* invK, int N, int H, int W, float* out, hipStream_t s);
+int invert_small_launch(const float* src, float* dst, int N, int dim, hipStream_t s);
+int project_features_plain(int C, int HD, const float* feat, const float* mlp, int N, int HW, float* proj, hipStream_t s) {
+  return project_features_impl(C, HD, feat, mlp, N, HW, proj, nullptr, s);
+}
+
+int eval_frame_impl(const BtsEvalFrame* f, hipStream_t stream) {
+  const BtsFieldCfg& c = f->cfg;
+  const int n = c.n, nv = c.nv;
+  int rc = camera_prep_launch(f->Ks, f->poses_c2w, n, f->v, f->id_encoder, nv, f->ids_render, f->cams, stream);
+  if (!rc && nv) rc = pack_rgb_views_launch(f->images, f->imgs_nhwc4, n, f->v, nv, f->ids_render, c.H, c.W, f->img_scale, f->img_shift, stream);
+  if (!rc) rc = project_features_plain(c.C, c.d_hidden, f->feat_nchw, f->mlp_params, n, c.H * c.W, f->proj_nhwc, stream);
+  if (!rc) rc = gen_rays_launch(f->poses_c2w, f->Ks, n * f->v, c.H, c.W, f->z_near, f->z_far, f->norm_dir, f->rays, stream);
+  if (rc) {
+    set_error("%s: a hand-over kernel launch failed", "bts_eval_frame");
+    return rc;
+  }
+  BtsFieldCfg cfg = c;
+  cfg.feat_shift = 0;
+  BtsFieldTensors t;
+  memset(&t, 0, sizeof(t));
+  float* K_enc = f->cams;
+  float* w2c_enc = K_enc + (long)n * 9;
+  float* K_r = w2c_enc + (long)n * 16;
+  float* w2c_r = K_r + (long)n * nv * 9;
+  t.proj_nhwc = f->proj_nhwc, t.K_enc = K_enc, t.w2c_enc = w2c_enc, t.imgs_nhwc4 = f->imgs_nhwc4, t.K_r = K_r, t.w2c_r = w2c_r;
+  t.empty_feature = c.learn_empty ? f->empty_feature : nullptr, t.mlp_params = f->mlp_params;
+  BtsRenderArgs a;
+  memset(&a, 0, sizeof(a));
+  a.rays_per_sample = f->v * c.H * c.W, a.K = f->K, a.hard_alpha_cap = f->hard_alpha_cap, a.rays = f->rays, a.jitter = f->jitter, a.lindisp = f->lindisp;
+  a.rgb = f->rgb, a.depth = f->depth, a.weights = f->weights, a.alphas = f->alphas, a.invalid = f->invalid;
+  rc = render_fwd_impl(&cfg, &t, &a, stream);
+  if (rc) return rc;
+  if (f->depth_z) {
+    rc = invert_small_launch(f->Ks, f->inv_K, n * f->v, 3, stream);
+    if (!rc) rc = distance_to_z_launch(f->depth, f->inv_K, n * f->v, c.H, c.W, f->depth_z, stream);
+    if (rc) {
+      set_error("%s: distance_to_z launch failed", "bts_eval_frame");
+      return rc;
+    }
+  }
+  return BTS_OK;
+}
+
 }  // namespace bts
 
 using namespace bts;
 
 extern "C" {
+
+int bts_eval_frame(const BtsEvalFrame* f, void* stream) {
+  if (!f) {
+    set_error("%s: NULL frame", "bts_eval_frame");
+    return BTS_E_INVALID;
+  }
+  const BtsFieldCfg& c = f->cfg;
+  if (c.n <= 0 || c.H <= 0 || c.W <= 0 || f->v <= 0 || f->K <= 0 || c.nv < 0 || c.nv > BTS_MAX_VIEWS) {
+    set_error("%s: non-positive size or more than 8 render views (n=%ld, v=%ld, K=%ld)", "bts_eval_frame", c.n, f->v, f->K);
+    return BTS_E_INVALID;
+  }
+  if (!shape_supported(c.C, c.d_hidden, c.n_blocks) || c.num_freqs != kNumFreqs) {
+    set_error("%s: configuration outside the compiled envelope (C=%ld d_hidden=%ld n_blocks=%ld)", "bts_eval_frame", c.C, c.d_hidden, c.n_blocks);
+    return BTS_E_UNSUPPORTED;
+  }
+  bool ids_ok = f->id_encoder >= 0 && f->id_encoder < f->v;
+  for (int j = 0; j < c.nv; ++j) ids_ok = ids_ok && f->ids_render[j] >= 0 && f->ids_render[j] < f->v;
+  if (!ids_ok || c.enc_render_view < -1 || c.enc_render_view >= c.nv) {
+    set_error("%s: a frame id outside [0, v=%ld) or enc_render_view out of range", "bts_eval_frame", f->v);
+    return BTS_E_INVALID;
+  }
+  if (!f->images || !f->Ks || !f->poses_c2w || !f->feat_nchw || !f->mlp_params || !f->jitter || !f->cams || !f->proj_nhwc || !f->rays || !f->rgb ||
+      !f->depth || (c.nv > 0 && !f->imgs_nhwc4) || (f->depth_z && !f->inv_K) || (c.learn_empty && !f->empty_feature)) {
+    set_error("%s: NULL input / output / scratch pointer", "bts_eval_frame");
+    return BTS_E_INVALID;
+  }
+  if ((long)c.n * f->v * c.H * c.W > 0x7FF00000L) {
+    set_error("%s: too many rays in one call (%ld)", "bts_eval_frame", (long)c.n * f->v * c.H * c.W);
+    return BTS_E_UNSUPPORTED;
+  }
+  return eval_frame_impl(f, (hipStream_t)stream);
+}
 
 int bts_train_step_fwd(const BtsTrainStep* st, void* stream) {
   if (int rc = check_step(st, "bts_train_step_fwd", false)) return rc;

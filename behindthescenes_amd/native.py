@@ -585,6 +585,11 @@ class Conv3x3Function(torch.autograd.Function):
         return d_x, d_w, d_b, None, None, None
 
 
+def eval_frame(fr, stream):
+    """bts_eval_frame on a filled ``_lib.BtsEvalFrame`` (behindthescenes_amd.train_step.FusedEvalFrame builds it)."""
+    _lib.check(_lib.load().bts_eval_frame(C.byref(fr), stream), "bts_eval_frame")
+
+
 def train_step_fwd(st, stream):
     """bts_train_step_fwd on a filled ``_lib.BtsTrainStep`` (behindthescenes_amd.train_step builds it)."""
     _lib.check(_lib.load().bts_train_step_fwd(C.byref(st), stream), "bts_train_step_fwd")

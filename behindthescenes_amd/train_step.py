@@ -354,3 +354,113 @@ class FusedTrainStep(torch.nn.Module):
 def native_take(x, ids):
     from .field import _take
     return _take(x, ids)
+
+
+class FusedEvalFrame(torch.nn.Module):
+    """``data = frame(images, projs, poses, ids_encoder=[0], ids_render=[0])`` -- the evaluator's forward after the data loader
+    (``BTSWrapper.forward``, models/bts/evaluator.py:60-79) in ONE library call (``bts_eval_frame``, ABI 7): encode's hand-over, the rays
+    of every pixel of every frame (``ImageRaySampler.sample``), the render with ``sample_coarse`` inside, ``distance_to_z``.  The same
+    kernels with the same arguments as the entry-by-entry sequence (bit-identical outputs, tests/test_gpu_train_fused.py); what goes away
+    is the host work between them -- 8 % of a 1.1 ms frame.  The jitter is the caller's ``torch.rand`` draw, as in the reference.
+
+    ``data``: ``coarse`` / ``fine`` (aliases, evaluator.py:70-71) with ``rgb (n, v, H, W, nv, 3)``, ``depth (n, v, H, W)`` (z-depth when
+    ``to_z``, evaluator.py:78-79), ``invalid (n, v, H, W, K, nv)``, ``weights`` / ``alphas (n, v, H, W, K)``; ``rgb_gt (n, v, H, W, 3)``;
+    ``rays (n, v*H*W, 8)``.  A configuration outside the call's envelope runs the entry-by-entry sequence (``why_not``)."""
+
+    def __init__(self, wrapped, sampler, fused=True):
+        super().__init__()
+        self.wrapped, self.sampler, self.fused = wrapped, sampler, bool(fused)
+        self.last_path = None
+        self._scratch = {}
+
+    def why_not(self, images=None, ids_encoder=(0,), ids_render=(0,)):
+        from .ray_sampler import ImageRaySampler
+        net, r = self.wrapped.net, self.wrapped.renderer
+        if not self.fused:
+            return "switched off (fused=False)"
+        if not isinstance(r, NeRFRenderer) or not isinstance(self.sampler, ImageRaySampler) or getattr(self.wrapped, "simple_output", False):
+            return "needs behindthescenes_amd's NeRFRenderer and ImageRaySampler"
+        if r.using_fine or r.n_fine or r.sched is not None or r.white_bkgd or (r.training and r.noise_std > 0.0):
+            return "fine pass / sampling schedule / white background / density noise"
+        if getattr(r.sample_coarse, "__func__", None) is not NeRFRenderer.sample_coarse:
+            return "sample_coarse is overridden"
+        if net.torch_mode or net.mlp_fine is not None or net.get_scale() != 0 or (net.flip_augmentation and net.training):
+            return "a PyTorch-composed field mode / a separate fine MLP / a scale other than 0 / flip augmentation"
+        if len(ids_encoder) != 1 or len(ids_render) > _lib.BTS_MAX_VIEWS or self.sampler.channels != 3:
+            return "more than one encoder view / more than 8 render views"
+        if images is not None and (not images.is_cuda or images.dtype != torch.float32 or images.shape[2] != 3 or
+                                   (self.sampler.height is not None and (self.sampler.height, self.sampler.width) != tuple(images.shape[-2:]))):
+            return "frames must be float32 (n, v, 3, H, W) on the GPU at the sampler's size"
+        return None
+
+    def _entries(self, images, projs, poses, ids_encoder, ids_render, want_weights, want_alphas, to_z):
+        from .projection import distance_to_z
+        net, smp = self.wrapped.net, self.sampler
+        net.encode(images, projs, poses, ids_encoder=ids_encoder, ids_render=ids_render)
+        all_rays, all_rgb_gt = smp.sample(images * .5 + .5, poses, projs)
+        rd = self.wrapped(all_rays, want_weights=want_weights, want_alphas=want_alphas)
+        if "fine" not in rd:
+            rd["fine"] = dict(rd["coarse"])
+        rd["rgb_gt"], rd["rays"] = all_rgb_gt, all_rays
+        rd = smp.reconstruct(rd)
+        if to_z:
+            rd["coarse"]["depth"] = distance_to_z(rd["coarse"]["depth"], projs)
+            rd["fine"]["depth"] = rd["coarse"]["depth"]
+        return dict(coarse=[rd["coarse"]], fine=[rd["fine"]], rgb_gt=rd["rgb_gt"], rays=rd["rays"])
+
+    @torch.no_grad()
+    def forward(self, images, projs, poses, ids_encoder=(0,), ids_render=(0,), want_weights=True, want_alphas=True, to_z=True):
+        ids_encoder, ids_render = [int(i) for i in ids_encoder], [int(i) for i in ids_render]
+        reason = self.why_not(images, ids_encoder, ids_render)
+        if reason is not None:
+            self.last_path = "entries: " + reason
+            return self._entries(images, projs, poses, ids_encoder, ids_render, want_weights, want_alphas, to_z)
+        self.last_path = "fused"
+        net, r, smp = self.wrapped.net, self.wrapped.renderer, self.sampler
+        n, v, _, H, W = images.shape
+        dev = images.device
+        images = images.contiguous()
+        projs, poses = projs.detach().float().contiguous(), poses.detach().float().contiguous()
+        id_enc, nv, K, spec = ids_encoder[0], len(ids_render), int(r.n_coarse), net.spec
+        net.mlp_coarse.invalidate_packed()
+        feat = net.encoder(images[:, id_enc])[0]
+        if tuple(feat.shape[-2:]) != (H, W):
+            raise native.BtsNativeError(f"the encoder's scale-0 map is {tuple(feat.shape[-2:])}, the frames are {(H, W)}")
+        feat = feat.detach().float().contiguous()
+        # the reference's order of draws: ImageRaySampler draws nothing, the renderer's jitter is one torch.rand (nerf.py:112)
+        rgb_gt = (images * .5 + .5).permute(0, 1, 3, 4, 2)                     # (n, v, H, W, 3): ray_sampler.py:253-258 (a view, as there)
+        B = n * v * H * W
+        jitter = torch.rand((B, K), device=dev, dtype=torch.float32)
+        f32 = dict(device=dev, dtype=torch.float32)
+        key = (dev, n, v, nv, H, W, spec.d_hidden)
+        sc = self._scratch.get(key)
+        if sc is None:
+            sc = self._scratch[key] = dict(cams=torch.empty(n * (25 + nv * 25), **f32), imgs=torch.empty((n, max(nv, 1), H, W, 4), **f32),
+                                           proj=torch.empty((n, H, W, spec.d_hidden), **f32), inv_K=torch.empty((n, v, 3, 3), **f32))
+        out = dict(rays=torch.empty((n, v * H * W, 8), **f32), rgb=torch.empty((n, v, H, W, nv, 3), **f32), depth=torch.empty((n, v, H, W), **f32),
+                   depth_z=torch.empty((n, v, H, W), **f32) if to_z else None, weights=torch.empty((n, v, H, W, K), **f32) if want_weights else None,
+                   alphas=torch.empty((n, v, H, W, K), **f32) if want_alphas else None, invalid=torch.empty((n, v, H, W, K, nv), **f32))
+        fr = _lib.BtsEvalFrame()
+        fr.cfg = native._spec_cfg(spec, n, H, W, nv, 0, ids_render.index(id_enc) if id_enc in ids_render else -1)
+        fr.v, fr.id_encoder = v, id_enc
+        for j, i in enumerate(ids_render):
+            fr.ids_render[j] = i
+        fr.K, fr.lindisp, fr.hard_alpha_cap, fr.norm_dir = K, int(bool(r.lindisp)), int(bool(r.hard_alpha_cap)), int(bool(smp.norm_dir))
+        fr.z_near, fr.z_far, fr.img_scale, fr.img_shift = float(smp.z_near), float(smp.z_far), 0.5, 0.5
+        params = net.mlp_coarse.packed().detach()
+        empty = net.empty_feature.detach() if net.learn_empty else None
+
+        def dp(t):
+            return None if t is None else t.data_ptr()
+        fr.images, fr.Ks, fr.poses_c2w, fr.feat_nchw, fr.mlp_params, fr.empty_feature, fr.jitter = (dp(images), dp(projs), dp(poses), dp(feat), dp(params),
+                                                                                                   dp(empty), dp(jitter))
+        fr.cams, fr.imgs_nhwc4, fr.proj_nhwc, fr.inv_K = dp(sc["cams"]), dp(sc["imgs"]), dp(sc["proj"]), dp(sc["inv_K"])
+        for k_ in ("rays", "rgb", "depth", "depth_z", "weights", "alphas", "invalid"):
+            setattr(fr, k_, dp(out[k_]))
+        native.eval_frame(fr, native._stream(images))
+        part = dict(rgb=out["rgb"], depth=out["depth_z"] if to_z else out["depth"], invalid=out["invalid"])
+        if want_weights:
+            part["weights"] = out["weights"]
+        if want_alphas:
+            part["alphas"] = out["alphas"]
+        return dict(coarse=[part], fine=[dict(part)], rgb_gt=rgb_gt, rays=out["rays"])

@@ -103,7 +103,7 @@ class KernelTimer:
     do NOT contain: torch's own kernels (the jitter draw, torch.cat of the parameters, DDP) and host gaps between entry points."""
     ENTRIES = ("nchw_to_nhwc", "nhwc_to_nchw", "pack_rgb", "gen_rays", "patch_rays", "photometric_loss", "sample_coarse", "invert_small",
                "distance_to_z", "project_features", "mark_sampled_tiles", "project_features_bwd", "render_fwd", "render_bwd", "field_query",
-               "occupancy_profile", "train_step_fwd", "train_step_bwd")
+               "occupancy_profile", "train_step_fwd", "train_step_bwd", "eval_frame")
 
     def __init__(self):
         from behindthescenes_amd import native
@@ -655,7 +655,13 @@ def main():
         S.set_feature_map(net, scene["feat"].to(dev))
         images, projs, poses = scene["images"].to(dev), scene["projs"].to(dev), scene["poses"].to(dev)
 
+    frame = bts.FusedEvalFrame(wrapped, sampler, fused=not args.entries and not shard_rays)
+
     def step():
+        # evaluator.py:60-79 after the CNN.  Default: behindthescenes_amd.FusedEvalFrame = ONE library call (bts_eval_frame: hand-over, rays of
+        # every pixel, render with sample_coarse inside, distance_to_z); --entries / --shard rays: the same kernels entry by entry
+        if frame.fused:
+            return frame(images, projs, poses, ids_encoder=[0], ids_render=[0])["coarse"][0]["depth"]
         with torch.no_grad():
             net.encode(images, projs, poses, ids_encoder=[0], ids_render=[0])
             all_rays, all_rgb_gt = sampler.sample(images * .5 + .5, poses, projs)
@@ -693,8 +699,27 @@ def main():
         elapsed = t.item()
 
     entry_ms = timer.ms_per_step(args.steps)
-    kernel_ms = entry_ms.get("render_fwd", float("nan"))          # bts::render_kernel_p alone
-    project_ms = entry_ms.get("project_features", 0.0)            # bts::project_kernel: the feature half of lin_in, once per texel
+    one_call = "eval_frame" in entry_ms
+    if one_call:
+        # the frame is ONE library call: its event pair holds every bts:: kernel of the frame (render_kernel_p, project_kernel and five
+        # small ones); the roofline prices the two kernels that carry FLOPs over the WHOLE call's time
+        kernel_ms, project_ms = entry_ms["eval_frame"], 0.0
+        # for reference, outside the timed region: the same kernels entry by entry, each in its own event pair
+        frame.fused = False
+        for _ in range(3):
+            step()
+        t2 = KernelTimer()
+        t2.install()
+        for _ in range(10):
+            step()
+        torch.cuda.synchronize()
+        t2.remove()
+        split_ms = t2.ms_per_step(10)
+        frame.fused = True
+    else:
+        kernel_ms = entry_ms.get("render_fwd", float("nan"))          # bts::render_kernel_p alone
+        project_ms = entry_ms.get("project_features", 0.0)            # bts::project_kernel: the feature half of lin_in, once per texel
+        split_ms = entry_ms
     # counters of the same kernel on the same workload from the committed rocprofv3 PMC passes (tools/profile.sh -> profiles/<tag>/)
     traffic, counters = None, {}
     prof = sorted(d for d in os.listdir(os.path.join(ROOT, "profiles")) if os.path.exists(os.path.join(ROOT, "profiles", d, "traffic.json"))) \
@@ -715,13 +740,14 @@ def main():
         exec_flop = rays_launch * K * EXEC_FLOP_PER_POINT + H * W * PROJECT_FLOP_PER_TEXEL      # what render_kernel_p + project_kernel execute
         exec_ms = kernel_ms + project_ms
         achieved = exec_flop / (exec_ms * 1e-3) / 1e12
-        algorithmic = flop_per_launch / (kernel_ms * 1e-3) / 1e12
+        render_ms = split_ms.get("render_fwd", kernel_ms)                  # the render kernel alone (entry-by-entry event pair)
+        algorithmic = flop_per_launch / (render_ms * 1e-3) / 1e12
         # how much of the kernel's time the SIMDs need just to ISSUE its VALU instructions: wave-instructions per SIMD x the measured issue
         # time per instruction at two resident waves (tools/ubench/valu_issue.hip), over the kernel time
         valu_issue = None
         if counters.get("valu_insts_per_ray"):
             per_simd = counters["valu_insts_per_ray"] * rays_launch / 1024
-            valu_issue = {k: per_simd * ns * 1e-6 / kernel_ms for k, ns in VALU_NS_PER_INST_2WAVES.items()}
+            valu_issue = {k: per_simd * ns * 1e-6 / render_ms for k, ns in VALU_NS_PER_INST_2WAVES.items()}
         out = {
             "metric": "rendered rays/sec (192x640x64 samples)", "value": value, "unit": "rays/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": step_ms, "higher_is_better": True, "scaling": "weak",
@@ -734,7 +760,10 @@ def main():
                            "all_gather": "rgb, depth, weights, alphas, invalid of all rays on every rank (what the un-sharded call returns)"} if shard_rays else {})},
             "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_MATRIX_TFLOPS, "traffic": traffic,
-                         "kernel": "bts::render_kernel_p<64,64,0,1,true,true> + bts::project_kernel<64,64>", "kernel_ms": kernel_ms, "project_ms": project_ms,
+                         "kernel": "bts::render_kernel_p<64,64,0,1,true,true> + bts::project_kernel<64,64>" + (" inside bts_eval_frame (one call: + cameras, "
+                                   "rgb0 packing, rays, two small inverses, distance_to_z)" if one_call else ""),
+                         "kernel_ms": kernel_ms, "project_ms": project_ms, "render_kernel_ms": render_ms,
+                         "entry_ms_entry_by_entry": {k: round(v, 4) for k, v in sorted(split_ms.items())} if one_call else None,
                          "executed_flop_per_launch": exec_flop, "algorithmic_flop_per_launch": flop_per_launch,
                          "algorithmic_tflops": algorithmic, "frac_algorithmic": algorithmic / PEAK_FP32_MATRIX_TFLOPS,
                          "valu_issue_frac": valu_issue, "entry_ms": {k: round(v, 4) for k, v in sorted(entry_ms.items())},
@@ -743,7 +772,9 @@ def main():
                                  "render kernel (5 760 / sample: 40 encoding + bias rows x 64 on the matrix pipe, lin_out, the 4-tap blend of G) "
                                  "and bts::project_kernel (2 x 64 x 64 / texel: the feature half of lin_in, hoisted out of the sample loop by "
                                  "the declared projected-feature shortcut, DESIGN.md section 3) EXECUTE, over their summed event time, against "
-                                 "the fp32 vector = fp32-input-MFMA peak: a true fraction.  `algorithmic_tflops` / `frac_algorithmic` price "
+                                 "the fp32 vector = fp32-input-MFMA peak: a true fraction (with the one-call frame the time is the whole call's: "
+                                 "every bts:: kernel of the frame; `render_kernel_ms` = the render kernel alone, from ten entry-by-entry frames "
+                                 "after the timed region).  `algorithmic_tflops` / `frac_algorithmic` price "
                                  "SURVEY 8d's 13 312 FLOP / sample over the render kernel's time: what a kernel without the shortcut would have "
                                  "to sustain; above 1 by construction.  `valu_issue_frac` = VALU wave-instructions per SIMD (PMC) x the measured "
                                  "issue time per instruction at two waves per SIMD (tools/ubench/valu_issue.hip; FMA-like / MUL-like mix) / "

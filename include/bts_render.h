@@ -431,6 +431,46 @@ size_t bts_conv3x3_bwd_workspace(const BtsConv3x3* c);
 int bts_conv3x3_bwd(const BtsConv3x3* c, const float* g_y, void* workspace, size_t workspace_bytes, float* d_x, float* d_weight, float* d_bias,
                     void* stream);
 
+
+/* ---------------------------------------------------------------------------------------------------------------------------------
+ * ABI 7: an evaluation frame in ONE call -- BTSWrapper.forward of models/bts/evaluator.py:60-79 after the CNN: encode's hand-over
+ * (models_bts.py:65-136: cameras, rgb0 packing of the render frames, the projection of the feature map), ImageRaySampler.sample
+ * (ray_sampler.py:233-260: the rays of every pixel of the `n_ray_views` frames), the render with sample_coarse inside (nerf.py:315-375),
+ * distance_to_z (utils/projection_operations.py:4-16).  The same kernels with the same arguments as the entry-by-entry path, enqueued
+ * without the host work between them (at 1 ms per frame that is 8 % of the frame).  Every buffer is the caller's.
+ * --------------------------------------------------------------------------------------------------------------------------------- */
+typedef struct BtsEvalFrame {
+  BtsFieldCfg cfg;           /* n, H, W, C, ..., nv = number of render (colour) views; enc_render_view as in ABI 5 */
+  int32_t v;                 /* frames per batch element */
+  int32_t id_encoder;
+  int32_t ids_render[BTS_MAX_VIEWS];
+  int32_t K, lindisp, hard_alpha_cap, norm_dir;
+  float z_near, z_far;       /* the ray sampler's */
+  float img_scale, img_shift;
+  /* inputs */
+  const float* images;       /* (n, v, 3, H, W) */
+  const float* Ks;           /* (n, v, 3, 3) */
+  const float* poses_c2w;    /* (n, v, 4, 4) */
+  const float* feat_nchw;    /* (n, C, H, W) the encoder's scale-0 map */
+  const float* mlp_params;
+  const float* empty_feature;/* (C) or NULL */
+  const float* jitter;       /* (n * v * H * W, K) in [0, 1) */
+  /* scratch */
+  float* cams;               /* n * (25 + nv * 25) floats, as in BtsTrainStep */
+  float* imgs_nhwc4;         /* (n, nv, H, W, 4) */
+  float* proj_nhwc;          /* (n, H, W, Hd) */
+  float* inv_K;              /* (n, v, 3, 3) */
+  /* outputs: rays of ALL v frames of every batch element, B = n * v * H * W */
+  float* rays;               /* (B, 8) */
+  float* rgb;                /* (B, nv*3) */
+  float* depth;              /* (B) distance along the ray */
+  float* depth_z;            /* (B) = (n, v, H, W): distance_to_z of `depth`, or NULL */
+  float* weights;            /* (B, K) or NULL */
+  float* alphas;             /* (B, K) or NULL */
+  float* invalid;            /* (B, K, nv) or NULL */
+} BtsEvalFrame;
+int bts_eval_frame(const BtsEvalFrame* f, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -60,6 +60,7 @@ int main(void) {
   printf("%zu %zu %zu %zu %zu %zu\n", offsetof(BtsTrainStep, ids_loss), offsetof(BtsTrainStep, loss_matrix), offsetof(BtsTrainStep, images),
          offsetof(BtsTrainStep, bwd_workspace_bytes), offsetof(BtsTrainStep, d_empty_feature), offsetof(BtsTrainStep, scale));
   printf("%zu %zu %zu\n", sizeof(BtsConv3x3), offsetof(BtsConv3x3, x), offsetof(BtsConv3x3, y));
+  printf("%zu %zu %zu\n", sizeof(BtsEvalFrame), offsetof(BtsEvalFrame, images), offsetof(BtsEvalFrame, invalid));
   return 0;
 }'''
     with tempfile.TemporaryDirectory() as d:
@@ -88,7 +89,8 @@ int main(void) {
     T = _lib.BtsTrainStep
     assert [int(x) for x in out[22:28]] == [T.ids_loss.offset, T.loss_matrix.offset, T.images.offset, T.bwd_workspace_bytes.offset,
                                             T.d_empty_feature.offset, T.scale.offset]
-    assert [int(x) for x in out[28:]] == [C.sizeof(_lib.BtsConv3x3), _lib.BtsConv3x3.x.offset, _lib.BtsConv3x3.y.offset]
+    assert [int(x) for x in out[28:31]] == [C.sizeof(_lib.BtsConv3x3), _lib.BtsConv3x3.x.offset, _lib.BtsConv3x3.y.offset]
+    assert [int(x) for x in out[31:]] == [C.sizeof(_lib.BtsEvalFrame), _lib.BtsEvalFrame.images.offset, _lib.BtsEvalFrame.invalid.offset]
 
 
 def test_host_only_entry_points(lib):

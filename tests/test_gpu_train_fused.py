@@ -160,3 +160,33 @@ def test_configurations_outside_the_two_call_path_run_entry_by_entry():
     step.wrapped.renderer.lean_training_outputs = True
     step.criterion.lambda_depth_reg = 0.1
     assert "regulariser" in step.why_not(inputs[0], [0], cfg["ids_render"], cfg["ids_loss"])
+
+
+def test_fused_eval_frame_equals_the_entry_by_entry_frame():
+    """bts_eval_frame (ABI 7: the evaluator's forward after the CNN in one call) against encode -> ImageRaySampler.sample -> renderer ->
+    reconstruct -> distance_to_z: the same kernels, the same jitter stream -- every output bit for bit; nv = 1 with the encoder frame as
+    the render view (eval_depth.yaml) and nv = 2 other frames."""
+    import behindthescenes_amd as bts
+    from behindthescenes_amd import synthetic as S
+    dev = torch.device("cuda")
+    for ids_render, learn_empty in (([0], True), ([1, 2], False)):
+        scene = S.synthetic_scene(2, 3, 48, 160, 64, seed=9, intrinsics=S.K_KITTIRAW, smooth=True)
+        torch.manual_seed(4)
+        net = bts.BTSNet(S.field_conf(64, 64, 0, 48, 160, learn_empty=learn_empty))
+        net.encoder = bts.FeatureMapEncoder((48, 160), 64, num_views=2)
+        S.init_mlp_(net.mlp_coarse, seed=7)
+        net = net.to(dev).eval()
+        wrapped = bts.NeRFRenderer.from_conf(dict(n_coarse=64, lindisp=True, hard_alpha_cap=True)).bind_parallel(net).eval().to(dev)
+        frame = bts.FusedEvalFrame(wrapped, bts.ImageRaySampler(3.0, 80.0))
+        inputs = [scene[k].to(dev) for k in ("images", "projs", "poses")]
+        outs = []
+        for fused in (False, True):
+            frame.fused = fused
+            torch.manual_seed(21)
+            outs.append(frame(*inputs, ids_encoder=[0], ids_render=ids_render))
+            assert frame.last_path == ("fused" if fused else "entries: switched off (fused=False)")
+        a, b = outs
+        assert torch.equal(a["rays"], b["rays"]) and torch.equal(a["rgb_gt"].contiguous(), b["rgb_gt"].contiguous())
+        for k in ("rgb", "depth", "invalid", "weights", "alphas"):
+            assert a["coarse"][0][k].shape == b["coarse"][0][k].shape, k
+            assert torch.equal(a["coarse"][0][k], b["coarse"][0][k]), (ids_render, k)
