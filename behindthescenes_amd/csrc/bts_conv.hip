@@ -385,13 +385,12 @@ int conv3x3_fwd_impl(const BtsConv3x3* c, hipStream_t s) {
   const long want = (p.n_tiles + 7) / 8;
   const int grid = (int)(want < conv_grid() ? want : conv_grid());
   const size_t lds = sizeof(float) * kConvLds;
+  // (the attribute is per device: set on every launch, like the render kernels' launchers do -- a host-side table write)
   if (c->out_nchw) {
-    static thread_local bool attr = false;
-    if (!attr) (void)hipFuncSetAttribute((const void*)conv_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), attr = true;
+    (void)hipFuncSetAttribute((const void*)conv_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     conv_fwd_kernel<true><<<grid, 512, lds, s>>>(p);
   } else {
-    static thread_local bool attr = false;
-    if (!attr) (void)hipFuncSetAttribute((const void*)conv_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), attr = true;
+    (void)hipFuncSetAttribute((const void*)conv_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     conv_fwd_kernel<false><<<grid, 512, lds, s>>>(p);
   }
   const hipError_t e = hipGetLastError();
@@ -440,8 +439,7 @@ int conv3x3_bwd_impl(const BtsConv3x3* c, const float* g_y, void* workspace, siz
     p.x = dy, p.w = c->weight, p.y = d_x, p.N = c->N, p.H = c->H, p.W = c->W, p.up2 = c->up2, p.tiles_per_row = tpr;
     p.n_tiles = (long)c->N * (c->up2 ? c->H / 2 : c->H) * tpr;
     const long want = (p.n_tiles + 7) / 8;
-    static thread_local bool attr = false;
-    if (!attr) (void)hipFuncSetAttribute((const void*)conv_dgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), attr = true;
+    (void)hipFuncSetAttribute((const void*)conv_dgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     conv_dgrad_kernel<<<(int)(want < conv_grid() ? want : conv_grid()), 512, lds, s>>>(p);
   }
   if (d_weight || d_bias) {

@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256) void empty_grad_kernel(const float* __restrict
 // tails.  The queues and their fork / join events are created once per host thread and device (handles only, no device memory) and
 // are ordered INSIDE the caller's stream: the first kernel of a side chain waits for an event recorded on the caller's stream, the
 // caller's stream waits for every chain's last kernel before the call's last kernel -- to the caller the call is still one stream-ordered
-// unit (and capturable in a hipGraph as a fork / join).
+// unit.
 struct SideQueues {
   hipStream_t q[BTS_MAX_SCALES - 1];
   hipEvent_t fork, first, join[BTS_MAX_SCALES - 1];
@@ -196,6 +196,10 @@ static int check_step(const BtsTrainStep* st, const char* who, bool bwd) {
     const int fs = q.feat_shift;
     if (fs < 0 || fs > 6 || (c.H & ((1 << fs) - 1)) || (c.W & ((1 << fs) - 1))) {
       set_error("%s: scale %ld: feat_shift=%ld needs 0..6 and H, W multiples of 2^feat_shift", who, s, fs);
+      return BTS_E_INVALID;
+    }
+    if ((reinterpret_cast<uintptr_t>(q.sampled_tiles) & 3) != 0) {
+      set_error("%s: scale %ld: sampled_tiles must be 4-byte aligned (the hand-over kernel clears the flags word-wise)", who, s);
       return BTS_E_INVALID;
     }
     if (!q.feat_nchw || !q.jitter || !q.rgb || !q.depth || !q.invalid_wsum || !q.invalid_any || !q.proj_nhwc || !q.sampled_tiles || !q.z_samp ||

@@ -324,7 +324,7 @@ typedef struct BtsTrainScale {
   float* invalid_any;        /* (n*Bp, nv)  } */
   /* state the forward leaves for the backward (contents need no initialisation) */
   float* proj_nhwc;          /* (n, H >> s, W >> s, Hd): valid in the tiles flagged in sampled_tiles only (ABI 6) */
-  uint8_t* sampled_tiles;    /* (n, tiles of the scale's map) */
+  uint8_t* sampled_tiles;    /* (n, tiles of the scale's map), 4-byte aligned */
   float* z_samp;             /* (n*Bp, K) */
   float* sigma_raw;          /* (n*Bp, K) */
   float* trans;              /* (n*Bp, K) */

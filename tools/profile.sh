@@ -1,6 +1,6 @@
 #!/bin/bash
 # rocprofv3 passes over the render kernels.  Run on the GPU box via gpurun:
-#   gpurun -- bash tools/profile.sh <tag> [fwd|train|bwd|bwd_re10k [K]|bwd_kitti_raw|profile]
+#   gpurun -- bash tools/profile.sh <tag> [fwd|train|bwd|bwd_re10k [K]|bwd_kitti_raw|profile|conv]
 # fwd (default): tools/kernel_probe.py = the bench.py kernel (BASELINE configs[1]); train: tools/train_probe.py = configs[2] shapes;
 # bwd: tools/bwd_probe.py = bts_render_bwd alone on the configs[2] shape; bwd_re10k [K] / bwd_kitti_raw: the same on configs[4] / [3];
 # profile: bench.py --workload profile (the occupancy-grid query kernel).
@@ -18,6 +18,7 @@ cd /tmp
 if [ "$MODE" = train ]; then CMD="python $REPO/tools/train_probe.py 16 3"; elif [ "$MODE" = bwd ]; then CMD="python $REPO/tools/bwd_probe.py 3";
 elif [ "$MODE" = bwd_re10k ]; then CMD="python $REPO/tools/bwd_probe.py 3 re10k ${3:-48}"; elif [ "$MODE" = bwd_kitti_raw ]; then CMD="python $REPO/tools/bwd_probe.py 3 kitti_raw";
 elif [ "$MODE" = profile ]; then CMD="python $REPO/bench.py --workload profile --steps 3 --warmup 1 --no-cpu-baseline";
+elif [ "$MODE" = conv ]; then CMD="python $REPO/tools/conv_probe.py 3";
 else CMD="python $REPO/tools/kernel_probe.py 5"; fi
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $CMD > $OUT/trace.log 2>&1 || tail -5 $OUT/trace.log
 for i in 0 1 2 3 4; do
@@ -46,7 +47,7 @@ for f in sorted(glob.glob("$OUT/trace/**/*kernel_stats.csv", recursive=True)):
 train = ["rows_kernel", "scatter_kernel", "dwpe_kernel", "render_bwd_kernel", "scatter_dg_kernel", "render_kernel_p", "project_kernel",
          "project_bwd_kernel", "photometric_loss_kernel"]
 rows = ["rowsb_kernel", "scatter_kernel", "dwpe_rows_kernel", "render_kernel_p"]
-pats = {"fwd": ["render_kernel_p"], "train": train, "bwd": train[:3], "bwd_re10k": rows, "bwd_kitti_raw": train[:3] + ["render_kernel_p"],
+pats = {"conv": ["conv_fwd_kernel", "conv_dgrad_kernel", "conv_wgrad_kernel", "elu_bwd_kernel"], "fwd": ["render_kernel_p"], "train": train, "bwd": train[:3], "bwd_re10k": rows, "bwd_kitti_raw": train[:3] + ["render_kernel_p"],
         "profile": ["query_kernel_p"]}[mode]
 per = {p: collections.defaultdict(list) for p in pats}
 for f in sorted(glob.glob("$OUT/pmc*/**/*counter_collection.csv", recursive=True)):
