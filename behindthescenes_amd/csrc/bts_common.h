@@ -13,6 +13,12 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #define BTS_EPS 1e-3f  // models_bts.py:14
 
+// work-groups per CU the forward kernel is compiled and launched for.  2 is the product; 3 exists for ONE experiment (review item 4: "is a
+// third wave per SIMD worth 168 VGPRs?", profiles/r05m) and only fits with -DBTS_GATHER_REGS (three rings do not fit the CU's LDS)
+#ifndef BTS_FWD_WAVES
+#define BTS_FWD_WAVES 2
+#endif
+
 namespace bts {
 
 constexpr int kNumFreqs = 6;            // every shipped config (configs/*.yaml `code.num_freqs`)

@@ -74,7 +74,7 @@ int device_cu_count() {
 }
 
 int render_grid(const FwdParams& p) {
-  const long cap = 2L * device_cu_count();
+  const long cap = (long)BTS_FWD_WAVES * device_cu_count();
   const long want = (p.groups + 3) / 4;
   long g = want < cap ? want : cap;
   g = (g + 7) / 8 * 8;

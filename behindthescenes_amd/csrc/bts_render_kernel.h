@@ -630,7 +630,7 @@ using IterHead = IterHeadT<false>;
 // EPI: also reduce weights * invalid and max invalid over each ray's samples (BtsRenderArgs.invalid_wsum / invalid_any).  A template
 // parameter, not a run-time test: the evaluation instantiations carry no trace of it (16 more spilled SGPRs otherwise).
 template <int C, int HD, int NB, int NVMAX, bool ONE_RAY, bool F16, bool EPI = false>
-__global__ __launch_bounds__(256, 2) void render_kernel_p(const FwdParams p) {
+__global__ __launch_bounds__(256, BTS_FWD_WAVES) void render_kernel_p(const FwdParams p) {
   static_assert(F16, "lin_in runs on the f16 matrix pipe in split precision: the fp32-input-MFMA form of rounds 1 - 2 is gone (git history)");
   using L = Lds<C, HD, NB, true>;
   using LH = LdsH<C, HD, NB>;
