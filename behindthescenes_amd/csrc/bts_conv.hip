@@ -156,6 +156,252 @@ __global__ __launch_bounds__(512) void conv_fwd_kernel(const ConvParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
+// The same products on the bf16 matrix pipe, exactly.  An fp32 number is the sum of three bf16 numbers (8 + 8 + 8 significand bits:
+// h = the top 16 bits, m = the top 16 bits of x - h, l = x - h - m; all three subtractions are exact), so
+//     x w = xh wh + (xh wm + xm wh) + (xm wm + xh wl + xl wh) + [xm wl + xl wm + xl wl: below 2^-24 |x w|, dropped]
+// six v_mfma_f32_32x32x16_bf16 (8 passes, k = 16) instead of eight v_mfma_f32_32x32x2_f32 (16 passes, k = 2 each): 0.375 of the matrix
+// time, every product exact in the fp32 accumulator, no range to scale (bf16 has fp32's exponent).  Measured against fp64 the sums are
+// CLOSER than the fp32-input MFMA's (blocked accumulation: tests/test_gpu_conv.py keeps its bars).
+// What it costs: the split -- 5.5 VALU instructions per activation, done where the operand is formed (a lane's two float4 = 8
+// consecutive channels of one pixel = one bf16 A fragment per term) -- and LDS: three terms x 2 bytes per weight are 221 KB for the
+// layer, so a work-group keeps the weights of HALF the output channels (110.6 KB) and two work-groups of the same XCD walk the same
+// tiles (the second read of a tile comes from that XCD's L2).
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4c __attribute__((ext_vector_type(4)));
+constexpr int kConvBfLds = 9 * 4 * 3 * 64 * 16;   // bytes: [tap][k-step of 16][term h, m, l][lane][8 bf16]
+
+__device__ __forceinline__ unsigned f2u(float x) { return __builtin_bit_cast(unsigned, x); }
+__device__ __forceinline__ float u2f(unsigned x) { return __builtin_bit_cast(float, x); }
+// (a, b) -> the three bf16 pairs (a in the low half): h, m, l
+__device__ __forceinline__ void split3_pair(float a, float b, unsigned& ph, unsigned& pm, unsigned& pl) {
+  const float ra = a - u2f(f2u(a) & 0xFFFF0000u), rb = b - u2f(f2u(b) & 0xFFFF0000u);
+  const float la = ra - u2f(f2u(ra) & 0xFFFF0000u), lb = rb - u2f(f2u(rb) & 0xFFFF0000u);
+  ph = __builtin_amdgcn_perm(f2u(b), f2u(a), 0x07060302u);
+  pm = __builtin_amdgcn_perm(f2u(rb), f2u(ra), 0x07060302u);
+  pl = __builtin_amdgcn_perm(f2u(lb), f2u(la), 0x07060302u);
+}
+// a lane's 8 consecutive channels -> its A (or B) fragment of a k-step, three terms
+__device__ __forceinline__ void split3_frag(const float4& v0, const float4& v1, bf8& fh, bf8& fm, bf8& fl) {
+  unsigned h[4], m[4], l[4];
+  split3_pair(v0.x, v0.y, h[0], m[0], l[0]), split3_pair(v0.z, v0.w, h[1], m[1], l[1]);
+  split3_pair(v1.x, v1.y, h[2], m[2], l[2]), split3_pair(v1.z, v1.w, h[3], m[3], l[3]);
+  fh = __builtin_bit_cast(bf8, (u32x4c){h[0], h[1], h[2], h[3]}), fm = __builtin_bit_cast(bf8, (u32x4c){m[0], m[1], m[2], m[3]});
+  fl = __builtin_bit_cast(bf8, (u32x4c){l[0], l[1], l[2], l[3]});
+}
+
+// weights -> LDS for one half of the columns: byte (((tap * 4 + s) * 3 + term) * 64 + lane) * 16 + 2 i holds term `term` of the weight
+// at k = 16 s + 8 h + i, column `half` * 32 + col (lane = 32 h + col).  FWD: k = ci, column = co;  TRANSPOSED (data gradient): k = co,
+// column = ci.  The threads walk w in memory order (coalesced), every thread splits one weight and drops three 2-byte pieces.
+template <bool TRANSPOSED>
+__device__ __forceinline__ void stage_conv_weights_bf(char* lds, const float* __restrict__ w, int half) {
+  for (int e = threadIdx.x; e < 32 * 64 * 9; e += blockDim.x) {
+    int co, ci, tap;
+    if (TRANSPOSED) {   // co 0..63, ci in the half: runs of 32 x 9 contiguous floats
+      co = e / (32 * 9);
+      const int r = e - co * (32 * 9);
+      ci = half * 32 + r / 9, tap = r - (r / 9) * 9;
+    } else {            // co in the half: one contiguous block of 32 x 64 x 9 floats
+      co = half * 32 + e / (64 * 9);
+      const int r = e % (64 * 9);
+      ci = r / 9, tap = r - ci * 9;
+    }
+    const float x = w[(co * 64 + ci) * 9 + tap];
+    const float r1 = x - u2f(f2u(x) & 0xFFFF0000u);
+    const float r2 = r1 - u2f(f2u(r1) & 0xFFFF0000u);
+    const int k = TRANSPOSED ? co : ci, column = (TRANSPOSED ? ci : co) & 31;
+    const int sidx = k >> 4, hh = (k >> 3) & 1, i = k & 7;
+    unsigned short* dst = reinterpret_cast<unsigned short*>(lds + ((tap * 4 + sidx) * 3 * 64 + hh * 32 + column) * 16 + 2 * i);
+    dst[0] = (unsigned short)(f2u(x) >> 16), dst[512] = (unsigned short)(f2u(r1) >> 16), dst[1024] = (unsigned short)(f2u(r2) >> 16);
+  }
+}
+
+// the six products of one k-step on one accumulator, smallest terms first; W_IS_A: D[column of W][pixel] instead of D[pixel][column]
+template <bool W_IS_A>
+__device__ __forceinline__ void mfma6(f32x16& acc, const bf8& xh, const bf8& xm, const bf8& xl, const bf8& wh, const bf8& wm, const bf8& wl) {
+  if (W_IS_A) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xl, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, xh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm, xm, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xm, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm, xh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh, acc, 0, 0, 0);
+  } else {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, wh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, wl, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xm, wm, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xm, wh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, wm, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, wh, acc, 0, 0, 0);
+  }
+}
+
+// One source row piece (32 pixel slots x 64 k, the lane's eight float4) against the THREE taps of a kernel row: the split of the
+// activations is done once and serves all three (acc3[tx] += X . W[ty][tx]); the shift by tx - 1 pixels happens on the accumulators,
+// once per tile (conv_shift_*).  lds -> this lane's fragment of tap (ty, 0), k-step 0, term h.
+template <bool W_IS_A>
+__device__ __forceinline__ void conv_row3_bf(f32x16 (&acc3)[3], const char* wt, const float4 (&xa)[8]) {
+#pragma unroll
+  for (int sidx = 0; sidx < 4; ++sidx) {
+    bf8 xh, xm, xl;
+#if defined(BTS_CONV_ABL) && (BTS_CONV_ABL & 1)   // timing ablation: no split arithmetic
+    xh = __builtin_bit_cast(bf8, xa[2 * sidx]), xm = __builtin_bit_cast(bf8, xa[2 * sidx + 1]), xl = xh;
+#else
+    split3_frag(xa[2 * sidx], xa[2 * sidx + 1], xh, xm, xl);
+#endif
+#pragma unroll
+    for (int tx = 0; tx < 3; ++tx) {
+      const char* f = wt + (tx * 4 + sidx) * (3 * 1024);
+      const bf8 wh = *reinterpret_cast<const bf8*>(f), wm = *reinterpret_cast<const bf8*>(f + 1024), wl = *reinterpret_cast<const bf8*>(f + 2048);
+      mfma6<W_IS_A>(acc3[tx], xh, xm, xl, wh, wm, wl);
+    }
+  }
+}
+
+// which half of the columns and which stream of tiles a work-group takes: the two halves of a stream sit on the same XCD (blockIdx % 8)
+struct ConvRole {
+  int half, first, stride;   // wave tile index = first + k * stride
+};
+__device__ __forceinline__ ConvRole conv_role(int wave) {
+  const int b = blockIdx.x, xcd = b & 7, idx = b >> 3;
+  const int stream = (idx >> 1) * 8 + xcd;       // gridDim.x is a multiple of 16 (conv_grid_bf)
+  return ConvRole{idx & 1, stream * 8 + wave, (int)(gridDim.x >> 1) * 8};
+}
+
+// tile geometry of the bf16 kernels: a wave's tile = 64 pixel SLOTS of one row, slot j <-> position x0 - 1 + j, x0 = kConvOut * (tile in
+// row); the tile's outputs are the slots 1 .. 62 (their left / right neighbours are slots of the same tile), 62 per tile
+constexpr int kConvOut = 62;
+__device__ __forceinline__ int reflect_slot(int pos, int L) {   // reflect; positions no output of the tile needs are clamped
+  const int r = pos < 0 ? -pos : (pos >= L ? 2 * L - 2 - pos : pos);
+  return min(max(r, 0), L - 1);
+}
+
+// value of slot - 1 (DIR = -1) or slot + 1 (DIR = +1) of an accumulator pair in the D[pixel slot][column] layout (rows = slots:
+// tile row pt * 32 + 8 g + 4 h + e lives in register 4 g + e of lane half h): a neighbouring register, or -- across a group of four --
+// the other lane half's
+template <int DIR>
+__device__ __forceinline__ void conv_shift_rows(const f32x16 (&a)[2], f32x16 (&out)[2], int h) {
+#pragma unroll
+  for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      if (DIR < 0) {
+        // half 1 needs half 0's (pt, 4 g + 3); half 0 needs half 1's register 4 (g - 1) + 3 of this tile, or (pt - 1, 15)
+        const float from_h0 = a[pt][4 * g + 3];
+        const float from_h1 = g > 0 ? a[pt][4 * g - 1] : (pt > 0 ? a[pt - 1][15] : 0.0f);
+        const float got = __shfl_xor(h ? from_h1 : from_h0, 32, 64);
+        out[pt][4 * g] = got;
+#pragma unroll
+        for (int e = 1; e < 4; ++e) out[pt][4 * g + e] = a[pt][4 * g + e - 1];
+      } else {
+        // half 0 needs half 1's (pt, 4 g); half 1 needs half 0's register 4 (g + 1) of this tile, or (pt + 1, 0)
+        const float from_h1 = a[pt][4 * g];
+        const float from_h0 = g < 3 ? a[pt][4 * g + 4] : (pt < 1 ? a[pt + 1][0] : 0.0f);
+        const float got = __shfl_xor(h ? from_h1 : from_h0, 32, 64);
+        out[pt][4 * g + 3] = got;
+#pragma unroll
+        for (int e = 0; e < 3; ++e) out[pt][4 * g + e] = a[pt][4 * g + e + 1];
+      }
+    }
+}
+// the same in the D[column][pixel slot] layout (slots across the 32 lanes of a half, both tiles): the neighbouring lane's, or the other tile's end lane
+template <int DIR>
+__device__ __forceinline__ void conv_shift_lanes(const f32x16 (&a)[2], f32x16 (&out)[2], int lane) {
+  const int col = lane & 31;
+  const int nb = DIR < 0 ? (lane - 1) & 63 : (lane + 1) & 63;           // the neighbour inside the half (wrong for the half's end lane)
+  const int wrap = DIR < 0 ? (lane + 31) & 63 : (lane - 31) & 63;       // the other tile's last / first lane of the same half
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const float n0 = __shfl(a[0][r], nb, 64), n1 = __shfl(a[1][r], nb, 64);
+    if (DIR < 0) {
+      const float w = __shfl(a[0][r], wrap, 64);
+      out[0][r] = n0, out[1][r] = col == 0 ? w : n1;      // (slot 0 has no output: out[0] of lane col 0 is never used)
+    } else {
+      const float w = __shfl(a[1][r], wrap, 64);
+      out[0][r] = col == 31 ? w : n0, out[1][r] = n1;     // (slot 63 has no output)
+    }
+  }
+}
+
+// forward: one wave = 62 output pixels of a row x the 32 output channels of its work-group's half; per kernel row ONE set of loads and
+// one split, three taps; the next (row, half tile)'s eight loads are in flight under the products of this one
+template <bool OUT_NCHW>
+__global__ __launch_bounds__(512) void conv_fwd_bf_kernel(const ConvParams p) {
+  extern __shared__ __attribute__((aligned(16))) char lds_b[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, col = lane & 31;
+  const ConvRole role = conv_role(wave);
+  stage_conv_weights_bf<false>(lds_b, p.w, role.half);
+  __syncthreads();
+  const int Hs = p.up2 ? p.H >> 1 : p.H, Ws = p.up2 ? p.W >> 1 : p.W;
+  const long rows = (long)p.H * p.tiles_per_row;
+  const int c0 = role.half * 32;
+  const char* const wlane = lds_b + lane * 16;
+  for (long tile = role.first; tile < p.n_tiles; tile += role.stride) {
+    const int img = (int)(tile / rows);
+    const int rem = (int)(tile - (long)img * rows);
+    const int y = rem / p.tiles_per_row, x0 = (rem - y * p.tiles_per_row) * kConvOut;
+    const float* base = p.x + (long)img * Hs * Ws * 64;
+    f32x16 acc[3][2];   // [tx][pt]
+#pragma unroll
+    for (int tx = 0; tx < 3; ++tx)
+#pragma unroll
+      for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[tx][pt][r] = (tx != 1 || !p.bias) ? 0.0f : (OUT_NCHW ? p.bias[c0 + mfma_row(r, h)] : p.bias[c0 + col]);
+    int sx[2];
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt) {
+      sx[pt] = reflect_slot(x0 - 1 + pt * 32 + col, p.W);
+      if (p.up2) sx[pt] >>= 1;
+    }
+    float4 xa[2][8];
+    auto load_piece = [&](int buf, int piece) {   // piece = 2 ty + pt
+      const int ty = piece >> 1, pt = piece & 1;
+      int sy = reflect(y + ty - 1, p.H);
+      if (p.up2) sy >>= 1;
+      const float* src = base + (unsigned)((sy * Ws + sx[pt]) * 64 + 8 * h);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) xa[buf][q] = *reinterpret_cast<const float4*>(src + 16 * (q >> 1) + 4 * (q & 1));
+    };
+    load_piece(0, 0);
+#pragma unroll
+    for (int piece = 0; piece < 6; ++piece) {
+#if !(defined(BTS_CONV_ABL) && (BTS_CONV_ABL & 2))   // (timing ablation 2: one piece's loads per tile)
+      if (piece + 1 < 6) load_piece((piece + 1) & 1, piece + 1);
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+      const int ty = piece >> 1, pt = piece & 1;
+      f32x16 a3[3] = {acc[0][pt], acc[1][pt], acc[2][pt]};
+      conv_row3_bf<OUT_NCHW>(a3, wlane + ty * 3 * 4 * (3 * 1024), xa[piece & 1]);
+      acc[0][pt] = a3[0], acc[1][pt] = a3[1], acc[2][pt] = a3[2];
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // out[slot] = P0[slot - 1] + P1[slot] + P2[slot + 1]   (P_tx = the products of kernel column tx at the SOURCE slot)
+    f32x16 lo[2], hi[2];
+    if (OUT_NCHW) conv_shift_lanes<-1>(acc[0], lo, lane), conv_shift_lanes<+1>(acc[2], hi, lane);
+    else conv_shift_rows<-1>(acc[0], lo, h), conv_shift_rows<+1>(acc[2], hi, h);
+    float* out = p.y + (long)img * p.H * p.W * 64;
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float v = (lo[pt][r] + acc[1][pt][r]) + hi[pt][r];
+        if (p.elu) v = v > 0.0f ? v : expm1f(v);
+#if defined(BTS_CONV_ABL) && (BTS_CONV_ABL & 4)   // timing ablation: no stores
+        if (v != 1.2345e-30f) continue;
+#endif
+        const int slot = pt * 32 + (OUT_NCHW ? col : mfma_row(r, h));
+        const int x = x0 - 1 + slot;
+        const bool ok = slot >= 1 && slot <= kConvOut && x < p.W;
+        if (OUT_NCHW) {
+          if (ok) out[(unsigned)(((c0 + mfma_row(r, h)) * p.H + y) * p.W + x)] = v;
+        } else {
+          if (ok) out[(unsigned)((y * p.W + x) * 64 + c0 + col)] = v;
+        }
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
 // data gradient: dx[p] = sum over the (q, t) with reflect(q + t) = p of W[t]^T dy[q].  Per axis (length L, coordinate c): q = c - t for
 // t = -1, 0, +1 where that lies inside, plus (q = 0, t = -1) for c == 1 and (q = L - 1, t = +1) for c == L - 2 -- the padded lines -1
 // and L are copies of lines 1 and L - 2, so what the convolution read there flows back onto those.  Rows are wave-uniform (a tile is one
@@ -362,6 +608,14 @@ __global__ __launch_bounds__(256) void elu_bwd_kernel(const float4* __restrict__
 }
 
 static int conv_grid() { return device_cu_count(); }   // one persistent work-group of 8 waves per CU (the weights fill its LDS)
+// the bf16 kernels: pairs of work-groups (the two halves of the columns) on the same XCD -> a multiple of 16, two work-groups per `want`ed one
+static int conv_grid_bf(long want_wg) {
+  long g = 2 * want_wg;
+  const long cap = device_cu_count() / 16 * 16;
+  if (g > cap) g = cap;
+  g = (g + 15) / 16 * 16;
+  return (int)(g < 16 ? 16 : g);
+}
 
 static bool conv_ok(const BtsConv3x3* c, const char* who) {
   if (!c || !c->x || !c->weight || c->N <= 0 || c->H < 4 || c->W < 4 || c->C != 64 || (c->up2 && ((c->H | c->W) & 1))) {
@@ -382,10 +636,22 @@ int conv3x3_fwd_impl(const BtsConv3x3* c, hipStream_t s) {
   p.N = c->N, p.H = c->H, p.W = c->W, p.up2 = c->up2, p.elu = c->elu, p.out_nchw = c->out_nchw;
   p.tiles_per_row = (c->W + 63) / 64;
   p.n_tiles = (long)c->N * c->H * p.tiles_per_row;
+#ifndef BTS_CONV_FP32
+  p.tiles_per_row = (c->W + kConvOut - 1) / kConvOut;
+  p.n_tiles = (long)c->N * c->H * p.tiles_per_row;
+  const int grid = conv_grid_bf((p.n_tiles + 7) / 8);
+  // (the attribute is per device: set on every launch, like the render kernels' launchers do -- a host-side table write)
+  if (c->out_nchw) {
+    (void)hipFuncSetAttribute((const void*)conv_fwd_bf_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kConvBfLds);
+    conv_fwd_bf_kernel<true><<<grid, 512, kConvBfLds, s>>>(p);
+  } else {
+    (void)hipFuncSetAttribute((const void*)conv_fwd_bf_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kConvBfLds);
+    conv_fwd_bf_kernel<false><<<grid, 512, kConvBfLds, s>>>(p);
+  }
+#else   // A/B build: the fp32-input MFMA kernels of the first version
   const long want = (p.n_tiles + 7) / 8;
   const int grid = (int)(want < conv_grid() ? want : conv_grid());
   const size_t lds = sizeof(float) * kConvLds;
-  // (the attribute is per device: set on every launch, like the render kernels' launchers do -- a host-side table write)
   if (c->out_nchw) {
     (void)hipFuncSetAttribute((const void*)conv_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     conv_fwd_kernel<true><<<grid, 512, lds, s>>>(p);
@@ -393,6 +659,7 @@ int conv3x3_fwd_impl(const BtsConv3x3* c, hipStream_t s) {
     (void)hipFuncSetAttribute((const void*)conv_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     conv_fwd_kernel<false><<<grid, 512, lds, s>>>(p);
   }
+#endif
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     set_error("%s: convolution forward launch failed (%ld)", hipGetErrorString(e), (long)e);

@@ -117,7 +117,8 @@ def test_monodepth2_with_the_fused_tail_equals_the_module_path():
     # the tail's OWN parameters (computed entirely by bts_conv3x3_bwd) keep the strict bar.  Everything upstream of the tail goes through
     # MIOpen for both paths, and which of its solvers runs -- direct, implicit GEMM, fp32 Winograd (1e-3 relative) -- depends on the
     # strides of the gradient it is handed and on what the process has run before: seen as 9e-4 on conv1.weight in a run behind the
-    # other convolution tests and 2e-6 in a fresh process, with identical kernels of ours.  Those get the bound of a library choice.
+    # other convolution tests and 2e-6 in a fresh process, with identical kernels of ours (and once 9.7e-3 on layer3 / layer4 weights behind
+    # `-k conv`, passing alone and in this file's own order: profiles/r05o).  Those get the bound of a library choice.
     dk = net.decoder.decoder_keys
     tail = tuple(f"decoder.decoder.{dk[k]}." for k in (("upconv", 0, 0), ("upconv", 0, 1), ("dispconv", 0)))
     bad = []
@@ -125,7 +126,7 @@ def test_monodepth2_with_the_fused_tail_equals_the_module_path():
         top = g_d[k].abs().max().item()
         e_m, e_f = (g_m[k] - g_d[k]).abs().max().item(), (g_f[k] - g_d[k]).abs().max().item()
         own = k.startswith(tail)
-        if not e_f <= (2 * e_m + 1e-5 * top + 1e-12 if own else max(2 * e_m, 5e-3 * top) + 1e-12):
+        if not e_f <= (2 * e_m + 1e-5 * top + 1e-12 if own else max(2 * e_m, 2e-2 * top) + 1e-12):
             bad.append((k, own, f"{e_f / (top + 1e-30):.2e}", f"{e_m / (top + 1e-30):.2e}"))
     assert sum(k.startswith(tail) for k in g_d) == 6
     assert not bad, (len(bad), len(g_d), bad[:8])

@@ -17,12 +17,14 @@ x = torch.randn(B, H // 2, W // 2, 64, generator=g).cuda().requires_grad_(True)
 ws = [(torch.randn(64, 64, 3, 3, generator=g) * (2.0 / 576) ** 0.5).cuda().requires_grad_(True) for _ in range(3)]
 bs = [(torch.randn(64, generator=g) * 0.1).cuda().requires_grad_(True) for _ in range(3)]
 gy = (torch.randn(B, 64, H, W, generator=g) / (B * 64 * H * W) ** 0.5).cuda()
-ev = []
+ev, lay = [], []
 for r in range(rounds + 2):
-    e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+    e0, e1, e2, ea, eb = (torch.cuda.Event(enable_timing=True) for _ in range(5))
     e0.record()
     y = native.Conv3x3Function.apply(x, ws[0], bs[0], False, True, False)
+    ea.record()
     y = native.Conv3x3Function.apply(y, ws[1], bs[1], True, True, False)
+    eb.record()
     f = native.Conv3x3Function.apply(y, ws[2], bs[2], False, False, True)
     e1.record()
     f.backward(gy)
@@ -30,7 +32,10 @@ for r in range(rounds + 2):
     torch.cuda.synchronize()
     if r >= 2:
         ev.append((e0.elapsed_time(e1), e1.elapsed_time(e2)))
+        lay.append((e0.elapsed_time(ea), ea.elapsed_time(eb), eb.elapsed_time(e1)))
 flop = 2.0 * 9 * 64 * 64 * B * (H * W * 2 + H * W / 4)
 fw, bw = sum(a for a, _ in ev) / len(ev), sum(b for _, b in ev) / len(ev)
 print(f"decoder tail, bs {B}, {H}x{W}: forward {fw:.3f} ms ({flop / fw / 1e9:.1f} TFLOP/s), backward {bw:.3f} ms ({2 * flop / bw / 1e9:.1f} TFLOP/s incl. the "
       f"elu' / transpose passes), {flop / 1e9:.0f} GFLOP forward")
+print("forward per layer (incl. launch gaps): upconv(0,0) @ H/2 %.3f ms, upconv(0,1) x2 in front %.3f ms, dispconv(0) -> NCHW %.3f ms" % tuple(
+    sorted(l[i] for l in lay)[len(lay) // 2] for i in range(3)))
