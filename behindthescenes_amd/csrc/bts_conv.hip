@@ -487,6 +487,134 @@ __global__ __launch_bounds__(512) void conv_dgrad_kernel(const ConvParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
+// data gradient on the bf16 pipe, the same economy: Q_t[q] = W[t]^T dy[q] for the three taps of a kernel row from ONE split of the
+// row piece of dy, accumulated over the (t_y, q_y) pairs of the output row (conv_dgrad_kernel's list), and
+//     dx[x] = Q_-1[x + 1] + Q_0[x] + Q_+1[x - 1]  (+ Q_-1[0] for x == 1, + Q_+1[W - 1] for x == W - 2: the reflected columns)
+// with dy read as zero outside the image -- shifts of the accumulators, once per tile.  Slots: position = x0 - off + slot; off = 1 and
+// 62 outputs per tile, or, with the x2 upsampling in front of the layer (its 2 x 2 children are summed here), off = 2 and 60 outputs
+// so that the two children of a source pixel are the slots (2 m, 2 m + 1): neighbouring registers of one lane.
+// ---------------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void conv_dgrad_bf_kernel(const ConvParams p) {
+  extern __shared__ __attribute__((aligned(16))) char lds_b[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, col = lane & 31;
+  const ConvRole role = conv_role(wave);
+  stage_conv_weights_bf<true>(lds_b, p.w, role.half);
+  __syncthreads();
+  const int out_rows = p.up2 ? p.H >> 1 : p.H;
+  const long rows = (long)out_rows * p.tiles_per_row;
+  const int c0 = role.half * 32;
+  const int off = p.up2 ? 2 : 1, n_out = p.up2 ? 60 : kConvOut;
+  const char* const wlane = lds_b + lane * 16;
+  for (long tile = role.first; tile < p.n_tiles; tile += role.stride) {
+    const int img = (int)(tile / rows);
+    const int rem = (int)(tile - (long)img * rows);
+    const int yt = rem / p.tiles_per_row, x0 = (rem - yt * p.tiles_per_row) * n_out;
+    const float* base = p.x + (long)img * p.H * p.W * 64;   // dy' (N, H, W, 64)
+    f32x16 acc[3][2];   // [tx + 1][pt]
+#pragma unroll
+    for (int tx = 0; tx < 3; ++tx)
+#pragma unroll
+      for (int pt = 0; pt < 2; ++pt) acc[tx][pt] = zero_acc();
+    int qx[2];
+    bool ok[2];
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt) {
+      const int pos = x0 - off + pt * 32 + col;
+      ok[pt] = pos >= 0 && pos < p.W;
+      qx[pt] = min(max(pos, 0), p.W - 1);
+    }
+    // the (t_y, q_y) pairs of the tile's output row(s), wave-uniform: up to 4 per row, two rows with up2
+    int pair_ty[8], pair_qy[8], n_pairs = 0;
+    for (int sub = 0; sub < (p.up2 ? 2 : 1); ++sub) {
+      const int y = p.up2 ? 2 * yt + sub : yt;
+      for (int ry = 0; ry < 5; ++ry) {
+        int ty, qy;
+        if (ry < 3) ty = ry - 1, qy = y - ty;
+        else if (ry == 3) ty = -1, qy = (y == 1) ? 0 : -1;
+        else ty = 1, qy = (y == p.H - 2) ? p.H - 1 : -1;
+        if (qy < 0 || qy >= p.H) continue;
+        pair_ty[n_pairs] = ty + 1, pair_qy[n_pairs] = qy, ++n_pairs;
+      }
+    }
+    float4 xa[2][8];
+    auto load_piece = [&](int buf, int piece) {   // piece = 2 pair + pt
+      const int qy = pair_qy[piece >> 1], pt = piece & 1;
+      const float* src = base + (unsigned)((qy * p.W + qx[pt]) * 64 + 8 * h);
+      const bool on = ok[pt];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) xa[buf][q] = on ? *reinterpret_cast<const float4*>(src + 16 * (q >> 1) + 4 * (q & 1)) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    };
+    // (the pair list is short and its length wave-uniform: a rolled loop with the two buffers switched by parity)
+    load_piece(0, 0);
+    for (int piece = 0; piece < 2 * n_pairs; piece += 2) {
+      load_piece(1, piece + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      {
+        f32x16 a3[3] = {acc[0][0], acc[1][0], acc[2][0]};
+        conv_row3_bf<false>(a3, wlane + pair_ty[piece >> 1] * 3 * 4 * (3 * 1024), xa[0]);
+        acc[0][0] = a3[0], acc[1][0] = a3[1], acc[2][0] = a3[2];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (piece + 2 < 2 * n_pairs) load_piece(0, piece + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      {
+        f32x16 a3[3] = {acc[0][1], acc[1][1], acc[2][1]};
+        conv_row3_bf<false>(a3, wlane + pair_ty[piece >> 1] * 3 * 4 * (3 * 1024), xa[1]);
+        acc[0][1] = a3[0], acc[1][1] = a3[1], acc[2][1] = a3[2];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // dx[slot] = Q_-1[slot + 1] + Q_0[slot] + Q_+1[slot - 1] (+ the reflected columns)
+    f32x16 up[2], dn[2];
+    conv_shift_rows<+1>(acc[0], up, h), conv_shift_rows<-1>(acc[2], dn, h);
+    f32x16 v[2];
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[pt][r] = (up[pt][r] + acc[1][pt][r]) + dn[pt][r];
+    const int s1 = 1 - x0 + off, s2 = p.W - 2 - x0 + off;   // the slots of x == 1 and x == W - 2 (wave-uniform; may lie outside this tile)
+    if (s1 >= off && s1 < off + n_out) {
+      f32x16 e[2];
+      conv_shift_rows<-1>(acc[0], e, h);
+#pragma unroll
+      for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[pt][r] += (pt * 32 + mfma_row(r, h) == s1) ? e[pt][r] : 0.0f;
+    }
+    if (s2 >= off && s2 < off + n_out) {
+      f32x16 e[2];
+      conv_shift_rows<+1>(acc[2], e, h);
+#pragma unroll
+      for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[pt][r] += (pt * 32 + mfma_row(r, h) == s2) ? e[pt][r] : 0.0f;
+    }
+    if (p.up2) {
+      const int Ws = p.W >> 1;
+      float* out = p.y + ((long)img * out_rows + yt) * Ws * 64;
+#pragma unroll
+      for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {   // slots (2 m, 2 m + 1): the two children of one source pixel along x
+          const int slot = pt * 32 + mfma_row(r, h);
+          const int x = x0 - off + slot;
+          if (slot >= off && slot < off + n_out && x < p.W) out[(unsigned)((x >> 1) * 64 + c0 + col)] = v[pt][r] + v[pt][r + 1];
+        }
+    } else {
+      float* out = p.y + ((long)img * p.H + yt) * p.W * 64;
+#pragma unroll
+      for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int slot = pt * 32 + mfma_row(r, h);
+          const int x = x0 - off + slot;
+          if (slot >= off && slot < off + n_out && x < p.W) out[(unsigned)(x * 64 + c0 + col)] = v[pt][r];
+        }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
 // weight gradient: dW[co][ci][t] = sum over all pixels p of dy'[p][co] x[reflect(p + t)][ci];  db[co] = sum_p dy'[p][co].
 // D[co][ci] = A[co][k = pixel] . B[k = pixel][ci]: both operands are 128-byte row pieces of the channels-last tensors (a lane half = 32
 // consecutive channels of one pixel; the two halves = the two pixels of a k-step).  A work-group = 8 waves = 2 pixel streams x the 4
@@ -571,6 +699,135 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgradParams p) {
     for (int r = 0; r < 16; ++r) part[(unsigned)(t * kTapFloats + (ct * 32 + mfma_row(r, h)) * 64 + cit * 32 + col)] = acc[t][r];
   if (cit == 0) {
     db += __shfl_xor(db, 32, 64);     // the two pixels of every k-step
+    if (h == 0) part[9 * kTapFloats + ct * 32 + col] = db;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// weight gradient on the bf16 pipe.  k = 16 consecutive pixels of a row per matrix instruction: lane (h, channel) holds the 8 pixels
+// 8 h .. 8 h + 7 of ITS channel -- 8 dword loads whose 32 lanes are 32 consecutive channels of one pixel (one 128-byte line) for dy, and
+// 10 for x: the pixels -1 .. 8, from which the fragments of the three taps of a kernel row are three different pairings of ONE split
+// (tap tx pairs the values i + tx, i + tx + 1).  A work-group = 12 waves = 3 kernel rows x the 4 (co half, ci half) quadrants, three
+// accumulator tiles per wave (the fp32 kernel's 9 per wave are 144 registers; with the operands of a k-step, three terms each, and
+// the next k-step's loads in flight this stays under 168: three waves per SIMD).  No LDS.  Partial sums per work-group into the
+// workspace, conv_wgrad_reduce_kernel adds them up -- no atomics, the same bits on every run.
+// ---------------------------------------------------------------------------------------------------------------------------------
+struct WSplit {
+  float v, r1, r2;   // x, x - h, x - h - m: the top 16 bits of the three are the bf16 terms
+};
+__device__ __forceinline__ WSplit wsplit(float x) {
+  WSplit o;
+  o.v = x;
+  o.r1 = x - u2f(f2u(x) & 0xFFFF0000u);
+  o.r2 = o.r1 - u2f(f2u(o.r1) & 0xFFFF0000u);
+  return o;
+}
+template <int N>
+__device__ __forceinline__ void wfrags(const WSplit (&sv)[N], int first, bf8& fh, bf8& fm, bf8& fl) {   // pairs (first + 2 j, first + 2 j + 1), j = 0..3
+  unsigned h[4], m[4], l[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const WSplit &a = sv[first + 2 * j], &b = sv[first + 2 * j + 1];
+    h[j] = __builtin_amdgcn_perm(f2u(b.v), f2u(a.v), 0x07060302u);
+    m[j] = __builtin_amdgcn_perm(f2u(b.r1), f2u(a.r1), 0x07060302u);
+    l[j] = __builtin_amdgcn_perm(f2u(b.r2), f2u(a.r2), 0x07060302u);
+  }
+  fh = __builtin_bit_cast(bf8, (u32x4c){h[0], h[1], h[2], h[3]}), fm = __builtin_bit_cast(bf8, (u32x4c){m[0], m[1], m[2], m[3]});
+  fl = __builtin_bit_cast(bf8, (u32x4c){l[0], l[1], l[2], l[3]});
+}
+
+__global__ __launch_bounds__(768) void conv_wgrad_bf_kernel(const WgradParams p) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, col = lane & 31;
+  const int ty = wave >> 2, quad = wave & 3, ct = quad >> 1, cit = quad & 1;
+  const int Hs = p.up2 ? p.H >> 1 : p.H, Ws = p.up2 ? p.W >> 1 : p.W;
+  const int nks = (p.W + 15) >> 4;                 // k-steps per row
+  const long n_rows = (long)p.N * p.H;
+  f32x16 acc[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t) acc[t] = zero_acc();
+  float db = 0.0f;
+  // the work-group's k-steps in order: rows blockIdx.x, + gridDim.x, ...; the loads of step f + 1 are issued before the products of step f
+  long row = blockIdx.x;
+  int ks = 0;
+  float an[8], bn[10];
+  auto load_step = [&](long r, int k) {
+    const int img = (int)(r / p.H), y = (int)(r - (long)img * p.H);
+    int sy = reflect(y + ty - 1, p.H);
+    if (p.up2) sy >>= 1;
+    const float* dyrow = p.dy + ((long)img * p.H + y) * p.W * 64 + ct * 32 + col;
+    const float* xrow = p.x + ((long)img * Hs + sy) * Ws * 64 + cit * 32 + col;
+    const int xa0 = 16 * k + 8 * h;                // this lane half's first pixel
+    if (16 * k >= 16 && 16 * k + 32 <= p.W) {      // interior step (wave-uniform): no reflection, no ragged end -- constant offsets
+      const float* ap = dyrow + (unsigned)(xa0 * 64);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) an[i] = ap[i * 64];
+      if (p.up2) {
+        const float* bp = xrow + (unsigned)((xa0 >> 1) * 64);      // pixel xa0 + i - 1 -> source (xa0 + i - 1) >> 1 = xa0 / 2 + ((i - 1) >> 1)
+#pragma unroll
+        for (int i = 0; i < 10; ++i) bn[i] = bp[((i - 1) >> 1) * 64];
+      } else {
+        const float* bp = xrow + (unsigned)((xa0 - 1) * 64);
+#pragma unroll
+        for (int i = 0; i < 10; ++i) bn[i] = bp[i * 64];
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int x = xa0 + i;
+        an[i] = x < p.W ? dyrow[(unsigned)(x * 64)] : 0.0f;   // (a pixel beyond a ragged row end contributes nothing)
+      }
+#pragma unroll
+      for (int i = 0; i < 10; ++i) {
+        int sx = reflect_slot(xa0 + i - 1, p.W);
+        if (p.up2) sx >>= 1;
+        bn[i] = xrow[(unsigned)(sx * 64)];
+      }
+    }
+  };
+  if (row < n_rows) load_step(row, 0);
+  while (row < n_rows) {
+    float a[8], b[10];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = an[i];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) b[i] = bn[i];
+    int nk = ks + 1;
+    long nrow = row;
+    if (nk == nks) nk = 0, nrow += gridDim.x;
+    if (nrow < n_rows) load_step(nrow, nk);
+    __builtin_amdgcn_sched_barrier(0);
+    WSplit sa[8], sb[10];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      db += a[i];
+      sa[i] = wsplit(a[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 10; ++i) sb[i] = wsplit(b[i]);
+    bf8 ah, am, al;
+    wfrags(sa, 0, ah, am, al);
+#pragma unroll
+    for (int tx = 0; tx < 3; ++tx) {
+      bf8 bh, bm, bl;
+      wfrags(sb, tx, bh, bm, bl);
+      // D[co][ci] += dy^T x: A = dy (rows = co), B = x (columns = ci); smallest terms first
+      acc[tx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[tx], 0, 0, 0);
+      acc[tx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[tx], 0, 0, 0);
+      acc[tx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc[tx], 0, 0, 0);
+      acc[tx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[tx], 0, 0, 0);
+      acc[tx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[tx], 0, 0, 0);
+      acc[tx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[tx], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    ks = nk, row = nrow;
+  }
+  float* part = p.part + (long)blockIdx.x * kWgradPart;
+#pragma unroll
+  for (int tx = 0; tx < 3; ++tx)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) part[(unsigned)((ty * 3 + tx) * kTapFloats + (ct * 32 + mfma_row(r, h)) * 64 + cit * 32 + col)] = acc[tx][r];
+  if (ty == 1 && cit == 0) {
+    db += __shfl_xor(db, 32, 64);     // the two pixel groups of every k-step
     if (h == 0) part[9 * kTapFloats + ct * 32 + col] = db;
   }
 }
@@ -704,20 +961,35 @@ int conv3x3_bwd_impl(const BtsConv3x3* c, const float* g_y, void* workspace, siz
     ConvParams p;
     memset(&p, 0, sizeof(p));
     p.x = dy, p.w = c->weight, p.y = d_x, p.N = c->N, p.H = c->H, p.W = c->W, p.up2 = c->up2, p.tiles_per_row = tpr;
+#ifndef BTS_CONV_FP32
+    const int n_out = c->up2 ? 60 : kConvOut;
+    p.tiles_per_row = (c->W + n_out - 1) / n_out;
+    p.n_tiles = (long)c->N * (c->up2 ? c->H / 2 : c->H) * p.tiles_per_row;
+    (void)hipFuncSetAttribute((const void*)conv_dgrad_bf_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kConvBfLds);
+    conv_dgrad_bf_kernel<<<conv_grid_bf((p.n_tiles + 7) / 8), 512, kConvBfLds, s>>>(p);
+#else
     p.n_tiles = (long)c->N * (c->up2 ? c->H / 2 : c->H) * tpr;
     const long want = (p.n_tiles + 7) / 8;
     (void)hipFuncSetAttribute((const void*)conv_dgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     conv_dgrad_kernel<<<(int)(want < conv_grid() ? want : conv_grid()), 512, lds, s>>>(p);
+#endif
   }
   if (d_weight || d_bias) {
     WgradParams q;
     memset(&q, 0, sizeof(q));
     q.x = c->x, q.dy = dy, q.part = part, q.N = c->N, q.H = c->H, q.W = c->W, q.up2 = c->up2, q.tiles_per_row = tpr;
     q.n_tiles = (long)c->N * c->H * tpr;
+#ifndef BTS_CONV_FP32
+    const long n_rows = (long)c->N * c->H;
+    const int grid = (int)(n_rows < conv_grid() ? n_rows : conv_grid());
+    conv_wgrad_bf_kernel<<<grid, 768, 0, s>>>(q);
+    conv_wgrad_reduce_kernel<<<(kWgradPart + 255) / 256, 256, 0, s>>>(part, grid, d_weight, d_bias);
+#else
     const long want = (q.n_tiles + 1) / 2;
     const int grid = (int)(want < conv_grid() ? want : conv_grid());
     conv_wgrad_kernel<<<grid, 512, 0, s>>>(q);
     conv_wgrad_reduce_kernel<<<(kWgradPart + 255) / 256, 256, 0, s>>>(part, grid * 2, d_weight, d_bias);
+#endif
   }
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
