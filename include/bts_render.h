@@ -408,7 +408,9 @@ int bts_train_step_bwd(const BtsTrainStep* st, const float* g_loss, void* stream
  *     upconv(0,0): {elu}            on (N, H/2, W/2, 64)   ->  upconv(0,1): {up2, elu}  ->  dispconv(0): {out_nchw}   at (N, H, W, 64)
  * and its last output, NCHW, is exactly what bts_project_features / bts_train_step_fwd take as feat_nchw.  Tensors are channels-last
  * (N, H, W, C) fp32 -- the memory of a torch tensor in channels_last format -- except an NCHW output when out_nchw is set.  C = 64.
- * fp32 throughout (v_mfma_f32_32x32x2_f32: exact products, fp32 accumulation; the summation order differs from a library convolution's).
+ * fp32 in, fp32 out, fp32 accuracy: every operand enters the bf16 matrix pipe as the exact sum of three bf16 terms, six products per
+ * pair reproduce the fp32 product to 2^-24, accumulation in fp32 (the summation order differs from a library convolution's).  A
+ * non-finite input gives NaN where a library convolution gives Inf.
  * --------------------------------------------------------------------------------------------------------------------------------- */
 typedef struct BtsConv3x3 {
   int32_t N, H, W;       /* OUTPUT size; the input is (N, H, W, C), or (N, H / 2, W / 2, C) with up2 (H, W even) */

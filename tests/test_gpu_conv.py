@@ -1,4 +1,5 @@
-"""GPU: the Monodepth2 decoder's tail as hand-written kernels (csrc/bts_conv.hip, bts_conv3x3_fwd / _bwd) against
+"""GPU: the Monodepth2 decoder's tail as hand-written kernels (csrc/bts_conv.hip, bts_conv3x3_fwd / _bwd -- since
+round 5 on the bf16 matrix pipe with every fp32 operand split into three exact bf16 terms) against
 PyTorch's own ops on the same weights: ``ReflectionPad2d(1)`` + ``Conv2d(3 x 3)`` [+ ``ELU``] with ``F.interpolate(nearest, x2)`` in
 front (models/common/model/layers.py:11-40, models/common/backbones/monodepth2.py:211-239).
 
@@ -26,6 +27,19 @@ CASES = [
     (1, 4, 4, False, True, False),         # the smallest frame: every pixel next to a border
     (3, 5, 131, False, False, False),      # odd sizes, three ragged tiles per row
     (1, 3, 33, True, False, True),         # up2 with odd source sizes, NCHW out
+    # the tile geometry of the bf16 kernels (csrc/bts_conv.hip): 62 outputs per wave tile (60 for the data gradient behind an x2 upsampling),
+    # 16 pixels per k-step of the weight gradient -- rows that end exactly on, one before and one after those boundaries
+    (1, 5, 62, False, True, False),
+    (1, 4, 63, False, False, True),
+    (2, 4, 124, False, True, False),
+    (1, 4, 125, False, False, False),
+    (1, 4, 30, True, True, False),         # 60 wide behind the upsampling
+    (1, 2, 31, True, False, True),         # 62 wide, the smallest height behind the upsampling
+    (1, 3, 61, True, True, False),         # 122 = two data-gradient tiles + 2
+    (1, 4, 16, False, False, False),
+    (1, 4, 17, False, False, True),
+    (2, 5, 33, False, False, False),
+    (1, 4, 48, False, True, False),
 ]
 
 
@@ -130,3 +144,26 @@ def test_monodepth2_with_the_fused_tail_equals_the_module_path():
             bad.append((k, own, f"{e_f / (top + 1e-30):.2e}", f"{e_m / (top + 1e-30):.2e}"))
     assert sum(k.startswith(tail) for k in g_d) == 6
     assert not bad, (len(bad), len(g_d), bad[:8])
+
+
+def test_conv3x3_wide_dynamic_range_vs_fp64():
+    """The bf16 three-term split is exact for every finite fp32 value (bf16 carries fp32's exponent: no range to scale, unlike an f16
+    split): activations spread over twelve decades, each output within 2e-6 of the sum of the ABSOLUTE products feeding it (the fp32
+    accumulator's share; an fp32-input convolution does no better), forward and weight gradient."""
+    from behindthescenes_amd import native
+    g = torch.Generator().manual_seed(11)
+    N, H, W = 1, 8, 70
+    x = (torch.randn(N, H, W, 64, generator=g) * 10.0 ** (torch.rand(N, H, W, 64, generator=g) * 12 - 6)).cuda().requires_grad_(True)
+    w = (torch.randn(64, 64, 3, 3, generator=g) * 10.0 ** (torch.rand(64, 64, 3, 3, generator=g) * 4 - 3)).cuda().requires_grad_(True)
+    y = native.Conv3x3Function.apply(x, w, None, False, False, False)
+    x64, w64 = x.detach().double().requires_grad_(True), w.detach().double().requires_grad_(True)
+    ref = _ref(x64.permute(0, 3, 1, 2), w64, None, False, False)
+    mag = _ref(x64.detach().abs().permute(0, 3, 1, 2), w64.detach().abs(), None, False, False)
+    assert ((y.detach().permute(0, 3, 1, 2).double() - ref.detach()).abs() <= 2e-6 * mag).all()
+    gy = torch.randn(ref.shape, generator=g).cuda()
+    ref.backward(gy.double()), y.backward(gy.permute(0, 2, 3, 1).contiguous())
+    xa = x64.detach().abs().requires_grad_(True)
+    wa = w64.detach().abs().requires_grad_(True)
+    _ref(xa.permute(0, 3, 1, 2), wa, None, False, False).backward(gy.double().abs())
+    assert ((w.grad.double() - w64.grad).abs() <= 2e-6 * wa.grad).all()
+    assert ((x.grad.double() - x64.grad).abs() <= 2e-6 * xa.grad).all()

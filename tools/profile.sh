@@ -47,7 +47,7 @@ for f in sorted(glob.glob("$OUT/trace/**/*kernel_stats.csv", recursive=True)):
 train = ["rows_kernel", "scatter_kernel", "dwpe_kernel", "render_bwd_kernel", "scatter_dg_kernel", "render_kernel_p", "project_kernel",
          "project_bwd_kernel", "photometric_loss_kernel"]
 rows = ["rowsb_kernel", "scatter_kernel", "dwpe_rows_kernel", "render_kernel_p"]
-pats = {"conv": ["conv_fwd", "conv_dgrad", "conv_wgrad_kernel", "elu_bwd_kernel"], "fwd": ["render_kernel_p"], "train": train, "bwd": train[:3], "bwd_re10k": rows, "bwd_kitti_raw": train[:3] + ["render_kernel_p"],
+pats = {"conv": ["conv_fwd", "conv_dgrad", "conv_wgrad_", "elu_bwd_kernel"], "fwd": ["render_kernel_p"], "train": train, "bwd": train[:3], "bwd_re10k": rows, "bwd_kitti_raw": train[:3] + ["render_kernel_p"],
         "profile": ["query_kernel_p"]}[mode]
 per = {p: collections.defaultdict(list) for p in pats}
 for f in sorted(glob.glob("$OUT/pmc*/**/*counter_collection.csv", recursive=True)):
