@@ -150,6 +150,20 @@ __device__ __forceinline__ void conv_row3_bf(f32x16 (&acc3)[3], const char* wt, 
   }
 }
 
+// How many 32-slot pixel tiles a wave's tile has: 2 (64 slots, 62 outputs; 8 waves per work-group, 256 VGPRs) or 1 (32 slots, 30 outputs;
+// 12 waves per work-group = three per SIMD inside 168 VGPRs -- more waves to hide the loads and the split behind, 3 % more matrix work
+// for the two halo slots).  The product's choice is the measured one (profiles/r05s); the other is an A/B build (-DBTS_CONV_PT=..).
+#ifndef BTS_CONV_PT
+#define BTS_CONV_PT 2
+#endif
+constexpr int kPT = BTS_CONV_PT;
+constexpr int kConvSlots = 32 * kPT;
+constexpr int kConvWaves = kPT == 2 ? 8 : 12;
+// tile geometry of the bf16 kernels: a wave's tile = kConvSlots pixel SLOTS of one row, slot j <-> position x0 - 1 + j, x0 = kConvOut *
+// (tile in row); the tile's outputs are the slots 1 .. kConvOut (their left / right neighbours are slots of the same tile).  The data
+// gradient behind an x2 upsampling: position x0 - 2 + j, outputs 2 .. kConvSlots - 3 (kConvOutUp of them)
+constexpr int kConvOut = kConvSlots - 2, kConvOutUp = kConvSlots - 4;
+
 // which half of the columns and which stream of tiles a work-group takes: the two halves of a stream sit on the same XCD (blockIdx % 8)
 struct ConvRole {
   int half, first, stride;   // wave tile index = first + k * stride
@@ -157,12 +171,9 @@ struct ConvRole {
 __device__ __forceinline__ ConvRole conv_role(int wave) {
   const int b = blockIdx.x, xcd = b & 7, idx = b >> 3;
   const int stream = (idx >> 1) * 8 + xcd;       // gridDim.x is a multiple of 16 (conv_grid_bf)
-  return ConvRole{idx & 1, stream * 8 + wave, (int)(gridDim.x >> 1) * 8};
+  return ConvRole{idx & 1, stream * kConvWaves + wave, (int)(gridDim.x >> 1) * kConvWaves};
 }
 
-// tile geometry of the bf16 kernels: a wave's tile = 64 pixel SLOTS of one row, slot j <-> position x0 - 1 + j, x0 = kConvOut * (tile in
-// row); the tile's outputs are the slots 1 .. 62 (their left / right neighbours are slots of the same tile), 62 per tile
-constexpr int kConvOut = 62;
 __device__ __forceinline__ int reflect_slot(int pos, int L) {   // reflect; positions no output of the tile needs are clamped
   const int r = pos < 0 ? -pos : (pos >= L ? 2 * L - 2 - pos : pos);
   return min(max(r, 0), L - 1);
@@ -172,15 +183,15 @@ __device__ __forceinline__ int reflect_slot(int pos, int L) {   // reflect; posi
 // tile row pt * 32 + 8 g + 4 h + e lives in register 4 g + e of lane half h): a neighbouring register, or -- across a group of four --
 // the other lane half's
 template <int DIR>
-__device__ __forceinline__ void conv_shift_rows(const f32x16 (&a)[2], f32x16 (&out)[2], int h) {
+__device__ __forceinline__ void conv_shift_rows(const f32x16 (&a)[kPT], f32x16 (&out)[kPT], int h) {
 #pragma unroll
-  for (int pt = 0; pt < 2; ++pt)
+  for (int pt = 0; pt < kPT; ++pt)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       if (DIR < 0) {
         // half 1 needs half 0's (pt, 4 g + 3); half 0 needs half 1's register 4 (g - 1) + 3 of this tile, or (pt - 1, 15)
         const float from_h0 = a[pt][4 * g + 3];
-        const float from_h1 = g > 0 ? a[pt][4 * g - 1] : (pt > 0 ? a[pt - 1][15] : 0.0f);
+        const float from_h1 = g > 0 ? a[pt][g > 0 ? 4 * g - 1 : 0] : (pt > 0 ? a[pt > 0 ? pt - 1 : 0][15] : 0.0f);
         const float got = __shfl_xor(h ? from_h1 : from_h0, 32, 64);
         out[pt][4 * g] = got;
 #pragma unroll
@@ -188,7 +199,7 @@ __device__ __forceinline__ void conv_shift_rows(const f32x16 (&a)[2], f32x16 (&o
       } else {
         // half 0 needs half 1's (pt, 4 g); half 1 needs half 0's register 4 (g + 1) of this tile, or (pt + 1, 0)
         const float from_h1 = a[pt][4 * g];
-        const float from_h0 = g < 3 ? a[pt][4 * g + 4] : (pt < 1 ? a[pt + 1][0] : 0.0f);
+        const float from_h0 = g < 3 ? a[pt][g < 3 ? 4 * g + 4 : 0] : (pt + 1 < kPT ? a[pt + 1 < kPT ? pt + 1 : 0][0] : 0.0f);
         const float got = __shfl_xor(h ? from_h1 : from_h0, 32, 64);
         out[pt][4 * g + 3] = got;
 #pragma unroll
@@ -196,29 +207,40 @@ __device__ __forceinline__ void conv_shift_rows(const f32x16 (&a)[2], f32x16 (&o
       }
     }
 }
-// the same in the D[column][pixel slot] layout (slots across the 32 lanes of a half, both tiles): the neighbouring lane's, or the other tile's end lane
+// the same in the D[column][pixel slot] layout (slots across the 32 lanes of a half, tile after tile): the neighbouring lane's, or the
+// neighbouring tile's end lane
 template <int DIR>
-__device__ __forceinline__ void conv_shift_lanes(const f32x16 (&a)[2], f32x16 (&out)[2], int lane) {
+__device__ __forceinline__ void conv_shift_lanes(const f32x16 (&a)[kPT], f32x16 (&out)[kPT], int lane) {
   const int col = lane & 31;
   const int nb = DIR < 0 ? (lane - 1) & 63 : (lane + 1) & 63;           // the neighbour inside the half (wrong for the half's end lane)
-  const int wrap = DIR < 0 ? (lane + 31) & 63 : (lane - 31) & 63;       // the other tile's last / first lane of the same half
+  const int wrap = DIR < 0 ? (lane + 31) & 63 : (lane - 31) & 63;       // the neighbouring tile's last / first lane of the same half
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const float n0 = __shfl(a[0][r], nb, 64), n1 = __shfl(a[1][r], nb, 64);
-    if (DIR < 0) {
-      const float w = __shfl(a[0][r], wrap, 64);
-      out[0][r] = n0, out[1][r] = col == 0 ? w : n1;      // (slot 0 has no output: out[0] of lane col 0 is never used)
-    } else {
-      const float w = __shfl(a[1][r], wrap, 64);
-      out[0][r] = col == 31 ? w : n0, out[1][r] = n1;     // (slot 63 has no output)
+  for (int r = 0; r < 16; ++r)
+#pragma unroll
+    for (int pt = 0; pt < kPT; ++pt) {
+      const float n = __shfl(a[pt][r], nb, 64);
+      if (DIR < 0) {
+        if (pt > 0) {
+          const float w = __shfl(a[pt > 0 ? pt - 1 : 0][r], wrap, 64);
+          out[pt][r] = col == 0 ? w : n;
+        } else {
+          out[pt][r] = n;      // (slot 0 has no output: what lane col 0 gets here is never used)
+        }
+      } else {
+        if (pt + 1 < kPT) {
+          const float w = __shfl(a[pt + 1 < kPT ? pt + 1 : 0][r], wrap, 64);
+          out[pt][r] = col == 31 ? w : n;
+        } else {
+          out[pt][r] = n;      // (the last slot has no output)
+        }
+      }
     }
-  }
 }
 
-// forward: one wave = 62 output pixels of a row x the 32 output channels of its work-group's half; per kernel row ONE set of loads and
+// forward: one wave = kConvOut output pixels of a row x the 32 output channels of its work-group's half; per kernel row ONE set of loads and
 // one split, three taps; the next (row, half tile)'s eight loads are in flight under the products of this one
 template <bool OUT_NCHW>
-__global__ __launch_bounds__(512) void conv_fwd_bf_kernel(const ConvParams p) {
+__global__ __launch_bounds__(64 * kConvWaves) void conv_fwd_bf_kernel(const ConvParams p) {
   extern __shared__ __attribute__((aligned(16))) char lds_b[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, col = lane & 31;
   const ConvRole role = conv_role(wave);
@@ -233,22 +255,22 @@ __global__ __launch_bounds__(512) void conv_fwd_bf_kernel(const ConvParams p) {
     const int rem = (int)(tile - (long)img * rows);
     const int y = rem / p.tiles_per_row, x0 = (rem - y * p.tiles_per_row) * kConvOut;
     const float* base = p.x + (long)img * Hs * Ws * 64;
-    f32x16 acc[3][2];   // [tx][pt]
+    f32x16 acc[3][kPT];   // [tx][pt]
 #pragma unroll
     for (int tx = 0; tx < 3; ++tx)
 #pragma unroll
-      for (int pt = 0; pt < 2; ++pt)
+      for (int pt = 0; pt < kPT; ++pt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[tx][pt][r] = (tx != 1 || !p.bias) ? 0.0f : (OUT_NCHW ? p.bias[c0 + mfma_row(r, h)] : p.bias[c0 + col]);
-    int sx[2];
+    int sx[kPT];
 #pragma unroll
-    for (int pt = 0; pt < 2; ++pt) {
+    for (int pt = 0; pt < kPT; ++pt) {
       sx[pt] = reflect_slot(x0 - 1 + pt * 32 + col, p.W);
       if (p.up2) sx[pt] >>= 1;
     }
     float4 xa[2][8];
-    auto load_piece = [&](int buf, int piece) {   // piece = 2 ty + pt
-      const int ty = piece >> 1, pt = piece & 1;
+    auto load_piece = [&](int buf, int piece) {   // piece = kPT ty + pt
+      const int ty = piece / kPT, pt = piece % kPT;
       int sy = reflect(y + ty - 1, p.H);
       if (p.up2) sy >>= 1;
       const float* src = base + (unsigned)((sy * Ws + sx[pt]) * 64 + 8 * h);
@@ -257,24 +279,24 @@ __global__ __launch_bounds__(512) void conv_fwd_bf_kernel(const ConvParams p) {
     };
     load_piece(0, 0);
 #pragma unroll
-    for (int piece = 0; piece < 6; ++piece) {
+    for (int piece = 0; piece < 3 * kPT; ++piece) {
 #if !(defined(BTS_CONV_ABL) && (BTS_CONV_ABL & 2))   // (timing ablation 2: one piece's loads per tile)
-      if (piece + 1 < 6) load_piece((piece + 1) & 1, piece + 1);
+      if (piece + 1 < 3 * kPT) load_piece((piece + 1) & 1, piece + 1);
 #endif
       __builtin_amdgcn_sched_barrier(0);
-      const int ty = piece >> 1, pt = piece & 1;
+      const int ty = piece / kPT, pt = piece % kPT;
       f32x16 a3[3] = {acc[0][pt], acc[1][pt], acc[2][pt]};
       conv_row3_bf<OUT_NCHW>(a3, wlane + ty * 3 * 4 * (3 * 1024), xa[piece & 1]);
       acc[0][pt] = a3[0], acc[1][pt] = a3[1], acc[2][pt] = a3[2];
       __builtin_amdgcn_sched_barrier(0);
     }
     // out[slot] = P0[slot - 1] + P1[slot] + P2[slot + 1]   (P_tx = the products of kernel column tx at the SOURCE slot)
-    f32x16 lo[2], hi[2];
+    f32x16 lo[kPT], hi[kPT];
     if (OUT_NCHW) conv_shift_lanes<-1>(acc[0], lo, lane), conv_shift_lanes<+1>(acc[2], hi, lane);
     else conv_shift_rows<-1>(acc[0], lo, h), conv_shift_rows<+1>(acc[2], hi, h);
     float* out = p.y + (long)img * p.H * p.W * 64;
 #pragma unroll
-    for (int pt = 0; pt < 2; ++pt)
+    for (int pt = 0; pt < kPT; ++pt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         float v = (lo[pt][r] + acc[1][pt][r]) + hi[pt][r];
@@ -302,7 +324,7 @@ __global__ __launch_bounds__(512) void conv_fwd_bf_kernel(const ConvParams p) {
 // 62 outputs per tile, or, with the x2 upsampling in front of the layer (its 2 x 2 children are summed here), off = 2 and 60 outputs
 // so that the two children of a source pixel are the slots (2 m, 2 m + 1): neighbouring registers of one lane.
 // ---------------------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512) void conv_dgrad_bf_kernel(const ConvParams p) {
+__global__ __launch_bounds__(64 * kConvWaves) void conv_dgrad_bf_kernel(const ConvParams p) {
   extern __shared__ __attribute__((aligned(16))) char lds_b[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, col = lane & 31;
   const ConvRole role = conv_role(wave);
@@ -311,22 +333,22 @@ __global__ __launch_bounds__(512) void conv_dgrad_bf_kernel(const ConvParams p) 
   const int out_rows = p.up2 ? p.H >> 1 : p.H;
   const long rows = (long)out_rows * p.tiles_per_row;
   const int c0 = role.half * 32;
-  const int off = p.up2 ? 2 : 1, n_out = p.up2 ? 60 : kConvOut;
+  const int off = p.up2 ? 2 : 1, n_out = p.up2 ? kConvOutUp : kConvOut;
   const char* const wlane = lds_b + lane * 16;
   for (long tile = role.first; tile < p.n_tiles; tile += role.stride) {
     const int img = (int)(tile / rows);
     const int rem = (int)(tile - (long)img * rows);
     const int yt = rem / p.tiles_per_row, x0 = (rem - yt * p.tiles_per_row) * n_out;
     const float* base = p.x + (long)img * p.H * p.W * 64;   // dy' (N, H, W, 64)
-    f32x16 acc[3][2];   // [tx + 1][pt]
+    f32x16 acc[3][kPT];   // [tx + 1][pt]
 #pragma unroll
     for (int tx = 0; tx < 3; ++tx)
 #pragma unroll
-      for (int pt = 0; pt < 2; ++pt) acc[tx][pt] = zero_acc();
-    int qx[2];
-    bool ok[2];
+      for (int pt = 0; pt < kPT; ++pt) acc[tx][pt] = zero_acc();
+    int qx[kPT];
+    bool ok[kPT];
 #pragma unroll
-    for (int pt = 0; pt < 2; ++pt) {
+    for (int pt = 0; pt < kPT; ++pt) {
       const int pos = x0 - off + pt * 32 + col;
       ok[pt] = pos >= 0 && pos < p.W;
       qx[pt] = min(max(pos, 0), p.W - 1);
@@ -345,55 +367,58 @@ __global__ __launch_bounds__(512) void conv_dgrad_bf_kernel(const ConvParams p) 
       }
     }
     float4 xa[2][8];
-    auto load_piece = [&](int buf, int piece) {   // piece = 2 pair + pt
-      const int qy = pair_qy[piece >> 1], pt = piece & 1;
+    auto load_piece = [&](int buf, int piece) {   // piece = kPT pair + pt
+      const int qy = pair_qy[piece / kPT], pt = piece % kPT;
       const float* src = base + (unsigned)((qy * p.W + qx[pt]) * 64 + 8 * h);
       const bool on = ok[pt];
 #pragma unroll
       for (int q = 0; q < 8; ++q) xa[buf][q] = on ? *reinterpret_cast<const float4*>(src + 16 * (q >> 1) + 4 * (q & 1)) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     };
-    // (the pair list is short and its length wave-uniform: a rolled loop with the two buffers switched by parity)
+    // (the pair list is short and its length wave-uniform: a rolled loop over TWO pieces at a time, so that the two buffers and the
+    // accumulators of a piece are compile-time choices: pieces 2 j and 2 j + 1 are the two tiles of pair j, or -- with one tile per wave --
+    // pairs 2 j and 2 j + 1)
+    const int n_pieces = kPT * n_pairs;
     load_piece(0, 0);
-    for (int piece = 0; piece < 2 * n_pairs; piece += 2) {
-      load_piece(1, piece + 1);
+    for (int piece = 0; piece < n_pieces; piece += 2) {
+      if (piece + 1 < n_pieces) load_piece(1, piece + 1);
       __builtin_amdgcn_sched_barrier(0);
       {
         f32x16 a3[3] = {acc[0][0], acc[1][0], acc[2][0]};
-        conv_row3_bf<false>(a3, wlane + pair_ty[piece >> 1] * 3 * 4 * (3 * 1024), xa[0]);
+        conv_row3_bf<false>(a3, wlane + pair_ty[piece / kPT] * 3 * 4 * (3 * 1024), xa[0]);
         acc[0][0] = a3[0], acc[1][0] = a3[1], acc[2][0] = a3[2];
       }
       __builtin_amdgcn_sched_barrier(0);
-      if (piece + 2 < 2 * n_pairs) load_piece(0, piece + 2);
-      __builtin_amdgcn_sched_barrier(0);
-      {
-        f32x16 a3[3] = {acc[0][1], acc[1][1], acc[2][1]};
-        conv_row3_bf<false>(a3, wlane + pair_ty[piece >> 1] * 3 * 4 * (3 * 1024), xa[1]);
-        acc[0][1] = a3[0], acc[1][1] = a3[1], acc[2][1] = a3[2];
+      if (piece + 1 < n_pieces) {
+        if (piece + 2 < n_pieces) load_piece(0, piece + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        f32x16 a3[3] = {acc[0][kPT - 1], acc[1][kPT - 1], acc[2][kPT - 1]};
+        conv_row3_bf<false>(a3, wlane + pair_ty[(piece + 1) / kPT] * 3 * 4 * (3 * 1024), xa[1]);
+        acc[0][kPT - 1] = a3[0], acc[1][kPT - 1] = a3[1], acc[2][kPT - 1] = a3[2];
       }
       __builtin_amdgcn_sched_barrier(0);
     }
     // dx[slot] = Q_-1[slot + 1] + Q_0[slot] + Q_+1[slot - 1] (+ the reflected columns)
-    f32x16 up[2], dn[2];
+    f32x16 up[kPT], dn[kPT];
     conv_shift_rows<+1>(acc[0], up, h), conv_shift_rows<-1>(acc[2], dn, h);
-    f32x16 v[2];
+    f32x16 v[kPT];
 #pragma unroll
-    for (int pt = 0; pt < 2; ++pt)
+    for (int pt = 0; pt < kPT; ++pt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) v[pt][r] = (up[pt][r] + acc[1][pt][r]) + dn[pt][r];
     const int s1 = 1 - x0 + off, s2 = p.W - 2 - x0 + off;   // the slots of x == 1 and x == W - 2 (wave-uniform; may lie outside this tile)
     if (s1 >= off && s1 < off + n_out) {
-      f32x16 e[2];
+      f32x16 e[kPT];
       conv_shift_rows<-1>(acc[0], e, h);
 #pragma unroll
-      for (int pt = 0; pt < 2; ++pt)
+      for (int pt = 0; pt < kPT; ++pt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) v[pt][r] += (pt * 32 + mfma_row(r, h) == s1) ? e[pt][r] : 0.0f;
     }
     if (s2 >= off && s2 < off + n_out) {
-      f32x16 e[2];
+      f32x16 e[kPT];
       conv_shift_rows<+1>(acc[2], e, h);
 #pragma unroll
-      for (int pt = 0; pt < 2; ++pt)
+      for (int pt = 0; pt < kPT; ++pt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) v[pt][r] += (pt * 32 + mfma_row(r, h) == s2) ? e[pt][r] : 0.0f;
     }
@@ -401,7 +426,7 @@ __global__ __launch_bounds__(512) void conv_dgrad_bf_kernel(const ConvParams p) 
       const int Ws = p.W >> 1;
       float* out = p.y + ((long)img * out_rows + yt) * Ws * 64;
 #pragma unroll
-      for (int pt = 0; pt < 2; ++pt)
+      for (int pt = 0; pt < kPT; ++pt)
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {   // slots (2 m, 2 m + 1): the two children of one source pixel along x
           const int slot = pt * 32 + mfma_row(r, h);
@@ -411,7 +436,7 @@ __global__ __launch_bounds__(512) void conv_dgrad_bf_kernel(const ConvParams p) 
     } else {
       float* out = p.y + ((long)img * p.H + yt) * p.W * 64;
 #pragma unroll
-      for (int pt = 0; pt < 2; ++pt)
+      for (int pt = 0; pt < kPT; ++pt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int slot = pt * 32 + mfma_row(r, h);
@@ -636,14 +661,14 @@ int conv3x3_fwd_impl(const BtsConv3x3* c, hipStream_t s) {
 #ifndef BTS_CONV_FP32
   p.tiles_per_row = (c->W + kConvOut - 1) / kConvOut;
   p.n_tiles = (long)c->N * c->H * p.tiles_per_row;
-  const int grid = conv_grid_bf((p.n_tiles + 7) / 8);
+  const int grid = conv_grid_bf((p.n_tiles + kConvWaves - 1) / kConvWaves);
   // (the attribute is per device: set on every launch, like the render kernels' launchers do -- a host-side table write)
   if (c->out_nchw) {
     (void)hipFuncSetAttribute((const void*)conv_fwd_bf_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kConvBfLds);
-    conv_fwd_bf_kernel<true><<<grid, 512, kConvBfLds, s>>>(p);
+    conv_fwd_bf_kernel<true><<<grid, 64 * kConvWaves, kConvBfLds, s>>>(p);
   } else {
     (void)hipFuncSetAttribute((const void*)conv_fwd_bf_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kConvBfLds);
-    conv_fwd_bf_kernel<false><<<grid, 512, kConvBfLds, s>>>(p);
+    conv_fwd_bf_kernel<false><<<grid, 64 * kConvWaves, kConvBfLds, s>>>(p);
   }
 #else   // A/B build: the fp32-input MFMA kernels of the first version
   const long want = (p.n_tiles + 7) / 8;
@@ -704,11 +729,11 @@ int conv3x3_bwd_impl(const BtsConv3x3* c, const float* g_y, void* workspace, siz
     memset(&p, 0, sizeof(p));
     p.x = dy, p.w = c->weight, p.y = d_x, p.N = c->N, p.H = c->H, p.W = c->W, p.up2 = c->up2, p.tiles_per_row = tpr;
 #ifndef BTS_CONV_FP32
-    const int n_out = c->up2 ? 60 : kConvOut;
+    const int n_out = c->up2 ? kConvOutUp : kConvOut;
     p.tiles_per_row = (c->W + n_out - 1) / n_out;
     p.n_tiles = (long)c->N * (c->up2 ? c->H / 2 : c->H) * p.tiles_per_row;
     (void)hipFuncSetAttribute((const void*)conv_dgrad_bf_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kConvBfLds);
-    conv_dgrad_bf_kernel<<<conv_grid_bf((p.n_tiles + 7) / 8), 512, kConvBfLds, s>>>(p);
+    conv_dgrad_bf_kernel<<<conv_grid_bf((p.n_tiles + kConvWaves - 1) / kConvWaves), 64 * kConvWaves, kConvBfLds, s>>>(p);
 #else
     p.n_tiles = (long)c->N * (c->up2 ? c->H / 2 : c->H) * tpr;
     const long want = (p.n_tiles + 7) / 8;
