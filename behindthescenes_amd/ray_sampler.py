@@ -95,13 +95,21 @@ class PatchRaySampler(RaySampler):
         assert (ray_batch_size % (self.patch_size_x * self.patch_size_y)) == 0
         self._patch_count = self.ray_batch_size // (self.patch_size_x * self.patch_size_y)
 
-    def draw_patches(self, n, v, h, w):
-        """The reference's CPU RNG draws, in its order (ray_sampler.py:141-143): per sample v, y, x vectors."""
+    def draw_patches(self, n, v, h, w, rows=None):
+        """The reference's CPU RNG draws, in its order (ray_sampler.py:141-143): per sample v, y, x vectors.  ``rows``: 3 n one-dimensional
+        integer CPU tensors (v, y, x of sample 0, then of sample 1, ...) to draw into instead -- ``t.random_(0, hi)`` is what
+        ``torch.randint(0, hi, ...)`` runs underneath and consumes the generator identically for int32 and int64 (tests/test_protocol_cpu.py)."""
+        P = self._patch_count
+        if rows is not None:
+            hy, hx = h - self.patch_size_y, w - self.patch_size_x
+            for i in range(n):
+                rows[3 * i].random_(0, v), rows[3 * i + 1].random_(0, hy), rows[3 * i + 2].random_(0, hx)
+            return None
         pv, py, px = [], [], []
         for _ in range(n):
-            pv.append(torch.randint(0, v, (self._patch_count,)))
-            py.append(torch.randint(0, h - self.patch_size_y, (self._patch_count,)))
-            px.append(torch.randint(0, w - self.patch_size_x, (self._patch_count,)))
+            pv.append(torch.randint(0, v, (P,)))
+            py.append(torch.randint(0, h - self.patch_size_y, (P,)))
+            px.append(torch.randint(0, w - self.patch_size_x, (P,)))
         return torch.stack(pv), torch.stack(py), torch.stack(px)
 
     def sample(self, images, poses, projs, patches=None):

@@ -43,6 +43,16 @@ class _Arena:
         self.imgs = torch.empty((n, nv, H, W, 4), **f32)
         self.ws = torch.empty(ws_bytes // 4 + 4, **f32)
         self.d_empty_proj = torch.empty(Hd, **f32)
+        # the step's parameter block: everything that depends on the shape and the configuration only is written once (st_key says for
+        # which configuration), a step then sets the handful of pointers that move
+        self.st, self.st_key, self.st_keep = _lib.BtsTrainStep(), None, None
+        # patch coordinates: a small ring of (pinned host, device) int32 blocks (3, n, P).  The draws go straight into the pinned block,
+        # one asynchronous copy follows; an event per slot keeps the host from overwriting a block whose copy has not run yet
+        self.idx_ring = [dict(pin=torch.empty((3, n, P), dtype=torch.int32).pin_memory(), dev=torch.empty((3, n, P), device=dev, dtype=torch.int32),
+                              ev=None) for _ in range(4)]
+        for sl in self.idx_ring:
+            sl["rows"] = [sl["pin"][j, i] for i in range(n) for j in range(3)]
+        self.idx_next = 0
         self.scales = []
         for sh in shifts:
             h, w = H >> sh, W >> sh
@@ -55,6 +65,20 @@ class _Arena:
                      # the kept pair of ABI 6: all zero between steps (the projection backward returns it to zero)
                      d_proj=torch.zeros((n, h, w, Hd), **f32), d_tiles=torch.zeros((n, tiles), device=dev, dtype=torch.uint8))
             self.scales.append(s)
+
+
+    def upload_patches(self, draw):
+        """``draw(rows)`` fills the next pinned block (PatchRaySampler.draw_patches); -> the device block (3, n, P) int32."""
+        sl = self.idx_ring[self.idx_next]
+        self.idx_next = (self.idx_next + 1) % len(self.idx_ring)
+        if sl["ev"] is not None and not sl["ev"].query():
+            sl["ev"].synchronize()
+        draw(sl["rows"])
+        sl["dev"].copy_(sl["pin"], non_blocking=True)
+        if sl["ev"] is None:
+            sl["ev"] = torch.cuda.Event()
+        sl["ev"].record()
+        return sl["dev"]
 
 
 _ARENAS = {}
@@ -272,25 +296,29 @@ class FusedTrainStep(torch.nn.Module):
             if sh is None:                                    # a size that is not H / 2^s: the reference's nearest resize (models_bts.py:115-117)
                 il, sh = F.interpolate(il, size0), 0
             feats.append(il.float().contiguous()), shifts.append(sh)
-        # ---- the step's draws: patches on the CPU generator in the reference's order, one jitter tensor per render on the device
+        # ---- buffers: the arena (kept per shape) and one fresh block for what the caller gets to keep
         P, ph, pw = smp._patch_count, smp.patch_size_y, smp.patch_size_x
-        pv, py, px = smp.draw_patches(n, len(ids_loss), H, W) if patches is None else patches
-        idx = torch.stack((pv, py, px)).to(torch.int32).pin_memory().to(dev, non_blocking=True)
         Bp, K = P * ph * pw, int(r.n_coarse)
         B = n * Bp
-        jit = [torch.rand((B, K), device=dev, dtype=torch.float32) for _ in scales]
-        # ---- buffers: the arena (kept per shape) and one fresh block for what the caller gets to keep
         spec, nv, S = net.spec, len(ids_render), len(scales)
         stream = torch.cuda.current_stream(dev).cuda_stream
         key = (dev, stream, n, v, nv, H, W, Bp, K, P, ph, pw, tuple(shifts), spec)
-        cfg = native._spec_cfg(spec, n, H, W, nv, 0, ids_render.index(id_enc) if id_enc in ids_render else -1)
 
         def make():
+            cfg0 = native._spec_cfg(spec, n, H, W, nv, 0, -1)
             args = _lib.BtsRenderArgs(rays_per_sample=Bp, K=K)
-            ws = int(_lib.load().bts_render_bwd_workspace(C.byref(cfg), C.byref(args)))
+            ws = int(_lib.load().bts_render_bwd_workspace(C.byref(cfg0), C.byref(args)))
             # one slice per scale: with `concurrent_scales` the scales' backward chains run side by side (BtsTrainStep.concurrent_scales)
             return _Arena(key, dev, n, nv, H, W, spec.d_hidden, Bp, K, P, shifts, spec, ((ws + 255) // 256 * 256) * len(shifts))
         arena = _arena(key, make)
+        # ---- the step's draws: patches on the CPU generator in the reference's order (straight into pinned memory, one asynchronous
+        # copy), one jitter tensor per render on the device generator
+        if patches is None:
+            idx = arena.upload_patches(lambda rows: smp.draw_patches(n, len(ids_loss), H, W, rows=rows))
+        else:
+            pv, py, px = patches
+            idx = torch.stack((pv, py, px)).to(torch.int32).pin_memory().to(dev, non_blocking=True)
+        jit = [torch.rand((B, K), device=dev, dtype=torch.float32) for _ in scales]
         per_scale = _r64(B * nv * 3) + _r64(B) + 2 * _r64(B * nv)
         out = torch.empty(_r64(B * 8) + _r64(B * 3) + 64 + S * per_scale, device=dev, dtype=torch.float32)
         o = [0]
@@ -302,39 +330,47 @@ class FusedTrainStep(torch.nn.Module):
         rays, rgb_gt, vals = take(B * 8, n, Bp, 8), take(B * 3, n, Bp, 3), take(9, 9)
         levels = [dict(rgb=take(B * nv * 3, n, Bp, nv * 3), depth=take(B, n, Bp), invalid_wsum=take(B * nv, n, Bp, nv),
                        invalid_any=take(B * nv, n, Bp, nv)) for _ in scales]
-        # ---- the struct
-        st = _lib.BtsTrainStep()
-        st.cfg = cfg
-        st.v, st.id_encoder, st.n_loss = v, id_enc, len(ids_loss)
-        for j, i in enumerate(ids_render):
-            st.ids_render[j] = i
-        for j, i in enumerate(ids_loss):
-            st.ids_loss[j] = i
-        st.P, st.ph, st.pw, st.K = P, ph, pw, K
-        st.lindisp, st.hard_alpha_cap = int(bool(r.lindisp)), int(bool(r.hard_alpha_cap))
-        st.invalid_policy = native.INVALID_POLICIES[crit.invalid_policy]
-        st.edge_aware_smoothness = int(crit.lambda_edge_aware_smoothness > 0)
-        st.n_scales = S
-        st.concurrent_scales = int(self.concurrent_scales and S > 1)
-        st.z_near, st.z_far, st.img_scale, st.img_shift = float(smp.z_near), float(smp.z_far), 0.5, 0.5
+        # ---- the struct: what depends on the configuration only is (re)written when that changes ...
+        st = arena.st
         M = crit.loss_matrix(S, (B,) * S, (True,) * S)            # trainer.py:247-248: fine = dict(coarse) on every scale
-        for i, x in enumerate(M.reshape(-1).tolist()):
-            st.loss_matrix[i] = x
+        ck = (tuple(ids_render), tuple(ids_loss), id_enc, bool(r.lindisp), bool(r.hard_alpha_cap), crit.invalid_policy,
+              crit.lambda_edge_aware_smoothness > 0, self.concurrent_scales, float(smp.z_near), float(smp.z_far), id(M))
+        if arena.st_key != ck:
+            st.cfg = native._spec_cfg(spec, n, H, W, nv, 0, ids_render.index(id_enc) if id_enc in ids_render else -1)
+            st.v, st.id_encoder, st.n_loss = v, id_enc, len(ids_loss)
+            for j, i in enumerate(ids_render):
+                st.ids_render[j] = i
+            for j, i in enumerate(ids_loss):
+                st.ids_loss[j] = i
+            st.P, st.ph, st.pw, st.K = P, ph, pw, K
+            st.lindisp, st.hard_alpha_cap = int(bool(r.lindisp)), int(bool(r.hard_alpha_cap))
+            st.invalid_policy = native.INVALID_POLICIES[crit.invalid_policy]
+            st.edge_aware_smoothness = int(crit.lambda_edge_aware_smoothness > 0)
+            st.n_scales = S
+            st.concurrent_scales = int(self.concurrent_scales and S > 1)
+            st.z_near, st.z_far, st.img_scale, st.img_shift = float(smp.z_near), float(smp.z_far), 0.5, 0.5
+            for i, x in enumerate(M.reshape(-1).tolist()):
+                st.loss_matrix[i] = x
+            st.cams, st.imgs_nhwc4 = arena.cams.data_ptr(), arena.imgs.data_ptr()
+            st.bwd_workspace, st.bwd_workspace_bytes = arena.ws.data_ptr(), arena.ws.numel() * 4
+            for s_ in range(S):
+                q, a = st.scale[s_], arena.scales[s_]
+                q.feat_shift = shifts[s_]
+                q.proj_nhwc, q.sampled_tiles = a["proj"].data_ptr(), a["tiles"].data_ptr()
+                q.z_samp, q.sigma_raw, q.trans, q.rgb_samps = a["z"].data_ptr(), a["sigma_raw"].data_ptr(), a["trans"].data_ptr(), a["rgb_samps"].data_ptr()
+                q.loss_parts, q.g_rgb, q.g_depth = a["parts"].data_ptr(), a["g_rgb"].data_ptr(), a["g_depth"].data_ptr()
+                q.gs_rgb, q.gs_depth = a["gs_rgb"].data_ptr(), a["gs_depth"].data_ptr()
+                q.d_proj_nhwc, q.d_proj_tiles = a["d_proj"].data_ptr(), a["d_tiles"].data_ptr()
+            arena.st_key, arena.st_keep = ck, M                   # (M is kept so that id(M) cannot be recycled while the key names it)
+        # ... and what moves from step to step
         st.images, st.Ks, st.poses_c2w = images.data_ptr(), projs.data_ptr(), poses.data_ptr()
         st.patch_v, st.patch_y, st.patch_x = idx[0].data_ptr(), idx[1].data_ptr(), idx[2].data_ptr()
         st.rays, st.rgb_gt, st.loss_vals = rays.data_ptr(), rgb_gt.data_ptr(), vals.data_ptr()
-        st.cams, st.imgs_nhwc4 = arena.cams.data_ptr(), arena.imgs.data_ptr()
-        st.bwd_workspace, st.bwd_workspace_bytes = arena.ws.data_ptr(), arena.ws.numel() * 4
-        for s in range(S):
-            q, a, lv = st.scale[s], arena.scales[s], levels[s]
-            q.jitter, q.feat_shift = jit[s].data_ptr(), shifts[s]
+        for s_ in range(S):
+            q, lv = st.scale[s_], levels[s_]
+            q.jitter = jit[s_].data_ptr()
             q.rgb, q.depth = lv["rgb"].data_ptr(), lv["depth"].data_ptr()
             q.invalid_wsum, q.invalid_any = lv["invalid_wsum"].data_ptr(), lv["invalid_any"].data_ptr()
-            q.proj_nhwc, q.sampled_tiles = a["proj"].data_ptr(), a["tiles"].data_ptr()
-            q.z_samp, q.sigma_raw, q.trans, q.rgb_samps = a["z"].data_ptr(), a["sigma_raw"].data_ptr(), a["trans"].data_ptr(), a["rgb_samps"].data_ptr()
-            q.loss_parts, q.g_rgb, q.g_depth = a["parts"].data_ptr(), a["g_rgb"].data_ptr(), a["g_depth"].data_ptr()
-            q.gs_rgb, q.gs_depth = a["gs_rgb"].data_ptr(), a["gs_depth"].data_ptr()
-            q.d_proj_nhwc, q.d_proj_tiles = a["d_proj"].data_ptr(), a["d_tiles"].data_ptr()
         job = _Job()
         job.st, job.arena, job.vals, job.grad_mode, job.token, job.C = st, arena, vals, torch.is_grad_enabled(), None, spec.C
         job.keep = (images, projs, poses, idx, jit, out)         # what the struct's pointers name, for as long as the graph lives

@@ -97,6 +97,18 @@ def parse():
     return ap.parse_args()
 
 
+def park_gc():
+    """Collect now, then park the cyclic collector: a generation-2 pass over a process with torch loaded takes ~30 ms, and when it falls
+    inside a timed loop of a 0.7 ms step it is 0.3 ms per step of a 100-step run (profiles/r05t; nothing in a 20-step run).  -> the
+    function that restores the previous state.  BTS_BENCH_KEEP_GC=1 leaves the collector on."""
+    import gc
+    gc.collect()
+    was_on = gc.isenabled()
+    if os.environ.get("BTS_BENCH_KEEP_GC") != "1":
+        gc.disable()
+    return gc.enable if was_on else (lambda: None)
+
+
 class KernelTimer:
     """HIP event pairs (on the launch stream) around the C-ABI entry points of behindthescenes_amd.native: every bts:: kernel of a step
     lies inside exactly one pair (nested entry points -- distance_to_z -> invert_small -- count once, at the outermost).  What the pairs
@@ -391,6 +403,7 @@ def train_workload(args, world, rank, dev):
         return
     timer = KernelTimer()
     timer.install()
+    unpark_gc = park_gc()
     torch.cuda.synchronize()
     if torch.distributed.is_initialized():
         torch.distributed.barrier()
@@ -400,6 +413,7 @@ def train_workload(args, world, rank, dev):
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
+    unpark_gc()
     if torch.distributed.is_initialized():
         torch.distributed.barrier()
         torch.cuda.synchronize()
@@ -537,12 +551,14 @@ def profile_workload(args, world, rank, dev):
     if torch.distributed.is_initialized():
         torch.distributed.barrier()
         torch.cuda.synchronize()
+    unpark_gc = park_gc()
     t0 = time.perf_counter()
     for i in range(args.steps):
         ev[i][0].record()
         prof = step()
         ev[i][1].record()
     torch.cuda.synchronize()
+    unpark_gc()
     if torch.distributed.is_initialized():
         torch.distributed.barrier()
         torch.cuda.synchronize()
@@ -685,12 +701,14 @@ def main():
     if launched:
         torch.distributed.barrier()
         torch.cuda.synchronize()
+    unpark_gc = park_gc()
     t0 = time.perf_counter()
     for i in range(args.steps):
         ev[i][0].record()
         step()
         ev[i][1].record()
     torch.cuda.synchronize()
+    unpark_gc()
     if launched:
         torch.distributed.barrier()
         torch.cuda.synchronize()

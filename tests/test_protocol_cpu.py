@@ -209,3 +209,22 @@ def test_fused_train_step_says_why_a_configuration_takes_the_entry_by_entry_path
     assert M.shape == (9, 6) and abs(M[8, 0].item() - 2.0 / 512 / 2) < 1e-12 and abs(M[8, 4].item() - 0.001 / 2 / 512 / 2) < 1e-12
     crit.lambda_edge_aware_smoothness = 0.01          # a schedule that changes a lambda gets a new matrix (the reference reads it per call)
     assert abs(crit.loss_matrix(2, (512, 512), (True, True))[8, 1].item() - 0.01 / 512 / 2) < 1e-12
+
+
+def test_patch_draws_into_preallocated_int32_rows_consume_the_generator_like_the_reference_calls():
+    """FusedTrainStep draws the patch coordinates straight into a pinned int32 block (``PatchRaySampler.draw_patches(rows=...)``):
+    ``t.random_(0, hi)`` per row must give the values -- and leave the generator in the state -- of the reference's
+    ``torch.randint(0, hi, (P,))`` calls in the same order (ray_sampler.py:141-143), for int32 as for int64."""
+    import behindthescenes_amd as bts
+    for P_rays, n, v, h, w in ((2048, 8, 3, 192, 640), (4096, 2, 4, 64, 96), (64, 3, 1, 9, 9)):
+        ps = bts.PatchRaySampler(ray_batch_size=P_rays, z_near=3.0, z_far=80.0, patch_size=8)
+        torch.manual_seed(123)
+        pv, py, px = ps.draw_patches(n, v, h, w)
+        after = torch.rand(3)
+        P = ps._patch_count
+        block = torch.full((3, n, P), -1, dtype=torch.int32)
+        rows = [block[j, i] for i in range(n) for j in range(3)]
+        torch.manual_seed(123)
+        assert ps.draw_patches(n, v, h, w, rows=rows) is None
+        assert torch.equal(block[0].long(), pv) and torch.equal(block[1].long(), py) and torch.equal(block[2].long(), px)
+        assert torch.equal(torch.rand(3), after)
