@@ -21,7 +21,7 @@
 // operand is the EXACT sum of three bf16 numbers, six bf16 products reproduce the fp32 product to 2^-24 (see below), and the bf16 pipe
 // is 16 x the fp32 one per instruction -- 0.375 of the matrix time with better sums than before (blocked accumulation).  bf16, not f16:
 // activations and gradients have no bounded range to scale an f16 split on, and bf16 carries fp32's exponent.
-#include "bts_common.h"
+#include "bts_bf16x3.h"
 
 #include <cstring>
 
@@ -59,29 +59,7 @@ __device__ __forceinline__ int reflect(int i, int L) { return i < 0 ? -i : (i >=
 // consecutive channels of one pixel = one bf16 A fragment per term) -- and LDS: three terms x 2 bytes per weight are 221 KB for the
 // layer, so a work-group keeps the weights of HALF the output channels (110.6 KB) and two work-groups of the same XCD walk the same
 // tiles (the second read of a tile comes from that XCD's L2).
-typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
-typedef unsigned u32x4c __attribute__((ext_vector_type(4)));
 constexpr int kConvBfLds = 9 * 4 * 3 * 64 * 16;   // bytes: [tap][k-step of 16][term h, m, l][lane][8 bf16]
-
-__device__ __forceinline__ unsigned f2u(float x) { return __builtin_bit_cast(unsigned, x); }
-__device__ __forceinline__ float u2f(unsigned x) { return __builtin_bit_cast(float, x); }
-// (a, b) -> the three bf16 pairs (a in the low half): h, m, l
-__device__ __forceinline__ void split3_pair(float a, float b, unsigned& ph, unsigned& pm, unsigned& pl) {
-  const float ra = a - u2f(f2u(a) & 0xFFFF0000u), rb = b - u2f(f2u(b) & 0xFFFF0000u);
-  const float la = ra - u2f(f2u(ra) & 0xFFFF0000u), lb = rb - u2f(f2u(rb) & 0xFFFF0000u);
-  ph = __builtin_amdgcn_perm(f2u(b), f2u(a), 0x07060302u);
-  pm = __builtin_amdgcn_perm(f2u(rb), f2u(ra), 0x07060302u);
-  pl = __builtin_amdgcn_perm(f2u(lb), f2u(la), 0x07060302u);
-}
-// a lane's 8 consecutive channels -> its A (or B) fragment of a k-step, three terms
-__device__ __forceinline__ void split3_frag(const float4& v0, const float4& v1, bf8& fh, bf8& fm, bf8& fl) {
-  unsigned h[4], m[4], l[4];
-  split3_pair(v0.x, v0.y, h[0], m[0], l[0]), split3_pair(v0.z, v0.w, h[1], m[1], l[1]);
-  split3_pair(v1.x, v1.y, h[2], m[2], l[2]), split3_pair(v1.z, v1.w, h[3], m[3], l[3]);
-  fh = __builtin_bit_cast(bf8, (u32x4c){h[0], h[1], h[2], h[3]}), fm = __builtin_bit_cast(bf8, (u32x4c){m[0], m[1], m[2], m[3]});
-  fl = __builtin_bit_cast(bf8, (u32x4c){l[0], l[1], l[2], l[3]});
-}
-
 // weights -> LDS for one half of the columns: byte (((tap * 4 + s) * 3 + term) * 64 + lane) * 16 + 2 i holds term `term` of the weight
 // at k = 16 s + 8 h + i, column `half` * 32 + col (lane = 32 h + col).  FWD: k = ci, column = co;  TRANSPOSED (data gradient): k = co,
 // column = ci.  The threads walk w in memory order (coalesced), every thread splits one weight and drops three 2-byte pieces.
@@ -473,30 +451,6 @@ constexpr int kWgradPart = 9 * kTapFloats + 64;
 // the next k-step's loads in flight this stays under 168: three waves per SIMD).  No LDS.  Partial sums per work-group into the
 // workspace, conv_wgrad_reduce_kernel adds them up -- no atomics, the same bits on every run.
 // ---------------------------------------------------------------------------------------------------------------------------------
-struct WSplit {
-  float v, r1, r2;   // x, x - h, x - h - m: the top 16 bits of the three are the bf16 terms
-};
-__device__ __forceinline__ WSplit wsplit(float x) {
-  WSplit o;
-  o.v = x;
-  o.r1 = x - u2f(f2u(x) & 0xFFFF0000u);
-  o.r2 = o.r1 - u2f(f2u(o.r1) & 0xFFFF0000u);
-  return o;
-}
-template <int N>
-__device__ __forceinline__ void wfrags(const WSplit (&sv)[N], int first, bf8& fh, bf8& fm, bf8& fl) {   // pairs (first + 2 j, first + 2 j + 1), j = 0..3
-  unsigned h[4], m[4], l[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const WSplit &a = sv[first + 2 * j], &b = sv[first + 2 * j + 1];
-    h[j] = __builtin_amdgcn_perm(f2u(b.v), f2u(a.v), 0x07060302u);
-    m[j] = __builtin_amdgcn_perm(f2u(b.r1), f2u(a.r1), 0x07060302u);
-    l[j] = __builtin_amdgcn_perm(f2u(b.r2), f2u(a.r2), 0x07060302u);
-  }
-  fh = __builtin_bit_cast(bf8, (u32x4c){h[0], h[1], h[2], h[3]}), fm = __builtin_bit_cast(bf8, (u32x4c){m[0], m[1], m[2], m[3]});
-  fl = __builtin_bit_cast(bf8, (u32x4c){l[0], l[1], l[2], l[3]});
-}
-
 __global__ __launch_bounds__(768) void conv_wgrad_bf_kernel(const WgradParams p) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, col = lane & 31;
   const int ty = wave >> 2, quad = wave & 3, ct = quad >> 1, cit = quad & 1;
