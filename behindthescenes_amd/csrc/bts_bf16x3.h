@@ -6,7 +6,8 @@
 // is six v_mfma_f32_32x32x16_bf16 (8 passes, k = 16) where the fp32-input pipe needs eight v_mfma_f32_32x32x2_f32 (16 passes, k = 2
 // each): 0.375 of the matrix time, every product exact in the fp32 accumulator; measured against fp64 the sums are CLOSER than the
 // fp32-input MFMA's (it adds 16 products at a time).  The price is the split: 5.5 VALU instructions per operand element.
-// Used by the decoder tail's convolutions (bts_conv.hip) and the sparse projection backward (bts_prep.hip).
+// Used by the decoder tail's convolutions (bts_conv.hip).  Tried for the sparse projection backward too and not kept: that pass is
+// traffic-bound, a third of its matrix time moves it by 4 % (profiles/r05u).
 #pragma once
 #include "bts_common.h"
 
