@@ -12,7 +12,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 # BTS_ALLOW_LIB_OVERRIDE=1 and announced on stderr, so that a stale variable in somebody's shell cannot silently swap the library.
 _OVERRIDE = os.environ.get("BTS_RENDER_LIB") if os.environ.get("BTS_ALLOW_LIB_OVERRIDE") == "1" else None
 LIB_PATH = _OVERRIDE or os.path.join(PKG, "libbts_render.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 BTS_MAX_SCALES = 4
 BTS_MAX_LOSS_VIEWS = 16
 
@@ -57,7 +57,7 @@ class BtsTrainScale(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in ("feat_nchw", "jitter", "rgb", "depth", "invalid_wsum", "invalid_any", "proj_nhwc", "sampled_tiles",
                                           "z_samp", "sigma_raw", "trans", "rgb_samps", "loss_parts", "g_rgb", "g_depth", "gs_rgb", "gs_depth",
                                           "d_proj_nhwc", "d_proj_tiles", "d_feat_nchw")] + \
-               [("feat_shift", C.c_int32), ("reserved_", C.c_int32)]
+               [("feat_shift", C.c_int32), ("feat_channels_last", C.c_int32)]
 
 
 class BtsTrainStep(C.Structure):
@@ -103,6 +103,8 @@ SYMBOLS = {
     "bts_project_features_bwd": (C.c_int, [C.POINTER(BtsFieldCfg), _P, _P, _P, _I, _P, _P, _P]),
     "bts_proj_tile_count": (C.c_int64, [C.POINTER(BtsFieldCfg)]),
     "bts_project_features_bwd_tiles": (C.c_int, [C.POINTER(BtsFieldCfg), _P, _P, _P, _P, _I, _P, _P, _I, _P]),
+    "bts_project_features_cl": (C.c_int, [C.POINTER(BtsFieldCfg), _P, _P, _I, _P, _P, _P]),
+    "bts_project_features_bwd_cl": (C.c_int, [C.POINTER(BtsFieldCfg), _P, _P, _P, _P, _I, _P, _P, _I, _P]),
     "bts_mark_sampled_tiles": (C.c_int, [C.POINTER(BtsFieldCfg), _P, _P, C.POINTER(BtsRenderArgs), _P, _P]),
     "bts_project_features_tiles": (C.c_int, [C.POINTER(BtsFieldCfg), _P, _P, _I, _P, _P, _P]),
     "bts_field_query": (C.c_int, [C.POINTER(BtsFieldCfg), C.POINTER(BtsFieldTensors), _P, _I, _I, _P, _P, _P, _P]),

@@ -13,12 +13,15 @@ def register_backbone(name, factory):
 
 
 class FeatureMapEncoder(nn.Module):
-    def __init__(self, size, feat_dim, num_views=1, n_scales=1, pyramid=False):
+    def __init__(self, size, feat_dim, num_views=1, n_scales=1, pyramid=False, channels_last=False):
         """pyramid=True halves the resolution per scale, like the decoder outputs of the reference's Monodepth2 (BTSNet.encode
-        resizes every scale back to scale 0's size, models_bts.py:111-119)."""
+        resizes every scale back to scale 0's size, models_bts.py:111-119).  channels_last=True keeps the maps in torch's channels_last
+        format -- (num_views, h, w, feat_dim) in memory, what a CNN running MIOpen's NHWC kernels (the shipped Monodepth2 does) hands
+        over; the default is the NCHW-contiguous tensor a plain ``nn.Conv2d`` stack returns."""
         super().__init__()
         sizes = [tuple(max(1, d >> s) for d in size) if pyramid else tuple(size) for s in range(n_scales)]
-        self.feats = nn.ParameterList([nn.Parameter(torch.randn(num_views, feat_dim, *sz)) for sz in sizes])
+        fmt = torch.channels_last if channels_last else torch.contiguous_format
+        self.feats = nn.ParameterList([nn.Parameter(torch.randn(num_views, feat_dim, *sz).contiguous(memory_format=fmt)) for sz in sizes])
         self.latent_size = feat_dim
         self.scales = list(range(n_scales))
 
@@ -32,7 +35,8 @@ class FeatureMapEncoder(nn.Module):
 
     @classmethod
     def from_conf(cls, conf, **kw):
-        return cls(tuple(conf["size"]), conf.get("d_out", 64), conf.get("num_views", 1), conf.get("n_scales", 1), conf.get("pyramid", False))
+        return cls(tuple(conf["size"]), conf.get("d_out", 64), conf.get("num_views", 1), conf.get("n_scales", 1), conf.get("pyramid", False),
+                   conf.get("channels_last", False))
 
 
 register_backbone("feature_map", FeatureMapEncoder.from_conf)

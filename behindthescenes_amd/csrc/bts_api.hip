@@ -22,11 +22,12 @@ int sample_coarse_launch(const float* rays, const float* u, long B, int K, int l
 int distance_to_z_launch(const float* depths, const float* invK, int N, int H, int W, float* out, hipStream_t s);
 int invert_small_launch(const float* src, float* dst, int N, int dim, hipStream_t s);
 
-int project_features_impl(int C, int HD, const float* feat, const float* mlp, int N, int HW, float* proj, const unsigned char* tiles, hipStream_t s);
+int project_features_impl(int C, int HD, const float* feat, const float* mlp, int N, int HW, float* proj, const unsigned char* tiles, hipStream_t s,
+                          bool feat_cl = false);
 int mark_tiles_impl(const float* rays, const float* z_samp, const float* jitter, const float* w2c_enc, const float* K_enc, long B, int Bp, int K, int lindisp,
                     int H, int W, int fs, unsigned char* tiles, hipStream_t s);
 int project_features_bwd_tiles_impl(int C, int HD, const float* feat, float* dproj, unsigned char* tiles, const float* mlp, int N, int HW, float* dfeat,
-                                    float* d_mlp, int clear, hipStream_t s);
+                                    float* d_mlp, int clear, hipStream_t s, bool feat_cl = false);
 int project_features_bwd_impl(int C, int HD, const float* feat, const float* dproj, const float* mlp, int N, int HW, float* dfeat,
                               float* d_mlp, hipStream_t s);
 int render_fwd_impl(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const BtsRenderArgs* a, hipStream_t s);
@@ -238,6 +239,41 @@ int bts_project_features_bwd_tiles(const BtsFieldCfg* cfg, const float* feat_nch
   int rc = project_features_bwd_tiles_impl(cfg->C, cfg->d_hidden, feat_nchw, d_proj_nhwc, tiles, mlp_params, N, (int)feat_texels(cfg), d_feat_nchw,
                                            d_mlp_params, clear_after, (hipStream_t)stream);
   if (rc) set_error("%s: kernel launch failed", "bts_project_features_bwd_tiles");
+  return rc;
+}
+
+int bts_project_features_cl(const BtsFieldCfg* cfg, const float* feat_nhwc, const float* mlp_params, int32_t N, const uint8_t* tiles, float* proj_nhwc,
+                            void* stream) {
+  if (!cfg || !feat_nhwc || !mlp_params || !proj_nhwc || N <= 0 || cfg->H <= 0 || cfg->W <= 0) {
+    set_error("%s: NULL pointer or non-positive size", "bts_project_features_cl");
+    return BTS_E_INVALID;
+  }
+  if (!bts_supported(cfg)) {
+    set_error("%s: configuration outside the compiled envelope (C=%ld d_hidden=%ld n_blocks=%ld)", "bts_project_features_cl", cfg->C, cfg->d_hidden,
+              cfg->n_blocks);
+    return BTS_E_UNSUPPORTED;
+  }
+  if (int rc = check_shift(cfg, "bts_project_features_cl")) return rc;
+  int rc = project_features_impl(cfg->C, cfg->d_hidden, feat_nhwc, mlp_params, N, (int)feat_texels(cfg), proj_nhwc, tiles, (hipStream_t)stream, true);
+  if (rc) set_error("%s: kernel launch failed", "bts_project_features_cl");
+  return rc;
+}
+
+int bts_project_features_bwd_cl(const BtsFieldCfg* cfg, const float* feat_nhwc, float* d_proj_nhwc, uint8_t* tiles, const float* mlp_params, int32_t N,
+                                float* d_feat_nhwc, float* d_mlp_params, int32_t clear_after, void* stream) {
+  if (!cfg || !d_proj_nhwc || !mlp_params || N <= 0 || cfg->H <= 0 || cfg->W <= 0 || (d_mlp_params && !feat_nhwc)) {
+    set_error("%s: NULL pointer or non-positive size", "bts_project_features_bwd_cl");
+    return BTS_E_INVALID;
+  }
+  if (!bts_supported(cfg)) {
+    set_error("%s: configuration outside the compiled envelope (C=%ld d_hidden=%ld n_blocks=%ld)", "bts_project_features_bwd_cl", cfg->C, cfg->d_hidden,
+              cfg->n_blocks);
+    return BTS_E_UNSUPPORTED;
+  }
+  if (int rc = check_shift(cfg, "bts_project_features_bwd_cl")) return rc;
+  int rc = project_features_bwd_tiles_impl(cfg->C, cfg->d_hidden, feat_nhwc, d_proj_nhwc, tiles, mlp_params, N, (int)feat_texels(cfg), d_feat_nhwc,
+                                           d_mlp_params, clear_after, (hipStream_t)stream, true);
+  if (rc) set_error("%s: kernel launch failed", "bts_project_features_bwd_cl");
   return rc;
 }
 

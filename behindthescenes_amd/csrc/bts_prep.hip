@@ -19,7 +19,10 @@ void set_error(const char* fmt, const char* a = "", long b = 0, long c = 0, long
 // Persistent work-groups (the weights are staged once per work-group, not once per 256 pixels) and ALL of a tile's loads issued
 // before its first MFMA: round 3 kept 8 loads (2 KB) per wave in flight and ran at 45 % of HBM speed (latency-bound by Little's law);
 // 64 loads per wave keep 16 KB in flight.
-template <int C, int HD>
+// FEAT_CL: F is channels-last, (N, H, W, C) in memory (a torch tensor of shape (N, C, H, W) in channels_last format: what MIOpen's NHWC
+// kernels and bts_conv3x3_fwd produce): a lane reads ITS pixel's channels as float4 pieces -- k-step (q, e) pairs channel 8 q + e
+// (lane half 0) with 8 q + 4 + e (half 1) -- and a tile is 64 x C x 4 contiguous bytes instead of C row pieces of 256.
+template <int C, int HD, bool FEAT_CL>
 __global__ __launch_bounds__(256, 2) void project_kernel(const float* __restrict__ feat, const float* __restrict__ mlp, float* __restrict__ proj,
                                                       int HW, int tiles_per_img, int n_tiles, const unsigned char* __restrict__ tiles) {
   constexpr int HT = HD / 32;
@@ -44,6 +47,34 @@ __global__ __launch_bounds__(256, 2) void project_kernel(const float* __restrict
     const int p0 = (tile - img * tiles_per_img) * 64;
     const float* F = feat + (long)img * C * HW;
     float* G = proj + (long)img * HW * HD;
+    f32x16 acc[2][HT];
+    if constexpr (FEAT_CL) {
+      const float4* F4 = reinterpret_cast<const float4*>(F);
+      const unsigned q0 = (unsigned)(min(p0 + col, HW - 1) * (C / 4) + h), q1 = (unsigned)(min(p0 + 32 + col, HW - 1) * (C / 4) + h);
+      float4 v0[C / 8], v1[C / 8];
+#pragma unroll
+      for (int q = 0; q < C / 8; ++q) v0[q] = F4[q0 + 2 * q], v1[q] = F4[q1 + 2 * q];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+        for (int ht = 0; ht < HT; ++ht) acc[pt][ht] = zero_acc();
+#pragma unroll
+      for (int q = 0; q < C / 8; ++q) {
+        const float* a0 = reinterpret_cast<const float*>(&v0[q]);
+        const float* a1 = reinterpret_cast<const float*>(&v1[q]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int c = 8 * q + 4 * h + e;
+#pragma unroll
+          for (int ht = 0; ht < HT; ++ht) {
+            const float b = wl[c * HD + ht * 32 + col];
+            acc[0][ht] = mfma(a0[e], b, acc[0][ht]);
+            acc[1][ht] = mfma(a1[e], b, acc[1][ht]);
+          }
+        }
+      }
+    } else {
     // wave-uniform base + 32-bit lane offset (one image's map is far below 4 GB): scalar-base loads, no 64-bit address per load
     const unsigned o0 = (unsigned)(h * HW + min(p0 + col, HW - 1)), o1 = (unsigned)(h * HW + min(p0 + 32 + col, HW - 1));
     float a0[C / 2], a1[C / 2];
@@ -53,7 +84,6 @@ __global__ __launch_bounds__(256, 2) void project_kernel(const float* __restrict
       a0[s] = row[o0], a1[s] = row[o1];
     }
     __builtin_amdgcn_sched_barrier(0);   // the scheduler otherwise sinks every load to its MFMA (two loads in flight, measured 2.9 TB/s)
-    f32x16 acc[2][HT];
 #pragma unroll
     for (int pt = 0; pt < 2; ++pt)
 #pragma unroll
@@ -67,6 +97,7 @@ __global__ __launch_bounds__(256, 2) void project_kernel(const float* __restrict
         acc[0][ht] = mfma(a0[s], b, acc[0][ht]);
         acc[1][ht] = mfma(a1[s], b, acc[1][ht]);
       }
+    }
     }
 #pragma unroll
     for (int pt = 0; pt < 2; ++pt)
@@ -236,6 +267,78 @@ __device__ __forceinline__ void project_df_half_tiles(const float* __restrict__ 
   }
 }
 
+// ---- the two contractions of a tile with F and dF channels-last ((N, H, W, C) in memory):
+//   dW: B[k = pix][j = c] = F[pix][c]: 32 lanes = 32 consecutive channels of one pixel, like the dG operand -- 128-byte pieces both
+//   dF: D[pix][c] = A[pix][hid] . B[hid][c]: the roles of the NCHW form swapped -- dG rows are the A operand, w_in from LDS the B operand,
+//       D rows (pixels) sit in registers, columns (channels) across the lanes: every store is a 128-byte piece of a pixel's channel vector
+template <int C, int HD>
+__device__ __forceinline__ void project_dw_tile_cl(const float* __restrict__ F, const float* __restrict__ dG, int p0, int HW, int h, int col,
+                                                   f32x16 (&accw)[HD / 32][C / 32]) {
+  constexpr int HT = HD / 32, CT = C / 32;
+  const bool full = p0 + 64 <= HW;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    float fv[4][4][CT];
+    float av[4][4][HT];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int pix4 = p0 + 8 * (4 * half + t) + 4 * h;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int pix = pix4 + e;
+        const bool in = full || pix < HW;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) fv[t][e][ct] = in ? F[(unsigned)(pix * C + ct * 32 + col)] : 0.0f;
+#pragma unroll
+        for (int ht = 0; ht < HT; ++ht) av[t][e][ht] = in ? dG[(unsigned)(pix * HD + ht * 32 + col)] : 0.0f;
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);   // all loads of the half are out before its first MFMA
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int ht = 0; ht < HT; ++ht)
+#pragma unroll
+          for (int ct = 0; ct < CT; ++ct) accw[ht][ct] = mfma(av[t][e][ht], fv[t][e][ct], accw[ht][ct]);
+  }
+}
+template <int C, int HD>
+__device__ __forceinline__ void project_df_half_tiles_cl(const float* __restrict__ dG, float* __restrict__ dF, const float* wl, int p0, int HW, int h, int col) {
+  constexpr int CT = C / 32;
+  const float4* dG4 = reinterpret_cast<const float4*>(dG);
+#pragma unroll 1
+  for (int pt = 0; pt < 2; ++pt) {
+    const int px = min(p0 + pt * 32 + col, HW - 1);
+    float4 v[HD / 8];
+#pragma unroll
+    for (int qq = 0; qq < HD / 8; ++qq) v[qq] = dG4[(unsigned)(px * (HD / 4) + (qq >> 2) * 8 + 4 * h + (qq & 3))];
+    __builtin_amdgcn_sched_barrier(0);
+    f32x16 acc[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) acc[ct] = zero_acc();
+#pragma unroll
+    for (int qq = 0; qq < HD / 8; ++qq) {
+      const float* a = reinterpret_cast<const float*>(&v[qq]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int hid = (qq >> 2) * 32 + 8 * (qq & 3) + 4 * h + e;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) acc[ct] = mfma(a[e], wl[hid * C + ct * 32 + col], acc[ct]);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int pix = p0 + pt * 32 + mfma_row(q, h);
+      if (pix < HW) {
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) dF[(unsigned)(pix * C + ct * 32 + col)] = acc[ct][q];
+      }
+    }
+  }
+}
+
 // the weight gradient's way out: registers -> work-group LDS (red = HD x C floats, reused from the staged weights) -> one atomic per (hid, c)
 template <int C, int HD>
 __device__ __forceinline__ void project_dw_flush(float* red, const f32x16 (&accw)[HD / 32][C / 32], bool has_acc, float* __restrict__ d_mlp, int h, int col) {
@@ -305,7 +408,9 @@ __global__ __launch_bounds__(256, 2) void project_bwd_kernel(const float* __rest
 // dense write of dF plus a tenth of the reads.  Every wave takes whole tiles: a dirty one gets both contractions (the second read of
 // its dG rows comes from L1 / L2), a clean one 16 wide zero stores.  With `clear` the wave then writes zeros over the dirty tile and
 // resets its byte -- the (dproj, tiles) pair is all zero again when the kernel ends, and the caller never fills 503 MB before a step.
-template <int C, int HD>
+// FEAT_CL: F and dF channels-last (see project_kernel).  tiles == NULL: every tile counts as flagged and nothing is cleared (the dense
+// backward of a channels-last map).
+template <int C, int HD, bool FEAT_CL>
 __global__ __launch_bounds__(256, 2) void project_bwd_tiles_kernel(const float* __restrict__ feat, float* dproj, unsigned char* tiles, const float* __restrict__ mlp,
                                                                 float* __restrict__ dfeat, float* __restrict__ d_mlp, int HW, int tiles_per_img, int n_tiles,
                                                                 int clear) {
@@ -330,17 +435,22 @@ __global__ __launch_bounds__(256, 2) void project_bwd_tiles_kernel(const float* 
   const float4 z4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 
   const int tile0 = blockIdx.x * 4 + wave, stride = gridDim.x * 4;
-  int flag_n = tile0 < n_tiles ? (int)tiles[tile0] : 0;   // a tile's flag is fetched one tile ahead
+  int flag_n = !tiles ? 1 : (tile0 < n_tiles ? (int)tiles[tile0] : 0);   // a tile's flag is fetched one tile ahead
   for (int tile = tile0; tile < n_tiles; tile += stride) {
     const int img = tile / tiles_per_img;
     const int p0 = (tile - img * tiles_per_img) * 64;
     const bool dirty = __builtin_amdgcn_readfirstlane(flag_n) != 0;
-    flag_n = tile + stride < n_tiles ? (int)tiles[tile + stride] : 0;
+    flag_n = !tiles ? 1 : (tile + stride < n_tiles ? (int)tiles[tile + stride] : 0);
     if (dirty) {
       float* dG = dproj + (long)img * HW * HD;
-      if (d_mlp) project_dw_tile<C, HD>(feat + (long)img * C * HW, dG, p0, HW, vec4, h, col, accw);
-      if (dfeat) project_df_half_tiles<C, HD>(dG, dfeat + (long)img * C * HW, wl, p0, HW, h, col);
-      if (clear) {
+      if constexpr (FEAT_CL) {
+        if (d_mlp) project_dw_tile_cl<C, HD>(feat + (long)img * C * HW, dG, p0, HW, h, col, accw);
+        if (dfeat) project_df_half_tiles_cl<C, HD>(dG, dfeat + (long)img * C * HW, wl, p0, HW, h, col);
+      } else {
+        if (d_mlp) project_dw_tile<C, HD>(feat + (long)img * C * HW, dG, p0, HW, vec4, h, col, accw);
+        if (dfeat) project_df_half_tiles<C, HD>(dG, dfeat + (long)img * C * HW, wl, p0, HW, h, col);
+      }
+      if (clear && tiles) {
         // (this wave is the only reader of the tile and its loads have returned: their values went through the MFMAs above)
         __builtin_amdgcn_sched_barrier(0);
         const int npx = min(64, HW - p0);
@@ -350,9 +460,22 @@ __global__ __launch_bounds__(256, 2) void project_bwd_tiles_kernel(const float* 
       }
     } else if (dfeat) {
       float* dF = dfeat + (long)img * C * HW;
+      if constexpr (FEAT_CL) {       // the tile's pixels x C floats are contiguous
+        const int npx = min(64, HW - p0);
+        float4* row = reinterpret_cast<float4*>(dF + (long)p0 * C);
+#ifdef BTS_PROJ_NT
+        for (int i = lane; i < npx * (C / 4); i += 64) __builtin_nontemporal_store((f32x4){0.0f, 0.0f, 0.0f, 0.0f}, reinterpret_cast<f32x4*>(row + i));
+#else
+        for (int i = lane; i < npx * (C / 4); i += 64) row[i] = z4;
+#endif
+      } else
       if (vec4 && p0 + 64 <= HW) {   // 16 stores of 4 channel rows x 64 pixels
 #pragma unroll
+#ifdef BTS_PROJ_NT
+        for (int i = 0; i < C / 4; ++i) __builtin_nontemporal_store((f32x4){0.0f, 0.0f, 0.0f, 0.0f}, reinterpret_cast<f32x4*>(dF + (unsigned)((4 * i + (lane >> 4)) * HW + p0 + 4 * (lane & 15))));
+#else
         for (int i = 0; i < C / 4; ++i) *reinterpret_cast<float4*>(dF + (unsigned)((4 * i + (lane >> 4)) * HW + p0 + 4 * (lane & 15))) = z4;
+#endif
       } else if (p0 + lane < HW) {
 #pragma unroll 8
         for (int c = 0; c < C; ++c) dF[(unsigned)(c * HW + p0 + lane)] = 0.0f;
@@ -374,11 +497,13 @@ static int prep_cus() {
 }
 
 template <int C, int HD>
-static int run_fwd(const float* feat, const float* mlp, int N, int HW, float* proj, const unsigned char* tiles, hipStream_t s) {
+static int run_fwd(const float* feat, const float* mlp, int N, int HW, float* proj, const unsigned char* tiles, bool feat_cl, hipStream_t s) {
   const int tpi = (HW + 63) / 64;
   const long n_tiles = (long)N * tpi;
   const long want = (n_tiles + 3) / 4, cap = 4L * prep_cus();     // persistent: <= 4 work-groups per CU (16 KB of LDS each)
-  project_kernel<C, HD><<<(int)(want < cap ? want : cap), 256, 0, s>>>(feat, mlp, proj, HW, tpi, (int)n_tiles, tiles);
+  const int grid = (int)(want < cap ? want : cap);
+  if (feat_cl) project_kernel<C, HD, true><<<grid, 256, 0, s>>>(feat, mlp, proj, HW, tpi, (int)n_tiles, tiles);
+  else project_kernel<C, HD, false><<<grid, 256, 0, s>>>(feat, mlp, proj, HW, tpi, (int)n_tiles, tiles);
   return hipGetLastError() == hipSuccess ? BTS_OK : BTS_E_LAUNCH;
 }
 
@@ -395,18 +520,21 @@ static int run_bwd(const float* feat, const float* dproj, const float* mlp, int 
 
 template <int C, int HD>
 static int run_bwd_tiles(const float* feat, float* dproj, unsigned char* tiles, const float* mlp, int N, int HW, float* dfeat, float* d_mlp, int clear,
-                         hipStream_t s) {
-  if (!dfeat && !d_mlp && !clear) return BTS_OK;
+                         bool feat_cl, hipStream_t s) {
+  if (!dfeat && !d_mlp && !(clear && tiles)) return BTS_OK;
   const int tpi = (HW + 63) / 64;
   const long n_tiles = (long)N * tpi;
   const long want = (n_tiles + 3) / 4, cap = 2L * prep_cus();
-  project_bwd_tiles_kernel<C, HD><<<(int)(want < cap ? want : cap), 256, 0, s>>>(feat, dproj, tiles, mlp, dfeat, d_mlp, HW, tpi, (int)n_tiles, clear);
+  const int grid = (int)(want < cap ? want : cap);
+  if (feat_cl) project_bwd_tiles_kernel<C, HD, true><<<grid, 256, 0, s>>>(feat, dproj, tiles, mlp, dfeat, d_mlp, HW, tpi, (int)n_tiles, clear);
+  else project_bwd_tiles_kernel<C, HD, false><<<grid, 256, 0, s>>>(feat, dproj, tiles, mlp, dfeat, d_mlp, HW, tpi, (int)n_tiles, clear);
   return hipGetLastError() == hipSuccess ? BTS_OK : BTS_E_LAUNCH;
 }
 
-int project_features_impl(int C, int HD, const float* feat, const float* mlp, int N, int HW, float* proj, const unsigned char* tiles, hipStream_t s) {
-  if (C == 64 && HD == 64) return run_fwd<64, 64>(feat, mlp, N, HW, proj, tiles, s);
-  if (C == 32 && HD == 32) return run_fwd<32, 32>(feat, mlp, N, HW, proj, tiles, s);
+int project_features_impl(int C, int HD, const float* feat, const float* mlp, int N, int HW, float* proj, const unsigned char* tiles, hipStream_t s,
+                          bool feat_cl) {
+  if (C == 64 && HD == 64) return run_fwd<64, 64>(feat, mlp, N, HW, proj, tiles, feat_cl, s);
+  if (C == 32 && HD == 32) return run_fwd<32, 32>(feat, mlp, N, HW, proj, tiles, feat_cl, s);
   return BTS_E_UNSUPPORTED;
 }
 
@@ -461,9 +589,9 @@ int project_features_bwd_impl(int C, int HD, const float* feat, const float* dpr
 }
 
 int project_features_bwd_tiles_impl(int C, int HD, const float* feat, float* dproj, unsigned char* tiles, const float* mlp, int N, int HW, float* dfeat,
-                                    float* d_mlp, int clear, hipStream_t s) {
-  if (C == 64 && HD == 64) return run_bwd_tiles<64, 64>(feat, dproj, tiles, mlp, N, HW, dfeat, d_mlp, clear, s);
-  if (C == 32 && HD == 32) return run_bwd_tiles<32, 32>(feat, dproj, tiles, mlp, N, HW, dfeat, d_mlp, clear, s);
+                                    float* d_mlp, int clear, hipStream_t s, bool feat_cl) {
+  if (C == 64 && HD == 64) return run_bwd_tiles<64, 64>(feat, dproj, tiles, mlp, N, HW, dfeat, d_mlp, clear, feat_cl, s);
+  if (C == 32 && HD == 32) return run_bwd_tiles<32, 32>(feat, dproj, tiles, mlp, N, HW, dfeat, d_mlp, clear, feat_cl, s);
   return BTS_E_UNSUPPORTED;
 }
 

@@ -244,8 +244,10 @@ class Monodepth2(nn.Module):
         """images (B, 3, H, W) in [-1, 1] -> [features (B, d_out, H / 2^s, W / 2^s) for s in scales]  (monodepth2.py:279-291)."""
         feats = self._trunk(x)
         dec = self.decoder
-        # scale 0's output convolution writes true NCHW: what bts_project_features takes, no layout pass in between (SURVEY 8 row f4)
-        return [dec._conv(("dispconv", 0), feats[0].permute(0, 2, 3, 1), out_nchw=True) if (s == 0 and dec.tail_is_fused(feats[0])) else
+        # scale 0's output convolution writes channels-last like every other layer here: a (B, d_out, H, W) view over (B, H, W, d_out)
+        # memory, which the hand-over reads as it is (ABI 8: bts_project_features_cl; the map's gradient comes back in the same format, so
+        # neither direction has a layout pass -- SURVEY 8 row f4)
+        return [dec._conv(("dispconv", 0), feats[0].permute(0, 2, 3, 1)).permute(0, 3, 1, 2) if (s == 0 and dec.tail_is_fused(feats[0])) else
                 dec.decoder[dec.decoder_keys[("dispconv", s)]](feats[s]) for s in self.scales]
 
     @classmethod

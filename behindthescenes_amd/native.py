@@ -233,17 +233,39 @@ def proj_storage_order(d_hidden: int) -> torch.Tensor:
     return ht * 32 + 8 * q + 4 * h + e
 
 
+def is_channels_last(t: torch.Tensor) -> bool:
+    """A 4-d tensor whose memory is (N, H, W, C) -- torch's channels_last format -- and not also plain contiguous (C = 1 or H = W = 1)."""
+    return t.dim() == 4 and not t.is_contiguous() and t.is_contiguous(memory_format=torch.channels_last)
+
+
+def as_feature_map(t: torch.Tensor) -> torch.Tensor:
+    """The encoder's map as the library takes it: fp32, dense, in the layout it ALREADY has when that is NCHW or channels-last (ABI 8:
+    bts_project_features_cl -- the format MIOpen's NHWC convolutions and bts_conv3x3_fwd write), a contiguous copy otherwise."""
+    t = t.float()
+    return t if (t.is_contiguous() or is_channels_last(t)) else t.contiguous()
+
+
 def project_features(spec: FieldSpec, feat_nchw: torch.Tensor, mlp_params: torch.Tensor, tiles: Optional[torch.Tensor] = None) -> torch.Tensor:
     """F (N,C,H,W) -> G (N,H,W,Hd) = F . w_in[:, :C]^T with the channels in storage order (proj_storage_order)
     (bts_project_features).  With ``tiles`` (N, proj_tile_count) uint8 only the flagged 64-texel tiles are evaluated and the rest of G
-    is UNINITIALISED (bts_project_features_tiles): a map for the render whose samples ``mark_sampled_tiles`` flagged, nothing else."""
+    is UNINITIALISED (bts_project_features_tiles): a map for the render whose samples ``mark_sampled_tiles`` flagged, nothing else.
+    A channels_last F (memory (N,H,W,C)) is read as it is (bts_project_features_cl): the same G bit for bit."""
     N, Cc, H, W = feat_nchw.shape
-    _req(feat_nchw, "feat_nchw", (N, spec.C, H, W)), _req(mlp_params, "mlp_params", (spec.mlp_param_count(),))
+    cl = is_channels_last(feat_nchw)
+    if cl:
+        _req(feat_nchw.permute(0, 2, 3, 1), "feat (channels_last)", (N, H, W, spec.C))
+    else:
+        _req(feat_nchw, "feat_nchw", (N, spec.C, H, W))
+    _req(mlp_params, "mlp_params", (spec.mlp_param_count(),))
     out = torch.empty((N, H, W, spec.d_hidden), device=feat_nchw.device, dtype=torch.float32)
     cfg = _spec_cfg(spec, N, H, W)
     if tiles is not None:
         if tiles.dtype != torch.uint8 or not tiles.is_contiguous() or tiles.numel() != N * proj_tile_count(spec, H, W) or tiles.device != out.device:
             raise ValueError("tiles: expected a contiguous uint8 tensor of (N, proj_tile_count) on the map's device")
+    if cl:
+        _lib.check(_lib.load().bts_project_features_cl(C.byref(cfg), _ptr(feat_nchw), _ptr(mlp_params), N, _ptr(tiles), _ptr(out), _stream(out)),
+                   "bts_project_features_cl")
+    elif tiles is not None:
         _lib.check(_lib.load().bts_project_features_tiles(C.byref(cfg), _ptr(feat_nchw), _ptr(mlp_params), N, _ptr(tiles), _ptr(out), _stream(out)),
                    "bts_project_features_tiles")
     else:
@@ -270,16 +292,27 @@ def mark_sampled_tiles(spec: FieldSpec, n: int, H: int, W: int, feat_shift: int,
 def project_features_bwd(spec: FieldSpec, feat_nchw, d_proj, mlp_params, need_feat=True, need_mlp=True, tiles=None, clear_after=False):
     """-> (d_feat_nchw | None, d_mlp_params | None) (bts_project_features_bwd).  With ``tiles`` (N, proj_tile_count) uint8 -- the flags
     ``render_bwd`` set next to a d_proj that was all zero before -- only the flagged 64-texel tiles of d_proj are read
-    (bts_project_features_bwd_tiles); ``clear_after`` returns the pair to all zero."""
+    (bts_project_features_bwd_tiles); ``clear_after`` returns the pair to all zero.  For a channels_last F the gradient comes back
+    channels_last as well (bts_project_features_bwd_cl): same values, a 64-texel tile of either is one contiguous piece."""
     N, Cc, H, W = feat_nchw.shape
-    _req(feat_nchw, "feat_nchw"), _req(d_proj, "d_proj", (N, H, W, spec.d_hidden)), _req(mlp_params, "mlp_params")
-    d_feat = torch.empty_like(feat_nchw) if need_feat else None
+    cl = is_channels_last(feat_nchw)
+    if cl:
+        _req(feat_nchw.permute(0, 2, 3, 1), "feat (channels_last)")
+    else:
+        _req(feat_nchw, "feat_nchw")
+    _req(d_proj, "d_proj", (N, H, W, spec.d_hidden)), _req(mlp_params, "mlp_params")
+    d_feat = torch.empty_like(feat_nchw) if need_feat else None          # (preserve_format: channels_last stays channels_last)
     d_mlp = torch.zeros_like(mlp_params) if need_mlp else None
     cfg = _spec_cfg(spec, N, H, W)
     lib = _lib.load()
     if tiles is not None:
         if tiles.dtype != torch.uint8 or not tiles.is_contiguous() or tiles.numel() != N * proj_tile_count(spec, H, W) or tiles.device != d_proj.device:
             raise ValueError("tiles: expected a contiguous uint8 tensor of (N, proj_tile_count) on d_proj's device")
+    if cl:
+        _lib.check(lib.bts_project_features_bwd_cl(C.byref(cfg), _ptr(feat_nchw), _ptr(d_proj), _ptr(tiles), _ptr(mlp_params), N, _ptr(d_feat),
+                                                   _ptr(d_mlp), 1 if (clear_after and tiles is not None) else 0, _stream(d_proj)),
+                   "bts_project_features_bwd_cl")
+    elif tiles is not None:
         _lib.check(lib.bts_project_features_bwd_tiles(C.byref(cfg), _ptr(feat_nchw), _ptr(d_proj), _ptr(tiles), _ptr(mlp_params), N, _ptr(d_feat),
                                                       _ptr(d_mlp), 1 if clear_after else 0, _stream(d_proj)), "bts_project_features_bwd_tiles")
     else:
@@ -660,7 +693,7 @@ class ProjectFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, feat_nchw, mlp_params, spec, link=None, tiles=None):
-        feat_nchw = feat_nchw.contiguous()
+        feat_nchw = as_feature_map(feat_nchw)
         ctx.set_materialize_grads(False)
         ctx.spec, ctx.link = spec, link
         ctx.save_for_backward(feat_nchw, mlp_params)

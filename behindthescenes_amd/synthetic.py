@@ -68,7 +68,7 @@ def init_mlp_(mlp, seed=7, out_std=0.3):
 def set_feature_map(net, feat):
     """Loads ``feat`` (n, C, H, W) into the feature-map stand-in encoder of ``net``."""
     with torch.no_grad():
-        net.encoder.feats[0].data = feat.clone()
+        net.encoder.feats[0].copy_(feat)          # (keeps the parameter's memory format: NCHW or channels_last)
     return net
 
 

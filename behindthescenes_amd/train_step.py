@@ -117,6 +117,7 @@ class _TrainStepFn(torch.autograd.Function):
         st.empty_feature = None if empty_feature is None else empty_feature.data_ptr()
         for s, f in enumerate(feats):
             st.scale[s].feat_nchw = f.data_ptr()
+            st.scale[s].feat_channels_last = int(native.is_channels_last(f))
         native.train_step_fwd(st, native._stream(mlp_params))
         vals = job.vals
         ctx.n_feats = len(feats)
@@ -157,6 +158,7 @@ class _TrainStepFn(torch.autograd.Function):
         st.d_empty_proj = arena.d_empty_proj.data_ptr() if ctx.has_empty else None
         for s, (f, d) in enumerate(zip(feats, d_feats)):
             st.scale[s].feat_nchw = f.data_ptr()
+            st.scale[s].feat_channels_last = int(native.is_channels_last(f))          # (empty_like keeps the format: d has f's layout)
             st.scale[s].d_feat_nchw = None if d is None else d.data_ptr()
         g = g_loss.detach().float().contiguous()
         try:
@@ -295,7 +297,7 @@ class FusedTrainStep(torch.nn.Module):
             sh = net._scale_shift(tuple(il.shape[-2:]), size0)
             if sh is None:                                    # a size that is not H / 2^s: the reference's nearest resize (models_bts.py:115-117)
                 il, sh = F.interpolate(il, size0), 0
-            feats.append(il.float().contiguous()), shifts.append(sh)
+            feats.append(native.as_feature_map(il)), shifts.append(sh)                 # (NCHW or channels_last, as the encoder wrote it)
         # ---- buffers: the arena (kept per shape) and one fresh block for what the caller gets to keep
         P, ph, pw = smp._patch_count, smp.patch_size_y, smp.patch_size_x
         Bp, K = P * ph * pw, int(r.n_coarse)

@@ -58,6 +58,10 @@ def parse():
                          "renderer's share of a training step, forward + loss + backward; profile: SURVEY 8f.3, the 64 x 256 x 256 occupancy grid of "
                          "scripts/inference_setup.py (render_profile) as one fused pass, density queries/s")
     ap.add_argument("--samples", type=int, default=0, help="re10k: samples per ray (default 48 = the yaml; BASELINE.json quotes 128)")
+    ap.add_argument("--feat-layout", choices=("nchw", "nhwc"), default="nchw",
+                    help="memory format of the stand-in feature maps of the training workloads: nchw = what a plain nn.Conv2d stack returns (the "
+                         "reference's encoder on CUDA), nhwc = torch channels_last, what the shipped Monodepth2 hands over (MIOpen's NHWC kernels, "
+                         "bts_conv3x3_fwd) -- read as it is through bts_project_features_cl (ABI 8)")
     ap.add_argument("--encoder", choices=("feature_map", "monodepth2"), default="feature_map",
                     help="training workloads: feature_map (default) = learnable stand-in for the CNN output (the renderer's share of the step); "
                          "monodepth2 = the shipped Monodepth2 (ResNet of the yaml, random weights): whole step incl. the CNN")
@@ -309,7 +313,7 @@ def train_workload(args, world, rank, dev):
             net.encoder.scales = [0]          # prediction_mode default renders scale 0 only; the other output convolutions still run
     else:
         net = bts.BTSNet(conf)
-        net.encoder = bts.FeatureMapEncoder((Hh, Ww), Cc, num_views=n, n_scales=n_scales, pyramid=n_scales > 1)
+        net.encoder = bts.FeatureMapEncoder((Hh, Ww), Cc, num_views=n, n_scales=n_scales, pyramid=n_scales > 1, channels_last=args.feat_layout == "nhwc")
         S.set_feature_map(net, scene["feat"])
     S.init_mlp_(net.mlp_coarse, seed=7)
     net = net.to(dev).train()
@@ -484,7 +488,8 @@ def train_workload(args, world, rank, dev):
             "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
             "config": {"workload": what, "rays_per_step_per_gpu": n_rays, "samples_per_ray": Kt, "renders_per_step": n_scales,
-                       "parallelism": f"batch x{world}", "peak_hbm_bytes": torch.cuda.max_memory_allocated()},
+                       "parallelism": f"batch x{world}", "peak_hbm_bytes": torch.cuda.max_memory_allocated(),
+                       "feat_layout": "nhwc (channels_last: Monodepth2's hand-over)" if args.encoder != "feature_map" else args.feat_layout},
             "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_MATRIX_TFLOPS, "traffic": traffic,
                          "kernel": ("bts_train_step_fwd + bts_train_step_bwd: every bts:: kernel of the step (hand-over, patch rays, tile flags, "

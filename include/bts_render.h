@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define BTS_ABI_VERSION 7
+#define BTS_ABI_VERSION 8
 
 enum {
   BTS_OK = 0,
@@ -208,6 +208,17 @@ int bts_project_features_tiles(const BtsFieldCfg* cfg, const float* feat_nchw, c
 int bts_project_features_bwd_tiles(const BtsFieldCfg* cfg, const float* feat_nchw, float* d_proj_nhwc, uint8_t* tiles,
                                    const float* mlp_params, int32_t N, float* d_feat_nchw, float* d_mlp_params, int32_t clear_after,
                                    void* stream);
+/* ABI 8: the encoder's map handed over CHANNELS-LAST -- (N, H >> s, W >> s, C) in memory, i.e. a torch tensor of shape (N, C, h, w) in
+ * channels_last format: what MIOpen's NHWC convolutions and bts_conv3x3_fwd (out_nchw = 0) write.  The same products as the NCHW entry
+ * points; the forward sums them in another order (G agrees to fp32 rounding), d_feat of a given d_proj is bit-identical.  A 64-texel
+ * tile of F / dF is ONE contiguous 64 * C * 4 byte piece instead of C row pieces of 256 bytes, and the sparse backward is traffic-bound
+ * (profiles/r05u, r05v).
+ * `tiles`: NULL = the whole map (dense forward / backward, nothing cleared); otherwise the flags of bts_mark_sampled_tiles (forward) or of
+ * bts_render_bwd's kept pair (backward, with clear_after as in bts_project_features_bwd_tiles). */
+int bts_project_features_cl(const BtsFieldCfg* cfg, const float* feat_nhwc, const float* mlp_params, int32_t N, const uint8_t* tiles,
+                            float* proj_nhwc, void* stream);
+int bts_project_features_bwd_cl(const BtsFieldCfg* cfg, const float* feat_nhwc, float* d_proj_nhwc, uint8_t* tiles, const float* mlp_params,
+                                int32_t N, float* d_feat_nhwc, float* d_mlp_params, int32_t clear_after, void* stream);
 
 /* BTSNet.forward on raw points (models_bts.py:266-338): xyz (n, P, 3) -> rgb (n, P, nv*3), invalid (n, P, max(nv,1)),
  * sigma (n, P).  only_density != 0 skips the colour taps: rgb may be NULL and invalid is (n, P, 1). */
@@ -339,7 +350,8 @@ typedef struct BtsTrainScale {
   uint8_t* d_proj_tiles;     /* (n, tiles)              ALL ZERO on entry, all zero again on return */
   float* d_feat_nchw;        /* (n, C, H >> s, W >> s) gradient of feat_nchw, WRITTEN by the backward, or NULL */
   int32_t feat_shift;
-  int32_t reserved_;
+  int32_t feat_channels_last; /* ABI 8: 1 = feat_nchw and d_feat_nchw of this scale are channels-last, (n, h, w, C) in memory (see
+                               * bts_project_features_cl); 0 = NCHW */
 } BtsTrainScale;
 
 typedef struct BtsTrainStep {

@@ -38,7 +38,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
         assert hasattr(lib, n), f"{n} declared in include/bts_render.h but not exported"
         assert n in _lib.SYMBOLS, f"{n} has no ctypes signature in _lib.SYMBOLS"
     assert set(_lib.SYMBOLS) == set(names)
-    assert lib.bts_abi_version() == _lib.ABI_VERSION == 7
+    assert lib.bts_abi_version() == _lib.ABI_VERSION == 8
 
 
 def test_ctypes_structs_match_the_c_layout():
@@ -61,6 +61,7 @@ int main(void) {
          offsetof(BtsTrainStep, bwd_workspace_bytes), offsetof(BtsTrainStep, d_empty_feature), offsetof(BtsTrainStep, scale));
   printf("%zu %zu %zu\n", sizeof(BtsConv3x3), offsetof(BtsConv3x3, x), offsetof(BtsConv3x3, y));
   printf("%zu %zu %zu\n", sizeof(BtsEvalFrame), offsetof(BtsEvalFrame, images), offsetof(BtsEvalFrame, invalid));
+  printf("%zu\n", offsetof(BtsTrainScale, feat_channels_last));   /* ABI 8: the former reserved_ word */
   return 0;
 }'''
     with tempfile.TemporaryDirectory() as d:
@@ -90,7 +91,9 @@ int main(void) {
     assert [int(x) for x in out[22:28]] == [T.ids_loss.offset, T.loss_matrix.offset, T.images.offset, T.bwd_workspace_bytes.offset,
                                             T.d_empty_feature.offset, T.scale.offset]
     assert [int(x) for x in out[28:31]] == [C.sizeof(_lib.BtsConv3x3), _lib.BtsConv3x3.x.offset, _lib.BtsConv3x3.y.offset]
-    assert [int(x) for x in out[31:]] == [C.sizeof(_lib.BtsEvalFrame), _lib.BtsEvalFrame.images.offset, _lib.BtsEvalFrame.invalid.offset]
+    assert [int(x) for x in out[31:34]] == [C.sizeof(_lib.BtsEvalFrame), _lib.BtsEvalFrame.images.offset, _lib.BtsEvalFrame.invalid.offset]
+    # ABI 8: the layout word of a scale's map sits where reserved_ was (same size, same offsets as ABI 7)
+    assert [int(x) for x in out[34:]] == [_lib.BtsTrainScale.feat_channels_last.offset] and _lib.BtsTrainScale.feat_channels_last.offset == _lib.BtsTrainScale.feat_shift.offset + 4
 
 
 def test_host_only_entry_points(lib):
@@ -186,6 +189,11 @@ def test_errors_are_codes_with_messages_never_exceptions(lib):
     assert lib.bts_project_features_bwd_tiles(C.byref(cfg), 16, 16, 16, 16, 1, 16, 16, 1, None) == -2 and b"envelope" in lib.bts_last_error()
     assert lib.bts_project_features_tiles(C.byref(ok_size), 16, 16, 1, None, 16, None) == -1 and b"NULL" in lib.bts_last_error()
     assert lib.bts_project_features_tiles(C.byref(cfg), 16, 16, 1, 16, 16, None) == -2 and b"envelope" in lib.bts_last_error()
+    # ABI 8: the channels-last hand-over
+    assert lib.bts_project_features_cl(C.byref(ok_size), 16, 16, 1, None, None, None) == -1 and b"NULL" in lib.bts_last_error()
+    assert lib.bts_project_features_cl(C.byref(cfg), 16, 16, 1, None, 16, None) == -2 and b"envelope" in lib.bts_last_error()
+    assert lib.bts_project_features_bwd_cl(C.byref(ok_size), None, 16, None, 16, 1, 16, 16, 0, None) == -1 and b"NULL" in lib.bts_last_error()
+    assert lib.bts_project_features_bwd_cl(C.byref(bad), 16, 16, None, 16, 1, 16, 16, 0, None) == -1 and b"feat_shift" in lib.bts_last_error()
     margs = _lib.BtsRenderArgs(rays_per_sample=8, K=4, rays=1)                      # neither z_samp nor jitter
     assert lib.bts_mark_sampled_tiles(C.byref(ok_size), 16, 16, C.byref(margs), 16, None) == -1 and b"jitter" in lib.bts_last_error()
     assert lib.bts_mark_sampled_tiles(C.byref(bad), 16, 16, C.byref(_lib.BtsRenderArgs(rays_per_sample=8, K=4, rays=1, z_samp=1)), 16, None) == -1

@@ -1,6 +1,6 @@
 """What does bts_project_features_bwd_tiles spend its time on?  The training shapes (KITTI-360: 16 x 64 x 192 x 640; KITTI-Raw: 8 frames), a
 clustered tile pattern at several dirty fractions, each gradient alone and both; next to a plain fill of d_feat (the write floor).
-    python tools/projbwd_probe.py [N]"""
+    python tools/projbwd_probe.py [N] [cl]        (cl: the map in channels_last format -- ABI 8, bts_project_features_cl / _bwd_cl)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -24,9 +24,11 @@ def main():
     spec = native.FieldSpec(C=64, d_hidden=64, n_blocks=0)
     g = torch.Generator(device="cuda").manual_seed(1)
     feat = torch.randn(N, 64, H, W, device="cuda", generator=g)
+    if "cl" in sys.argv[2:]:
+        feat = feat.contiguous(memory_format=torch.channels_last)
     mlp = torch.randn(spec.mlp_param_count(), device="cuda", generator=g) * 0.1
     tpi = native.proj_tile_count(spec, H, W)
-    print(f"N={N} tiles/img={tpi} d_feat={feat.numel() * 4 / 1e6:.0f} MB")
+    print(f"N={N} tiles/img={tpi} d_feat={feat.numel() * 4 / 1e6:.0f} MB  layout={'channels_last' if native.is_channels_last(feat) else 'nchw'}")
     print(f"fill(d_feat) {timed(lambda: torch.zeros_like(feat)):.4f} ms")
     for frac in (0.0, 0.1, 0.3, 1.0):
         tiles = torch.zeros(N, tpi, dtype=torch.uint8, device="cuda")
