@@ -463,19 +463,11 @@ __global__ __launch_bounds__(256, 2) void project_bwd_tiles_kernel(const float* 
       if constexpr (FEAT_CL) {       // the tile's pixels x C floats are contiguous
         const int npx = min(64, HW - p0);
         float4* row = reinterpret_cast<float4*>(dF + (long)p0 * C);
-#ifdef BTS_PROJ_NT
-        for (int i = lane; i < npx * (C / 4); i += 64) __builtin_nontemporal_store((f32x4){0.0f, 0.0f, 0.0f, 0.0f}, reinterpret_cast<f32x4*>(row + i));
-#else
         for (int i = lane; i < npx * (C / 4); i += 64) row[i] = z4;
-#endif
       } else
       if (vec4 && p0 + 64 <= HW) {   // 16 stores of 4 channel rows x 64 pixels
 #pragma unroll
-#ifdef BTS_PROJ_NT
-        for (int i = 0; i < C / 4; ++i) __builtin_nontemporal_store((f32x4){0.0f, 0.0f, 0.0f, 0.0f}, reinterpret_cast<f32x4*>(dF + (unsigned)((4 * i + (lane >> 4)) * HW + p0 + 4 * (lane & 15))));
-#else
         for (int i = 0; i < C / 4; ++i) *reinterpret_cast<float4*>(dF + (unsigned)((4 * i + (lane >> 4)) * HW + p0 + 4 * (lane & 15))) = z4;
-#endif
       } else if (p0 + lane < HW) {
 #pragma unroll 8
         for (int c = 0; c < C; ++c) dF[(unsigned)(c * HW + p0 + lane)] = 0.0f;
