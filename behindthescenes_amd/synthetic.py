@@ -68,7 +68,10 @@ def init_mlp_(mlp, seed=7, out_std=0.3):
 def set_feature_map(net, feat):
     """Loads ``feat`` (n, C, H, W) into the feature-map stand-in encoder of ``net``."""
     with torch.no_grad():
-        net.encoder.feats[0].copy_(feat)          # (keeps the parameter's memory format: NCHW or channels_last)
+        p = net.encoder.feats[0]
+        from .native import is_channels_last
+        fmt = torch.channels_last if is_channels_last(p) else torch.contiguous_format      # (the parameter keeps its memory format)
+        p.data = feat.to(p.device).clone().contiguous(memory_format=fmt)
     return net
 
 
