@@ -859,11 +859,13 @@ def sub_records(args, world, rank, dev, launched):
             torch.cuda.empty_cache()
 
     def run_child(workload, samples=0):
-        """`python bench.py --workload X --steps 10 --warmup 3` in its own process -- the very command a reader would run by hand (in this
-        process the allocator and host state the previous workload leaves behind cost the next one up to a millisecond per step)."""
+        """`python bench.py --workload X --steps 40 --warmup 10` in its own process -- the very command a reader would run by hand (in this
+        process the allocator and host state the previous workload leaves behind cost the next one up to a millisecond per step).  40 + 10
+        steps: with 10 + 3 a 0.7 ms step still carries the process' first-use costs (0.82 vs 0.71 ms for kitti_raw, profiles/r05z vs r05t);
+        the extra steps are ~0.1 s of a child process that spends seconds importing torch."""
         env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK",
                                                                   "LOCAL_WORLD_SIZE", "ROLE_RANK", "TORCHELASTIC_RUN_ID")}
-        cmd = [sys.executable, os.path.abspath(__file__), "--workload", workload, "--steps", "10", "--warmup", "3", "--no-cpu-baseline", "--no-others"]
+        cmd = [sys.executable, os.path.abspath(__file__), "--workload", workload, "--steps", "40", "--warmup", "10", "--no-cpu-baseline", "--no-others"]
         if samples:
             cmd += ["--samples", str(samples)]
         try:
