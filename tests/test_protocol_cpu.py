@@ -228,3 +228,29 @@ def test_patch_draws_into_preallocated_int32_rows_consume_the_generator_like_the
         assert ps.draw_patches(n, v, h, w, rows=rows) is None
         assert torch.equal(block[0].long(), pv) and torch.equal(block[1].long(), py) and torch.equal(block[2].long(), px)
         assert torch.equal(torch.rand(3), after)
+
+
+def test_feature_map_layout_helpers_and_the_stand_in_encoder_keep_the_memory_format():
+    """ABI 8's host side: which entry point a map takes is read off its strides (``native.is_channels_last`` / ``as_feature_map``); the
+    stand-in encoder can hold its maps in either format and ``set_feature_map`` replaces the data without changing it."""
+    import behindthescenes_amd as bts
+    from behindthescenes_amd import native, synthetic as S
+    x = torch.randn(2, 8, 5, 7)
+    xc = x.contiguous(memory_format=torch.channels_last)
+    assert not native.is_channels_last(x) and native.is_channels_last(xc)
+    assert not native.is_channels_last(torch.randn(2, 1, 5, 7).contiguous(memory_format=torch.channels_last))   # also plain contiguous
+    assert native.as_feature_map(x) is x and native.as_feature_map(xc) is xc                                     # no copies
+    sl = x[:, :, ::2]                                                                                            # neither: one dense copy
+    y = native.as_feature_map(sl)
+    assert y.is_contiguous() and torch.equal(y, sl)
+    assert native.as_feature_map(xc.half()).dtype == torch.float32 and native.is_channels_last(native.as_feature_map(xc.half()))
+    for cl in (False, True):
+        enc = bts.FeatureMapEncoder((6, 10), 8, num_views=2, n_scales=2, pyramid=True, channels_last=cl)
+        assert [tuple(p.shape) for p in enc.feats] == [(2, 8, 6, 10), (2, 8, 3, 5)]
+        assert all(native.is_channels_last(p) == cl for p in enc.feats)
+
+        class Net:                                   # what set_feature_map touches
+            encoder = enc
+        S.set_feature_map(Net, torch.arange(3 * 8 * 6 * 10, dtype=torch.float32).reshape(3, 8, 6, 10))          # another batch size
+        p = enc.feats[0]
+        assert tuple(p.shape) == (3, 8, 6, 10) and native.is_channels_last(p) == cl and p[2, 7, 5, 9].item() == 3 * 8 * 6 * 10 - 1
