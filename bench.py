@@ -552,11 +552,11 @@ def profile_workload(args, world, rank, dev):
     for _ in range(args.warmup):
         step()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    unpark_gc = park_gc()               # (in front of the barrier: the collection takes a different time on every rank)
     torch.cuda.synchronize()
     if torch.distributed.is_initialized():
         torch.distributed.barrier()
         torch.cuda.synchronize()
-    unpark_gc = park_gc()
     t0 = time.perf_counter()
     for i in range(args.steps):
         ev[i][0].record()
@@ -702,11 +702,11 @@ def main():
     for _ in range(args.warmup):
         step()
     timer.install()
+    unpark_gc = park_gc()               # (in front of the barrier: the collection takes a different time on every rank)
     torch.cuda.synchronize()
     if launched:
         torch.distributed.barrier()
         torch.cuda.synchronize()
-    unpark_gc = park_gc()
     t0 = time.perf_counter()
     for i in range(args.steps):
         ev[i][0].record()
