@@ -226,6 +226,10 @@ class FusedTrainStep(torch.nn.Module):
             return "patches of more than 64 pixels / other than 3 colour channels"
         if net.mlp_fine is not None or not net.native_scale_maps:
             return "a separate fine MLP / resized scale maps"
+        if (not net.sample_color) or net._d_out != 1:
+            # the field's MLP is four outputs wide and served by torch_modes.py: the fused kernels know the one-output
+            # density layout only (net._combined is encode's state; the two-call path has exactly one encoder view, checked next)
+            return "sample_color=False (MLP-predicted colours run as a PyTorch composition, torch_modes.py)"
         if len(ids_encoder) != 1:
             return "more than one encoder view"
         if not (1 <= len(ids_render) <= _lib.BTS_MAX_VIEWS) or not (1 <= len(ids_loss) <= _lib.BTS_MAX_LOSS_VIEWS):
@@ -260,7 +264,9 @@ class FusedTrainStep(torch.nn.Module):
         return loss, loss_dict, data
 
     # ---- the two-call path -------------------------------------------------------------------------------------------------------
-    def forward(self, images, projs, poses, ids_encoder=(0,), ids_render=None, ids_loss=None, patches=None):
+    def forward(self, images, projs, poses, ids_encoder=(0,), ids_render=None, ids_loss=None, patches=None, jitter=None):
+        """``patches`` = (frame, y, x) index tensors and ``jitter`` = one (n * rays, K) tensor of U[0, 1) per rendered scale replace the step's
+        own draws (the deterministic sub-seam of SURVEY 8b: the reference's seeded draws are injected, tests/test_gpu_fused_anchor.py)."""
         def ids(x, default):
             if x is None:
                 return default
@@ -320,7 +326,12 @@ class FusedTrainStep(torch.nn.Module):
         else:
             pv, py, px = patches
             idx = torch.stack((pv, py, px)).to(torch.int32).pin_memory().to(dev, non_blocking=True)
-        jit = [torch.rand((B, K), device=dev, dtype=torch.float32) for _ in scales]
+        if jitter is None:
+            jit = [torch.rand((B, K), device=dev, dtype=torch.float32) for _ in scales]
+        else:
+            jit = [j.to(dev, torch.float32).contiguous() for j in ([jitter] if torch.is_tensor(jitter) else list(jitter))]
+            if len(jit) != len(scales) or any(tuple(j.shape) != (B, K) for j in jit):
+                raise native.BtsNativeError(f"jitter: {len(scales)} tensor(s) of shape {(B, K)} expected")
         per_scale = _r64(B * nv * 3) + _r64(B) + 2 * _r64(B * nv)
         out = torch.empty(_r64(B * 8) + _r64(B * 3) + 64 + S * per_scale, device=dev, dtype=torch.float32)
         o = [0]
@@ -377,7 +388,10 @@ class FusedTrainStep(torch.nn.Module):
         job.st, job.arena, job.vals, job.grad_mode, job.token, job.C = st, arena, vals, torch.is_grad_enabled(), None, spec.C
         job.keep = (images, projs, poses, idx, jit, out)         # what the struct's pointers name, for as long as the graph lives
         empty = net.empty_feature if net.learn_empty else None
-        loss, vals_out = _TrainStepFn.apply(net.mlp_coarse.packed(), empty, job, *feats)
+        packed = net.mlp_coarse.packed()
+        if packed.numel() != spec.mlp_param_count():            # the library sees a pointer only: a mis-sized vector would be read past its end
+            raise native.BtsNativeError(f"the packed MLP holds {packed.numel()} values, the field's layout {spec.mlp_param_count()}")
+        loss, vals_out = _TrainStepFn.apply(packed, empty, job, *feats)
         loss_dict = LazyScalars(crit._KEYS, vals_out)
         # ---- the reference's data dict (reconstruct's views)
         data = dict(coarse=[], fine=[])
@@ -447,10 +461,17 @@ class FusedEvalFrame(torch.nn.Module):
         return dict(coarse=[rd["coarse"]], fine=[rd["fine"]], rgb_gt=rd["rgb_gt"], rays=rd["rays"])
 
     @torch.no_grad()
-    def forward(self, images, projs, poses, ids_encoder=(0,), ids_render=(0,), want_weights=True, want_alphas=True, to_z=True):
+    def forward(self, images, projs, poses, ids_encoder=(0,), ids_render=(0,), want_weights=True, want_alphas=True, to_z=True, jitter=None):
+        """``jitter`` (n * v * H * W, K) of U[0, 1) replaces the frame's own ``torch.rand`` draw (fused path only: the deterministic sub-seam
+        of SURVEY 8b, tests/test_gpu_fused_anchor.py)."""
         ids_encoder, ids_render = [int(i) for i in ids_encoder], [int(i) for i in ids_render]
         reason = self.why_not(images, ids_encoder, ids_render)
+        if reason is None and jitter is not None and tuple(jitter.shape) != (images.shape[0] * images.shape[1] * images.shape[3] * images.shape[4],
+                                                                             int(self.wrapped.renderer.n_coarse)):
+            raise native.BtsNativeError("jitter: one (n * v * H * W, K) tensor expected")
         if reason is not None:
+            if jitter is not None:
+                raise native.BtsNativeError("jitter can only be injected into the fused frame (" + reason + ")")
             self.last_path = "entries: " + reason
             return self._entries(images, projs, poses, ids_encoder, ids_render, want_weights, want_alphas, to_z)
         self.last_path = "fused"
@@ -468,7 +489,7 @@ class FusedEvalFrame(torch.nn.Module):
         # the reference's order of draws: ImageRaySampler draws nothing, the renderer's jitter is one torch.rand (nerf.py:112)
         rgb_gt = (images * .5 + .5).permute(0, 1, 3, 4, 2)                     # (n, v, H, W, 3): ray_sampler.py:253-258 (a view, as there)
         B = n * v * H * W
-        jitter = torch.rand((B, K), device=dev, dtype=torch.float32)
+        jitter = torch.rand((B, K), device=dev, dtype=torch.float32) if jitter is None else jitter.to(dev, torch.float32).contiguous()
         f32 = dict(device=dev, dtype=torch.float32)
         key = (dev, n, v, nv, H, W, spec.d_hidden)
         sc = self._scratch.get(key)

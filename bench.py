@@ -12,7 +12,7 @@ resident in HBM before the timed region.  N > 1: every rank renders its own fram
 no collective on the data path); value = total rays of all ranks / max-over-ranks time.
 
 Prints ONE JSON line (rank 0).  Next to the headline it carries `others` (N = 1: BASELINE configs[2], [3], [4], [4] at K = 128 and the
-occupancy profile, each = `bench.py --workload X --steps 10 --warmup 3` in a child process) and, under torch.distributed.run, `ddp_train`
+occupancy profile, each = `bench.py --workload X --steps CHILD_STEPS --warmup CHILD_WARMUP` in a child process) and, under torch.distributed.run, `ddp_train`
 (KITTI-Raw shapes with the Monodepth2 encoder through DistributedDataParallel: the path's one collective, with `allreduce_ms`);
 `--no-others` skips both.  `roofline` is for the dominant kernel (bts::render_kernel_p = bts_render_fwd) TOGETHER WITH bts::project_kernel
 (the feature half of lin_in, hoisted out of the render kernel by the declared projected-feature shortcut), both timed live with HIP
@@ -45,6 +45,8 @@ VALU_NS_PER_INST_2WAVES = {"fma_like": 1.88, "mul_like": 1.14}
 PEAK_FP32_MATRIX_TFLOPS = 157.3               # MI355X_MICROARCH.md: fp32 vector / fp32-input MFMA peak (256 CU x 256 FLOP/clk x 2.4 GHz)
 DTYPE = "f32 (lin_in as 3-term f16 split products on the f16 MFMA, f32 accumulate; everything else f32)"
 H, W, K, C, HD, V = 192, 640, 64, 64, 64, 2
+# timed / untimed steps of every `others` sub-record (each one a child process, see run_child); tests read these, never a literal
+CHILD_STEPS, CHILD_WARMUP = 40, 10
 
 
 def parse():
@@ -865,7 +867,7 @@ def sub_records(args, world, rank, dev, launched):
         the extra steps are ~0.1 s of a child process that spends seconds importing torch."""
         env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK",
                                                                   "LOCAL_WORLD_SIZE", "ROLE_RANK", "TORCHELASTIC_RUN_ID")}
-        cmd = [sys.executable, os.path.abspath(__file__), "--workload", workload, "--steps", "40", "--warmup", "10", "--no-cpu-baseline", "--no-others"]
+        cmd = [sys.executable, os.path.abspath(__file__), "--workload", workload, "--steps", str(CHILD_STEPS), "--warmup", str(CHILD_WARMUP), "--no-cpu-baseline", "--no-others"]
         if samples:
             cmd += ["--samples", str(samples)]
         try:

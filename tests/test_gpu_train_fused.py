@@ -160,6 +160,12 @@ def test_configurations_outside_the_two_call_path_run_entry_by_entry():
     step.wrapped.renderer.lean_training_outputs = True
     step.criterion.lambda_depth_reg = 0.1
     assert "regulariser" in step.why_not(inputs[0], [0], cfg["ids_render"], cfg["ids_loss"])
+    step.criterion.lambda_depth_reg = 0.0
+    assert step.why_not(inputs[0], [0], cfg["ids_render"], cfg["ids_loss"]) is None
+    # MLP-predicted colours (sample_color=False: a four-output MLP served by torch_modes.py) never reach the one-output kernels
+    net.sample_color = False
+    assert "sample_color=False" in step.why_not(inputs[0], [0], cfg["ids_render"], cfg["ids_loss"])
+    net.sample_color = True
 
 
 def test_fused_eval_frame_equals_the_entry_by_entry_frame():
