@@ -1,7 +1,8 @@
 """GPU: one training-step data flow after the CNN through the drop-in modules (BTSNet.encode -> NeRFRenderer.composite on the
 reference's seeded patch rays -> _format_outputs -> PatchRaySampler.reconstruct -> photometric loss -> backward), against the
 loss value and gradients the REAL reference produced for the same inputs (tests/golden/train_step.npz).
-Tolerances (north_star): loss within 1e-5 absolute; gradients within 1e-4 of the largest entry."""
+Tolerances (north_star): loss within 1e-5 absolute; gradients within 2e-5 of the largest entry outside the footprint of fp32-undecidable
+relu gates (tests/test_gpu_fused_anchor.py::_check_grads_up_to_gate_events), 1e-3 inside it."""
 import ast
 
 import numpy as np
@@ -59,12 +60,13 @@ def test_train_step_loss_and_gradients_vs_reference_golden(fused_loss):
         assert abs(parts["loss_invalid_ratio"].item() - t["loss_invalid_ratio"].item()) <= 1e-6
     assert abs(loss.item() - t["loss"].item()) <= 1e-5, (loss.item(), t["loss"].item())
     loss.backward()
-    got = dict(g_w_in=net.mlp_coarse.lin_in.weight.grad, g_b_in=net.mlp_coarse.lin_in.bias.grad,
-               g_w_out=net.mlp_coarse.lin_out.weight.grad, g_b_out=net.mlp_coarse.lin_out.bias.grad, g_feat=net.encoder.feats[0].grad)
-    for k, g in got.items():
-        ref = t[k].view_as(g.cpu())
-        err = (g.cpu() - ref).abs().max().item() / (ref.abs().max().item() + 1e-20)
-        assert err <= 1e-4, (k, err)
+    # gradients: within 2e-5 of each tensor's largest entry, except the footprint of the relu gates the fp64 evaluation shows to be undecidable
+    # in fp32 (on this fixture ONE: unit 30 at one sample -- its four tap texels sit at 1.0e-4, right ON the former flat 1e-4 bar)
+    from tests.test_gpu_fused_anchor import _check_grads_up_to_gate_events, _gate_ambiguity, _hip_grads
+    golden = {"lin_in.weight": t["g_w_in"], "lin_in.bias": t["g_b_in"], "lin_out.weight": t["g_w_out"], "lin_out.bias": t["g_b_out"], "feat": t["g_feat"]}
+    scene = dict(images=t["images"], feat=t["feat"], projs=t["projs"], poses=t["poses"])
+    amb, taps = _gate_ambiguity(scene, O.MlpParams(t["w_in"], t["b_in"], [], t["w_out"], t["b_out"]), cfg, t["rays"], t["z_samp"])
+    _check_grads_up_to_gate_events("golden, entry by entry", _hip_grads(net), golden, amb, taps)
 
 
 @pytest.mark.parametrize("policy", ["weight_guided", "strict"])
