@@ -12,7 +12,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 # BTS_ALLOW_LIB_OVERRIDE=1 and announced on stderr, so that a stale variable in somebody's shell cannot silently swap the library.
 _OVERRIDE = os.environ.get("BTS_RENDER_LIB") if os.environ.get("BTS_ALLOW_LIB_OVERRIDE") == "1" else None
 LIB_PATH = _OVERRIDE or os.path.join(PKG, "libbts_render.so")
-ABI_VERSION = 8
+ABI_VERSION = 9
 BTS_MAX_SCALES = 4
 BTS_MAX_LOSS_VIEWS = 16
 
@@ -79,7 +79,8 @@ class BtsEvalFrame(C.Structure):
                [(k, C.c_int32) for k in ("K", "lindisp", "hard_alpha_cap", "norm_dir")] + \
                [(k, C.c_float) for k in ("z_near", "z_far", "img_scale", "img_shift")] + \
                [(k, C.c_void_p) for k in ("images", "Ks", "poses_c2w", "feat_nchw", "mlp_params", "empty_feature", "jitter", "cams", "imgs_nhwc4",
-                                          "proj_nhwc", "inv_K", "rays", "rgb", "depth", "depth_z", "weights", "alphas", "invalid")]
+                                          "proj_nhwc", "inv_K", "rays", "rgb", "depth", "depth_z", "weights", "alphas", "invalid")] + \
+               [("feat_channels_last", C.c_int32), ("reserved_", C.c_int32)]      # ABI 9 (appended)
 
 
 class BtsConv3x3(C.Structure):

@@ -762,6 +762,11 @@ void render_bwd_flush_region(const BtsFieldCfg* cfg, const BtsRenderArgs* a, voi
 int render_bwd_impl(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const BtsRenderArgs* a, const BtsRenderGrads* g, void* workspace,
                     size_t, hipStream_t s, bool flush_clean) {
   BwdParams bp;
+#ifdef BTS_PROBE
+  // the probe build sizes the workspace as the maximum of three layouts, so render_bwd_flush_region's "tail of the workspace" is not where
+  // the layout taken below puts pass C's slot copies: never trust a caller-side clear here (the passes zero the slots themselves)
+  flush_clean = false;
+#endif
   bp.flush_clean = flush_clean;
   bp.f = make_params(cfg, t);
   bp.f.rays = a->rays, bp.f.z_samp = a->z_samp;

@@ -397,8 +397,8 @@ int train_step_bwd_impl(const BtsTrainStep* st, const float* g_loss, hipStream_t
 int gen_rays_launch(const float* poses, const float* projs, int V, int H, int W, float zn, float zf, int norm_dir, float* rays, hipStream_t s);
 int distance_to_z_launch(const float* depths, const float* invK, int N, int H, int W, float* out, hipStream_t s);
 int invert_small_launch(const float* src, float* dst, int N, int dim, hipStream_t s);
-int project_features_plain(int C, int HD, const float* feat, const float* mlp, int N, int HW, float* proj, hipStream_t s) {
-  return project_features_impl(C, HD, feat, mlp, N, HW, proj, nullptr, s);
+int project_features_plain(int C, int HD, const float* feat, const float* mlp, int N, int HW, float* proj, hipStream_t s, bool channels_last) {
+  return project_features_impl(C, HD, feat, mlp, N, HW, proj, nullptr, s, channels_last);
 }
 
 int eval_frame_impl(const BtsEvalFrame* f, hipStream_t stream) {
@@ -406,7 +406,7 @@ int eval_frame_impl(const BtsEvalFrame* f, hipStream_t stream) {
   const int n = c.n, nv = c.nv;
   int rc = camera_prep_launch(f->Ks, f->poses_c2w, n, f->v, f->id_encoder, nv, f->ids_render, f->cams, stream);
   if (!rc && nv) rc = pack_rgb_views_launch(f->images, f->imgs_nhwc4, n, f->v, nv, f->ids_render, c.H, c.W, f->img_scale, f->img_shift, stream);
-  if (!rc) rc = project_features_plain(c.C, c.d_hidden, f->feat_nchw, f->mlp_params, n, c.H * c.W, f->proj_nhwc, stream);
+  if (!rc) rc = project_features_plain(c.C, c.d_hidden, f->feat_nchw, f->mlp_params, n, c.H * c.W, f->proj_nhwc, stream, f->feat_channels_last != 0);
   if (!rc) rc = gen_rays_launch(f->poses_c2w, f->Ks, n * f->v, c.H, c.W, f->z_near, f->z_far, f->norm_dir, f->rays, stream);
   if (rc) {
     set_error("%s: a hand-over kernel launch failed", "bts_eval_frame");

@@ -236,6 +236,15 @@ class BTSNet(nn.Module):
         self.grid_c_Ks, self.grid_c_poses_w2c, self.grid_c_combine = _take(Ks, ids_render), _take(poses_w2c, ids_render), ren_groups
         self._native = {}
 
+    def invalidate_field_state(self):
+        """Forget what the last ``encode`` left behind (maps, cameras, the projected-map cache).  The fused step / frame
+        (train_step.py) hand the encoder's output to the library themselves: a later ``forward`` / ``occupancy_profile`` / render must
+        not silently run on the PREVIOUS encode's maps -- it raises until ``encode`` is called again."""
+        self._has_latents = False
+        self._native = {}
+        self._latents_ms = self._shift_ms = self._grid_f_features = None
+        self._grid_c_src = None
+
     def native_field(self, coarse=True, sampled=None) -> "native.FieldTensors":
         """Field state of the current scale in the C-ABI layouts.  The projected feature map G = F . w_in[:, :C]^T is built lazily
         per scale (one HIP pass that also does the NCHW -> channels-last hand-over) and cached until the next ``encode`` or until
@@ -247,6 +256,8 @@ class BTSNet(nn.Module):
         if self.torch_mode:
             raise native.BtsNativeError("this field runs as a PyTorch composition (sample_color=False / merged encoder views, torch_modes.py): "
                                         "it has no state in the fused kernels' layouts")
+        if not getattr(self, "_has_latents", False) or self._latents_ms is None:
+            raise native.BtsNativeError("no field state: call encode() first (a fused training step / evaluation frame leaves none behind)")
         s = self._scale
         fine = not coarse and self.mlp_fine is not None
         mlp, spec = (self.mlp_fine, self.spec_fine) if fine else (self.mlp_coarse, self.spec)

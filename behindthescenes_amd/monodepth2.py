@@ -177,8 +177,18 @@ class Decoder(nn.Module):
     fused_tail = True
 
     def tail_is_fused(self, x):
-        return (self.fused_tail and x.is_cuda and x.dtype == torch.float32 and 0 in self.scales and self.num_ch_dec[0] == 64
-                and self.num_ch_dec[1] == 64 and self.d_out == 64)
+        """x = the (N, 64, H/2, W/2) input of upconv(0, 0).  The envelope of bts_conv3x3_* (conv_ok in csrc/bts_conv.hip): fp32 on the
+        GPU, 64 -> 64 channels, every layer's input at least 4 x 4 (reflection padding reads two pixels inwards) and a single image's
+        full-resolution map below 2^31 elements; fp32 weights, no autocast (Conv3x3Function computes in fp32 only).  Anything else
+        keeps the nn.Module layers."""
+        if not (self.fused_tail and x.is_cuda and x.dtype == torch.float32 and 0 in self.scales and self.num_ch_dec[0] == 64
+                and self.num_ch_dec[1] == 64 and self.d_out == 64):
+            return False
+        h, w = x.shape[-2:]
+        if h < 4 or w < 4 or (2 * h) * (2 * w) * 64 >= 2 ** 31 or torch.is_autocast_enabled():
+            return False
+        m0 = self.decoder[self.decoder_keys[("upconv", 0, 0)]].conv.conv
+        return m0.weight.dtype == torch.float32
 
     def _conv(self, key, x_nhwc, up2=False, elu=False, out_nchw=False):
         from . import native

@@ -286,6 +286,7 @@ class FusedTrainStep(torch.nn.Module):
         id_enc = ids_encoder[0]
         # ---- the CNN (PyTorch): models_bts.py:99-110, flip augmentation included (its draw comes first, as in the reference)
         net.mlp_coarse.invalidate_packed()
+        net.invalidate_field_state()                          # (the two calls bypass encode: nothing it cached describes this batch)
         enc_in = images[:, id_enc]
         do_flip = bool(net.flip_augmentation and net.training and (torch.rand(1) > .5).item())
         if do_flip:
@@ -485,7 +486,8 @@ class FusedEvalFrame(torch.nn.Module):
         feat = net.encoder(images[:, id_enc])[0]
         if tuple(feat.shape[-2:]) != (H, W):
             raise native.BtsNativeError(f"the encoder's scale-0 map is {tuple(feat.shape[-2:])}, the frames are {(H, W)}")
-        feat = feat.detach().float().contiguous()
+        feat = native.as_feature_map(feat.detach())           # NCHW or channels-last (the shipped decoder's format), read as it is: ABI 9
+        net.invalidate_field_state()                          # (this call bypasses encode: nothing it cached describes this frame)
         # the reference's order of draws: ImageRaySampler draws nothing, the renderer's jitter is one torch.rand (nerf.py:112)
         rgb_gt = (images * .5 + .5).permute(0, 1, 3, 4, 2)                     # (n, v, H, W, 3): ray_sampler.py:253-258 (a view, as there)
         B = n * v * H * W
@@ -506,6 +508,7 @@ class FusedEvalFrame(torch.nn.Module):
             fr.ids_render[j] = i
         fr.K, fr.lindisp, fr.hard_alpha_cap, fr.norm_dir = K, int(bool(r.lindisp)), int(bool(r.hard_alpha_cap)), int(bool(smp.norm_dir))
         fr.z_near, fr.z_far, fr.img_scale, fr.img_shift = float(smp.z_near), float(smp.z_far), 0.5, 0.5
+        fr.feat_channels_last = int(native.is_channels_last(feat))
         params = net.mlp_coarse.packed().detach()
         empty = net.empty_feature.detach() if net.learn_empty else None
 

@@ -54,7 +54,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", choices=("eval", "train", "kitti_raw", "re10k", "profile"), default="eval",
+    ap.add_argument("--workload", choices=("eval", "train", "kitti_raw", "re10k", "profile", "glue"), default="eval",
                     help="eval (default): BASELINE configs[1], the headline line.  train: configs[2] (exp_kitti_360.yaml shapes), kitti_raw: "
                          "configs[3] (exp_kitti_raw.yaml, bs 8 / GPU), re10k: configs[4] (exp_re10k.yaml, 256x384, four scales per step): the "
                          "renderer's share of a training step, forward + loss + backward; profile: SURVEY 8f.3, the 64 x 256 x 256 occupancy grid of "
@@ -113,6 +113,103 @@ def park_gc():
     if os.environ.get("BTS_BENCH_KEEP_GC") != "1":
         gc.disable()
     return gc.enable if was_on else (lambda: None)
+
+
+def gc_parked():
+    """what the JSON line records as `gc_parked`: was the cyclic collector off during the timed loops of this process?"""
+    return os.environ.get("BTS_BENCH_KEEP_GC") != "1"
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------
+# launch glue: ONE implementation for every workload (and for the CPU stand-in `--workload glue`, which tests/test_distributed_cpu.py
+# launches at world size 2 over gloo, so that a first multi-GPU run cannot die in this code)
+# ------------------------------------------------------------------------------------------------------------------------------------
+def launch_context(env=None):
+    """-> (world, rank, local_rank, launched): the torch.distributed.run contract (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*)."""
+    env = os.environ if env is None else env
+    world, rank, local_rank = int(env.get("WORLD_SIZE", "1")), int(env.get("RANK", "0")), int(env.get("LOCAL_RANK", "0"))
+    launched = "RANK" in env and "WORLD_SIZE" in env and "MASTER_PORT" in env
+    return world, rank, local_rank, launched
+
+
+def init_group(launched, local_rank, use_cuda=True):
+    """One process per GPU over RCCL (backend "nccl", `device_id` so that the communicator is bound to this rank's device) -- also at world
+    size 1, so that barrier / MAX all-reduce / DDP run exactly as at N > 1.  Without CUDA (the glue workload on a CPU box): gloo.
+    -> the device of this rank."""
+    if use_cuda:
+        torch.cuda.set_device(local_rank if launched else 0)
+    if launched:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if use_cuda:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
+    return torch.device("cuda", local_rank if launched else 0) if use_cuda else torch.device("cpu")
+
+
+def _sync(dev):
+    if dev.type == "cuda":
+        torch.cuda.synchronize()
+
+
+def timed_region(step, steps, dev, events=None, before=None):
+    """The contract's timed region: barrier + synchronize, EXACTLY `steps` calls of step(), synchronize + barrier, and the MAXIMUM of the
+    wall time over the ranks.  `events`: one (start, end) HIP event pair per step, recorded on the current stream around the call.
+    `before`: runs between the opening barrier and the clock (e.g. reset_peak_memory_stats).  -> (seconds, the last step's return value)."""
+    dist = torch.distributed
+    unpark_gc = park_gc()               # (in front of the barrier: the collection takes a different time on every rank)
+    _sync(dev)
+    if dist.is_initialized():
+        dist.barrier()
+        _sync(dev)
+    if before is not None:
+        before()
+    last = None
+    t0 = time.perf_counter()
+    for i in range(steps):
+        if events is not None:
+            events[i][0].record()
+        last = step()
+        if events is not None:
+            events[i][1].record()
+    _sync(dev)
+    unpark_gc()
+    if dist.is_initialized():
+        dist.barrier()
+        _sync(dev)
+    elapsed = time.perf_counter() - t0
+    if dist.is_initialized():
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    return elapsed, last
+
+
+def parallelism(kind, world):
+    """config.parallelism of the JSON line: what is split over the ranks"""
+    return {"frames": f"frames x{world}", "rays": f"rays x{world} of one frame", "batch": f"batch x{world}"}[kind]
+
+
+def glue_workload(args, world, rank, dev):
+    """NOT a benchmark: the launch glue (launch_context, init_group, timed_region, the JSON line's contract keys) around a stand-in step
+    that runs wherever torch runs.  tests/test_distributed_cpu.py starts it as `python -m torch.distributed.run --nproc-per-node 2 bench.py
+    --gpus 2 --workload glue` on the CPU container (gloo); rank r's step sleeps (r + 1) ms so that the MAX over the ranks is checkable."""
+    x = torch.ones(64, 64, device=dev)
+
+    def step():
+        time.sleep(1e-3 * (rank + 1))
+        return (x @ x).sum()
+    for _ in range(args.warmup):
+        step()
+    elapsed, _ = timed_region(step, args.steps, dev)
+    if rank != 0:
+        return None
+    return {"metric": "launch glue stand-in (not a measurement)", "value": world * args.steps / elapsed, "unit": "steps/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic", "gc_parked": gc_parked(),
+            "config": {"workload": "glue", "parallelism": parallelism(args.shard, world), "backend": torch.distributed.get_backend() if
+                       torch.distributed.is_initialized() else None}}
 
 
 class KernelTimer:
@@ -409,26 +506,8 @@ def train_workload(args, world, rank, dev):
         return
     timer = KernelTimer()
     timer.install()
-    unpark_gc = park_gc()
-    torch.cuda.synchronize()
-    if torch.distributed.is_initialized():
-        torch.distributed.barrier()
-        torch.cuda.synchronize()
-    torch.cuda.reset_peak_memory_stats()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    unpark_gc()
-    if torch.distributed.is_initialized():
-        torch.distributed.barrier()
-        torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    elapsed, _ = timed_region(step, args.steps, dev, before=torch.cuda.reset_peak_memory_stats)
     timer.remove()
-    if torch.distributed.is_initialized():
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = t.item()
     allreduce = None
     if is_ddp:
         # the gradient all-reduce under a profiler range: device time of the RCCL kernels of two more steps (outside the timed region)
@@ -488,9 +567,9 @@ def train_workload(args, world, rank, dev):
             "metric": f"training-step rays/sec ({cfg['yaml']} shapes): render forward + loss + backward" + (" + CNN" if args.encoder != "feature_map" else ""),
             "value": world * n_rays * args.steps / elapsed,
             "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE, "data": "synthetic", "gc_parked": gc_parked(),
             "config": {"workload": what, "rays_per_step_per_gpu": n_rays, "samples_per_ray": Kt, "renders_per_step": n_scales,
-                       "parallelism": f"batch x{world}", "peak_hbm_bytes": torch.cuda.max_memory_allocated(),
+                       "parallelism": parallelism("batch", world), "peak_hbm_bytes": torch.cuda.max_memory_allocated(),
                        "feat_layout": "nhwc (channels_last: Monodepth2's hand-over)" if args.encoder != "feature_map" else args.feat_layout},
             "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_MATRIX_TFLOPS, "traffic": traffic,
@@ -554,26 +633,7 @@ def profile_workload(args, world, rank, dev):
     for _ in range(args.warmup):
         step()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    unpark_gc = park_gc()               # (in front of the barrier: the collection takes a different time on every rank)
-    torch.cuda.synchronize()
-    if torch.distributed.is_initialized():
-        torch.distributed.barrier()
-        torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        ev[i][0].record()
-        prof = step()
-        ev[i][1].record()
-    torch.cuda.synchronize()
-    unpark_gc()
-    if torch.distributed.is_initialized():
-        torch.distributed.barrier()
-        torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if torch.distributed.is_initialized():
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = t.item()
+    elapsed, prof = timed_region(step, args.steps, dev, events=ev)
     kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
     n_pts = Y * Z * X
     if rank == 0:
@@ -593,10 +653,10 @@ def profile_workload(args, world, rank, dev):
         out = {
             "metric": "density-field queries/sec (64x256x256 occupancy profile, scripts/inference_setup.py)", "value": world * n_pts * args.steps / elapsed,
             "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE, "data": "synthetic", "gc_parked": gc_parked(),
             "config": {"workload": "occupancy profile of one KITTI-360 frame: 64 x 256 x 256 = 4 194 304 query points (get_pts defaults), nv = 2 "
                                    "views flag invalid points, learn_empty=True, one fused pass (bts_occupancy_profile)", "points_per_step_per_gpu": n_pts,
-                       "parallelism": f"frames x{world}",
+                       "parallelism": parallelism("frames", world),
                        "reference_flow_on_hip_queries_ms": ref_ms, "columns_equal_to_reference_flow": agree},
             "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MATRIX_TFLOPS,
                          "traffic": None, "kernel": "bts::query_kernel_p<64,64,0,2> (profile mode)", "kernel_ms": kernel_ms,
@@ -633,18 +693,16 @@ def main():
     args = parse()
     if args.cpu_child:
         return cpu_child(args)
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ and "MASTER_PORT" in os.environ     # torch.distributed.run contract
-    if launched:   # also at world 1: init("nccl", device_id), barrier and the MAX all-reduce then run over RCCL exactly as at N > 1
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(0)
-    dev = torch.device("cuda", local_rank if launched else 0)
+    world, rank, local_rank, launched = launch_context()
+    if args.workload == "glue":         # the launch glue alone, wherever torch runs (CPU: gloo) -- see glue_workload
+        dev = init_group(launched, local_rank, use_cuda=torch.cuda.is_available())
+        out = glue_workload(args, world, rank, dev)
+        if out is not None:
+            print(json.dumps(out))
+        if launched:
+            torch.distributed.destroy_process_group()
+        return
+    dev = init_group(launched, local_rank)
 
     import behindthescenes_amd as bts
     from behindthescenes_amd import _lib
@@ -704,27 +762,16 @@ def main():
     for _ in range(args.warmup):
         step()
     timer.install()
-    unpark_gc = park_gc()               # (in front of the barrier: the collection takes a different time on every rank)
-    torch.cuda.synchronize()
-    if launched:
-        torch.distributed.barrier()
-        torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        ev[i][0].record()
-        step()
-        ev[i][1].record()
-    torch.cuda.synchronize()
-    unpark_gc()
-    if launched:
-        torch.distributed.barrier()
-        torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    elapsed, _ = timed_region(step, args.steps, dev, events=ev)
     timer.remove()
-    if launched:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = t.item()
+    # the same loop once more with Python's cyclic collector ON (what an evaluation loop that does not park it sees), outside the timed
+    # region: reported beside the headline as `ms_per_step_gc_on` (round-5 advice: the headline's loop runs with the collector parked)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for i in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    gc_on_ms = (time.perf_counter() - t1) * 1e3 / args.steps
 
     entry_ms = timer.ms_per_step(args.steps)
     one_call = "eval_frame" in entry_ms
@@ -779,11 +826,11 @@ def main():
         out = {
             "metric": "rendered rays/sec (192x640x64 samples)", "value": value, "unit": "rays/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": step_ms, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
+            "vs_baseline": None, "dtype": DTYPE, "data": "synthetic", "gc_parked": gc_parked(), "ms_per_step_gc_on": gc_on_ms,
             "config": {"workload": "KITTI eval_depth.yaml forward, bs=1/GPU, 192x640, 2 views x 122880 rays, 64 samples/ray, nv=1, "
                                    "learn_empty=True (the yaml's effective default), want_weights+alphas, renderer only (feature-map "
                                    "encoder stand-in)" + (": ONE frame, its rays sharded over the ranks + all-gather of the per-ray outputs" if shard_rays else ""),
-                       "rays_per_step_per_gpu": rays_launch, "samples_per_ray": K, "parallelism": f"rays x{world} of one frame" if shard_rays else f"frames x{world}",
+                       "rays_per_step_per_gpu": rays_launch, "samples_per_ray": K, "parallelism": parallelism("rays" if shard_rays else "frames", world),
                        **({"all_gather_bytes_per_step": n_rays * (3 + 1 + 3 * K) * 4,
                            "all_gather": "rgb, depth, weights, alphas, invalid of all rays on every rank (what the un-sharded call returns)"} if shard_rays else {})},
             "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",

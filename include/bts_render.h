@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define BTS_ABI_VERSION 8
+#define BTS_ABI_VERSION 9
 
 enum {
   BTS_OK = 0,
@@ -482,6 +482,9 @@ typedef struct BtsEvalFrame {
   float* weights;            /* (B, K) or NULL */
   float* alphas;             /* (B, K) or NULL */
   float* invalid;            /* (B, K, nv) or NULL */
+  int32_t feat_channels_last; /* ABI 9: 1 = feat_nchw is channels-last, (n, H, W, C) in memory -- what the shipped Monodepth2 decoder writes
+                              * (as BtsTrainScale.feat_channels_last, ABI 8): read as it is, no layout pass.  Appended: every ABI 8 offset stands */
+  int32_t reserved_;
 } BtsEvalFrame;
 int bts_eval_frame(const BtsEvalFrame* f, void* stream);
 

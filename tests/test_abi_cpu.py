@@ -38,7 +38,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
         assert hasattr(lib, n), f"{n} declared in include/bts_render.h but not exported"
         assert n in _lib.SYMBOLS, f"{n} has no ctypes signature in _lib.SYMBOLS"
     assert set(_lib.SYMBOLS) == set(names)
-    assert lib.bts_abi_version() == _lib.ABI_VERSION == 8
+    assert lib.bts_abi_version() == _lib.ABI_VERSION == 9
 
 
 def test_ctypes_structs_match_the_c_layout():
@@ -62,6 +62,7 @@ int main(void) {
   printf("%zu %zu %zu\n", sizeof(BtsConv3x3), offsetof(BtsConv3x3, x), offsetof(BtsConv3x3, y));
   printf("%zu %zu %zu\n", sizeof(BtsEvalFrame), offsetof(BtsEvalFrame, images), offsetof(BtsEvalFrame, invalid));
   printf("%zu\n", offsetof(BtsTrainScale, feat_channels_last));   /* ABI 8: the former reserved_ word */
+  printf("%zu\n", offsetof(BtsEvalFrame, feat_channels_last));    /* ABI 9: appended behind the last ABI 8 field */
   return 0;
 }'''
     with tempfile.TemporaryDirectory() as d:
@@ -93,7 +94,8 @@ int main(void) {
     assert [int(x) for x in out[28:31]] == [C.sizeof(_lib.BtsConv3x3), _lib.BtsConv3x3.x.offset, _lib.BtsConv3x3.y.offset]
     assert [int(x) for x in out[31:34]] == [C.sizeof(_lib.BtsEvalFrame), _lib.BtsEvalFrame.images.offset, _lib.BtsEvalFrame.invalid.offset]
     # ABI 8: the layout word of a scale's map sits where reserved_ was (same size, same offsets as ABI 7)
-    assert [int(x) for x in out[34:]] == [_lib.BtsTrainScale.feat_channels_last.offset] and _lib.BtsTrainScale.feat_channels_last.offset == _lib.BtsTrainScale.feat_shift.offset + 4
+    assert int(out[35]) == _lib.BtsEvalFrame.feat_channels_last.offset == _lib.BtsEvalFrame.invalid.offset + 8     # ABI 9: appended
+    assert [int(x) for x in out[34:35]] == [_lib.BtsTrainScale.feat_channels_last.offset] and _lib.BtsTrainScale.feat_channels_last.offset == _lib.BtsTrainScale.feat_shift.offset + 4
 
 
 def test_host_only_entry_points(lib):

@@ -107,3 +107,35 @@ def test_shard_range_covers_everything():
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             assert max(e - s for s, e in spans) - min(e - s for s, e in spans) <= 1
+
+
+def test_bench_launch_glue_under_torch_distributed_run_world_2():
+    """The driver's multi-GPU launch line -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N --steps K --warmup W` -- at N = 2 on this CPU container: bench.py's `--workload glue` runs the launch
+    code every workload shares (launch_context's env parsing, init_group, timed_region's barriers and MAX all-reduce, the parallelism
+    strings, rank 0 printing ONE JSON line) around a stand-in step; without CUDA the group is gloo.  Rank r's step sleeps (r + 1) ms: the
+    reported time must be the SLOWER rank's (the MAX over the ranks), value = the units of ALL ranks over it."""
+    import json
+    import subprocess
+    import sys
+    import bench
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
+           str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "2", "--workload", "glue"]
+    env = dict(os.environ, CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES="", OMP_NUM_THREADS="1")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=root, env=env)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]            # rank 0 only
+    out = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert k in out, k
+    assert out["n_gpus"] == 2 and out["steps"] == 20 and out["warmup"] == 2 and out["scaling"] == "weak" and out["vs_baseline"] is None
+    assert out["config"]["backend"] == "gloo" and out["config"]["parallelism"] == "frames x2"
+    assert 2.0 <= out["ms_per_step"] < 20.0, out["ms_per_step"]            # rank 1 sleeps 2 ms per step, rank 0 only 1 ms: the MAX
+    assert abs(out["value"] - 2 * 20 / (out["ms_per_step"] * 20e-3)) <= 1e-6 * out["value"]
+    # the pieces, in process
+    assert bench.launch_context({}) == (1, 0, 0, False)
+    assert bench.launch_context(dict(RANK="3", LOCAL_RANK="1", WORLD_SIZE="8", MASTER_PORT="1")) == (8, 3, 1, True)
+    assert bench.launch_context(dict(RANK="0", WORLD_SIZE="1")) == (1, 0, 0, False)        # no rendezvous port: not a distributed launch
+    assert [bench.parallelism(k, 8) for k in ("frames", "rays", "batch")] == ["frames x8", "rays x8 of one frame", "batch x8"]

@@ -196,3 +196,50 @@ def test_fused_eval_frame_equals_the_entry_by_entry_frame():
         for k in ("rgb", "depth", "invalid", "weights", "alphas"):
             assert a["coarse"][0][k].shape == b["coarse"][0][k].shape, k
             assert torch.equal(a["coarse"][0][k], b["coarse"][0][k]), (ids_render, k)
+
+
+def test_fused_eval_frame_reads_a_channels_last_map_as_it_is_and_leaves_no_stale_state():
+    """ABI 9 (BtsEvalFrame.feat_channels_last): an encoder whose scale-0 map is in torch's channels_last format -- what the shipped
+    Monodepth2 decoder writes -- goes through bts_eval_frame without a layout copy, bit-identical to the NCHW map.  And a fused frame
+    leaves no field state behind: a field query afterwards raises instead of running on the previous encode's maps (round-5 advice)."""
+    import behindthescenes_amd as bts
+    from behindthescenes_amd import native, synthetic as S
+    dev = torch.device("cuda")
+    scene = S.synthetic_scene(1, 2, 48, 160, 64, seed=9, intrinsics=S.K_KITTIRAW, smooth=True)
+    torch.manual_seed(4)
+    net = bts.BTSNet(S.field_conf(64, 64, 0, 48, 160))
+    net.encoder = bts.FeatureMapEncoder((48, 160), 64, num_views=1)
+    S.init_mlp_(net.mlp_coarse, seed=7)
+    net = net.to(dev).eval()
+    wrapped = bts.NeRFRenderer.from_conf(dict(n_coarse=64, lindisp=True, hard_alpha_cap=True)).bind_parallel(net).eval().to(dev)
+    frame = bts.FusedEvalFrame(wrapped, bts.ImageRaySampler(3.0, 80.0))
+    inputs = [scene[k].to(dev) for k in ("images", "projs", "poses")]
+    jit = torch.rand(2 * 48 * 160, 64, device=dev)
+    a = frame(*inputs, ids_encoder=[0], ids_render=[0], jitter=jit)
+
+    class ChannelsLast(torch.nn.Module):          # the same maps, channels_last in memory
+        def __init__(self, inner):
+            super().__init__()
+            self.inner, self.latent_size, self.scales = inner, inner.latent_size, inner.scales
+
+        def forward(self, x):
+            return [m.contiguous(memory_format=torch.channels_last) for m in self.inner(x)]
+    net.encoder = ChannelsLast(net.encoder)
+    seen = {}
+    orig = native.eval_frame
+
+    def spy(fr, stream):
+        seen["cl"] = int(fr.feat_channels_last)
+        return orig(fr, stream)
+    native.eval_frame = spy
+    try:
+        b = frame(*inputs, ids_encoder=[0], ids_render=[0], jitter=jit)
+    finally:
+        native.eval_frame = orig
+    assert frame.last_path == "fused" and seen["cl"] == 1
+    for k in ("rgb", "depth", "invalid", "weights", "alphas"):
+        assert torch.equal(a["coarse"][0][k], b["coarse"][0][k]), k
+    with pytest.raises(native.BtsNativeError, match="encode"):
+        net(torch.zeros(1, 8, 3, device=dev))
+    net.encode(*inputs, ids_encoder=[0], ids_render=[0])
+    net(torch.zeros(1, 8, 3, device=dev))
