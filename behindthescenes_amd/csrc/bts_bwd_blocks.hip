@@ -100,17 +100,19 @@ __device__ __forceinline__ void hidden_layer_h1(f32x16& out, const f32x16& in, c
   for (int sl = 0; sl < 2; ++sl) {
     const h8 ah = *reinterpret_cast<const h8*>(wl + sl * 256);
     const h8 al = *reinterpret_cast<const h8*>(wl + term_stride + sl * 256);
-    _Float16 hi[8], lo[8];
+    float vc[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const float v = __builtin_amdgcn_fmed3f(in[8 * sl + i], 0.0f, 3.4028234663852886e38f) * inv_scale;
-      float vc = fminf(v, 6.0e4f);
-      asm("" : "+v"(vc));   // opaque fp32 value: both conversions below must see the same rounding (see f16_region)
-      hi[i] = (_Float16)vc;
-      lo[i] = (_Float16)(vc - (float)hi[i]);
+      vc[i] = fminf(v, 6.0e4f);
+      asm("" : "+v"(vc[i]));   // opaque fp32 value: both conversions of the split must see the same rounding (see f16_region)
     }
-    const h8 bh = __builtin_bit_cast(h8, (u32x4){pack_h2(hi[0], hi[1]), pack_h2(hi[2], hi[3]), pack_h2(hi[4], hi[5]), pack_h2(hi[6], hi[7])});
-    const h8 bl = __builtin_bit_cast(h8, (u32x4){pack_h2(lo[0], lo[1]), pack_h2(lo[2], lo[3]), pack_h2(lo[4], lo[5]), pack_h2(lo[6], lo[7])});
+    const float neg1 = opaque_neg1();
+    unsigned uh[4], ul[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) split2_f16(vc[2 * j], vc[2 * j + 1], neg1, uh[j], ul[j]);
+    const h8 bh = __builtin_bit_cast(h8, (u32x4){uh[0], uh[1], uh[2], uh[3]});
+    const h8 bl = __builtin_bit_cast(h8, (u32x4){ul[0], ul[1], ul[2], ul[3]});
     out = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, out, 0, 0, 0);
     out = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, out, 0, 0, 0);
     out = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, out, 0, 0, 0);
@@ -125,16 +127,18 @@ __device__ __forceinline__ void hidden_layer_ht(f32x16& out, const f32x16& in, c
   for (int sl = 0; sl < 2; ++sl) {
     const h8 ah = *reinterpret_cast<const h8*>(wl + sl * 256);
     const h8 al = *reinterpret_cast<const h8*>(wl + term_stride + sl * 256);
-    _Float16 hi[8], lo[8];
+    float vc[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      float vc = __builtin_amdgcn_fmed3f(in[8 * sl + i] * in_mul, -6.0e4f, 6.0e4f);
-      asm("" : "+v"(vc));   // opaque fp32 value: both conversions below must see the same rounding (see f16_region)
-      hi[i] = (_Float16)vc;
-      lo[i] = (_Float16)(vc - (float)hi[i]);
+      vc[i] = __builtin_amdgcn_fmed3f(in[8 * sl + i] * in_mul, -6.0e4f, 6.0e4f);
+      asm("" : "+v"(vc[i]));   // opaque fp32 value: both conversions of the split must see the same rounding (see f16_region)
     }
-    const h8 bh = __builtin_bit_cast(h8, (u32x4){pack_h2(hi[0], hi[1]), pack_h2(hi[2], hi[3]), pack_h2(hi[4], hi[5]), pack_h2(hi[6], hi[7])});
-    const h8 bl = __builtin_bit_cast(h8, (u32x4){pack_h2(lo[0], lo[1]), pack_h2(lo[2], lo[3]), pack_h2(lo[4], lo[5]), pack_h2(lo[6], lo[7])});
+    const float neg1 = opaque_neg1();
+    unsigned uh[4], ul[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) split2_f16(vc[2 * j], vc[2 * j + 1], neg1, uh[j], ul[j]);
+    const h8 bh = __builtin_bit_cast(h8, (u32x4){uh[0], uh[1], uh[2], uh[3]});
+    const h8 bl = __builtin_bit_cast(h8, (u32x4){ul[0], ul[1], ul[2], ul[3]});
     out = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, out, 0, 0, 0);
     out = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, out, 0, 0, 0);
     out = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, out, 0, 0, 0);
@@ -301,8 +305,9 @@ __global__ __launch_bounds__(256, 2) void rowsb_kernel(const BwdParams bp, const
     gl.tab = reinterpret_cast<unsigned*>(base + 3 * 4096);
     gl.m = lane >> 3;
     gl.piece16 = 16u * (unsigned)(((lane & 7) + (lane >> 4)) & 7);
+    gl.piece16x = gl.piece16 ^ 64u;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) gl.rd[q] = (unsigned)(col * 128 + ((4 * h0 + q - ((col & 7) >> 1)) & 7) * 16);
+    for (int q = 0; q < 4; ++q) gl.rd[q] = (unsigned)(col * 128 + ((4 * h0 + q - (col >> 1)) & 7) * 16);
   }
   // the ring is idle between the last gather block of a ray and the first of the next: its memory serves as the transposition
   // tiles of the weight-gradient contraction ([32 points][33] x 2) and as the cold path's h0 tile ([32 points][HD + 1])
@@ -758,7 +763,7 @@ __global__ __launch_bounds__(256, 2) void rowsb_kernel(const BwdParams bp, const
                 *reinterpret_cast<float4*>(u0t + ht * 4096 + gl.rd[j]) =
                     make_float4(v[ht][4 * j] * gs_v[pt], v[ht][4 * j + 1] * gs_v[pt], v[ht][4 * j + 2] * gs_v[pt], v[ht][4 * j + 3] * gs_v[pt]);
             wave_lds_fence();
-            // position (jj, m = lane >> 3, lane & 7) of a block holds piece gl.piece16 / 16 of row 8 jj + m (GatherLds)
+            // position (jj, m = lane >> 3, lane & 7) of a block holds piece gl.piece16 / 16 (jj even) or gl.piece16x / 16 (jj odd) of row 8 jj + m (GatherLds)
 #pragma unroll
             for (int ht = 0; ht < HT; ++ht)
 #pragma unroll
@@ -768,7 +773,7 @@ __global__ __launch_bounds__(256, 2) void rowsb_kernel(const BwdParams bp, const
                 const int ks = PK ? (pos < 48 ? pos : 16 * (kc >> 6) + pos - 48) : kc + pos;
                 const int kr = PK ? (pos < 48 ? (kc >> 6) : 3) * K + ks : ks;
                 if (ks < K)
-                  *reinterpret_cast<float4*>(reinterpret_cast<char*>(ro.u0_ws + rowk * (long)HD) + (unsigned)(kr * HD * 4 + ht * 128) + gl.piece16) = x;
+                  *reinterpret_cast<float4*>(reinterpret_cast<char*>(ro.u0_ws + rowk * (long)HD) + (unsigned)(kr * HD * 4 + ht * 128) + (jj & 1 ? gl.piece16x : gl.piece16)) = x;
               }
           }
         }

@@ -206,9 +206,10 @@ __global__ __launch_bounds__(256, 2) void rows_kernel(const BwdParams bp) {
     gl.tab = reinterpret_cast<unsigned*>(base + 3 * 4096);
     gl.m = lane >> 3;
     gl.piece16 = 16u * (unsigned)(((lane & 7) + (lane >> 4)) & 7);
+    gl.piece16x = gl.piece16 ^ 64u;
     const int col = lane & 31;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) gl.rd[q] = (unsigned)(col * 128 + ((4 * h0 + q - ((col & 7) >> 1)) & 7) * 16);
+    for (int q = 0; q < 4; ++q) gl.rd[q] = (unsigned)(col * 128 + ((4 * h0 + q - (col >> 1)) & 7) * 16);
   }
 #endif
   const int nwg = gridDim.x;  // multiple of 8

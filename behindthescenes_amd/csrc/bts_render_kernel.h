@@ -232,6 +232,27 @@ __device__ __forceinline__ unsigned pack_h2(_Float16 a, _Float16 b) {
   typedef _Float16 h2 __attribute__((ext_vector_type(2)));
   return __builtin_bit_cast(unsigned, (h2){a, b});
 }
+// The f16 split of TWO fp32 values, packed: hi = {f16_rne(e0), f16_rne(e1)}, lo = {f16_rne(e0 - hi0), f16_rne(e1 - hi1)} in THREE
+// instructions -- v_cvt_pk_f16_f32, v_fma_mixlo_f16, v_fma_mixhi_f16 (the mixed-precision fma reads the f16 half in place and rounds the
+// EXACT difference once: e - hi has at most 13 significant bits, so this is the very value f16(e - float(hi)) of the scalar form).
+// Rounds 2 - 5 wrote hi = (_Float16)e; lo = (_Float16)(e - (float)hi) per value, which hipcc compiles to EIGHT instructions per pair (each
+// hi converted twice, once alone for the way back to fp32 and once packed; two conversions back; two subtractions; the packed lo).
+// `neg1` = -1.0f as an OPAQUE scalar (opaque_neg1()): with the literal the compiler rewrites fma(x, -1, e) as e - x and the mixed form is gone.
+// e0, e1 must be opaque fp32 VALUES (see f16_region: a producer folded into one of the conversions is rounded differently there).
+__device__ __forceinline__ float opaque_neg1() {
+  float k = -1.0f;
+  asm("" : "+s"(k));
+  return k;
+}
+__device__ __forceinline__ void split2_f16(float e0, float e1, float neg1, unsigned& hi, unsigned& lo) {
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  const h2 hp = __builtin_convertvector((f2){e0, e1}, h2);
+  h2 lp;
+  lp[0] = (_Float16)__builtin_fmaf((float)hp[0], neg1, e0);
+  lp[1] = (_Float16)__builtin_fmaf((float)hp[1], neg1, e1);
+  hi = __builtin_bit_cast(unsigned, hp), lo = __builtin_bit_cast(unsigned, lp);
+}
 
 // 12 encoding entries (two octaves) of this lane's sample -> both point tiles' B operands (high and low halves) -> 12 f16 MFMAs
 template <int HD, int NE = 12, bool FIRST = false>
@@ -239,24 +260,23 @@ __device__ __forceinline__ void f16_region(f32x16 (&acc)[HD / 32][2], const floa
                                            const float (&e)[NE], const f32x16* bias = nullptr) {
   static_assert(NE >= 8 && NE <= 16, "one 16-row k-slice");
   constexpr int HT = HD / 32;
-  _Float16 hi[16], lo[16];
+  // The entries as opaque fp32 VALUES.  Otherwise hipcc folds the producing fma / multiply into ONE of the two conversions of the split
+  // (v_fma_mixlo_f16: a single rounding of the exact result) while the other goes through v_cvt_pk_f16_f32 of the rounded fp32
+  // value; in the 2^-13 of cases where double rounding matters the MFMA operand hi and the hi inside lo then differ by one f16
+  // ulp and hi + lo misses e by 5e-4 |e| (tools/ubench/f16_split_fusion.hip; seen as 1e-4 jumps of the MLP output).
+  float ev[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
-    // The entry as an opaque fp32 VALUE.  Otherwise hipcc folds the producing fma / multiply into ONE of the two conversions below
-    // (v_fma_mixlo_f16: a single rounding of the exact result) while the other goes through v_cvt_pk_f16_f32 of the rounded fp32
-    // value; in the 2^-13 of cases where double rounding matters the MFMA operand hi and the hi inside lo then differ by one f16
-    // ulp and hi + lo misses e by 5e-4 |e| (tools/ubench/f16_split_fusion.hip; seen as 1e-4 jumps of the MLP output).
-    float ev = e[i < NE ? i : 0];
-    asm("" : "+v"(ev));
-    hi[i] = i < NE ? (_Float16)ev : (_Float16)0.0f;
-    lo[i] = i < NE ? (_Float16)(ev - (float)hi[i]) : (_Float16)0.0f;
+    ev[i] = i < NE ? e[i] : 0.0f;
+    if (i < NE) asm("" : "+v"(ev[i]));
   }
+  const float neg1 = opaque_neg1();
   unsigned ph[4], qh[4], pl[4], ql[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    ph[j] = pack_h2(hi[2 * j], hi[2 * j + 1]), pl[j] = pack_h2(lo[2 * j], lo[2 * j + 1]);
-    qh[j] = 8 + 2 * j < NE ? pack_h2(hi[8 + 2 * j], hi[9 + 2 * j]) : 0u;
-    ql[j] = 8 + 2 * j < NE ? pack_h2(lo[8 + 2 * j], lo[9 + 2 * j]) : 0u;
+    split2_f16(ev[2 * j], ev[2 * j + 1], neg1, ph[j], pl[j]);
+    if (8 + 2 * j < NE) split2_f16(ev[8 + 2 * j], ev[9 + 2 * j], neg1, qh[j], ql[j]);   // (an odd NE: entry NE is the constant 0, hi = lo = 0)
+    else qh[j] = 0u, ql[j] = 0u;
     swap32u(ph[j], qh[j]);  // p*: point tile 0 (k 0-7 from its own lanes, k 8-15 from the partner half), q*: point tile 1
     swap32u(pl[j], ql[j]);
   }
@@ -299,18 +319,20 @@ __device__ __forceinline__ void hidden_layer_h(f32x16 (&out)[1][2], const f32x16
     const h8 al = *reinterpret_cast<const h8*>(wl + term_stride + sl * 256);
 #pragma unroll
     for (int pt = 0; pt < 2; ++pt) {
-      _Float16 hi[8], lo[8];
+      float vc[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         // relu, then back to the true magnitude; the upper clamp only keeps a (never observed) 6e4 activation from turning into inf
         const float v = __builtin_amdgcn_fmed3f(in[0][pt][8 * sl + i], 0.0f, 3.4028234663852886e38f) * inv_scale;
-        float vc = fminf(v, 6.0e4f);
-        asm("" : "+v"(vc));   // opaque fp32 value: both conversions below must see the same rounding (see f16_region)
-        hi[i] = (_Float16)vc;
-        lo[i] = (_Float16)(vc - (float)hi[i]);
+        vc[i] = fminf(v, 6.0e4f);
+        asm("" : "+v"(vc[i]));   // opaque fp32 value: both conversions of the split must see the same rounding (see f16_region)
       }
-      const h8 bh = __builtin_bit_cast(h8, (u32x4){pack_h2(hi[0], hi[1]), pack_h2(hi[2], hi[3]), pack_h2(hi[4], hi[5]), pack_h2(hi[6], hi[7])});
-      const h8 bl = __builtin_bit_cast(h8, (u32x4){pack_h2(lo[0], lo[1]), pack_h2(lo[2], lo[3]), pack_h2(lo[4], lo[5]), pack_h2(lo[6], lo[7])});
+      const float neg1 = opaque_neg1();
+      unsigned uh[4], ul[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) split2_f16(vc[2 * j], vc[2 * j + 1], neg1, uh[j], ul[j]);
+      const h8 bh = __builtin_bit_cast(h8, (u32x4){uh[0], uh[1], uh[2], uh[3]});
+      const h8 bl = __builtin_bit_cast(h8, (u32x4){ul[0], ul[1], ul[2], ul[3]});
       out[0][pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, out[0][pt], 0, 0, 0);
       out[0][pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, out[0][pt], 0, 0, 0);
       out[0][pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, out[0][pt], 0, 0, 0);
@@ -418,8 +440,13 @@ constexpr int kGatherLdsPerWave = 3 * 4096 + 768;
 // rays (whose samples share their texels: one line per instruction).
 // Here EIGHT ADJACENT LANES fetch one whole 128-byte row half (global_load_lds_dwordx4: 16 bytes per lane straight into LDS, no
 // VGPRs): 8 lines per instruction instead of 64.  The hardware puts lane L's 16 bytes at M0 + 16 L, so the row of point 8j + m
-// (instruction j of a block, m = L >> 3) lands at block + j * 1024 + m * 128; the pieces are fetched rotated by m >> 1 so that the
-// consumer -- lane (h, col) reading the four pieces 4h .. 4h + 3 of row col as ds_read_b128 -- spreads over all banks.
+// (instruction j of a block, m = L >> 3) lands at block + j * 1024 + m * 128; the pieces of row r = 8 j + m are fetched rotated by
+// (r >> 1) & 7 = (4 j + (m >> 1)) & 7 so that the consumer -- lane (h, col) reading the four pieces 4h .. 4h + 3 of row col as
+// ds_read_b128 -- spreads over all banks.  gfx950 serves a ds_read_b128 in four 16-lane groups, {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}
+// and the same + 32 (MI355X_MICROARCH.md, LDS), 256 bytes = 16 slots of 16 bytes per cycle: a group's eight even rows need eight different
+// rotations, and so do its eight odd rows (slot = 8 (r & 1) + ((piece - rot) & 7)).  (r >> 1) & 7 is a bijection on each of those sets;
+// rounds 2 - 5 rotated by (r & 7) >> 1, which pairs rows 0-3 with 24-27 and 12-15 with 20-23: every read took two cycles per group
+// -- SQ_LDS_BANK_CONFLICT 62.9 M cycles per eval frame = 64 reads x 4 extra cycles x 245 760 rays, profiles/r05m/traffic_fwd_def.json.)
 // A block = one tap of one (point tile, hidden tile) = 32 rows = 4 KB; a ring of three blocks per wave; block T + 3 is issued into
 // the slot of block T once T has been blended.  The tap offsets of the 64 samples go through a 768-byte per-wave table (lane = sample
 // writes, lane (m, piece) reads the row of sample 32 pt + 8 j + m).  52 KB of dynamic LDS per work-group on top of the weights: two
@@ -429,7 +456,8 @@ struct GatherLds {
   unsigned ring_m0;     // ... as an LDS byte address (M0 of the DMA loads)
   unsigned* tab;        // this wave's tap table: [64 samples][3] byte offsets into G of the taps nw, ne, sw
   unsigned rd[4];       // byte offset inside a block of this lane's piece q as the CONSUMER (h, col)
-  unsigned piece16;     // 16 * the piece this lane FETCHES: ((L & 7) + (L >> 4)) & 7, i.e. rotated by (m >> 1), m = L >> 3
+  unsigned piece16;     // 16 * the piece this lane FETCHES in the EVEN instructions of a block: ((L & 7) + (L >> 4)) & 7, i.e. rotated by m >> 1, m = L >> 3
+  unsigned piece16x;    // ... in the ODD instructions (rows 8 .. 15, 24 .. 31): rotated by 4 more = piece16 ^ 64
   int m;                // L >> 3
 };
 template <int HD, int T>
@@ -449,7 +477,7 @@ __device__ __forceinline__ void gl_offsets(const GatherLds& c, unsigned (&off)[4
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const unsigned* row = c.tab + (32 * B::pt + 8 * j + c.m) * 3;   // [o00, o01, o10]; o11 = o10 + (o01 - o00) (clamped taps included)
-    off[j] = (B::tap < 3 ? row[B::tap] : row[2] + row[1] - row[0]) + (c.piece16 + kGlBias - 1024u * j);
+    off[j] = (B::tap < 3 ? row[B::tap] : row[2] + row[1] - row[0]) + ((j & 1 ? c.piece16x : c.piece16) + kGlBias - 1024u * j);
   }
 }
 // what the overwrite of a slot must wait for: one value computed from EACH of the four row pieces (ds_read_b128) of the block that
@@ -661,9 +689,10 @@ __global__ __launch_bounds__(256, BTS_FWD_WAVES) void render_kernel_p(const FwdP
     gl.tab = reinterpret_cast<unsigned*>(base + 3 * 4096);
     gl.m = lane >> 3;
     gl.piece16 = 16u * (unsigned)(((lane & 7) + (lane >> 4)) & 7);
+    gl.piece16x = gl.piece16 ^ 64u;
     const int col = lane & 31;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) gl.rd[q] = (unsigned)(col * 128 + ((4 * h0 + q - ((col & 7) >> 1)) & 7) * 16);
+    for (int q = 0; q < 4; ++q) gl.rd[q] = (unsigned)(col * 128 + ((4 * h0 + q - (col >> 1)) & 7) * 16);
   }
 #endif
   const int nwg = gridDim.x;  // multiple of 8

@@ -249,7 +249,7 @@ def project_features(spec: FieldSpec, feat_nchw: torch.Tensor, mlp_params: torch
     """F (N,C,H,W) -> G (N,H,W,Hd) = F . w_in[:, :C]^T with the channels in storage order (proj_storage_order)
     (bts_project_features).  With ``tiles`` (N, proj_tile_count) uint8 only the flagged 64-texel tiles are evaluated and the rest of G
     is UNINITIALISED (bts_project_features_tiles): a map for the render whose samples ``mark_sampled_tiles`` flagged, nothing else.
-    A channels_last F (memory (N,H,W,C)) is read as it is (bts_project_features_cl): the same G bit for bit."""
+    A channels_last F (memory (N,H,W,C)) is read as it is (bts_project_features_cl): the same G to fp32 rounding (another summation order)."""
     N, Cc, H, W = feat_nchw.shape
     cl = is_channels_last(feat_nchw)
     if cl:

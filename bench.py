@@ -348,6 +348,36 @@ TRAIN_WORKLOADS = {
 }
 
 
+def train_byte_model(cfg, Kt, shifts, flagged_tiles):
+    """HBM bytes of ONE fused training step as the design moves them, for `traffic_ratio`.  Two parts:
+      algorithmic  what a perfectly fused step would have to move -- the step's inputs read once and its outputs written once: F of
+                   every flagged 64-texel tile, the render frames, the loss patches' colours, one jitter value per sample; the DENSE
+                   feature-map gradient (autograd's contract), the per-ray outputs the caller gets (rays, rgb_gt, rgb, depth, two
+                   invalid-ray reductions per view);
+      state        what the three-pass design parks in HBM between its kernels, each tensor counted once per write and once per read it
+                   needs: the projected tiles G (project: write; render, pass A: read), the rgb0-packed render frames (write), per sample
+                   z / sigma_raw / trans / rgb_samps (render: write; pass A: read) and g_s (pass A: write; passes B, C: read), the relu
+                   gates (plain MLP: 12 B per sample and channel word) or the u0 rows (ResnetBlockFC: 4 d_hidden B per sample) between
+                   pass A and passes B / C, dG tiles (scatter: read-modify-write; projection backward: read + the write that returns them to zero).
+    `flagged_tiles[s]` = tiles of scale s one step's samples touch (counted on the device after the timed loop)."""
+    n, V, H, W, C, HD, NB = cfg["n"], cfg["V"], cfg["H"], cfg["W"], cfg["C"], cfg["HD"], cfg["NB"]
+    nv, B = len(cfg["ids_render"]), cfg["n"] * cfg["rays"]
+    S = B * Kt                                                    # samples per render
+    alg = n * nv * H * W * 3 * 4 + B * 3 * 4 + B * 8 * 4          # render frames, the patches' colours, the rays
+    state = n * nv * H * W * 4 * 4                                # rgb0-packed frames
+    parts = {}
+    for s, sh in enumerate(shifts):
+        tile_px = flagged_tiles[s] * 64
+        dense = n * C * (H >> sh) * (W >> sh) * 4
+        alg += tile_px * C * 4 + S * 4 + dense + B * (nv * 3 + 1 + 2 * nv) * 4          # F tiles, jitter, dF, per-ray outputs
+        g = tile_px * HD * 4
+        per_sample = (3 * 4 + nv * 3 * 4) * 2 + 4 * 3                                   # z, sigma_raw, trans, rgb_samps w + r; g_s w + 2 r
+        per_sample += (4 * HD) * 3 if NB else (HD // 32) * 4 * 3 + (HD * 8) // 64 * 2   # u0 rows w + 2 r | gate words w + r (per-sample + per-channel forms)
+        state += 3 * g + S * per_sample + 4 * g + tile_px * C * 4                        # G w + 2 r; dG rmw (2) + r + zero w; F re-read by the projection backward
+        parts[f"scale{s}"] = dict(flagged_tiles=int(flagged_tiles[s]), tile_fraction=flagged_tiles[s] / max(1, n * (((H >> sh) * (W >> sh) + 63) // 64)))
+    return dict(algorithmic_bytes=int(alg), state_bytes=int(state), detail=parts)
+
+
 def train_cpu_baseline(cfg, net, scene, rank):
     """cpu_baseline of a training workload: the oracle (the reference's torch ops on the CPU) forward + backward of the render for ONE
     batch sample (bounded: cfg.rays rays x K samples, scale 0), best of 2 after a warm-up, min(16, nproc) threads (the eval sweep's
@@ -508,6 +538,17 @@ def train_workload(args, world, rank, dev):
     timer.install()
     elapsed, _ = timed_region(step, args.steps, dev, before=torch.cuda.reset_peak_memory_stats)
     timer.remove()
+    # for the byte model of `traffic_ratio`: the 64-texel tiles of every scale's map the LAST step's samples touched (the forward's flags stay
+    # in the arena until the next hand-over clears them), outside the timed region
+    flagged_tiles, step_shifts = None, None
+    try:
+        from behindthescenes_amd import train_step as TS
+        arenas = [a for pool in TS._ARENAS.values() for a in pool]
+        if len(arenas) == 1:
+            flagged_tiles = [int(sc["tiles"].ne(0).sum().item()) for sc in arenas[0].scales]
+            step_shifts = list(arenas[0].key[12])
+    except Exception:
+        pass
     allreduce = None
     if is_ddp:
         # the gradient all-reduce under a profiler range: device time of the RCCL kernels of two more steps (outside the timed region)
@@ -542,18 +583,34 @@ def train_workload(args, world, rank, dev):
         # (a pass at another K than the yaml's carries the K in its name: tools/profile.sh <tag> bwd_re10k 128 -> traffic_bwd_re10k_k128.json;
         # a line never shows the counters of another K)
         ksfx = f"_k{args.samples}" if args.samples and args.samples != TRAIN_WORKLOADS[args.workload]["K"] else ""
-        tnames = ["traffic_train.json"] if args.workload == "train" and not ksfx else [f"traffic_{args.workload}{ksfx}.json", f"traffic_bwd_{args.workload}{ksfx}.json"]
-        prof = sorted((d, t) for d in (os.listdir(pdir) if os.path.isdir(pdir) else []) for t in tnames if os.path.exists(os.path.join(pdir, d, t)))
-        if prof:
-            tname = prof[-1][1]
-            prof = [prof[-1][0]]
-            tj = json.load(open(os.path.join(pdir, prof[-1], tname)))
-            render = [k for k in ("render_kernel_p", "rows_kernel", "scatter_kernel", "dwpe_kernel", "rowsb_kernel", "dwpe_rows_kernel") if k in tj and "fetch_bytes" in tj[k]]
-            traffic = sum(tj[k]["fetch_bytes"] + tj[k]["write_bytes"] for k in render) if render else None
-            counters = {k: {f: v[f] for f in ("kernel_ms_rocprof", "fetch_bytes", "write_bytes", "valu_busy", "mfma_busy", "wait_frac", "l2_hit") if f in v}
-                        for k, v in tj.items()}
-            counters["source"] = (f"profiles/{prof[-1]}/{tname}: rocprofv3 --pmc passes of tools/train_probe.py (same shapes); `traffic` = "
-                                  "fetch + write bytes of " + ", ".join(render) + " per launch; FETCH_SIZE doubled per MI355X_MICROARCH.md")
+        byte_model, traffic_ratio, traffic_over_model = None, None, None
+        sname = f"traffic_step_{args.workload}{ksfx}.json"
+        sprof = sorted(d for d in (os.listdir(pdir) if os.path.isdir(pdir) else []) if os.path.exists(os.path.join(pdir, d, sname)))
+        if sprof and args.encoder == "feature_map":
+            # tools/profile_step.sh: rocprofv3 --pmc passes of THIS command (the fused step), every bts:: kernel of the step summed
+            tj = json.load(open(os.path.join(pdir, sprof[-1], sname)))
+            traffic = tj["step"]["fetch_bytes"] + tj["step"]["write_bytes"]
+            counters = {k: {f: round(v[f], 4) for f in ("launches_per_step", "kernel_ms", "fetch_bytes", "write_bytes", "l2_hit", "tb_per_s") if f in v}
+                        for k, v in tj["kernels"].items()}
+            counters["source"] = (f"profiles/{sprof[-1]}/{sname}: rocprofv3 --pmc passes of `bench.py --workload {args.workload}` (tools/profile_step.sh); "
+                                  "`traffic` = fetch + write bytes of every bts:: kernel of one fused step; FETCH_SIZE doubled per MI355X_MICROARCH.md")
+            if flagged_tiles is not None:
+                byte_model = train_byte_model(cfg, Kt, step_shifts, flagged_tiles)
+                traffic_ratio = traffic / byte_model["algorithmic_bytes"]
+                traffic_over_model = traffic / (byte_model["algorithmic_bytes"] + byte_model["state_bytes"])
+        else:
+            tnames = ["traffic_train.json"] if args.workload == "train" and not ksfx else [f"traffic_{args.workload}{ksfx}.json", f"traffic_bwd_{args.workload}{ksfx}.json"]
+            prof = sorted((d, t) for d in (os.listdir(pdir) if os.path.isdir(pdir) else []) for t in tnames if os.path.exists(os.path.join(pdir, d, t)))
+            if prof:
+                tname = prof[-1][1]
+                prof = [prof[-1][0]]
+                tj = json.load(open(os.path.join(pdir, prof[-1], tname)))
+                render = [k for k in ("render_kernel_p", "rows_kernel", "scatter_kernel", "dwpe_kernel", "rowsb_kernel", "dwpe_rows_kernel") if k in tj and "fetch_bytes" in tj[k]]
+                traffic = sum(tj[k]["fetch_bytes"] + tj[k]["write_bytes"] for k in render) if render else None
+                counters = {k: {f: v[f] for f in ("kernel_ms_rocprof", "fetch_bytes", "write_bytes", "valu_busy", "mfma_busy", "wait_frac", "l2_hit") if f in v}
+                            for k, v in tj.items()}
+                counters["source"] = (f"profiles/{prof[-1]}/{tname}: rocprofv3 --pmc passes of tools/train_probe.py (same shapes); `traffic` = "
+                                      "fetch + write bytes of " + ", ".join(render) + " per launch; FETCH_SIZE doubled per MI355X_MICROARCH.md")
         what = (f"{cfg['yaml']} shapes: bs={n}/GPU, {Vt} frames ({len(ids_loss)} loss + {len(ids_render)} render views), {Hh}x{Ww}, {cfg['rays']} patch "
                 f"rays (8x8) per sample, {Kt} samples/ray, C={Cc}, d_hidden={Hd}, {Nb} ResnetBlockFC, code {cfg['code_mode']}, "
                 + (f"{n_scales} renders per step (multiscale, trainer.py:220-242), " if n_scales > 1 else "")
@@ -573,6 +630,8 @@ def train_workload(args, world, rank, dev):
                        "feat_layout": "nhwc (channels_last: Monodepth2's hand-over)" if args.encoder != "feature_map" else args.feat_layout},
             "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_MATRIX_TFLOPS, "traffic": traffic,
+                         **({"algorithmic_bytes": byte_model["algorithmic_bytes"], "state_bytes": byte_model["state_bytes"], "traffic_ratio": traffic_ratio,
+                             "traffic_over_model": traffic_over_model, "byte_model": byte_model["detail"]} if byte_model else {}),
                          "kernel": ("bts_train_step_fwd + bts_train_step_bwd: every bts:: kernel of the step (hand-over, patch rays, tile flags, "
                                     "projection, render, loss, the backward's passes, projection backward)" if fused.last_path == "fused" else
                                     "every library call of the step, entry by entry: " + ", ".join(sorted(ms))),
@@ -877,7 +936,7 @@ def _condense(rec):
     r = rec["roofline"]
     keep = {"metric": rec["metric"], "value": rec["value"], "unit": rec["unit"], "steps": rec["steps"], "warmup": rec["warmup"],
             "ms_per_step": rec["ms_per_step"], "workload": rec["config"]["workload"],
-            "roofline": {k: r[k] for k in ("bound", "achieved", "peak", "unit", "frac", "frac_step", "frac_algorithmic", "gpu_busy_frac", "traffic", "kernel", "kernel_ms", "fwd_ms", "bwd_ms", "entry_ms", "path") if k in r}}
+            "roofline": {k: r[k] for k in ("bound", "achieved", "peak", "unit", "frac", "frac_step", "frac_algorithmic", "gpu_busy_frac", "traffic", "algorithmic_bytes", "state_bytes", "traffic_ratio", "traffic_over_model", "kernel", "kernel_ms", "fwd_ms", "bwd_ms", "entry_ms", "path") if k in r}}
     if "allreduce" in rec:
         keep["allreduce"] = rec["allreduce"]
     return keep

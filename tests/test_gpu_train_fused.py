@@ -200,7 +200,8 @@ def test_fused_eval_frame_equals_the_entry_by_entry_frame():
 
 def test_fused_eval_frame_reads_a_channels_last_map_as_it_is_and_leaves_no_stale_state():
     """ABI 9 (BtsEvalFrame.feat_channels_last): an encoder whose scale-0 map is in torch's channels_last format -- what the shipped
-    Monodepth2 decoder writes -- goes through bts_eval_frame without a layout copy, bit-identical to the NCHW map.  And a fused frame
+    Monodepth2 decoder writes -- goes through bts_eval_frame without a layout copy; the projected map G differs from the NCHW route's by
+    fp32 rounding (another summation order, tests/test_gpu_channels_last.py), the frame's outputs accordingly.  And a fused frame
     leaves no field state behind: a field query afterwards raises instead of running on the previous encode's maps (round-5 advice)."""
     import behindthescenes_amd as bts
     from behindthescenes_amd import native, synthetic as S
@@ -237,8 +238,11 @@ def test_fused_eval_frame_reads_a_channels_last_map_as_it_is_and_leaves_no_stale
     finally:
         native.eval_frame = orig
     assert frame.last_path == "fused" and seen["cl"] == 1
-    for k in ("rgb", "depth", "invalid", "weights", "alphas"):
-        assert torch.equal(a["coarse"][0][k], b["coarse"][0][k]), k
+    ca, cb = a["coarse"][0], b["coarse"][0]
+    assert torch.equal(ca["invalid"], cb["invalid"])
+    assert ((ca["depth"] - cb["depth"]).abs() / cb["depth"].abs()).max().item() <= 1e-5
+    for k in ("rgb", "weights", "alphas"):
+        assert (ca[k] - cb[k]).abs().max().item() <= 1e-5, (k, (ca[k] - cb[k]).abs().max().item())
     with pytest.raises(native.BtsNativeError, match="encode"):
         net(torch.zeros(1, 8, 3, device=dev))
     net.encode(*inputs, ids_encoder=[0], ids_render=[0])

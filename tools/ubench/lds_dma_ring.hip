@@ -62,9 +62,10 @@ __global__ __launch_bounds__(256, 2) void ring_kernel(const float4* __restrict__
     gl.tab = reinterpret_cast<unsigned*>(base + 3 * 4096);
     gl.m = lane >> 3;
     gl.piece16 = 16u * (unsigned)(((lane & 7) + (lane >> 4)) & 7);
+    gl.piece16x = gl.piece16 ^ 64u;
     const int col = lane & 31;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) gl.rd[q] = (unsigned)(col * 128 + ((4 * h0 + q - ((col & 7) >> 1)) & 7) * 16);
+    for (int q = 0; q < 4; ++q) gl.rd[q] = (unsigned)(col * 128 + ((4 * h0 + q - (col >> 1)) & 7) * 16);
   }
   f32x16 busy = zero_acc();
   const h8 ma = {(_Float16)1, (_Float16)0.5f, (_Float16)0.25f, (_Float16)2, (_Float16)1, (_Float16)1, (_Float16)0.125f, (_Float16)3};
