@@ -27,7 +27,8 @@ class BtsNativeError(RuntimeError):
 class BtsFieldCfg(C.Structure):
     _fields_ = [(k, C.c_int32) for k in ("n", "H", "W", "C", "d_hidden", "n_blocks", "nv", "num_freqs", "code_mode", "inv_z",
                                          "learn_empty", "empty_empty")] + \
-               [("freq_factor", C.c_float), ("d_min", C.c_float), ("d_max", C.c_float), ("feat_shift", C.c_int32), ("enc_render_view", C.c_int32)]
+               [("freq_factor", C.c_float), ("d_min", C.c_float), ("d_max", C.c_float), ("feat_shift", C.c_int32), ("enc_render_view", C.c_int32),
+                ("tile_blocks", C.c_int32)]       # ABI 9
 
 
 class BtsFieldTensors(C.Structure):

@@ -23,11 +23,11 @@ int distance_to_z_launch(const float* depths, const float* invK, int N, int H, i
 int invert_small_launch(const float* src, float* dst, int N, int dim, hipStream_t s);
 
 int project_features_impl(int C, int HD, const float* feat, const float* mlp, int N, int HW, float* proj, const unsigned char* tiles, hipStream_t s,
-                          bool feat_cl = false);
+                          bool feat_cl = false, int Wm = 0);   // Wm: the map's width when `tiles` are 16 x 4 blocks (BtsFieldCfg.tile_blocks), 0 = runs of 64 texels
 int mark_tiles_impl(const float* rays, const float* z_samp, const float* jitter, const float* w2c_enc, const float* K_enc, long B, int Bp, int K, int lindisp,
-                    int H, int W, int fs, unsigned char* tiles, hipStream_t s);
+                    int H, int W, int fs, unsigned char* tiles, hipStream_t s, int blocks);
 int project_features_bwd_tiles_impl(int C, int HD, const float* feat, float* dproj, unsigned char* tiles, const float* mlp, int N, int HW, float* dfeat,
-                                    float* d_mlp, int clear, hipStream_t s, bool feat_cl = false);
+                                    float* d_mlp, int clear, hipStream_t s, bool feat_cl = false, int Wm = 0);
 int project_features_bwd_impl(int C, int HD, const float* feat, const float* dproj, const float* mlp, int N, int HW, float* dfeat,
                               float* d_mlp, hipStream_t s);
 int render_fwd_impl(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const BtsRenderArgs* a, hipStream_t s);
@@ -177,7 +177,8 @@ int bts_project_features_tiles(const BtsFieldCfg* cfg, const float* feat_nchw, c
     return BTS_E_UNSUPPORTED;
   }
   if (int rc = check_shift(cfg, "bts_project_features_tiles")) return rc;
-  int rc = project_features_impl(cfg->C, cfg->d_hidden, feat_nchw, mlp_params, N, (int)feat_texels(cfg), proj_nhwc, tiles, (hipStream_t)stream);
+  int rc = project_features_impl(cfg->C, cfg->d_hidden, feat_nchw, mlp_params, N, (int)feat_texels(cfg), proj_nhwc, tiles, (hipStream_t)stream, false,
+                                 cfg->tile_blocks ? cfg->W >> cfg->feat_shift : 0);
   if (rc) set_error("%s: kernel launch failed", "bts_project_features_tiles");
   return rc;
 }
@@ -190,7 +191,7 @@ int bts_mark_sampled_tiles(const BtsFieldCfg* cfg, const float* K_enc, const flo
   }
   if (int rc = check_shift(cfg, "bts_mark_sampled_tiles")) return rc;
   int rc = mark_tiles_impl(a->rays, a->z_samp, a->z_samp ? nullptr : a->jitter, w2c_enc, K_enc, (long)cfg->n * a->rays_per_sample, a->rays_per_sample, a->K,
-                           a->lindisp, cfg->H, cfg->W, cfg->feat_shift, tiles, (hipStream_t)stream);
+                           a->lindisp, cfg->H, cfg->W, cfg->feat_shift, tiles, (hipStream_t)stream, cfg->tile_blocks);
   if (rc) set_error("%s: kernel launch failed", "bts_mark_sampled_tiles");
   return rc;
 }
@@ -237,7 +238,7 @@ int bts_project_features_bwd_tiles(const BtsFieldCfg* cfg, const float* feat_nch
   }
   if (int rc = check_shift(cfg, "bts_project_features_bwd_tiles")) return rc;
   int rc = project_features_bwd_tiles_impl(cfg->C, cfg->d_hidden, feat_nchw, d_proj_nhwc, tiles, mlp_params, N, (int)feat_texels(cfg), d_feat_nchw,
-                                           d_mlp_params, clear_after, (hipStream_t)stream);
+                                           d_mlp_params, clear_after, (hipStream_t)stream, false, cfg->tile_blocks ? cfg->W >> cfg->feat_shift : 0);
   if (rc) set_error("%s: kernel launch failed", "bts_project_features_bwd_tiles");
   return rc;
 }
@@ -254,7 +255,8 @@ int bts_project_features_cl(const BtsFieldCfg* cfg, const float* feat_nhwc, cons
     return BTS_E_UNSUPPORTED;
   }
   if (int rc = check_shift(cfg, "bts_project_features_cl")) return rc;
-  int rc = project_features_impl(cfg->C, cfg->d_hidden, feat_nhwc, mlp_params, N, (int)feat_texels(cfg), proj_nhwc, tiles, (hipStream_t)stream, true);
+  int rc = project_features_impl(cfg->C, cfg->d_hidden, feat_nhwc, mlp_params, N, (int)feat_texels(cfg), proj_nhwc, tiles, (hipStream_t)stream, true,
+                                 cfg->tile_blocks ? cfg->W >> cfg->feat_shift : 0);
   if (rc) set_error("%s: kernel launch failed", "bts_project_features_cl");
   return rc;
 }
@@ -272,7 +274,7 @@ int bts_project_features_bwd_cl(const BtsFieldCfg* cfg, const float* feat_nhwc, 
   }
   if (int rc = check_shift(cfg, "bts_project_features_bwd_cl")) return rc;
   int rc = project_features_bwd_tiles_impl(cfg->C, cfg->d_hidden, feat_nhwc, d_proj_nhwc, tiles, mlp_params, N, (int)feat_texels(cfg), d_feat_nhwc,
-                                           d_mlp_params, clear_after, (hipStream_t)stream, true);
+                                           d_mlp_params, clear_after, (hipStream_t)stream, true, cfg->tile_blocks ? cfg->W >> cfg->feat_shift : 0);
   if (rc) set_error("%s: kernel launch failed", "bts_project_features_bwd_cl");
   return rc;
 }

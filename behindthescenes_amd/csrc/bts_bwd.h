@@ -19,6 +19,7 @@ struct BwdParams {
   uint2* pmask_ws;        //                    (n*Bp, HD) the same gates per channel, one bit per sample of the ray
   unsigned char* tiles;   // (n, tiles_per_img) dirty flags of d_proj's 64-texel tiles (BtsRenderGrads.d_proj_tiles), or null
   int tiles_per_img;
+  int tile_tw;            // tile_cols(H >> fs, W >> fs, cfg->tile_blocks): blocks per row of the 16 x 4 tile form, 0 = runs of 64 texels
 #ifdef BTS_TICKS
   unsigned long long* ticks;   // diagnostic build: [waves][16] cycles per section (rows_kernel: tools/bwd_ticks.py; scatter_kernel behind them)
 #endif

@@ -783,6 +783,7 @@ int render_bwd_impl(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const BtsR
 #endif
   bp.tiles = bp.d_proj ? g->d_proj_tiles : nullptr;
   bp.tiles_per_img = (int)((((long)(cfg->H >> cfg->feat_shift) * (cfg->W >> cfg->feat_shift)) + 63) / 64);
+  bp.tile_tw = tile_cols(cfg->H >> cfg->feat_shift, cfg->W >> cfg->feat_shift, cfg->tile_blocks);
 #ifdef BTS_PROBE
   static const bool direct = getenv("BTS_BWD_DIRECT_ATOMICS") != nullptr;   // A/B (probe build): round-1 kernel, every tap update an L2 atomic
   static const bool v1 = getenv("BTS_BWD_V1") != nullptr || direct;         // A/B (probe build): the round-1 lane = ray pass for every shape

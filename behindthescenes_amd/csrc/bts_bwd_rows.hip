@@ -532,6 +532,7 @@ struct ScatterMaskParams {
   float* d_empty_proj;       // or null
   unsigned char* tiles;      // or null.  (n, tiles_per_img) dirty flags of d_proj (BtsRenderGrads.d_proj_tiles): the byte of every 64-texel
   int tiles_per_img;         // tile that receives a contribution is set to 1
+  int tile_tw;               // tile_cols(H >> fs, W >> fs, BtsFieldCfg.tile_blocks)
   int groups_per_sample;
   int w_out_off;             // offset of w_out in the packed parameter vector
 #ifdef BTS_TICKS
@@ -598,6 +599,7 @@ __global__ __launch_bounds__(64) void scatter_kernel(const ScatterMaskParams sp)
   const unsigned* mrow = ROWS ? nullptr : sp.mask_ws + (ray * NW + wv) * K;
   float* __restrict__ dG = sp.d_proj + (long)sample * H * W * HD + chg;
   unsigned char* __restrict__ const dirty = sp.tiles ? sp.tiles + (long)sample * sp.tiles_per_img : nullptr;
+  const int tw = sp.tile_tw;        // the map's tile geometry (bts_common.h): blocks per row of the 16 x 4 form, 0 = runs of 64 texels
   const float w_out_ch = ROWS ? 0.0f : p.mlp[sp.w_out_off + proj_hidden_of_storage(chg)];
   // ROWS: channel chg of point i of this lane's half at step k is urow[(i K + k) HD]
   const float* urow = ROWS ? sp.u0_ws + ((long)sample * Bp + g_in * 64 + 32 * h) * K * HD + chg : nullptr;
@@ -613,7 +615,7 @@ __global__ __launch_bounds__(64) void scatter_kernel(const ScatterMaskParams sp)
     const float v = *cc;
     if (v != 0.0f) {
       atomic_add_f32(dG + ((long)ty * W + tx) * HD, v);
-      if (dirty) dirty[(unsigned)(ty * W + tx) >> 6] = 1;   // (same byte from every lane that added something: one request)
+      if (dirty) dirty[tile_of(ty, tx, W, tw)] = 1;   // (same byte from every lane that added something: one request)
       *cc = 0.0f;
     }
   };
@@ -840,8 +842,8 @@ __global__ __launch_bounds__(64) void scatter_kernel(const ScatterMaskParams sp)
           atomic_add_f32(dG + (yb + xa) * HD, w10 * gv);
           atomic_add_f32(dG + (yb + xb) * HD, w11 * gv);
           if (dirty)
-            dirty[(unsigned)(ya + xa) >> 6] = 1, dirty[(unsigned)(ya + xb) >> 6] = 1, dirty[(unsigned)(yb + xa) >> 6] = 1,
-            dirty[(unsigned)(yb + xb) >> 6] = 1;
+            dirty[tile_of(bc_i(y0, i), xa, W, tw)] = 1, dirty[tile_of(bc_i(y0, i), xb, W, tw)] = 1, dirty[tile_of(bc_i(y1, i), xa, W, tw)] = 1,
+            dirty[tile_of(bc_i(y1, i), xb, W, tw)] = 1;
         }
       }
     }
@@ -1291,7 +1293,7 @@ static int launch_rows(const BwdParams& bp, int n, int grid, hipStream_t s) {
     const MlpLayout ml{C + kPeDim, HD, 0};
     ScatterMaskParams sp;
     sp.f = p, sp.mask_ws = bp.mask_ws, sp.u0_ws = nullptr, sp.gs_ws = bp.gs_ws, sp.d_proj = bp.d_proj, sp.d_empty_proj = bp.d_empty_proj;
-    sp.tiles = bp.tiles, sp.tiles_per_img = bp.tiles_per_img;
+    sp.tiles = bp.tiles, sp.tiles_per_img = bp.tiles_per_img, sp.tile_tw = bp.tile_tw;
 #ifdef BTS_TICKS
     sp.ticks = bp.ticks;
 #endif
@@ -1344,7 +1346,7 @@ int launch_scatter_rows(const BwdParams& bp, const float* u0_ws, int HD, int n, 
   const FwdParams& p = bp.f;
   ScatterMaskParams sp;
   sp.f = p, sp.mask_ws = nullptr, sp.u0_ws = u0_ws, sp.gs_ws = bp.gs_ws, sp.d_proj = bp.d_proj, sp.d_empty_proj = bp.d_empty_proj;
-  sp.tiles = bp.tiles, sp.tiles_per_img = bp.tiles_per_img;
+  sp.tiles = bp.tiles, sp.tiles_per_img = bp.tiles_per_img, sp.tile_tw = bp.tile_tw;
 #ifdef BTS_TICKS
   sp.ticks = bp.ticks;
 #endif

@@ -243,6 +243,28 @@ __device__ __forceinline__ Taps make_taps(float x, float y, int H, int W, int fs
   return make_taps_xy(x, y, H, W, x0, y0, x1, y1, fs);
 }
 
+// ---- tiles of the projected map G / its gradient (one flag byte per tile: BtsRenderGrads.d_proj_tiles, bts_mark_sampled_tiles).
+// A tile is 64 texels: 64 consecutive texels of the row-major map (rounds 4 - 5: always), or -- BtsFieldCfg.tile_blocks, where the map's
+// height is a multiple of 4 and its width a multiple of 16: every shipped config at every scale -- a block of 4 rows x 16 texels,
+// numbered row-major over the (H / 4) x (W / 16) blocks.  A training step's samples project onto streaks along the epipolar lines:
+// at exp_kitti_360.yaml's batch they touch 14.6 % of the texels, 38.4 % of the 64 x 1 runs and 26.1 % of the 16 x 4 blocks
+// (profiles/r04n/tile_stats.txt) -- a third less for both projection passes to read, contract and return to zero.  That pays where a
+// block is four 4 KB pieces (channels-last F / dF, like G / dG); an NCHW map's 256-byte row pieces become 64-byte ones and the
+// backward loses more than it saves (profiles/r06f): the caller picks.  The tile COUNT of a map is the same in both forms: ceil(H W / 64).
+//   tw = tile_cols(Hm, Wm, blocks): blocks per map row in the 2-D form, 0 in the linear form
+//   tile_of(y, x, Wm, tw):  the tile of texel (y, x)
+//   tile_base(t, Wm, tw):   the first texel (y * Wm + x) of tile t;   tile_rs(Wm, tw): slot i of a tile is texel base + i + (i >> 4) * rs
+__host__ __device__ inline int tile_cols(int Hm, int Wm, int blocks) { return (blocks && (Hm & 3) == 0 && (Wm & 15) == 0) ? (Wm >> 4) : 0; }
+__device__ __forceinline__ unsigned tile_of(int y, int x, int Wm, int tw) {
+  return tw ? (unsigned)((y >> 2) * tw + (x >> 4)) : (unsigned)(y * Wm + x) >> 6;
+}
+__device__ __forceinline__ int tile_base(int t, int Wm, int tw) {
+  if (!tw) return t * 64;
+  const int ty = t / tw;
+  return ty * 4 * Wm + (t - ty * tw) * 16;
+}
+__device__ __forceinline__ int tile_rs(int Wm, int tw) { return tw ? Wm - 16 : 0; }
+
 // depth code in [-1,1] (models_bts.py:157-171) of the projected point's depth (code_mode z) or distance (by_distance)
 __device__ __forceinline__ float depth_code(const Proj& pe, bool by_distance, bool inv_z, float inv_dmax, float inv_range, float d_min, float range) {
   const float v = by_distance ? pe.dist : pe.z;

@@ -13,6 +13,12 @@ namespace bts {
 
 void set_error(const char* fmt, const char* a = "", long b = 0, long c = 0, long d = 0);
 
+// texel (index inside its image) of slot i of the tile whose first texel is p0: bts_common.h, tile_rs
+__device__ __forceinline__ int tile_px(int p0, int i, int rs) { return p0 + i + (i >> 4) * rs; }
+// the same for a slot = cslot (wave-uniform, mostly a compile-time constant) + lslot (per lane, never carrying into bit 4 of the slot):
+// the row piece (cslot >> 4) stays a uniform -- the address is scalar base + lane offset + immediate instead of one VGPR per access
+__device__ __forceinline__ int tile_px_c(int p0, int cslot, int lslot, int rs) { return p0 + cslot + (cslot >> 4) * rs + lslot; }
+
 // ---- forward: one wave = 64 pixels x all Hd outputs.  D[pix][hid] = A[pix][c] . B[c][hid]:
 // A operand = F (lane l: pixel l&31, channel parity l>>5) read straight from the NCHW rows, B = w_in^T from LDS (k-major),
 // D rows (pixels) sit in registers, columns (hidden) across lanes -> every store is a 128-byte row segment of G.
@@ -24,7 +30,7 @@ void set_error(const char* fmt, const char* a = "", long b = 0, long c = 0, long
 // (lane half 0) with 8 q + 4 + e (half 1) -- and a tile is 64 x C x 4 contiguous bytes instead of C row pieces of 256.
 template <int C, int HD, bool FEAT_CL>
 __global__ __launch_bounds__(256, 2) void project_kernel(const float* __restrict__ feat, const float* __restrict__ mlp, float* __restrict__ proj,
-                                                      int HW, int tiles_per_img, int n_tiles, const unsigned char* __restrict__ tiles) {
+                                                      int HW, int tiles_per_img, int n_tiles, const unsigned char* __restrict__ tiles, int Wm, int tw) {
   constexpr int HT = HD / 32;
   constexpr int D_IN = C + kPeDim;
   __shared__ float wl[C * HD];  // wl[c*HD + s] = w_in[hidden_of_storage(s)][c]: G comes out in its storage channel order
@@ -44,13 +50,15 @@ __global__ __launch_bounds__(256, 2) void project_kernel(const float* __restrict
     flag_n = (tiles && tile + tstride < n_tiles) ? (int)tiles[tile + tstride] : 1;
     if (!wanted) continue;
     const int img = tile / tiles_per_img;
-    const int p0 = (tile - img * tiles_per_img) * 64;
+    // slot i of the tile is texel p0 + i + (i >> 4) * rs of the image (bts_common.h: a 16 x 4 block, or 64 consecutive texels with rs = 0)
+    const int p0 = tile_base(tile - img * tiles_per_img, Wm, tw), rs = tile_rs(Wm, tw);
+    const int px0 = p0 + col + (col >> 4) * rs, px1 = p0 + 32 + col + ((32 + col) >> 4) * rs;   // this lane's texels of the two point tiles
     const float* F = feat + (long)img * C * HW;
     float* G = proj + (long)img * HW * HD;
     f32x16 acc[2][HT];
     if constexpr (FEAT_CL) {
       const float4* F4 = reinterpret_cast<const float4*>(F);
-      const unsigned q0 = (unsigned)(min(p0 + col, HW - 1) * (C / 4) + h), q1 = (unsigned)(min(p0 + 32 + col, HW - 1) * (C / 4) + h);
+      const unsigned q0 = (unsigned)(min(px0, HW - 1) * (C / 4) + h), q1 = (unsigned)(min(px1, HW - 1) * (C / 4) + h);
       float4 v0[C / 8], v1[C / 8];
 #pragma unroll
       for (int q = 0; q < C / 8; ++q) v0[q] = F4[q0 + 2 * q], v1[q] = F4[q1 + 2 * q];
@@ -76,7 +84,7 @@ __global__ __launch_bounds__(256, 2) void project_kernel(const float* __restrict
       }
     } else {
     // wave-uniform base + 32-bit lane offset (one image's map is far below 4 GB): scalar-base loads, no 64-bit address per load
-    const unsigned o0 = (unsigned)(h * HW + min(p0 + col, HW - 1)), o1 = (unsigned)(h * HW + min(p0 + 32 + col, HW - 1));
+    const unsigned o0 = (unsigned)(h * HW + min(px0, HW - 1)), o1 = (unsigned)(h * HW + min(px1, HW - 1));
     float a0[C / 2], a1[C / 2];
 #pragma unroll
     for (int s = 0; s < C / 2; ++s) {
@@ -103,7 +111,7 @@ __global__ __launch_bounds__(256, 2) void project_kernel(const float* __restrict
     for (int pt = 0; pt < 2; ++pt)
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
-        const int pix = p0 + pt * 32 + mfma_row(q, h);
+        const int pix = tile_px_c(p0, pt * 32 + mfma_row(q, 0), 4 * h, rs);   // mfma_row(q, h) = mfma_row(q, 0) + 4 h, (.. & 15) <= 11
         if (pix < HW) {
 #pragma unroll
           for (int ht = 0; ht < HT; ++ht) G[(unsigned)(pix * HD + ht * 32 + col)] = acc[pt][ht][q];
@@ -131,9 +139,9 @@ __global__ __launch_bounds__(256, 2) void project_kernel(const float* __restrict
 // half (a float4 of F per channel tile and four dG values per hidden tile and group: 64 registers) are issued before its first MFMA
 template <int C, int HD>
 __device__ __forceinline__ void project_dw_tile(const float* __restrict__ F, const float* __restrict__ dG, int p0, int HW, bool vec4, int h, int col,
-                                                f32x16 (&accw)[HD / 32][C / 32]) {
+                                                f32x16 (&accw)[HD / 32][C / 32], int rs = 0) {
   constexpr int HT = HD / 32, CT = C / 32;
-  const bool full = vec4 && p0 + 64 <= HW;   // wave-uniform: whole tile inside the image, rows 16-byte aligned -> no per-load guards
+  const bool full = vec4 && tile_px(p0, 63, rs) < HW;   // wave-uniform: whole tile inside the image, rows 16-byte aligned -> no per-load guards
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
     float4 fb[4][CT];
@@ -141,7 +149,7 @@ __device__ __forceinline__ void project_dw_tile(const float* __restrict__ F, con
     if (full) {
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        const int pix4 = p0 + 8 * (4 * half + t) + 4 * h;
+        const int pix4 = tile_px_c(p0, 8 * (4 * half + t), 4 * h, rs);   // four consecutive texels (slots 4-aligned: inside one 16-texel row piece)
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) fb[t][ct] = *reinterpret_cast<const float4*>(F + (unsigned)((ct * 32 + col) * HW + pix4));
 #pragma unroll
@@ -152,7 +160,7 @@ __device__ __forceinline__ void project_dw_tile(const float* __restrict__ F, con
     } else {
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        const int pix4 = p0 + 8 * (4 * half + t) + 4 * h;
+        const int pix4 = tile_px_c(p0, 8 * (4 * half + t), 4 * h, rs);   // four consecutive texels (slots 4-aligned: inside one 16-texel row piece)
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
           const unsigned ro = (unsigned)((ct * 32 + col) * HW + pix4);     // element offset inside the image's map (< 2^32)
@@ -185,10 +193,10 @@ __device__ __forceinline__ void project_dw_tile(const float* __restrict__ F, con
 
 // dF = dG w_in[:, :C] over one tile of 64 pixels; wl[hid*C + c] = w_in[hid][c] in LDS
 template <int C, int HD>
-__device__ __forceinline__ void project_df_tile(const float* __restrict__ dG, float* __restrict__ dF, const float* wl, int p0, int HW, int h, int col) {
+__device__ __forceinline__ void project_df_tile(const float* __restrict__ dG, float* __restrict__ dF, const float* wl, int p0, int HW, int h, int col, int rs = 0) {
   constexpr int CT = C / 32;
   const float4* dG4 = reinterpret_cast<const float4*>(dG);
-  const int px0 = min(p0 + col, HW - 1), px1 = min(p0 + 32 + col, HW - 1);
+  const int px0 = min(tile_px(p0, col, rs), HW - 1), px1 = min(tile_px(p0, 32 + col, rs), HW - 1);
   float4 v0[HD / 8], v1[HD / 8];
 #pragma unroll
   for (int qq = 0; qq < HD / 8; ++qq) {
@@ -223,7 +231,7 @@ __device__ __forceinline__ void project_df_tile(const float* __restrict__ dG, fl
   for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
     for (int pt = 0; pt < 2; ++pt) {
-      const int pix = p0 + pt * 32 + col;
+      const int pix = tile_px(p0, pt * 32 + col, rs);
       if (pix < HW) {
 #pragma unroll
         for (int q = 0; q < 16; ++q) dF[(unsigned)((ct * 32 + mfma_row(q, h)) * HW + pix)] = acc[ct][pt][q];
@@ -234,12 +242,13 @@ __device__ __forceinline__ void project_df_tile(const float* __restrict__ dG, fl
 // the same, one half of the tile (32 pixels) after the other: half the registers, for the kernel whose waves hold the weight
 // gradient's accumulators as well
 template <int C, int HD>
-__device__ __forceinline__ void project_df_half_tiles(const float* __restrict__ dG, float* __restrict__ dF, const float* wl, int p0, int HW, int h, int col) {
+__device__ __forceinline__ void project_df_half_tiles(const float* __restrict__ dG, float* __restrict__ dF, const float* wl, int p0, int HW, int h, int col,
+                                                      int rs = 0) {
   constexpr int CT = C / 32;
   const float4* dG4 = reinterpret_cast<const float4*>(dG);
 #pragma unroll 1
   for (int pt = 0; pt < 2; ++pt) {
-    const int pix = p0 + pt * 32 + col;
+    const int pix = tile_px(p0, pt * 32 + col, rs);
     const int px = min(pix, HW - 1);
     float4 v[HD / 8];
 #pragma unroll
@@ -273,16 +282,16 @@ __device__ __forceinline__ void project_df_half_tiles(const float* __restrict__ 
 //       D rows (pixels) sit in registers, columns (channels) across the lanes: every store is a 128-byte piece of a pixel's channel vector
 template <int C, int HD>
 __device__ __forceinline__ void project_dw_tile_cl(const float* __restrict__ F, const float* __restrict__ dG, int p0, int HW, int h, int col,
-                                                   f32x16 (&accw)[HD / 32][C / 32]) {
+                                                   f32x16 (&accw)[HD / 32][C / 32], int rs = 0) {
   constexpr int HT = HD / 32, CT = C / 32;
-  const bool full = p0 + 64 <= HW;
+  const bool full = tile_px(p0, 63, rs) < HW;
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
     float fv[4][4][CT];
     float av[4][4][HT];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      const int pix4 = p0 + 8 * (4 * half + t) + 4 * h;
+      const int pix4 = tile_px_c(p0, 8 * (4 * half + t), 4 * h, rs);   // four consecutive texels (slots 4-aligned: inside one 16-texel row piece)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int pix = pix4 + e;
@@ -305,12 +314,13 @@ __device__ __forceinline__ void project_dw_tile_cl(const float* __restrict__ F, 
   }
 }
 template <int C, int HD>
-__device__ __forceinline__ void project_df_half_tiles_cl(const float* __restrict__ dG, float* __restrict__ dF, const float* wl, int p0, int HW, int h, int col) {
+__device__ __forceinline__ void project_df_half_tiles_cl(const float* __restrict__ dG, float* __restrict__ dF, const float* wl, int p0, int HW, int h, int col,
+                                                         int rs = 0) {
   constexpr int CT = C / 32;
   const float4* dG4 = reinterpret_cast<const float4*>(dG);
 #pragma unroll 1
   for (int pt = 0; pt < 2; ++pt) {
-    const int px = min(p0 + pt * 32 + col, HW - 1);
+    const int px = min(tile_px(p0, pt * 32 + col, rs), HW - 1);
     float4 v[HD / 8];
 #pragma unroll
     for (int qq = 0; qq < HD / 8; ++qq) v[qq] = dG4[(unsigned)(px * (HD / 4) + (qq >> 2) * 8 + 4 * h + (qq & 3))];
@@ -330,7 +340,7 @@ __device__ __forceinline__ void project_df_half_tiles_cl(const float* __restrict
     }
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
-      const int pix = p0 + pt * 32 + mfma_row(q, h);
+      const int pix = tile_px_c(p0, pt * 32 + mfma_row(q, 0), 4 * h, rs);
       if (pix < HW) {
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) dF[(unsigned)(pix * C + ct * 32 + col)] = acc[ct][q];
@@ -413,10 +423,11 @@ __global__ __launch_bounds__(256, 2) void project_bwd_kernel(const float* __rest
 template <int C, int HD, bool FEAT_CL>
 __global__ __launch_bounds__(256, 2) void project_bwd_tiles_kernel(const float* __restrict__ feat, float* dproj, unsigned char* tiles, const float* __restrict__ mlp,
                                                                 float* __restrict__ dfeat, float* __restrict__ d_mlp, int HW, int tiles_per_img, int n_tiles,
-                                                                int clear) {
+                                                                int clear, int Wm, int tw) {
   constexpr int HT = HD / 32, CT = C / 32;
   constexpr int D_IN = C + kPeDim;
   __shared__ float wl[HD * C];
+  const int rs = tile_rs(Wm, tw);   // slot i of a tile is texel p0 + i + (i >> 4) * rs (bts_common.h: a 16 x 4 block, or rs = 0: 64 consecutive texels)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int h = lane >> 5, col = lane & 31;
   if (dfeat) {
@@ -438,39 +449,45 @@ __global__ __launch_bounds__(256, 2) void project_bwd_tiles_kernel(const float* 
   int flag_n = !tiles ? 1 : (tile0 < n_tiles ? (int)tiles[tile0] : 0);   // a tile's flag is fetched one tile ahead
   for (int tile = tile0; tile < n_tiles; tile += stride) {
     const int img = tile / tiles_per_img;
-    const int p0 = (tile - img * tiles_per_img) * 64;
+    const int p0 = tile_base(tile - img * tiles_per_img, Wm, tw);
     const bool dirty = __builtin_amdgcn_readfirstlane(flag_n) != 0;
     flag_n = !tiles ? 1 : (tile + stride < n_tiles ? (int)tiles[tile + stride] : 0);
+    // the tile as runs of consecutive texels: ONE run of (up to) 64 in the linear form, four rows of 16 in the block form
+    const int n_runs = rs ? 4 : 1, run_px = rs ? 16 : min(64, HW - p0), run_step = rs ? Wm : 0;
     if (dirty) {
       float* dG = dproj + (long)img * HW * HD;
       if constexpr (FEAT_CL) {
-        if (d_mlp) project_dw_tile_cl<C, HD>(feat + (long)img * C * HW, dG, p0, HW, h, col, accw);
-        if (dfeat) project_df_half_tiles_cl<C, HD>(dG, dfeat + (long)img * C * HW, wl, p0, HW, h, col);
+        if (d_mlp) project_dw_tile_cl<C, HD>(feat + (long)img * C * HW, dG, p0, HW, h, col, accw, rs);
+        if (dfeat) project_df_half_tiles_cl<C, HD>(dG, dfeat + (long)img * C * HW, wl, p0, HW, h, col, rs);
       } else {
-        if (d_mlp) project_dw_tile<C, HD>(feat + (long)img * C * HW, dG, p0, HW, vec4, h, col, accw);
-        if (dfeat) project_df_half_tiles<C, HD>(dG, dfeat + (long)img * C * HW, wl, p0, HW, h, col);
+        if (d_mlp) project_dw_tile<C, HD>(feat + (long)img * C * HW, dG, p0, HW, vec4, h, col, accw, rs);
+        if (dfeat) project_df_half_tiles<C, HD>(dG, dfeat + (long)img * C * HW, wl, p0, HW, h, col, rs);
       }
       if (clear && tiles) {
         // (this wave is the only reader of the tile and its loads have returned: their values went through the MFMAs above)
         __builtin_amdgcn_sched_barrier(0);
-        const int npx = min(64, HW - p0);
-        float4* row = reinterpret_cast<float4*>(dG + (long)p0 * HD);   // 64 pixels x HD floats, contiguous
-        for (int i = lane; i < npx * (HD / 4); i += 64) row[i] = z4;
+        for (int r = 0; r < n_runs; ++r) {
+          float4* row = reinterpret_cast<float4*>(dG + (long)(p0 + r * run_step) * HD);   // run_px texels x HD floats, contiguous
+          for (int i = lane; i < run_px * (HD / 4); i += 64) row[i] = z4;
+        }
         if (lane == 0) tiles[tile] = 0;
       }
     } else if (dfeat) {
       float* dF = dfeat + (long)img * C * HW;
-      if constexpr (FEAT_CL) {       // the tile's pixels x C floats are contiguous
-        const int npx = min(64, HW - p0);
-        float4* row = reinterpret_cast<float4*>(dF + (long)p0 * C);
-        for (int i = lane; i < npx * (C / 4); i += 64) row[i] = z4;
+      if constexpr (FEAT_CL) {       // a run's texels x C floats are contiguous
+        for (int r = 0; r < n_runs; ++r) {
+          float4* row = reinterpret_cast<float4*>(dF + (long)(p0 + r * run_step) * C);
+          for (int i = lane; i < run_px * (C / 4); i += 64) row[i] = z4;
+        }
       } else
-      if (vec4 && p0 + 64 <= HW) {   // 16 stores of 4 channel rows x 64 pixels
+      if (vec4 && tile_px(p0, 63, rs) < HW) {   // 16 stores of 4 channel rows x 64 texels (lane & 15: four texels of slot group 4 (lane & 15))
+        const int px4 = tile_px(p0, 4 * (lane & 15), rs);
 #pragma unroll
-        for (int i = 0; i < C / 4; ++i) *reinterpret_cast<float4*>(dF + (unsigned)((4 * i + (lane >> 4)) * HW + p0 + 4 * (lane & 15))) = z4;
-      } else if (p0 + lane < HW) {
+        for (int i = 0; i < C / 4; ++i) *reinterpret_cast<float4*>(dF + (unsigned)((4 * i + (lane >> 4)) * HW + px4)) = z4;
+      } else if (tile_px(p0, lane, rs) < HW) {
+        const int px = tile_px(p0, lane, rs);
 #pragma unroll 8
-        for (int c = 0; c < C; ++c) dF[(unsigned)(c * HW + p0 + lane)] = 0.0f;
+        for (int c = 0; c < C; ++c) dF[(unsigned)(c * HW + px)] = 0.0f;
       }
     }
   }
@@ -489,13 +506,14 @@ static int prep_cus() {
 }
 
 template <int C, int HD>
-static int run_fwd(const float* feat, const float* mlp, int N, int HW, float* proj, const unsigned char* tiles, bool feat_cl, hipStream_t s) {
+static int run_fwd(const float* feat, const float* mlp, int N, int HW, float* proj, const unsigned char* tiles, bool feat_cl, hipStream_t s, int Wm) {
   const int tpi = (HW + 63) / 64;
+  const int tw = Wm > 0 && HW % Wm == 0 ? tile_cols(HW / Wm, Wm, 1) : 0;   // (Wm = 0: runs of 64 consecutive texels)
   const long n_tiles = (long)N * tpi;
   const long want = (n_tiles + 3) / 4, cap = 4L * prep_cus();     // persistent: <= 4 work-groups per CU (16 KB of LDS each)
   const int grid = (int)(want < cap ? want : cap);
-  if (feat_cl) project_kernel<C, HD, true><<<grid, 256, 0, s>>>(feat, mlp, proj, HW, tpi, (int)n_tiles, tiles);
-  else project_kernel<C, HD, false><<<grid, 256, 0, s>>>(feat, mlp, proj, HW, tpi, (int)n_tiles, tiles);
+  if (feat_cl) project_kernel<C, HD, true><<<grid, 256, 0, s>>>(feat, mlp, proj, HW, tpi, (int)n_tiles, tiles, Wm, tw);
+  else project_kernel<C, HD, false><<<grid, 256, 0, s>>>(feat, mlp, proj, HW, tpi, (int)n_tiles, tiles, Wm, tw);
   return hipGetLastError() == hipSuccess ? BTS_OK : BTS_E_LAUNCH;
 }
 
@@ -512,21 +530,22 @@ static int run_bwd(const float* feat, const float* dproj, const float* mlp, int 
 
 template <int C, int HD>
 static int run_bwd_tiles(const float* feat, float* dproj, unsigned char* tiles, const float* mlp, int N, int HW, float* dfeat, float* d_mlp, int clear,
-                         bool feat_cl, hipStream_t s) {
+                         bool feat_cl, hipStream_t s, int Wm) {
   if (!dfeat && !d_mlp && !(clear && tiles)) return BTS_OK;
   const int tpi = (HW + 63) / 64;
+  const int tw = Wm > 0 && HW % Wm == 0 ? tile_cols(HW / Wm, Wm, 1) : 0;
   const long n_tiles = (long)N * tpi;
   const long want = (n_tiles + 3) / 4, cap = 2L * prep_cus();
   const int grid = (int)(want < cap ? want : cap);
-  if (feat_cl) project_bwd_tiles_kernel<C, HD, true><<<grid, 256, 0, s>>>(feat, dproj, tiles, mlp, dfeat, d_mlp, HW, tpi, (int)n_tiles, clear);
-  else project_bwd_tiles_kernel<C, HD, false><<<grid, 256, 0, s>>>(feat, dproj, tiles, mlp, dfeat, d_mlp, HW, tpi, (int)n_tiles, clear);
+  if (feat_cl) project_bwd_tiles_kernel<C, HD, true><<<grid, 256, 0, s>>>(feat, dproj, tiles, mlp, dfeat, d_mlp, HW, tpi, (int)n_tiles, clear, Wm, tw);
+  else project_bwd_tiles_kernel<C, HD, false><<<grid, 256, 0, s>>>(feat, dproj, tiles, mlp, dfeat, d_mlp, HW, tpi, (int)n_tiles, clear, Wm, tw);
   return hipGetLastError() == hipSuccess ? BTS_OK : BTS_E_LAUNCH;
 }
 
 int project_features_impl(int C, int HD, const float* feat, const float* mlp, int N, int HW, float* proj, const unsigned char* tiles, hipStream_t s,
-                          bool feat_cl) {
-  if (C == 64 && HD == 64) return run_fwd<64, 64>(feat, mlp, N, HW, proj, tiles, feat_cl, s);
-  if (C == 32 && HD == 32) return run_fwd<32, 32>(feat, mlp, N, HW, proj, tiles, feat_cl, s);
+                          bool feat_cl, int Wm) {
+  if (C == 64 && HD == 64) return run_fwd<64, 64>(feat, mlp, N, HW, proj, tiles, feat_cl, s, Wm);
+  if (C == 32 && HD == 32) return run_fwd<32, 32>(feat, mlp, N, HW, proj, tiles, feat_cl, s, Wm);
   return BTS_E_UNSUPPORTED;
 }
 
@@ -534,11 +553,12 @@ int project_features_impl(int C, int HD, const float* feat, const float* mlp, in
 // (o + z d: mul, then add), projection and tap routine -- the same texels bit for bit -- and a byte store per tap into the tile flags.
 __global__ __launch_bounds__(256) void mark_tiles_kernel(const float* __restrict__ rays, const float* __restrict__ z_samp, const float* __restrict__ jitter,
                                                        const float* __restrict__ w2c_enc, const float* __restrict__ K_enc, long B, int Bp, int K,
-                                                       int lindisp, int H, int W, int fs, int tiles_per_img, unsigned char* __restrict__ tiles) {
+                                                       int lindisp, int H, int W, int fs, int tiles_per_img, unsigned char* __restrict__ tiles, int tw) {
   // lane = sample, one ray per wave iteration (ray, camera: wave-uniform scalar loads), as the render kernels walk them
   const int lane = threadIdx.x & 63;
   const long wave = blockIdx.x * 4L + (threadIdx.x >> 6), n_waves = gridDim.x * 4L;
   const float step = 1.0f / (float)K;
+  const int Wm = W >> fs;   // (tw: the map's tile geometry, bts_common.h)
   for (long b = wave; b < B; b += n_waves) {
     const int sample = (int)(b / Bp);
     const cfp rp = as_const(rays) + b * 8;
@@ -549,10 +569,11 @@ __global__ __launch_bounds__(256) void mark_tiles_kernel(const float* __restrict
       const float z = z_samp ? z_samp[b * K + k] : coarse_depth(jitter[b * K + k], coarse_base(K, k), step, near, far, lindisp != 0);
       const float px = ox + z * dx, py = oy + z * dy, pz = oz + z * dz;
       const Proj pe = project<false>(enc, px, py, pz);
-      const Taps tp = make_taps(pe.x, pe.y, H, W, fs);
+      int x0, y0, x1, y1;
+      (void)make_taps_xy(pe.x, pe.y, H, W, x0, y0, x1, y1, fs);      // (x0 .. y1: texels of the map in memory, H >> fs x W >> fs)
       // a sample's two taps of a row share their tile but for a tile border; neighbouring samples mostly share both: one store per
       // distinct tile and lane run instead of four per sample
-      const unsigned ta = (unsigned)tp.o00 >> 6, tb = (unsigned)tp.o01 >> 6, tc = (unsigned)tp.o10 >> 6, td = (unsigned)tp.o11 >> 6;
+      const unsigned ta = tile_of(y0, x0, Wm, tw), tb = tile_of(y0, x1, Wm, tw), tc = tile_of(y1, x0, Wm, tw), td = tile_of(y1, x1, Wm, tw);
       const unsigned pa = (unsigned)__builtin_amdgcn_update_dpp((int)~0u, (int)ta, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
       const unsigned pc = (unsigned)__builtin_amdgcn_update_dpp((int)~0u, (int)tc, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
       if (ta != pa) t[ta] = 1;
@@ -564,12 +585,13 @@ __global__ __launch_bounds__(256) void mark_tiles_kernel(const float* __restrict
 }
 
 int mark_tiles_impl(const float* rays, const float* z_samp, const float* jitter, const float* w2c_enc, const float* K_enc, long B, int Bp, int K, int lindisp,
-                    int H, int W, int fs, unsigned char* tiles, hipStream_t s) {
+                    int H, int W, int fs, unsigned char* tiles, hipStream_t s, int blocks) {
   const long total = B * K;
   const int tpi = (int)((((long)(H >> fs) * (W >> fs)) + 63) / 64);
   const long want = (B + 3) / 4;   // one ray per wave iteration
   (void)total;
-  mark_tiles_kernel<<<(int)(want < 8192 ? want : 8192), 256, 0, s>>>(rays, z_samp, jitter, w2c_enc, K_enc, B, Bp, K, lindisp, H, W, fs, tpi, tiles);
+  mark_tiles_kernel<<<(int)(want < 8192 ? want : 8192), 256, 0, s>>>(rays, z_samp, jitter, w2c_enc, K_enc, B, Bp, K, lindisp, H, W, fs, tpi, tiles,
+                                                                     tile_cols(H >> fs, W >> fs, blocks));
   return hipGetLastError() == hipSuccess ? BTS_OK : BTS_E_LAUNCH;
 }
 
@@ -581,9 +603,9 @@ int project_features_bwd_impl(int C, int HD, const float* feat, const float* dpr
 }
 
 int project_features_bwd_tiles_impl(int C, int HD, const float* feat, float* dproj, unsigned char* tiles, const float* mlp, int N, int HW, float* dfeat,
-                                    float* d_mlp, int clear, hipStream_t s, bool feat_cl) {
-  if (C == 64 && HD == 64) return run_bwd_tiles<64, 64>(feat, dproj, tiles, mlp, N, HW, dfeat, d_mlp, clear, feat_cl, s);
-  if (C == 32 && HD == 32) return run_bwd_tiles<32, 32>(feat, dproj, tiles, mlp, N, HW, dfeat, d_mlp, clear, feat_cl, s);
+                                    float* d_mlp, int clear, hipStream_t s, bool feat_cl, int Wm) {
+  if (C == 64 && HD == 64) return run_bwd_tiles<64, 64>(feat, dproj, tiles, mlp, N, HW, dfeat, d_mlp, clear, feat_cl, s, Wm);
+  if (C == 32 && HD == 32) return run_bwd_tiles<32, 32>(feat, dproj, tiles, mlp, N, HW, dfeat, d_mlp, clear, feat_cl, s, Wm);
   return BTS_E_UNSUPPORTED;
 }
 

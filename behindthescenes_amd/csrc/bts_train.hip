@@ -24,11 +24,11 @@ int patch_rays_views_launch(const float* poses, const float* projs, const float*
                             const int* ids, float gt_scale, float gt_shift, hipStream_t s);
 int photometric_loss_impl(const BtsLossArgs* a, hipStream_t s);
 int project_features_impl(int C, int HD, const float* feat, const float* mlp, int N, int HW, float* proj, const unsigned char* tiles, hipStream_t s,
-                          bool feat_cl = false);
+                          bool feat_cl = false, int Wm = 0);   // Wm: the map's width when `tiles` are 16 x 4 blocks (BtsFieldCfg.tile_blocks), 0 = runs of 64 texels
 int mark_tiles_impl(const float* rays, const float* z_samp, const float* jitter, const float* w2c_enc, const float* K_enc, long B, int Bp, int K, int lindisp,
-                    int H, int W, int fs, unsigned char* tiles, hipStream_t s);
+                    int H, int W, int fs, unsigned char* tiles, hipStream_t s, int blocks);
 int project_features_bwd_tiles_impl(int C, int HD, const float* feat, float* dproj, unsigned char* tiles, const float* mlp, int N, int HW, float* dfeat,
-                                    float* d_mlp, int clear, hipStream_t s, bool feat_cl = false);
+                                    float* d_mlp, int clear, hipStream_t s, bool feat_cl = false, int Wm = 0);
 int render_fwd_impl(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const BtsRenderArgs* a, hipStream_t s);
 size_t render_bwd_workspace_impl(const BtsFieldCfg* cfg, const BtsRenderArgs* a);
 int render_bwd_impl(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const BtsRenderArgs* a, const BtsRenderGrads* g, void* ws, size_t ws_bytes,
@@ -229,6 +229,9 @@ static ScaleView scale_view(const BtsTrainStep* st, int s) {
   const int n = st->cfg.n, nv = st->cfg.nv;
   v.cfg = st->cfg;
   v.cfg.feat_shift = q.feat_shift;
+  // the scale's tile geometry: 16 x 4 blocks for a channels-last map, runs of 64 texels for an NCHW one (BtsFieldCfg.tile_blocks: what each
+  // layout is faster with); the step's own flag arrays never leave the two calls, so the step decides for itself
+  v.cfg.tile_blocks = q.feat_channels_last != 0;
   float* K_enc = st->cams;
   float* w2c_enc = K_enc + (long)n * 9;
   float* K_r = w2c_enc + (long)n * 16;
@@ -268,8 +271,9 @@ int train_step_fwd_impl(const BtsTrainStep* st, hipStream_t main_stream) {
     ScaleView v = scale_view(st, s);
     const long texels = map_texels(st, s);
     rc = mark_tiles_impl(st->rays, nullptr, q.jitter, v.t.w2c_enc, v.t.K_enc, (long)n * Bp, Bp, st->K, st->lindisp, c.H, c.W, q.feat_shift, q.sampled_tiles,
-                         stream);
-    if (!rc) rc = project_features_impl(c.C, c.d_hidden, q.feat_nchw, st->mlp_params, n, (int)texels, q.proj_nhwc, q.sampled_tiles, stream, q.feat_channels_last != 0);
+                         stream, v.cfg.tile_blocks);
+    if (!rc) rc = project_features_impl(c.C, c.d_hidden, q.feat_nchw, st->mlp_params, n, (int)texels, q.proj_nhwc, q.sampled_tiles, stream, q.feat_channels_last != 0,
+                                        v.cfg.tile_blocks ? c.W >> q.feat_shift : 0);
     if (rc) {
       set_error("%s: projection launch failed at scale %ld", "bts_train_step_fwd", s);
       return rc;
@@ -373,7 +377,7 @@ int train_step_bwd_impl(const BtsTrainStep* st, const float* g_loss, hipStream_t
     if (rc) return rc;
     if (need_map) {
       rc = project_features_bwd_tiles_impl(c.C, c.d_hidden, q.feat_nchw, q.d_proj_nhwc, q.d_proj_tiles, st->mlp_params, n, (int)map_texels(st, s),
-                                           q.d_feat_nchw, st->d_mlp_params, 1, stream, q.feat_channels_last != 0);
+                                           q.d_feat_nchw, st->d_mlp_params, 1, stream, q.feat_channels_last != 0, v.cfg.tile_blocks ? c.W >> q.feat_shift : 0);
       if (rc) {
         set_error("%s: projection backward launch failed at scale %ld", "bts_train_step_bwd", s);
         return rc;

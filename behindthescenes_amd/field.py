@@ -265,6 +265,9 @@ class BTSNet(nn.Module):
             rays, z_samp, jitter, lindisp = sampled
             f = self._latents_ms[s]
             f = f.reshape(f.shape[0], *f.shape[2:]).float()
+            # the tile flags' geometry follows the map's layout (BtsFieldCfg.tile_blocks: 16 x 4 blocks are faster with a channels-last
+            # map, runs of 64 texels with an NCHW one); everything that touches this render's flag arrays shares this spec
+            spec = dataclasses.replace(spec, tile_blocks=native.is_channels_last(f))
             sh = self._shift_ms[s]
             tiles = native.mark_sampled_tiles(spec, f.shape[0], f.shape[-2] << sh, f.shape[-1] << sh, sh, self._K_enc, self._w2c_enc, rays, z_samp,
                                               jitter, lindisp)
@@ -280,6 +283,7 @@ class BTSNet(nn.Module):
         if hit is None or hit[1] != version:
             f = self._latents_ms[s]                            # (n, 1, C, h, w) -> (n, C, h, w): a pure view (selecting [:, 0] would
             f = f.reshape(f.shape[0], *f.shape[2:]).float()    # cost a zero fill + a copy of the whole map in its backward)
+            spec = dataclasses.replace(spec, tile_blocks=native.is_channels_last(f))   # (the geometry of the gradient's tile flags, see above)
             link = native.ProjLink()   # lets a single render of this map hand its (sparse) gradient to the projection's backward as tiles
             proj = native.ProjectFunction.apply(f, mlp.packed(), spec, link)
             ft = native.FieldTensors(spec, proj, self._K_enc, self._w2c_enc, self._imgs_nhwc4, self._K_r, self._w2c_r,

@@ -28,6 +28,9 @@ class FieldSpec:
     code_mode: str = "z"
     learn_empty: bool = False
     empty_empty: bool = False
+    # the geometry of the map's tile flags (BtsFieldCfg.tile_blocks, ABI 9): 16 x 4 blocks (True: faster with a channels-last feature map)
+    # or runs of 64 texels (False: faster with an NCHW one).  Every call on one (d_proj, tiles) pair must use the same spec.
+    tile_blocks: bool = False
 
     @property
     def d_in(self):
@@ -221,7 +224,7 @@ def _spec_cfg(spec: FieldSpec, n=1, H=1, W=1, nv=0, feat_shift=0, enc_view=-1) -
     return BtsFieldCfg(n=n, H=H, W=W, C=spec.C, d_hidden=spec.d_hidden, n_blocks=spec.n_blocks, nv=nv, num_freqs=spec.num_freqs,
                        code_mode={"z": 0, "distance": 1}[spec.code_mode], inv_z=int(spec.inv_z), learn_empty=int(spec.learn_empty),
                        empty_empty=int(spec.empty_empty), freq_factor=spec.freq_factor, d_min=spec.d_min, d_max=spec.d_max,
-                       feat_shift=feat_shift, enc_render_view=enc_view if 0 <= enc_view < nv else -1)
+                       feat_shift=feat_shift, enc_render_view=enc_view if 0 <= enc_view < nv else -1, tile_blocks=int(spec.tile_blocks))
 
 
 def proj_storage_order(d_hidden: int) -> torch.Tensor:
@@ -321,8 +324,18 @@ def project_features_bwd(spec: FieldSpec, feat_nchw, d_proj, mlp_params, need_fe
     return d_feat, d_mlp
 
 
+def proj_tile_map(H: int, W: int, blocks: bool = False) -> torch.Tensor:
+    """(H, W) int64: the tile (0 .. proj_tile_count - 1) of every texel of an (H, W) projected map -- the geometry of csrc/bts_common.h:
+    ``blocks`` (FieldSpec.tile_blocks) and H a multiple of 4, W of 16: blocks of 4 rows x 16 texels, numbered row-major; else 64
+    consecutive texels of the row-major map.  What `tiles` flags mean; ``flags[:, proj_tile_map(H, W, blocks)]`` is the per-texel mask."""
+    if blocks and H % 4 == 0 and W % 16 == 0:
+        y, x = torch.arange(H).view(-1, 1), torch.arange(W).view(1, -1)
+        return (y // 4) * (W // 16) + (x // 16)
+    return (torch.arange(H * W) // 64).view(H, W)
+
+
 def proj_tile_count(spec: FieldSpec, H: int, W: int) -> int:
-    """Tiles (64 consecutive texels) per image of an (H, W) projected map (bts_proj_tile_count)."""
+    """Tiles (64 texels each: proj_tile_map) per image of an (H, W) projected map (bts_proj_tile_count)."""
     cfg = _spec_cfg(spec, 1, H, W)
     n = int(_lib.load().bts_proj_tile_count(C.byref(cfg)))
     if n < 0:

@@ -60,10 +60,13 @@ def parse():
                          "renderer's share of a training step, forward + loss + backward; profile: SURVEY 8f.3, the 64 x 256 x 256 occupancy grid of "
                          "scripts/inference_setup.py (render_profile) as one fused pass, density queries/s")
     ap.add_argument("--samples", type=int, default=0, help="re10k: samples per ray (default 48 = the yaml; BASELINE.json quotes 128)")
-    ap.add_argument("--feat-layout", choices=("nchw", "nhwc"), default="nchw",
-                    help="memory format of the stand-in feature maps of the training workloads: nchw = what a plain nn.Conv2d stack returns (the "
-                         "reference's encoder on CUDA), nhwc = torch channels_last, what the shipped Monodepth2 hands over (MIOpen's NHWC kernels, "
-                         "bts_conv3x3_fwd) -- read as it is through bts_project_features_cl (ABI 8)")
+    ap.add_argument("--feat-layout", choices=("nchw", "nhwc"), default="nhwc",
+                    help="memory format of the stand-in feature maps of the training workloads: nhwc (default since round 6) = torch channels_last, "
+                         "what the SHIPPED Monodepth2 hands over (MIOpen's NHWC kernels, bts_conv3x3_fwd) -- read as it is through "
+                         "bts_project_features_cl (ABI 8), tile flags as 16 x 4 blocks (ABI 9); nchw = what a plain nn.Conv2d stack returns (the "
+                         "reference's encoder on CUDA; rounds 1 - 5 benched this).  The line of one layout carries the other's ms_per_step as "
+                         "`other_layout`")
+    ap.add_argument("--no-other-layout", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--encoder", choices=("feature_map", "monodepth2"), default="feature_map",
                     help="training workloads: feature_map (default) = learnable stand-in for the CNN output (the renderer's share of the step); "
                          "monodepth2 = the shipped Monodepth2 (ResNet of the yaml, random weights): whole step incl. the CNN")
@@ -501,7 +504,7 @@ def train_workload(args, world, rank, dev):
             flat = torch.nn.functional.pad(flat, (0, pad))
             blk = on[:, :Hm // 8 * 8, :Wm // 8 * 8].reshape(N, Hm // 8, 8, Wm // 8, 8)
             print(f"map {tuple(d_proj.shape)}: texels {on.float().mean().item():.3f}  16-texel segments "
-                  f"{flat.reshape(N, -1, 16).any(-1).float().mean().item():.3f}  64-texel tiles {flat.reshape(N, -1, 64).any(-1).float().mean().item():.3f}"
+                  f"{flat.reshape(N, -1, 16).any(-1).float().mean().item():.3f}  64 x 1 tiles {flat.reshape(N, -1, 64).any(-1).float().mean().item():.3f}"
                   f"  flagged {'-' if tiles is None else round(tiles.float().mean().item(), 3)}  8x8 blocks {blk.any(4).any(2).float().mean().item():.3f}"
                   f"  16x4 blocks {on[:, :Hm // 4 * 4, :Wm // 16 * 16].reshape(N, Hm // 4, 4, Wm // 16, 16).any(4).any(2).float().mean().item():.3f}",
                   file=sys.stderr)
@@ -584,7 +587,7 @@ def train_workload(args, world, rank, dev):
         # a line never shows the counters of another K)
         ksfx = f"_k{args.samples}" if args.samples and args.samples != TRAIN_WORKLOADS[args.workload]["K"] else ""
         byte_model, traffic_ratio, traffic_over_model = None, None, None
-        sname = f"traffic_step_{args.workload}{ksfx}.json"
+        sname = f"traffic_step_{args.workload}{ksfx}" + ("" if args.feat_layout == "nhwc" else f"_{args.feat_layout}") + ".json"
         sprof = sorted(d for d in (os.listdir(pdir) if os.path.isdir(pdir) else []) if os.path.exists(os.path.join(pdir, d, sname)))
         if sprof and args.encoder == "feature_map":
             # tools/profile_step.sh: rocprofv3 --pmc passes of THIS command (the fused step), every bts:: kernel of the step summed
@@ -650,6 +653,18 @@ def train_workload(args, world, rank, dev):
             out["cpu_baseline"] = train_cpu_baseline(cfg, net, scene, rank)
         if allreduce is not None:
             out["allreduce"] = allreduce
+        if world == 1 and args.encoder == "feature_map" and not args.no_other_layout and not args.entries:
+            # the same step with the stand-in maps in the OTHER memory format (20 steps after 5, same process): both are always on the line
+            import copy
+            a2 = copy.copy(args)
+            a2.feat_layout, a2.steps, a2.warmup, a2.no_cpu_baseline, a2.no_other_layout = ("nchw" if args.feat_layout == "nhwc" else "nhwc"), 20, 5, True, True
+            torch.cuda.empty_cache()
+            try:
+                o2 = train_workload(a2, world, rank, dev)
+                out["other_layout"] = {"feat_layout": a2.feat_layout, "ms_per_step": o2["ms_per_step"], "kernel_ms": o2["roofline"]["kernel_ms"],
+                                       "steps": a2.steps, "warmup": a2.warmup}
+            except Exception as e:      # a side figure never costs the line
+                out["other_layout"] = {"feat_layout": a2.feat_layout, "error": f"{type(e).__name__}: {e}"[:300]}
         return out
     return None
 
@@ -936,6 +951,8 @@ def _condense(rec):
     r = rec["roofline"]
     keep = {"metric": rec["metric"], "value": rec["value"], "unit": rec["unit"], "steps": rec["steps"], "warmup": rec["warmup"],
             "ms_per_step": rec["ms_per_step"], "workload": rec["config"]["workload"],
+            **({"feat_layout": rec["config"]["feat_layout"]} if "feat_layout" in rec["config"] else {}),
+            **({"other_layout": rec["other_layout"]} if "other_layout" in rec else {}),
             "roofline": {k: r[k] for k in ("bound", "achieved", "peak", "unit", "frac", "frac_step", "frac_algorithmic", "gpu_busy_frac", "traffic", "algorithmic_bytes", "state_bytes", "traffic_ratio", "traffic_over_model", "kernel", "kernel_ms", "fwd_ms", "bwd_ms", "entry_ms", "path") if k in r}}
     if "allreduce" in rec:
         keep["allreduce"] = rec["allreduce"]

@@ -83,6 +83,15 @@ typedef struct BtsFieldCfg {
    * projection, frustum flag and bilinear weights from the encoder view's instead of evaluating them a second time: same inputs, same
    * instruction sequence, bit-identical results (tests/test_gpu_abi5.py).  A hint: -1 is always correct. */
   int32_t enc_render_view;
+  /* ABI 9: the geometry of this map's tile flags (BtsRenderGrads.d_proj_tiles, every `tiles` argument).  0: tile t = texels 64 t .. 64 t + 63
+   * of the row-major map (ABI 6 - 8).  1: tile t = the block of 4 rows x 16 texels at rows 4 (t / (W' / 16)) .., columns 16 (t % (W' / 16)) ..
+   * of the (H', W') = (H >> feat_shift, W >> feat_shift) map -- honoured where H' is a multiple of 4 and W' of 16, otherwise the
+   * linear form is used as with 0 (bts_proj_tile_count is ceil(H' W' / 64) either way).  A training step's samples lie on streaks along
+   * the epipolar lines: they touch 38 % of the 64 x 1 runs and 26 % of the 16 x 4 blocks of exp_kitti_360.yaml's maps.  Blocks pay with a
+   * CHANNELS-LAST feature map (a block = four 4 KB pieces of F, dF, G, dG each: train step -3 %); with an NCHW map its rows come
+   * apart into 64-byte pieces and the projection backward is 2 % SLOWER than with runs (profiles/r06f) -- so: 1 for channels-last maps, 0
+   * for NCHW ones.  Every call that produces or consumes one flag array must see the same value. */
+  int32_t tile_blocks;
 } BtsFieldCfg;
 
 #define BTS_MAX_VIEWS 8
@@ -145,9 +154,13 @@ typedef struct BtsRenderGrads {
   float* d_proj_nhwc;      /* (n, H, W, Hd) gradient w.r.t. proj_nhwc, ACCUMULATED into (caller zero-fills), or NULL to skip */
   float* d_mlp_params;     /* packed like mlp_params, ACCUMULATED into (caller zero-fills), or NULL to skip */
   float* d_empty_proj;     /* (Hd) gradient w.r.t. the PROJECTED empty feature (w_in[:, :C] . empty_feature), accumulated, or NULL */
-  /* ABI 6: which parts of d_proj_nhwc received anything.  (n, bts_proj_tile_count(cfg)) bytes, one per tile of 64 consecutive texels
-   * of an image's (flattened, row-major) map: the backward SETS the byte of every tile it adds into (it never clears one), or NULL.
-   * A training step's rays touch 8-15 % of the tiles; bts_project_features_bwd_tiles reads only those. */
+  /* ABI 6: which parts of d_proj_nhwc received anything.  (n, bts_proj_tile_count(cfg)) bytes, one per tile of 64 texels of an image's
+   * map: the backward SETS the byte of every tile it adds into (it never clears one), or NULL.  A training step's rays touch 8-15 % of
+   * the texels; bts_project_features_bwd_tiles reads only the flagged tiles.
+   * TILE GEOMETRY (ABI 9; the same for every `tiles` argument of this header): BtsFieldCfg.tile_blocks -- runs of 64 consecutive texels
+   * (0; ABI 6 - 8: always) or blocks of 4 rows x 16 texels (1).  Flags are produced and consumed by this library (bts_render_bwd,
+   * bts_mark_sampled_tiles -> bts_project_features_tiles / _bwd_tiles / _cl); a caller that writes its own needs the mapping
+   * (behindthescenes_amd.native.proj_tile_map). */
   uint8_t* d_proj_tiles;
 } BtsRenderGrads;
 

@@ -63,6 +63,7 @@ int main(void) {
   printf("%zu %zu %zu\n", sizeof(BtsEvalFrame), offsetof(BtsEvalFrame, images), offsetof(BtsEvalFrame, invalid));
   printf("%zu\n", offsetof(BtsTrainScale, feat_channels_last));   /* ABI 8: the former reserved_ word */
   printf("%zu\n", offsetof(BtsEvalFrame, feat_channels_last));    /* ABI 9: appended behind the last ABI 8 field */
+  printf("%zu\n", offsetof(BtsFieldCfg, tile_blocks));            /* ABI 9: the tile flags' geometry, behind enc_render_view */
   return 0;
 }'''
     with tempfile.TemporaryDirectory() as d:
@@ -95,6 +96,7 @@ int main(void) {
     assert [int(x) for x in out[31:34]] == [C.sizeof(_lib.BtsEvalFrame), _lib.BtsEvalFrame.images.offset, _lib.BtsEvalFrame.invalid.offset]
     # ABI 8: the layout word of a scale's map sits where reserved_ was (same size, same offsets as ABI 7)
     assert int(out[35]) == _lib.BtsEvalFrame.feat_channels_last.offset == _lib.BtsEvalFrame.invalid.offset + 8     # ABI 9: appended
+    assert int(out[36]) == _lib.BtsFieldCfg.tile_blocks.offset == _lib.BtsFieldCfg.enc_render_view.offset + 4
     assert [int(x) for x in out[34:35]] == [_lib.BtsTrainScale.feat_channels_last.offset] and _lib.BtsTrainScale.feat_channels_last.offset == _lib.BtsTrainScale.feat_shift.offset + 4
 
 

@@ -10,16 +10,17 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _spec(C, Hd):
+def _spec(C, Hd, blocks=False):
     from behindthescenes_amd import native
-    return native.FieldSpec(C=C, d_hidden=Hd, n_blocks=0 if C == 64 else 1)
+    return native.FieldSpec(C=C, d_hidden=Hd, n_blocks=0 if C == 64 else 1, tile_blocks=blocks)
 
 
+@pytest.mark.parametrize("blocks", [False, True], ids=["runs64", "blocks16x4"])
 @pytest.mark.parametrize("C,Hd,N,H,W", [(64, 64, 2, 24, 40), (64, 64, 1, 7, 13), (32, 32, 2, 16, 48), (32, 32, 1, 5, 31), (64, 64, 1, 192, 640)])
-def test_projection_of_a_channels_last_map_equals_the_nchw_one(C, Hd, N, H, W):
+def test_projection_of_a_channels_last_map_equals_the_nchw_one(C, Hd, N, H, W, blocks):
     from behindthescenes_amd import native
     g = torch.Generator().manual_seed(C + H)
-    spec = _spec(C, Hd)
+    spec = _spec(C, Hd, blocks)
     feat = torch.randn(N, C, H, W, generator=g).cuda()
     feat_cl = feat.contiguous(memory_format=torch.channels_last)
     assert native.is_channels_last(feat_cl) and not native.is_channels_last(feat)
@@ -34,7 +35,7 @@ def test_projection_of_a_channels_last_map_equals_the_nchw_one(C, Hd, N, H, W):
     tol = 2e-6 * G.abs().max().item()                  # (64 products per output, summed in a different order)
     assert (G_cl - G).abs().max().item() <= tol
     Gt, Gt_cl = native.project_features(spec, feat, mlp, tiles), native.project_features(spec, feat_cl, mlp, tiles)
-    on = flags.repeat_interleave(64, dim=1)[:, :H * W].reshape(N, H, W).cuda()
+    on = flags[:, native.proj_tile_map(H, W, blocks)].cuda()
     assert torch.equal(Gt_cl[on], G_cl[on]) and torch.equal(Gt[on], G[on])
     # backward: dense, then the tile form with and without clearing
     texel_on = on.unsqueeze(-1)

@@ -26,23 +26,26 @@ def hip():
     return bts
 
 
-def _spec(C, Hd, nb):
+def _spec(C, Hd, nb, blocks=False):
     from behindthescenes_amd.native import FieldSpec
-    return FieldSpec(C=C, d_hidden=Hd, n_blocks=nb)
+    return FieldSpec(C=C, d_hidden=Hd, n_blocks=nb, tile_blocks=blocks)
 
 
+@pytest.mark.parametrize("blocks", [False, True], ids=["runs64", "blocks16x4"])
 @pytest.mark.parametrize("C,Hd,N,H,W", [(64, 64, 3, 24, 40), (64, 64, 2, 7, 13), (32, 32, 2, 16, 48), (32, 32, 1, 5, 31), (64, 64, 1, 192, 640)])
-def test_tile_kernel_matches_the_dense_kernel(hip, C, Hd, N, H, W):
+def test_tile_kernel_matches_the_dense_kernel(hip, C, Hd, N, H, W, blocks):
+    """Both tile geometries (BtsFieldCfg.tile_blocks, ABI 9): runs of 64 consecutive texels and blocks of 4 rows x 16 texels -- the latter only
+    where H is a multiple of 4 and W of 16 ((16, 48), (192, 640)); the other sizes fall back to runs, which proj_tile_map mirrors."""
     from behindthescenes_amd import native
     g = torch.Generator().manual_seed(C + H)
-    spec = _spec(C, Hd, 0)
+    spec = _spec(C, Hd, 0, blocks)
     feat = torch.randn(N, C, H, W, generator=g).cuda()
     mlp = torch.randn(spec.mlp_param_count(), generator=g).cuda()
     nt = native.proj_tile_count(spec, H, W)
     assert nt == (H * W + 63) // 64
     flags = (torch.rand(N, nt, generator=g) < 0.25)
     flags[0, -1] = True                                        # the (possibly ragged) last tile of an image
-    texel_on = flags.repeat_interleave(64, dim=1)[:, :H * W].reshape(N, H, W, 1)
+    texel_on = flags[:, native.proj_tile_map(H, W, blocks)].unsqueeze(-1)      # (N, H, W, 1): 16 x 4 blocks or 64 consecutive texels
     dG = (torch.randn(N, H, W, Hd, generator=g) * texel_on).cuda()
     tiles = flags.to(torch.uint8).cuda()
     ref_f, ref_w = native.project_features_bwd(spec, feat, dG, mlp)
@@ -111,7 +114,7 @@ def test_render_bwd_flags_every_tile_it_writes(hip, model):
     assert (got - dense).abs().max().item() <= 2e-5 * scale                  # float atomics: summation order only
     assert (dm1 - dm0).abs().max().item() <= 2e-5 * dm0.abs().max().item()
     texel_written = (got != 0).any(dim=-1).reshape(2, -1)
-    flagged = tiles.bool().repeat_interleave(64, dim=1)[:, :texel_written.shape[1]]
+    flagged = tiles.bool()[:, native.proj_tile_map(64, 160, ft.spec.tile_blocks).cuda()].reshape(2, -1)
     assert not (texel_written & ~flagged).any(), "a texel outside the flagged tiles received a contribution"
     frac = tiles.float().mean().item()
     assert 0.0 < frac < 0.9, frac
@@ -202,7 +205,7 @@ def test_sparse_forward_projection_covers_every_tap(hip, model):
         frac = tiles.float().mean().item()
         assert 0.0 < frac < 0.9, frac
         G = native.project_features(ft.spec, feat, params, tiles=tiles)
-        flagged = tiles.bool().repeat_interleave(64, dim=1)[:, :64 * 160].reshape(2, 64, 160)
+        flagged = tiles.bool()[:, native.proj_tile_map(64, 160, ft.spec.tile_blocks).cuda()]
         assert torch.equal(G[flagged], ft.proj_nhwc.detach()[flagged])                 # the flagged tiles are the dense map's
         G = torch.where(flagged.unsqueeze(-1), G, torch.full_like(G, float("nan")))      # everything else must never be read
         sp = native.FieldTensors(ft.spec, G, ft.K_enc, ft.w2c_enc, ft.imgs_nhwc4, ft.K_r, ft.w2c_r, ft.empty_feature, enc_view=ft.enc_view)

@@ -11,7 +11,7 @@
 #                           once-per-step kernel <marker>) -> <name>_steps.txt
 #   ubench:<name>           tools/ubench/<name> -> <name>.txt
 #   prof:<mode>[:K]         tools/profile.sh <tag> <mode> [K]   (PMC passes; summaries under gpurun_out/prof_<tag>/)
-#   profstep:<workload>[:K] tools/profile_step.sh <tag> <workload> [K]   (HBM traffic of every bts:: kernel of ONE fused training step)
+#   profstep:<workload>[:K[:layout]] tools/profile_step.sh <tag> <workload> [K] [nhwc|nchw]   (HBM traffic of every bts:: kernel of ONE fused training step)
 #   py:<script>[:<args>]    python tools/<script>.py <args> -> <script>[_<args>].txt
 set -u
 cd "${GRAFT_REPO_ROOT:-.}"
@@ -46,7 +46,7 @@ for STEP in "$@"; do
       rm -rf $O/strace_$NAME ;;
     ubench) timeout 600 tools/ubench/$REST > $O/$REST.txt 2>&1; cat $O/$REST.txt ;;
     prof) MODE=${REST%%:*}; KK=${REST#*:}; [ "$KK" = "$REST" ] && KK=""; timeout 1200 bash tools/profile.sh $TAG $MODE $KK 2>&1 | tail -20 ;;
-    profstep) WL=${REST%%:*}; KK=${REST#*:}; [ "$KK" = "$REST" ] && KK=""; timeout 900 bash tools/profile_step.sh $TAG $WL $KK 2>&1 | tail -14 ;;
+    profstep) IFS=: read -r WL KK LAY <<< "$REST"; timeout 900 bash tools/profile_step.sh $TAG "$WL" "${KK:-}" "${LAY:-nhwc}" 2>&1 | tail -14 ;;
     py)
       NAME=${REST%%:*}; ARGS=${REST#*:}; [ "$ARGS" = "$REST" ] && ARGS=""
       timeout 900 python tools/$NAME.py ${ARGS//,/ } > $O/${NAME}$(echo "_$ARGS" | tr -c 'A-Za-z0-9\n' '_' | sed 's/__*/_/g;s/_$//').txt 2>&1; tail -40 $O/${NAME}*.txt ;;

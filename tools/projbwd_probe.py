@@ -35,16 +35,16 @@ def main():
         if frac >= 1.0:
             tiles.fill_(1)
         elif frac > 0:
-            # clusters: runs of 2 consecutive tiles in 8 consecutive image rows (an 8 x 8 patch's footprint), W / 64 = 10 tiles per row
-            n_cl = int(frac * N * tpi / 16)
+            # clusters: 2 x 2 neighbouring 16 x 4 blocks (an 8 x 8 patch's footprint and a bit), W / 16 blocks per block row
+            n_cl = int(frac * N * tpi / 4)
             img = torch.randint(0, N, (n_cl,), device="cuda", generator=g)
-            row = torch.randint(0, H - 8, (n_cl,), device="cuda", generator=g)
-            cx = torch.randint(0, W // 64 - 1, (n_cl,), device="cuda", generator=g)
-            for dy in range(8):
+            by = torch.randint(0, H // 4 - 1, (n_cl,), device="cuda", generator=g)
+            bx = torch.randint(0, W // 16 - 1, (n_cl,), device="cuda", generator=g)
+            for dy in range(2):
                 for dx in range(2):
-                    tiles[img, (row + dy) * (W // 64) + cx + dx] = 1
+                    tiles[img, (by + dy) * (W // 16) + bx + dx] = 1
         d_proj = torch.zeros(N, H, W, 64, device="cuda")
-        d_proj.view(N, tpi, 64 * 64)[tiles.bool()] = 0.01
+        d_proj[tiles.bool()[:, native.proj_tile_map(H, W).cuda()]] = 0.01
         real = tiles.float().mean().item()
         t = timed(lambda: native.project_features(spec, feat, mlp, tiles=tiles))
         print(f"dirty {real:.3f}  forward (flagged tiles only)  {t:.4f} ms")
