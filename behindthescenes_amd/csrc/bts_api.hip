@@ -23,11 +23,13 @@ int distance_to_z_launch(const float* depths, const float* invK, int N, int H, i
 int invert_small_launch(const float* src, float* dst, int N, int dim, hipStream_t s);
 
 int project_features_impl(int C, int HD, const float* feat, const float* mlp, int N, int HW, float* proj, const unsigned char* tiles, hipStream_t s,
-                          bool feat_cl = false, int Wm = 0);   // Wm: the map's width when `tiles` are 16 x 4 blocks (BtsFieldCfg.tile_blocks), 0 = runs of 64 texels
+                          bool feat_cl = false, int Wm = 0,     // Wm: the map's width when `tiles` are 16 x 4 blocks (BtsFieldCfg.tile_blocks), 0 = runs of 64 texels
+                          void* list_ws = nullptr, size_t list_ws_bytes = 0);   // scratch for the balanced (list-driven) form
 int mark_tiles_impl(const float* rays, const float* z_samp, const float* jitter, const float* w2c_enc, const float* K_enc, long B, int Bp, int K, int lindisp,
                     int H, int W, int fs, unsigned char* tiles, hipStream_t s, int blocks);
 int project_features_bwd_tiles_impl(int C, int HD, const float* feat, float* dproj, unsigned char* tiles, const float* mlp, int N, int HW, float* dfeat,
-                                    float* d_mlp, int clear, hipStream_t s, bool feat_cl = false, int Wm = 0);
+                                    float* d_mlp, int clear, hipStream_t s, bool feat_cl = false, int Wm = 0, void* list_ws = nullptr,
+                                    size_t list_ws_bytes = 0);   // list_ws: scratch for the balanced (list-driven) form, project_bwd_list_bytes(N * tiles) bytes
 int project_features_bwd_impl(int C, int HD, const float* feat, const float* dproj, const float* mlp, int N, int HW, float* dfeat,
                               float* d_mlp, hipStream_t s);
 int render_fwd_impl(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const BtsRenderArgs* a, hipStream_t s);

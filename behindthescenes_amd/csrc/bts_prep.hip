@@ -8,6 +8,7 @@
 // v_mfma_f32_32x32x2_f32 so that the pass costs what the plain NCHW<->NHWC transposes it replaces would cost.  Layouts
 // are chosen so that every global access is a coalesced row: F is read along pixels (NCHW rows), G / dG along channels.
 #include "bts_common.h"
+#include <cstdlib>
 
 namespace bts {
 
@@ -30,7 +31,8 @@ __device__ __forceinline__ int tile_px_c(int p0, int cslot, int lslot, int rs) {
 // (lane half 0) with 8 q + 4 + e (half 1) -- and a tile is 64 x C x 4 contiguous bytes instead of C row pieces of 256.
 template <int C, int HD, bool FEAT_CL>
 __global__ __launch_bounds__(256, 2) void project_kernel(const float* __restrict__ feat, const float* __restrict__ mlp, float* __restrict__ proj,
-                                                      int HW, int tiles_per_img, int n_tiles, const unsigned char* __restrict__ tiles, int Wm, int tw) {
+                                                      int HW, int tiles_per_img, int n_tiles, const unsigned char* __restrict__ tiles, int Wm, int tw,
+                                                      const int* __restrict__ list = nullptr) {
   constexpr int HT = HD / 32;
   constexpr int D_IN = C + kPeDim;
   __shared__ float wl[C * HD];  // wl[c*HD + s] = w_in[hidden_of_storage(s)][c]: G comes out in its storage channel order
@@ -43,12 +45,16 @@ __global__ __launch_bounds__(256, 2) void project_kernel(const float* __restrict
   const int h = lane >> 5, col = lane & 31;
   // `tiles` (bts_project_features_tiles): only the flagged tiles are computed -- a training step's samples read 38 % of them
   // (exp_kitti_360.yaml's batch), the rest of the map is never looked at and stays as it is.  A tile's flag is fetched one tile ahead.
+  // `list` (bts_train_step_fwd, large maps): the flagged tiles as a compact list (compact_tiles_kernel), dealt round-robin -- every wave
+  // the same number of tiles to within one instead of a binomial share of the flags it happens to walk over
   const int tile0 = blockIdx.x * 4 + wave, tstride = gridDim.x * 4;
-  int flag_n = (tiles && tile0 < n_tiles) ? (int)tiles[tile0] : 1;
-  for (int tile = tile0; tile < n_tiles; tile += tstride) {   // tile = 64 pixels of one image
-    const bool wanted = __builtin_amdgcn_readfirstlane(flag_n) != 0;
-    flag_n = (tiles && tile + tstride < n_tiles) ? (int)tiles[tile + tstride] : 1;
-    if (!wanted) continue;
+  const int n_work = list ? min(n_tiles, list[0]) : n_tiles;
+  int flag_n = list ? (tile0 < n_work ? list[4 + tile0] : 0) : ((tiles && tile0 < n_tiles) ? (int)tiles[tile0] : 1);
+  for (int it = tile0; it < n_work; it += tstride) {   // tile = 64 pixels of one image
+    const int fetched = __builtin_amdgcn_readfirstlane(flag_n);
+    flag_n = list ? (it + tstride < n_work ? list[4 + it + tstride] : 0) : ((tiles && it + tstride < n_tiles) ? (int)tiles[it + tstride] : 1);
+    if (!list && fetched == 0) continue;
+    const int tile = list ? fetched : it;
     const int img = tile / tiles_per_img;
     // slot i of the tile is texel p0 + i + (i >> 4) * rs of the image (bts_common.h: a 16 x 4 block, or 64 consecutive texels with rs = 0)
     const int p0 = tile_base(tile - img * tiles_per_img, Wm, tw), rs = tile_rs(Wm, tw);
@@ -420,10 +426,16 @@ __global__ __launch_bounds__(256, 2) void project_bwd_kernel(const float* __rest
 // resets its byte -- the (dproj, tiles) pair is all zero again when the kernel ends, and the caller never fills 503 MB before a step.
 // FEAT_CL: F and dF channels-last (see project_kernel).  tiles == NULL: every tile counts as flagged and nothing is cleared (the dense
 // backward of a channels-last map).
-template <int C, int HD, bool FEAT_CL>
+// LIST (bts_train_step_bwd, large maps): the flagged tiles come as a compact list (compact_tiles_kernel below) and are dealt round-robin
+// over the waves -- every wave gets the same number of dirty tiles to within one.  With the flags read in place a wave's share of the
+// dirty tiles is binomial: at exp_kitti_raw.yaml's batch 1.15 on average and 5 for the unluckiest of the 2 048 waves, and the kernel lasts
+// as long as that one.  The clean tiles (zero rows of dF) follow in a second round-robin loop over `copy`, the compaction's copy of the
+// flags -- the flags themselves are already back to zero.
+template <int C, int HD, bool FEAT_CL, bool LIST = false>
 __global__ __launch_bounds__(256, 2) void project_bwd_tiles_kernel(const float* __restrict__ feat, float* dproj, unsigned char* tiles, const float* __restrict__ mlp,
                                                                 float* __restrict__ dfeat, float* __restrict__ d_mlp, int HW, int tiles_per_img, int n_tiles,
-                                                                int clear, int Wm, int tw) {
+                                                                int clear, int Wm, int tw, const int* __restrict__ list = nullptr,
+                                                                const unsigned char* __restrict__ copy = nullptr) {
   constexpr int HT = HD / 32, CT = C / 32;
   constexpr int D_IN = C + kPeDim;
   __shared__ float wl[HD * C];
@@ -444,55 +456,112 @@ __global__ __launch_bounds__(256, 2) void project_bwd_tiles_kernel(const float* 
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) accw[ht][ct] = zero_acc();
   const float4 z4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  const int n_runs = rs ? 4 : 1, run_step = rs ? Wm : 0;   // a tile as runs of consecutive texels: ONE run of (up to) 64 in the linear form, four rows of 16 in the block form
 
-  const int tile0 = blockIdx.x * 4 + wave, stride = gridDim.x * 4;
-  int flag_n = !tiles ? 1 : (tile0 < n_tiles ? (int)tiles[tile0] : 0);   // a tile's flag is fetched one tile ahead
-  for (int tile = tile0; tile < n_tiles; tile += stride) {
+  auto do_dirty = [&](int tile, bool reset_flag) {
     const int img = tile / tiles_per_img;
     const int p0 = tile_base(tile - img * tiles_per_img, Wm, tw);
-    const bool dirty = __builtin_amdgcn_readfirstlane(flag_n) != 0;
-    flag_n = !tiles ? 1 : (tile + stride < n_tiles ? (int)tiles[tile + stride] : 0);
-    // the tile as runs of consecutive texels: ONE run of (up to) 64 in the linear form, four rows of 16 in the block form
-    const int n_runs = rs ? 4 : 1, run_px = rs ? 16 : min(64, HW - p0), run_step = rs ? Wm : 0;
-    if (dirty) {
-      float* dG = dproj + (long)img * HW * HD;
-      if constexpr (FEAT_CL) {
-        if (d_mlp) project_dw_tile_cl<C, HD>(feat + (long)img * C * HW, dG, p0, HW, h, col, accw, rs);
-        if (dfeat) project_df_half_tiles_cl<C, HD>(dG, dfeat + (long)img * C * HW, wl, p0, HW, h, col, rs);
-      } else {
-        if (d_mlp) project_dw_tile<C, HD>(feat + (long)img * C * HW, dG, p0, HW, vec4, h, col, accw, rs);
-        if (dfeat) project_df_half_tiles<C, HD>(dG, dfeat + (long)img * C * HW, wl, p0, HW, h, col, rs);
+    const int run_px = rs ? 16 : min(64, HW - p0);
+    float* dG = dproj + (long)img * HW * HD;
+    if constexpr (FEAT_CL) {
+      if (d_mlp) project_dw_tile_cl<C, HD>(feat + (long)img * C * HW, dG, p0, HW, h, col, accw, rs);
+      if (dfeat) project_df_half_tiles_cl<C, HD>(dG, dfeat + (long)img * C * HW, wl, p0, HW, h, col, rs);
+    } else {
+      if (d_mlp) project_dw_tile<C, HD>(feat + (long)img * C * HW, dG, p0, HW, vec4, h, col, accw, rs);
+      if (dfeat) project_df_half_tiles<C, HD>(dG, dfeat + (long)img * C * HW, wl, p0, HW, h, col, rs);
+    }
+    if (LIST || (clear && tiles)) {
+      // (this wave is the only reader of the tile and its loads have returned: their values went through the MFMAs above)
+      __builtin_amdgcn_sched_barrier(0);
+      for (int r = 0; r < n_runs; ++r) {
+        float4* row = reinterpret_cast<float4*>(dG + (long)(p0 + r * run_step) * HD);   // run_px texels x HD floats, contiguous
+        for (int i = lane; i < run_px * (HD / 4); i += 64) row[i] = z4;
       }
-      if (clear && tiles) {
-        // (this wave is the only reader of the tile and its loads have returned: their values went through the MFMAs above)
-        __builtin_amdgcn_sched_barrier(0);
-        for (int r = 0; r < n_runs; ++r) {
-          float4* row = reinterpret_cast<float4*>(dG + (long)(p0 + r * run_step) * HD);   // run_px texels x HD floats, contiguous
-          for (int i = lane; i < run_px * (HD / 4); i += 64) row[i] = z4;
-        }
-        if (lane == 0) tiles[tile] = 0;
+      if (reset_flag && lane == 0) tiles[tile] = 0;
+    }
+  };
+  auto do_clean = [&](int tile) {
+    const int img = tile / tiles_per_img;
+    const int p0 = tile_base(tile - img * tiles_per_img, Wm, tw);
+    const int run_px = rs ? 16 : min(64, HW - p0);
+    float* dF = dfeat + (long)img * C * HW;
+    if constexpr (FEAT_CL) {       // a run's texels x C floats are contiguous
+      for (int r = 0; r < n_runs; ++r) {
+        float4* row = reinterpret_cast<float4*>(dF + (long)(p0 + r * run_step) * C);
+        for (int i = lane; i < run_px * (C / 4); i += 64) row[i] = z4;
       }
-    } else if (dfeat) {
-      float* dF = dfeat + (long)img * C * HW;
-      if constexpr (FEAT_CL) {       // a run's texels x C floats are contiguous
-        for (int r = 0; r < n_runs; ++r) {
-          float4* row = reinterpret_cast<float4*>(dF + (long)(p0 + r * run_step) * C);
-          for (int i = lane; i < run_px * (C / 4); i += 64) row[i] = z4;
-        }
-      } else
-      if (vec4 && tile_px(p0, 63, rs) < HW) {   // 16 stores of 4 channel rows x 64 texels (lane & 15: four texels of slot group 4 (lane & 15))
-        const int px4 = tile_px(p0, 4 * (lane & 15), rs);
+    } else
+    if (vec4 && tile_px(p0, 63, rs) < HW) {   // 16 stores of 4 channel rows x 64 texels (lane & 15: four texels of slot group 4 (lane & 15))
+      const int px4 = tile_px(p0, 4 * (lane & 15), rs);
 #pragma unroll
-        for (int i = 0; i < C / 4; ++i) *reinterpret_cast<float4*>(dF + (unsigned)((4 * i + (lane >> 4)) * HW + px4)) = z4;
-      } else if (tile_px(p0, lane, rs) < HW) {
-        const int px = tile_px(p0, lane, rs);
+      for (int i = 0; i < C / 4; ++i) *reinterpret_cast<float4*>(dF + (unsigned)((4 * i + (lane >> 4)) * HW + px4)) = z4;
+    } else if (tile_px(p0, lane, rs) < HW) {
+      const int px = tile_px(p0, lane, rs);
 #pragma unroll 8
-        for (int c = 0; c < C; ++c) dF[(unsigned)(c * HW + px)] = 0.0f;
+      for (int c = 0; c < C; ++c) dF[(unsigned)(c * HW + px)] = 0.0f;
+    }
+  };
+
+  const int tile0 = blockIdx.x * 4 + wave, stride = gridDim.x * 4;
+  if constexpr (LIST) {
+    const int n_dirty = min(n_tiles, list[0]);
+    int id_n = tile0 < n_dirty ? list[4 + tile0] : 0;               // an entry is fetched one tile ahead
+    for (int j = tile0; j < n_dirty; j += stride) {
+      const int tile = __builtin_amdgcn_readfirstlane(id_n);
+      id_n = j + stride < n_dirty ? list[4 + j + stride] : 0;
+      do_dirty(tile, false);
+    }
+    if (dfeat) {
+      int flag_n = tile0 < n_tiles ? (int)copy[tile0] : 1;
+      for (int tile = tile0; tile < n_tiles; tile += stride) {
+        const bool was_dirty = __builtin_amdgcn_readfirstlane(flag_n) != 0;
+        flag_n = tile + stride < n_tiles ? (int)copy[tile + stride] : 1;
+        if (!was_dirty) do_clean(tile);
       }
+    }
+  } else {
+    int flag_n = !tiles ? 1 : (tile0 < n_tiles ? (int)tiles[tile0] : 0);   // a tile's flag is fetched one tile ahead
+    for (int tile = tile0; tile < n_tiles; tile += stride) {
+      const bool dirty = __builtin_amdgcn_readfirstlane(flag_n) != 0;
+      flag_n = !tiles ? 1 : (tile + stride < n_tiles ? (int)tiles[tile + stride] : 0);
+      if (dirty) do_dirty(tile, true);
+      else if (dfeat) do_clean(tile);
     }
   }
   if (d_mlp) project_dw_flush<C, HD>(wl, accw, true, d_mlp, h, col);
 }
+
+// The compaction in front of the LIST form: list[0] (zeroed by the launcher) counts the flagged tiles, list[4 ..] holds their indices (in
+// no particular order: one atomic per work-group reserves its stretch), copy[t] keeps the flag of tile t for the kernel's clean pass, and
+// the flags themselves go back to zero -- the (d_proj, tiles) pair is all zero again once the LIST kernel has run.  One thread per tile.
+// copy == NULL (the forward's sampled-tile flags): the flags are only read.
+__global__ __launch_bounds__(256) void compact_tiles_kernel(unsigned char* __restrict__ tiles, int n_tiles, int* __restrict__ list,
+                                                          unsigned char* __restrict__ copy) {
+  __shared__ int wave_sum[4], base;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool on = t < n_tiles && tiles[t] != 0;
+  if (t < n_tiles && copy) {
+    copy[t] = on ? 1 : 0;
+    if (on) tiles[t] = 0;
+  }
+  const unsigned long long m = __ballot(on);
+  const int before = __popcll(m & ((1ull << lane) - 1ull));
+  if (lane == 0) wave_sum[wave] = __popcll(m);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int total = wave_sum[0] + wave_sum[1] + wave_sum[2] + wave_sum[3];
+    base = total ? atomicAdd(&list[0], total) : 0;
+  }
+  __syncthreads();
+  int off = base + before;
+  for (int w = 0; w < wave; ++w) off += wave_sum[w];
+  if (on) list[4 + off] = t;
+}
+
+constexpr long kListMinTiles = 4096;
+// workspace of the LIST form for a map of n_tiles tiles: the count (16 bytes), the indices, the copy of the flags
+size_t project_bwd_list_bytes(long n_tiles) { return (size_t)(4 + n_tiles) * sizeof(int) + (size_t)n_tiles + 16; }
 
 static int prep_cus() {
   static thread_local int cus[16] = {0};
@@ -506,12 +575,21 @@ static int prep_cus() {
 }
 
 template <int C, int HD>
-static int run_fwd(const float* feat, const float* mlp, int N, int HW, float* proj, const unsigned char* tiles, bool feat_cl, hipStream_t s, int Wm) {
+static int run_fwd(const float* feat, const float* mlp, int N, int HW, float* proj, const unsigned char* tiles, bool feat_cl, hipStream_t s, int Wm,
+                   void* list_ws, size_t list_ws_bytes) {
   const int tpi = (HW + 63) / 64;
   const int tw = Wm > 0 && HW % Wm == 0 ? tile_cols(HW / Wm, Wm, 1) : 0;   // (Wm = 0: runs of 64 consecutive texels)
   const long n_tiles = (long)N * tpi;
   const long want = (n_tiles + 3) / 4, cap = 4L * prep_cus();     // persistent: <= 4 work-groups per CU (16 KB of LDS each)
   const int grid = (int)(want < cap ? want : cap);
+  if (list_ws && tiles && n_tiles >= kListMinTiles && list_ws_bytes >= project_bwd_list_bytes(n_tiles) && !getenv("BTS_NO_TILE_LIST")) {
+    int* list = static_cast<int*>(list_ws);    // the balanced form (see project_bwd_tiles_kernel): the flags stay as they are
+    if (hipMemsetAsync(list, 0, 16, s) != hipSuccess) return BTS_E_LAUNCH;
+    compact_tiles_kernel<<<(int)((n_tiles + 255) / 256), 256, 0, s>>>(const_cast<unsigned char*>(tiles), (int)n_tiles, list, nullptr);
+    if (feat_cl) project_kernel<C, HD, true><<<grid, 256, 0, s>>>(feat, mlp, proj, HW, tpi, (int)n_tiles, tiles, Wm, tw, list);
+    else project_kernel<C, HD, false><<<grid, 256, 0, s>>>(feat, mlp, proj, HW, tpi, (int)n_tiles, tiles, Wm, tw, list);
+    return hipGetLastError() == hipSuccess ? BTS_OK : BTS_E_LAUNCH;
+  }
   if (feat_cl) project_kernel<C, HD, true><<<grid, 256, 0, s>>>(feat, mlp, proj, HW, tpi, (int)n_tiles, tiles, Wm, tw);
   else project_kernel<C, HD, false><<<grid, 256, 0, s>>>(feat, mlp, proj, HW, tpi, (int)n_tiles, tiles, Wm, tw);
   return hipGetLastError() == hipSuccess ? BTS_OK : BTS_E_LAUNCH;
@@ -530,22 +608,32 @@ static int run_bwd(const float* feat, const float* dproj, const float* mlp, int 
 
 template <int C, int HD>
 static int run_bwd_tiles(const float* feat, float* dproj, unsigned char* tiles, const float* mlp, int N, int HW, float* dfeat, float* d_mlp, int clear,
-                         bool feat_cl, hipStream_t s, int Wm) {
+                         bool feat_cl, hipStream_t s, int Wm, void* list_ws, size_t list_ws_bytes) {
   if (!dfeat && !d_mlp && !(clear && tiles)) return BTS_OK;
   const int tpi = (HW + 63) / 64;
   const int tw = Wm > 0 && HW % Wm == 0 ? tile_cols(HW / Wm, Wm, 1) : 0;
   const long n_tiles = (long)N * tpi;
   const long want = (n_tiles + 3) / 4, cap = 2L * prep_cus();
   const int grid = (int)(want < cap ? want : cap);
+  // the balanced form: worth its two small extra launches on maps of a few thousand tiles and more (below that a wave holds a tile or two)
+  if (list_ws && tiles && clear && n_tiles >= kListMinTiles && list_ws_bytes >= project_bwd_list_bytes(n_tiles) && !getenv("BTS_NO_TILE_LIST")) {
+    int* list = static_cast<int*>(list_ws);
+    unsigned char* copy = reinterpret_cast<unsigned char*>(list + 4 + n_tiles);
+    if (hipMemsetAsync(list, 0, 16, s) != hipSuccess) return BTS_E_LAUNCH;
+    compact_tiles_kernel<<<(int)((n_tiles + 255) / 256), 256, 0, s>>>(tiles, (int)n_tiles, list, copy);
+    if (feat_cl) project_bwd_tiles_kernel<C, HD, true, true><<<grid, 256, 0, s>>>(feat, dproj, tiles, mlp, dfeat, d_mlp, HW, tpi, (int)n_tiles, 1, Wm, tw, list, copy);
+    else project_bwd_tiles_kernel<C, HD, false, true><<<grid, 256, 0, s>>>(feat, dproj, tiles, mlp, dfeat, d_mlp, HW, tpi, (int)n_tiles, 1, Wm, tw, list, copy);
+    return hipGetLastError() == hipSuccess ? BTS_OK : BTS_E_LAUNCH;
+  }
   if (feat_cl) project_bwd_tiles_kernel<C, HD, true><<<grid, 256, 0, s>>>(feat, dproj, tiles, mlp, dfeat, d_mlp, HW, tpi, (int)n_tiles, clear, Wm, tw);
   else project_bwd_tiles_kernel<C, HD, false><<<grid, 256, 0, s>>>(feat, dproj, tiles, mlp, dfeat, d_mlp, HW, tpi, (int)n_tiles, clear, Wm, tw);
   return hipGetLastError() == hipSuccess ? BTS_OK : BTS_E_LAUNCH;
 }
 
 int project_features_impl(int C, int HD, const float* feat, const float* mlp, int N, int HW, float* proj, const unsigned char* tiles, hipStream_t s,
-                          bool feat_cl, int Wm) {
-  if (C == 64 && HD == 64) return run_fwd<64, 64>(feat, mlp, N, HW, proj, tiles, feat_cl, s, Wm);
-  if (C == 32 && HD == 32) return run_fwd<32, 32>(feat, mlp, N, HW, proj, tiles, feat_cl, s, Wm);
+                          bool feat_cl, int Wm, void* list_ws, size_t list_ws_bytes) {
+  if (C == 64 && HD == 64) return run_fwd<64, 64>(feat, mlp, N, HW, proj, tiles, feat_cl, s, Wm, list_ws, list_ws_bytes);
+  if (C == 32 && HD == 32) return run_fwd<32, 32>(feat, mlp, N, HW, proj, tiles, feat_cl, s, Wm, list_ws, list_ws_bytes);
   return BTS_E_UNSUPPORTED;
 }
 
@@ -603,9 +691,9 @@ int project_features_bwd_impl(int C, int HD, const float* feat, const float* dpr
 }
 
 int project_features_bwd_tiles_impl(int C, int HD, const float* feat, float* dproj, unsigned char* tiles, const float* mlp, int N, int HW, float* dfeat,
-                                    float* d_mlp, int clear, hipStream_t s, bool feat_cl, int Wm) {
-  if (C == 64 && HD == 64) return run_bwd_tiles<64, 64>(feat, dproj, tiles, mlp, N, HW, dfeat, d_mlp, clear, feat_cl, s, Wm);
-  if (C == 32 && HD == 32) return run_bwd_tiles<32, 32>(feat, dproj, tiles, mlp, N, HW, dfeat, d_mlp, clear, feat_cl, s, Wm);
+                                    float* d_mlp, int clear, hipStream_t s, bool feat_cl, int Wm, void* list_ws, size_t list_ws_bytes) {
+  if (C == 64 && HD == 64) return run_bwd_tiles<64, 64>(feat, dproj, tiles, mlp, N, HW, dfeat, d_mlp, clear, feat_cl, s, Wm, list_ws, list_ws_bytes);
+  if (C == 32 && HD == 32) return run_bwd_tiles<32, 32>(feat, dproj, tiles, mlp, N, HW, dfeat, d_mlp, clear, feat_cl, s, Wm, list_ws, list_ws_bytes);
   return BTS_E_UNSUPPORTED;
 }
 

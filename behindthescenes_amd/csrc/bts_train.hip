@@ -24,11 +24,13 @@ int patch_rays_views_launch(const float* poses, const float* projs, const float*
                             const int* ids, float gt_scale, float gt_shift, hipStream_t s);
 int photometric_loss_impl(const BtsLossArgs* a, hipStream_t s);
 int project_features_impl(int C, int HD, const float* feat, const float* mlp, int N, int HW, float* proj, const unsigned char* tiles, hipStream_t s,
-                          bool feat_cl = false, int Wm = 0);   // Wm: the map's width when `tiles` are 16 x 4 blocks (BtsFieldCfg.tile_blocks), 0 = runs of 64 texels
+                          bool feat_cl = false, int Wm = 0,     // Wm: the map's width when `tiles` are 16 x 4 blocks (BtsFieldCfg.tile_blocks), 0 = runs of 64 texels
+                          void* list_ws = nullptr, size_t list_ws_bytes = 0);   // scratch for the balanced (list-driven) form
 int mark_tiles_impl(const float* rays, const float* z_samp, const float* jitter, const float* w2c_enc, const float* K_enc, long B, int Bp, int K, int lindisp,
                     int H, int W, int fs, unsigned char* tiles, hipStream_t s, int blocks);
 int project_features_bwd_tiles_impl(int C, int HD, const float* feat, float* dproj, unsigned char* tiles, const float* mlp, int N, int HW, float* dfeat,
-                                    float* d_mlp, int clear, hipStream_t s, bool feat_cl = false, int Wm = 0);
+                                    float* d_mlp, int clear, hipStream_t s, bool feat_cl = false, int Wm = 0, void* list_ws = nullptr,
+                                    size_t list_ws_bytes = 0);   // list_ws: scratch for the balanced (list-driven) form, project_bwd_list_bytes(N * tiles) bytes
 int render_fwd_impl(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const BtsRenderArgs* a, hipStream_t s);
 size_t render_bwd_workspace_impl(const BtsFieldCfg* cfg, const BtsRenderArgs* a);
 int render_bwd_impl(const BtsFieldCfg* cfg, const BtsFieldTensors* t, const BtsRenderArgs* a, const BtsRenderGrads* g, void* ws, size_t ws_bytes,
@@ -265,6 +267,8 @@ int train_step_fwd_impl(const BtsTrainStep* st, hipStream_t main_stream) {
     for (int s = 1; s < st->n_scales; ++s)
       if (hipStreamWaitEvent(sq->q[s - 1], sq->fork, 0) != hipSuccess) return BTS_E_LAUNCH;
   }
+  // one slice of the (idle) backward workspace per scale for the projection's tile list
+  const size_t fwd_ws = st->bwd_workspace ? (st->bwd_workspace_bytes / (size_t)st->n_scales) & ~(size_t)255 : 0;
   for (int s = 0; s < st->n_scales; ++s) {
     hipStream_t stream = (sq && s > 0) ? sq->q[s - 1] : main_stream;
     const BtsTrainScale& q = st->scale[s];
@@ -273,7 +277,9 @@ int train_step_fwd_impl(const BtsTrainStep* st, hipStream_t main_stream) {
     rc = mark_tiles_impl(st->rays, nullptr, q.jitter, v.t.w2c_enc, v.t.K_enc, (long)n * Bp, Bp, st->K, st->lindisp, c.H, c.W, q.feat_shift, q.sampled_tiles,
                          stream, v.cfg.tile_blocks);
     if (!rc) rc = project_features_impl(c.C, c.d_hidden, q.feat_nchw, st->mlp_params, n, (int)texels, q.proj_nhwc, q.sampled_tiles, stream, q.feat_channels_last != 0,
-                                        v.cfg.tile_blocks ? c.W >> q.feat_shift : 0);
+                                        v.cfg.tile_blocks ? c.W >> q.feat_shift : 0,
+                                        // the backward's workspace is idle during the forward: the scale's slice of it holds the tile list
+                                        fwd_ws ? static_cast<char*>(st->bwd_workspace) + fwd_ws * (size_t)s : nullptr, fwd_ws);
     if (rc) {
       set_error("%s: projection launch failed at scale %ld", "bts_train_step_fwd", s);
       return rc;
@@ -376,8 +382,14 @@ int train_step_bwd_impl(const BtsTrainStep* st, const float* g_loss, hipStream_t
     int rc = render_bwd_impl(&v.cfg, &v.t, &v.a, &g, ws, ws_bytes, stream, true);
     if (rc) return rc;
     if (need_map) {
+      float* slots;
+      size_t slot_bytes;
+      render_bwd_flush_region(&v.cfg, &v.a, ws, &slots, &slot_bytes);   // (pass C's slot copies at the END of the slice stay zero between the scales)
       rc = project_features_bwd_tiles_impl(c.C, c.d_hidden, q.feat_nchw, q.d_proj_nhwc, q.d_proj_tiles, st->mlp_params, n, (int)map_texels(st, s),
-                                           q.d_feat_nchw, st->d_mlp_params, 1, stream, q.feat_channels_last != 0, v.cfg.tile_blocks ? c.W >> q.feat_shift : 0);
+                                           q.d_feat_nchw, st->d_mlp_params, 1, stream, q.feat_channels_last != 0, v.cfg.tile_blocks ? c.W >> q.feat_shift : 0,
+                                           // the scale's slice of the backward workspace is dead by now (everything bts_render_bwd parked there was
+                                           // read by its own passes, enqueued above on this stream) except pass C's slot copies at its END
+                                           ws, need > slot_bytes ? need - slot_bytes : 0);
       if (rc) {
         set_error("%s: projection backward launch failed at scale %ld", "bts_train_step_bwd", s);
         return rc;
