@@ -560,6 +560,14 @@ __global__ __launch_bounds__(256) void compact_tiles_kernel(unsigned char* __res
 }
 
 constexpr long kListMinTiles = 4096;
+// (A/B switch of the list-driven forms: the product reads no environment variables -- probe build only, as every other switch)
+static bool tile_list_on() {
+#ifdef BTS_PROBE
+  return getenv("BTS_NO_TILE_LIST") == nullptr;
+#else
+  return true;
+#endif
+}
 // workspace of the LIST form for a map of n_tiles tiles: the count (16 bytes), the indices, the copy of the flags
 size_t project_bwd_list_bytes(long n_tiles) { return (size_t)(4 + n_tiles) * sizeof(int) + (size_t)n_tiles + 16; }
 
@@ -582,7 +590,7 @@ static int run_fwd(const float* feat, const float* mlp, int N, int HW, float* pr
   const long n_tiles = (long)N * tpi;
   const long want = (n_tiles + 3) / 4, cap = 4L * prep_cus();     // persistent: <= 4 work-groups per CU (16 KB of LDS each)
   const int grid = (int)(want < cap ? want : cap);
-  if (list_ws && tiles && n_tiles >= kListMinTiles && list_ws_bytes >= project_bwd_list_bytes(n_tiles) && !getenv("BTS_NO_TILE_LIST")) {
+  if (list_ws && tiles && n_tiles >= kListMinTiles && list_ws_bytes >= project_bwd_list_bytes(n_tiles) && tile_list_on()) {
     int* list = static_cast<int*>(list_ws);    // the balanced form (see project_bwd_tiles_kernel): the flags stay as they are
     if (hipMemsetAsync(list, 0, 16, s) != hipSuccess) return BTS_E_LAUNCH;
     compact_tiles_kernel<<<(int)((n_tiles + 255) / 256), 256, 0, s>>>(const_cast<unsigned char*>(tiles), (int)n_tiles, list, nullptr);
@@ -616,7 +624,7 @@ static int run_bwd_tiles(const float* feat, float* dproj, unsigned char* tiles, 
   const long want = (n_tiles + 3) / 4, cap = 2L * prep_cus();
   const int grid = (int)(want < cap ? want : cap);
   // the balanced form: worth its two small extra launches on maps of a few thousand tiles and more (below that a wave holds a tile or two)
-  if (list_ws && tiles && clear && n_tiles >= kListMinTiles && list_ws_bytes >= project_bwd_list_bytes(n_tiles) && !getenv("BTS_NO_TILE_LIST")) {
+  if (list_ws && tiles && clear && n_tiles >= kListMinTiles && list_ws_bytes >= project_bwd_list_bytes(n_tiles) && tile_list_on()) {
     int* list = static_cast<int*>(list_ws);
     unsigned char* copy = reinterpret_cast<unsigned char*>(list + 4 + n_tiles);
     if (hipMemsetAsync(list, 0, 16, s) != hipSuccess) return BTS_E_LAUNCH;
