@@ -577,7 +577,19 @@ __global__ __launch_bounds__(64) void scatter_kernel(const ScatterMaskParams sp)
   const int lane = threadIdx.x;
   const int h = lane >> 5, c = lane & 31;
   const unsigned c4 = (unsigned)c * 4u, cbit = 1u << c;
+#ifndef BTS_SCATTER_ORDER
+#define BTS_SCATTER_ORDER 0
+#endif
+  // which (unit, segment) a block takes: blocks are dispatched in index order, and the launch lasts until its last block ends
+#if BTS_SCATTER_ORDER == 1      // segment-major, the segment of the NEAR samples first
+  const int n_units = (int)gridDim.x / sp.nseg;
+  const int seg = blockIdx.x / n_units, unit = blockIdx.x - seg * n_units;
+#elif BTS_SCATTER_ORDER == 2    // segment-major, the segment of the FAR samples first
+  const int n_units = (int)gridDim.x / sp.nseg;
+  const int seg_r = blockIdx.x / n_units, unit = blockIdx.x - seg_r * n_units, seg = sp.nseg - 1 - seg_r;
+#else
   const int unit = blockIdx.x / sp.nseg, seg = blockIdx.x - unit * sp.nseg;
+#endif
   const int grp = unit / NW, wv = unit - grp * NW;
   const int chg = wv * 32 + c;   // this lane's channel of the row
   const int sample = grp / sp.groups_per_sample;
