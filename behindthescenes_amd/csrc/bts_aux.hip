@@ -2,6 +2,7 @@
 // ray generation (util.py:113-149, 244-273), stratified depth sampling (nerf.py:103-123) and distance->z
 // (projection_operations.py:4-16).  All are coalesced streaming kernels; none does arithmetic worth an MFMA.
 #include "bts_common.h"
+#include <cstdint>
 
 namespace bts {
 
@@ -58,17 +59,33 @@ struct FrameIds {
 };
 __device__ __forceinline__ void pack_rgb_body(const float* __restrict__ src, float4* __restrict__ dst, long HW, long total, float scale, float shift,
                                               const FrameIds& f, long block, long n_blocks) {
-  for (long i = block * 256L + threadIdx.x; i < total; i += n_blocks * 256) {
+  // four pixels per thread and trip, 256 apart (every load and every store of a wave stays one contiguous piece): twelve independent
+  // loads in flight per thread instead of three dependent round trips per pixel -- the pass is a pure stream (98 MB in, 129 MB out at
+  // exp_kitti_360.yaml's batch).  (Four CONSECUTIVE pixels per thread -- float4 loads -- was tried first: its 16-byte stores are 64 bytes
+  // apart across the lanes, four partial writes per 64-byte piece, and the pass did not get faster: profiles/r06n.)
+  long i0 = block * 1024L + threadIdx.x;
+  for (; i0 + 768 < total; i0 += n_blocks * 1024) {
+    float v[4][3];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const long i = i0 + 256 * k;
+      long n = i / HW;
+      const long p = i - n * HW;
+      if (f.nv > 0) n = (n / f.nv) * f.v + f.ids[n % f.nv];
+      const float* s = src + n * 3 * HW + p;
+      v[k][0] = s[0], v[k][1] = s[HW], v[k][2] = s[2 * HW];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dst[i0 + 256 * k] = make_float4(v[k][0] * scale + shift, v[k][1] * scale + shift, v[k][2] * scale + shift, 0.0f);
+  }
+  // the ragged end of this thread's last trip
+  for (long i = i0; i < total; i += 256) {
+    if (i >= i0 + 1024) break;
     long n = i / HW;
     const long p = i - n * HW;
     if (f.nv > 0) n = (n / f.nv) * f.v + f.ids[n % f.nv];
     const float* s = src + n * 3 * HW + p;
-    float4 o;
-    o.x = s[0] * scale + shift;
-    o.y = s[HW] * scale + shift;
-    o.z = s[2 * HW] * scale + shift;
-    o.w = 0.0f;
-    dst[i] = o;
+    dst[i] = make_float4(s[0] * scale + shift, s[HW] * scale + shift, s[2 * HW] * scale + shift, 0.0f);
   }
 }
 __global__ __launch_bounds__(256) void pack_rgb_kernel(const float* __restrict__ src, float4* __restrict__ dst, long HW, long total,
