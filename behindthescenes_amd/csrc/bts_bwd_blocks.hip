@@ -843,6 +843,10 @@ __global__ __launch_bounds__(256, 2) void rowsb_kernel(const BwdParams bp, const
 // launch
 // ---------------------------------------------------------------------------------------------------------------
 int launch_scatter_rows(const BwdParams& bp, const float* u0_ws, int HD, int n, hipStream_t s);
+struct PassQueue;
+PassQueue* pass_queue();
+hipStream_t pass_fork(PassQueue* pq, hipStream_t s);
+void pass_join(PassQueue* pq, hipStream_t side, hipStream_t s);
 int launch_dwpe_rows(const FwdParams& p, const float* u0_ws, float* d_mlp, float* flush_ws, int C, int HD, int NB, int n, int grid, hipStream_t s,
                      bool flush_clean);
 
@@ -882,8 +886,13 @@ int launch_bwd_blocks(const BwdParams& bp, float* u0_ws, int C, int HD, int NB, 
   if (C == 64 && HD == 64 && NB == 0) rc = launch_rowsb<64, 64, 0>(bp, ro, grid, s);
   else if (C == 32 && HD == 32 && NB == 1) rc = launch_rowsb<32, 32, 1>(bp, ro, grid, s);
   else if (C == 32 && HD == 32 && NB == 0) rc = launch_rowsb<32, 32, 0>(bp, ro, grid, s);
-  if (rc == BTS_OK && (bp.d_proj || bp.d_empty_proj)) rc = launch_scatter_rows(bp, u0_ws, HD, n, s);
-  if (rc == BTS_OK && bp.d_mlp) rc = launch_dwpe_rows(bp.f, u0_ws, bp.d_mlp, bp.flush_ws, C, HD, NB, n, grid, s, bp.flush_clean);
+  // pass C on a side queue of the library next to pass B (bts_bwd_rows.hip: pass_queue)
+  const bool want_b = bp.d_proj || bp.d_empty_proj, want_c = bp.d_mlp != nullptr;
+  PassQueue* pq = (rc == BTS_OK && want_b && want_c) ? pass_queue() : nullptr;
+  const hipStream_t sc = pq ? pass_fork(pq, s) : s;
+  if (rc == BTS_OK && want_c) rc = launch_dwpe_rows(bp.f, u0_ws, bp.d_mlp, bp.flush_ws, C, HD, NB, n, grid, sc, bp.flush_clean);
+  if (rc == BTS_OK && want_b) rc = launch_scatter_rows(bp, u0_ws, HD, n, s);
+  pass_join(pq, sc, s);
   return rc;
 }
 

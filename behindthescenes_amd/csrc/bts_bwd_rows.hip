@@ -1280,6 +1280,49 @@ __global__ __launch_bounds__(256, HD == 32 ? 3 : 2) void dwpe_rows_kernel(const 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// pass B and pass C side by side
+// ---------------------------------------------------------------------------------------------------------------
+// Pass B (scatter: dG) and pass C (dW_pe) both read what pass A left and write different things.  One after the other on the caller's
+// stream, each is bound by latency at its own occupancy -- and the scatter pass ends in a tail of slow blocks (its slowest block lives
+// 1.8 x the average one).  -DBTS_PASS_OVERLAP puts pass C on a side queue of the library (fork after pass A, join before the call's
+// last kernel: the caller's stream sees one ordered sequence) so that it can fill what pass B leaves idle.  MEASURED SLOWER and NOT the
+// default (round 6, profiles/r06o: backward +7 % at exp_kitti_360.yaml, +6 % exp_kitti_raw.yaml, +4 % exp_re10k.yaml): pass C is a
+// persistent grid that takes two work-groups' worth of every CU the moment it starts, and the scatter blocks then queue for what is
+// left -- the same finding as for whole per-scale chains side by side (profiles/r05i).
+struct PassQueue {
+  hipStream_t q;
+  hipEvent_t fork, join;
+  bool ok;
+};
+PassQueue* pass_queue() {
+#ifndef BTS_PASS_OVERLAP
+  return nullptr;
+#else
+  static thread_local PassQueue* per_dev[16] = {nullptr};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  if (!per_dev[dev]) {
+    PassQueue* pq = new PassQueue;
+    pq->ok = hipStreamCreateWithFlags(&pq->q, hipStreamNonBlocking) == hipSuccess &&
+             hipEventCreateWithFlags(&pq->fork, hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&pq->join, hipEventDisableTiming) == hipSuccess;
+    per_dev[dev] = pq;
+  }
+  return per_dev[dev]->ok ? per_dev[dev] : nullptr;
+#endif
+}
+// -> the stream pass C goes to (the side queue, forked from s here; s itself if there is none)
+hipStream_t pass_fork(PassQueue* pq, hipStream_t s) {
+  if (!pq || hipEventRecord(pq->fork, s) != hipSuccess || hipStreamWaitEvent(pq->q, pq->fork, 0) != hipSuccess) return s;
+  return pq->q;
+}
+void pass_join(PassQueue* pq, hipStream_t side, hipStream_t s) {
+  if (side == s) return;
+  (void)hipEventRecord(pq->join, side);
+  (void)hipStreamWaitEvent(s, pq->join, 0);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // launch
 // ---------------------------------------------------------------------------------------------------------------
 static void scatter_segments(ScatterMaskParams& sp, long units, int K);
@@ -1301,7 +1344,21 @@ static int launch_rows(const BwdParams& bp, int n, int grid, hipStream_t s) {
   else if (p.nv <= 4) go(rows_kernel<C, HD, 4>);
   else go(rows_kernel<C, HD, 8>);
   hipError_t e = hipGetLastError();
-  if (e == hipSuccess && (bp.d_proj || bp.d_empty_proj)) {
+  const bool want_b = bp.d_proj || bp.d_empty_proj, want_c = bp.d_mlp != nullptr;
+  PassQueue* pq = (want_b && want_c) ? pass_queue() : nullptr;
+  const hipStream_t sc = (e == hipSuccess && pq) ? pass_fork(pq, s) : s;     // pass C's stream
+  if (e == hipSuccess && want_c) {
+    DwpeParams dp;
+    dp.f = p, dp.pmask_ws = bp.pmask_ws, dp.gs_ws = bp.gs_ws, dp.d_mlp = bp.d_mlp, dp.slots = bp.flush_ws, dp.rays = (long)n * p.Bp;
+    const long wgs = (dp.rays + 3) / 4;
+    auto kern = dwpe_kernel<C, HD>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, DwpeLds::TOTAL);
+    if (!bp.flush_clean) (void)hipMemsetAsync(bp.flush_ws, 0, sizeof(float) * kFlushSlots * kFlushRows * HD, sc);
+    kern<<<(int)(wgs < grid ? wgs : grid), 256, DwpeLds::TOTAL, sc>>>(dp);   // grid = 2 work-groups per CU
+    dwpe_reduce_kernel<C, HD><<<(kFlushRows * HD + 255) / 256, 256, 0, sc>>>(bp.flush_ws, bp.d_mlp);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess && want_b) {
     const MlpLayout ml{C + kPeDim, HD, 0};
     ScatterMaskParams sp;
     sp.f = p, sp.mask_ws = bp.mask_ws, sp.u0_ws = nullptr, sp.gs_ws = bp.gs_ws, sp.d_proj = bp.d_proj, sp.d_empty_proj = bp.d_empty_proj;
@@ -1315,17 +1372,7 @@ static int launch_rows(const BwdParams& bp, int n, int grid, hipStream_t s) {
     scatter_kernel<HD><<<(int)(units * sp.nseg), 64, 0, s>>>(sp);
     e = hipGetLastError();
   }
-  if (e == hipSuccess && bp.d_mlp) {
-    DwpeParams dp;
-    dp.f = p, dp.pmask_ws = bp.pmask_ws, dp.gs_ws = bp.gs_ws, dp.d_mlp = bp.d_mlp, dp.slots = bp.flush_ws, dp.rays = (long)n * p.Bp;
-    const long wgs = (dp.rays + 3) / 4;
-    auto kern = dwpe_kernel<C, HD>;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, DwpeLds::TOTAL);
-    if (!bp.flush_clean) (void)hipMemsetAsync(bp.flush_ws, 0, sizeof(float) * kFlushSlots * kFlushRows * HD, s);
-    kern<<<(int)(wgs < grid ? wgs : grid), 256, DwpeLds::TOTAL, s>>>(dp);   // grid = 2 work-groups per CU
-    dwpe_reduce_kernel<C, HD><<<(kFlushRows * HD + 255) / 256, 256, 0, s>>>(bp.flush_ws, bp.d_mlp);
-    e = hipGetLastError();
-  }
+  pass_join(pq, sc, s);
   if (e != hipSuccess) {
     set_error("%s: backward kernel launch failed (%ld)", hipGetErrorString(e), (long)e);
     return BTS_E_LAUNCH;
