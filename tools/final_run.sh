@@ -12,4 +12,4 @@ echo "tree: ${2:-unknown}  ($(date -u +%FT%TZ); sha256 of bench.py $(sha256sum b
 timeout 1700 python -m pytest tests -m gpu -x -q --timeout 900 2>&1 | tail -5 > gpurun_out/$TAG/pytest_gpu_x.txt; tail -3 gpurun_out/$TAG/pytest_gpu_x.txt
 bash tools/gpu.sh $TAG smoke bench
 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29611 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/$TAG/bench_torchrun_n1.json 2> gpurun_out/$TAG/bench_torchrun_n1.err; python tools/bench_summary.py gpurun_out/$TAG/bench_torchrun_n1.json | head -3
-bash tools/gpu.sh $TAG steptrace:train:handover_kernel:--workload,train,--no-cpu-baseline,--steps,6,--warmup,3 steptrace:kitti_raw:handover_kernel:--workload,kitti_raw,--no-cpu-baseline,--steps,6,--warmup,3 steptrace:re10k:handover_kernel:--workload,re10k,--no-cpu-baseline,--steps,6,--warmup,3 steptrace:eval:gen_rays_kernel:--workload,eval,--no-cpu-baseline,--steps,12,--warmup,4 > gpurun_out/$TAG/steptraces.log 2>&1
+bash tools/gpu.sh $TAG steptrace:train:handover_kernel:--workload,train,--no-cpu-baseline,--no-other-layout,--steps,6,--warmup,3 steptrace:kitti_raw:handover_kernel:--workload,kitti_raw,--no-cpu-baseline,--no-other-layout,--steps,6,--warmup,3 steptrace:re10k:handover_kernel:--workload,re10k,--no-cpu-baseline,--no-other-layout,--steps,6,--warmup,3 steptrace:eval:gen_rays_kernel:--workload,eval,--no-cpu-baseline,--steps,12,--warmup,4 > gpurun_out/$TAG/steptraces.log 2>&1
