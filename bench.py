@@ -156,12 +156,30 @@ def _sync(dev):
         torch.cuda.synchronize()
 
 
-def timed_region(step, steps, dev, events=None, before=None):
+# HIP event pairs inside the timed region on every EVENT_EVERY-th step (default: every step).  Round 6 suspected the pairs themselves of
+# slowing the loop (an event record between two kernels is a barrier packet) and measured it: 1.10 ms per eval step with pairs on every
+# step, on every 4th, on every 10th and on the first only -- no difference (profiles/r06q/event_every.txt).  What did cost 0.12 ms per step
+# was the collector pass between warm-up and timing (see timed_region).  BTS_BENCH_EVENT_EVERY keeps the experiment repeatable.
+EVENT_EVERY = int(os.environ.get("BTS_BENCH_EVENT_EVERY", "1"))
+
+
+def timed_region(step, steps, dev, events=None, before=None, timer=None, warmup=0):
     """The contract's timed region: barrier + synchronize, EXACTLY `steps` calls of step(), synchronize + barrier, and the MAXIMUM of the
-    wall time over the ranks.  `events`: one (start, end) HIP event pair per step, recorded on the current stream around the call.
-    `before`: runs between the opening barrier and the clock (e.g. reset_peak_memory_stats).  -> (seconds, the last step's return value)."""
+    wall time over the ranks.  `events`: one (start, end) HIP event pair per step, recorded on the current stream around the call -- on
+    the sampled steps (every EVENT_EVERY-th), like `timer`'s pairs (a KernelTimer, installed by the caller).
+    `before`: runs between the opening barrier and the clock (e.g. reset_peak_memory_stats).
+    `warmup`: the W untimed steps, run HERE -- behind the collector pass, directly in front of the opening synchronize.  Until round 6 the
+    workloads warmed up first and park_gc() came after: its gc.collect() is ~30 ms of host time with the GPU idle, and the first steps of
+    the timed region then ran on a device that had dropped out of its steady state -- a fixed ~2.4 ms per timed region, i.e. 1.10 ms per
+    step over 20 steps against 0.98 over 200 (profiles/r06q/event_every.txt: independent of how many steps carry event pairs).  The warm-up
+    exists so that timing starts in steady state; a pause between the two defeats it.
+    -> (seconds, the last step's return value); timed_region.sampled = the indices of the sampled steps."""
     dist = torch.distributed
-    unpark_gc = park_gc()               # (in front of the barrier: the collection takes a different time on every rank)
+    unpark_gc = park_gc()               # (in front of the warm-up and the barrier: the collection takes a different time on every rank)
+    if timer is not None:
+        timer.enabled = False
+    for _ in range(warmup):
+        step()
     _sync(dev)
     if dist.is_initialized():
         dist.barrier()
@@ -170,12 +188,21 @@ def timed_region(step, steps, dev, events=None, before=None):
         before()
     last = None
     t0 = time.perf_counter()
+    sampled = []
     for i in range(steps):
-        if events is not None:
+        on = i % EVENT_EVERY == 0
+        if timer is not None:
+            timer.enabled = on
+        if on:
+            sampled.append(i)
+        if events is not None and on:
             events[i][0].record()
         last = step()
-        if events is not None:
+        if events is not None and on:
             events[i][1].record()
+    timed_region.sampled = sampled
+    if timer is not None:
+        timer.enabled = True
     _sync(dev)
     unpark_gc()
     if dist.is_initialized():
@@ -203,9 +230,7 @@ def glue_workload(args, world, rank, dev):
     def step():
         time.sleep(1e-3 * (rank + 1))
         return (x @ x).sum()
-    for _ in range(args.warmup):
-        step()
-    elapsed, _ = timed_region(step, args.steps, dev)
+    elapsed, _ = timed_region(step, args.steps, dev, warmup=args.warmup)
     if rank != 0:
         return None
     return {"metric": "launch glue stand-in (not a measurement)", "value": world * args.steps / elapsed, "unit": "steps/s", "n_gpus": world,
@@ -226,10 +251,11 @@ class KernelTimer:
     def __init__(self):
         from behindthescenes_amd import native
         self.native, self.orig, self.ev, self.depth = native, {}, {k: [] for k in self.ENTRIES}, 0
+        self.enabled = True          # timed_region switches the pairs on for the SAMPLED steps only (see EVENT_EVERY)
 
     def _wrap(self, name, fn):
         def f(*a, **kw):
-            if self.depth:
+            if self.depth or not self.enabled:
                 return fn(*a, **kw)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             self.depth += 1
@@ -491,8 +517,9 @@ def train_workload(args, world, rank, dev):
         model(images, projs, poses).backward()
 
     native.SPARSE_PROJ_GRAD = not args.dense_proj_grad
-    for _ in range(args.warmup):
-        step()
+    if args.tile_stats or args.ops_profile:      # (the diagnostics below want a warmed-up process; the timed path warms up inside timed_region)
+        for _ in range(args.warmup):
+            step()
     if args.tile_stats:
         orig_pb = native.project_features_bwd
 
@@ -539,7 +566,8 @@ def train_workload(args, world, rank, dev):
         return
     timer = KernelTimer()
     timer.install()
-    elapsed, _ = timed_region(step, args.steps, dev, before=torch.cuda.reset_peak_memory_stats)
+    elapsed, _ = timed_region(step, args.steps, dev, before=torch.cuda.reset_peak_memory_stats, timer=timer, warmup=args.warmup)
+    n_event_steps = len(timed_region.sampled)
     timer.remove()
     # for the byte model of `traffic_ratio`: the 64-texel tiles of every scale's map the LAST step's samples touched (the forward's flags stay
     # in the arena until the next hand-over clears them), outside the timed region
@@ -569,7 +597,7 @@ def train_workload(args, world, rank, dev):
                               "collective is a local copy -- the number says the path ran, not what xGMI costs")
     n_rays = n * cfg["rays"]
     # per STEP and entry point: the four scales of re10k are four calls each on the entry-by-entry path
-    ms = timer.ms_per_step(args.steps)
+    ms = timer.ms_per_step(n_event_steps)
     if rank == 0:
         flop_pt = 2 * ((Cc + 39) * Hd + Nb * 2 * Hd * Hd + Hd)     # 13 312 (KITTI MLP) / 8 704 (RE10K MLP) per field query
         flop = 3 * n_rays * Kt * flop_pt * n_scales                # training = 3x forward (dX + dW); every scale renders all rays
@@ -632,7 +660,7 @@ def train_workload(args, world, rank, dev):
                        "parallelism": parallelism("batch", world), "peak_hbm_bytes": torch.cuda.max_memory_allocated(),
                        "feat_layout": "nhwc (channels_last: Monodepth2's hand-over)" if args.encoder != "feature_map" else args.feat_layout},
             "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_MATRIX_TFLOPS, "traffic": traffic,
+                         "frac": achieved / PEAK_FP32_MATRIX_TFLOPS, "traffic": traffic, "event_steps": n_event_steps,
                          **({"algorithmic_bytes": byte_model["algorithmic_bytes"], "state_bytes": byte_model["state_bytes"], "traffic_ratio": traffic_ratio,
                              "traffic_over_model": traffic_over_model, "byte_model": byte_model["detail"]} if byte_model else {}),
                          "kernel": ("bts_train_step_fwd + bts_train_step_bwd: every bts:: kernel of the step (hand-over, patch rays, tile flags, "
@@ -704,11 +732,9 @@ def profile_workload(args, world, rank, dev):
         a = sigmas.reshape(Y, Z, X)
         return (torch.cumsum(a, 0) <= 8).float().sum(0) / Y
 
-    for _ in range(args.warmup):
-        step()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    elapsed, prof = timed_region(step, args.steps, dev, events=ev)
-    kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
+    elapsed, prof = timed_region(step, args.steps, dev, events=ev, warmup=args.warmup)
+    kernel_ms = sum(ev[i][0].elapsed_time(ev[i][1]) for i in timed_region.sampled) / len(timed_region.sampled)
     n_pts = Y * Z * X
     if rank == 0:
         ref_ms, agree = None, None
@@ -833,10 +859,9 @@ def main():
             depth_z = bts.distance_to_z(rd["coarse"]["depth"], projs)
         return depth_z
 
-    for _ in range(args.warmup):
-        step()
     timer.install()
-    elapsed, _ = timed_region(step, args.steps, dev, events=ev)
+    elapsed, _ = timed_region(step, args.steps, dev, timer=timer, warmup=args.warmup)
+    n_event_steps = len(timed_region.sampled)
     timer.remove()
     # the same loop once more with Python's cyclic collector ON (what an evaluation loop that does not park it sees), outside the timed
     # region: reported beside the headline as `ms_per_step_gc_on` (round-5 advice: the headline's loop runs with the collector parked)
@@ -847,7 +872,7 @@ def main():
     torch.cuda.synchronize()
     gc_on_ms = (time.perf_counter() - t1) * 1e3 / args.steps
 
-    entry_ms = timer.ms_per_step(args.steps)
+    entry_ms = timer.ms_per_step(n_event_steps)
     one_call = "eval_frame" in entry_ms
     if one_call:
         # the frame is ONE library call: its event pair holds every bts:: kernel of the frame (render_kernel_p, project_kernel and five
@@ -911,7 +936,7 @@ def main():
                          "frac": achieved / PEAK_FP32_MATRIX_TFLOPS, "traffic": traffic,
                          "kernel": "bts::render_kernel_p<64,64,0,1,true,true> + bts::project_kernel<64,64>" + (" inside bts_eval_frame (one call: + cameras, "
                                    "rgb0 packing, rays, two small inverses, distance_to_z)" if one_call else ""),
-                         "kernel_ms": kernel_ms, "project_ms": project_ms, "render_kernel_ms": render_ms,
+                         "kernel_ms": kernel_ms, "project_ms": project_ms, "render_kernel_ms": render_ms, "event_steps": n_event_steps,
                          "entry_ms_entry_by_entry": {k: round(v, 4) for k, v in sorted(split_ms.items())} if one_call else None,
                          "executed_flop_per_launch": exec_flop, "algorithmic_flop_per_launch": flop_per_launch,
                          "algorithmic_tflops": algorithmic, "frac_algorithmic": algorithmic / PEAK_FP32_MATRIX_TFLOPS,
