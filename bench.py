@@ -976,7 +976,24 @@ def main():
     # ---- the other BASELINE configs on the same line (every rank runs them: their barriers are collectives)
     del net, wrapped, scene, images
     torch.cuda.empty_cache()
+    # Under torch.distributed.run the sub-record `ddp_train` is the first thing in this file that runs a real collective over RCCL at N > 1
+    # (no multi-GPU node has been available to any round).  Should it never return -- a rank that failed while its peers wait inside an
+    # all-reduce --, the headline measured above must still reach the driver: a watchdog prints the line without it and ends the process.
+    watchdog = None
+    if launched and not args.no_others:
+        import threading
+
+        def bail():
+            if rank == 0:
+                out["ddp_train"] = {"error": "did not finish within 300 s (a collective that never completed?); the headline above stands"}
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+        watchdog = threading.Timer(300.0, bail)
+        watchdog.daemon = True
+        watchdog.start()
     subs = sub_records(args, world, rank, dev, launched)
+    if watchdog is not None:
+        watchdog.cancel()
     if rank == 0:
         out.update(subs)
         print(json.dumps(out))
